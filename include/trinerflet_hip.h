@@ -1,0 +1,195 @@
+/*
+ * trinerflet_hip.h -- C ABI of libtrinerflet_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for TriNeRFLet's volume-rendering hot path.  Every entry point
+ * takes plain device pointers, sizes and a HIP stream (hipStream_t passed as void*; NULL = the
+ * null stream) and returns a hipError_t value as int (0 = hipSuccess; launch errors only --
+ * like the reference, no argument validation is done on the raymarching entry points,
+ * SURVEY.md 8(b) "Error conventions").  The caller allocates every buffer.  No torch types.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference
+ * repository root).  INTEGRATION.md shows the binding a reference maintainer would add.
+ */
+#ifndef TRINERFLET_HIP_H
+#define TRINERFLET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNL_API __attribute__((visibility("default")))
+
+/* ABI version; bumped when a signature changes. */
+TNL_API int tnl_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * raymarching: replaces the 10 pybind functions of aux_libs/raymarching/src/raymarching.h:7-17
+ * (kernels in aux_libs/raymarching/src/raymarching.cu).  All float buffers are fp32 (the
+ * reference wrappers force fp32 with custom_fwd(cast_inputs=torch.float32)).
+ * ------------------------------------------------------------------------------------------- */
+
+/* raymarching.h:7  near_far_from_aabb ; kernel raymarching.cu:92-145.
+ * rays_o,rays_d:[N,3] aabb:[6] -> nears,fars:[N]; a miss writes FLT_MAX to both. */
+TNL_API int tnl_near_far_from_aabb(const float *rays_o, const float *rays_d, const float *aabb,
+                                   uint32_t N, float min_near, float *nears, float *fars,
+                                   void *stream);
+
+/* raymarching.h:8  sph_from_ray ; kernel raymarching.cu:163-198.  coords:[N,2] */
+TNL_API int tnl_sph_from_ray(const float *rays_o, const float *rays_d, float radius, uint32_t N,
+                             float *coords, void *stream);
+
+/* raymarching.h:9  morton3D ; kernel raymarching.cu:214-226.  coords:[N,3] i32 -> indices:[N] */
+TNL_API int tnl_morton3D(const int32_t *coords, uint32_t N, int32_t *indices, void *stream);
+
+/* raymarching.h:10 morton3D_invert ; kernel raymarching.cu:237-254 */
+TNL_API int tnl_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coords, void *stream);
+
+/* raymarching.h:11 packbits ; kernel raymarching.cu:268-289.  grid:[8N] fp32 -> bitfield:[N] u8 */
+TNL_API int tnl_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield,
+                         void *stream);
+
+/* Number of int32 scratch words tnl_march_rays_train needs for N rays. */
+TNL_API uint32_t tnl_march_rays_train_workspace(uint32_t N);
+
+/* raymarching.h:13 march_rays_train ; kernel raymarching.cu:312-480.
+ * Same arguments as the reference plus a scratch buffer.  Packing is DETERMINISTIC: rays[n] =
+ * (n, exclusive prefix of num_steps, num_steps), i.e. the ray-id arrival order of the
+ * reference's atomics (which are nondeterministic there).  counter[0] += total steps,
+ * counter[1] += N.  xyzs/dirs/deltas rows that no ray owns are left untouched (the caller
+ * zero-fills them, raymarching.py:205-207). */
+TNL_API int tnl_march_rays_train(const float *rays_o, const float *rays_d, const uint8_t *grid,
+                                 float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                                 uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                                 const float *fars, float *xyzs, float *dirs, float *deltas,
+                                 int32_t *rays, int32_t *counter, const float *noises,
+                                 int32_t *workspace, void *stream);
+
+/* raymarching.h:14 composite_rays_train_forward ; kernel raymarching.cu:501-577.
+ * One 64-lane wavefront per ray; transmittance by a wavefront product scan. */
+TNL_API int tnl_composite_rays_train_forward(const float *sigmas, const float *rgbs,
+                                             const float *deltas, const int32_t *rays, uint32_t M,
+                                             uint32_t N, float T_thresh, float *weights_sum,
+                                             float *depth, float *image, void *stream);
+
+/* raymarching.h:15 composite_rays_train_backward ; kernel raymarching.cu:602-682.
+ * Writes every sample row a ray owns (zero where the reference would have stopped early). */
+TNL_API int tnl_composite_rays_train_backward(const float *grad_weights_sum, const float *grad_image,
+                                              const float *sigmas, const float *rgbs,
+                                              const float *deltas, const int32_t *rays,
+                                              const float *weights_sum, const float *image,
+                                              uint32_t M, uint32_t N, float T_thresh,
+                                              float *grad_sigmas, float *grad_rgbs, void *stream);
+
+/* raymarching.h:16 march_rays ; kernel raymarching.cu:701-805 */
+TNL_API int tnl_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t *rays_alive,
+                           const float *rays_t, const float *rays_o, const float *rays_d,
+                           float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                           const uint8_t *grid, const float *nears, const float *fars, float *xyzs,
+                           float *dirs, float *deltas, const float *noises, void *stream);
+
+/* raymarching.h:17 composite_rays ; kernel raymarching.cu:819-905 (in place) */
+TNL_API int tnl_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
+                               int32_t *rays_alive, float *rays_t, const float *sigmas,
+                               const float *rgbs, const float *deltas, float *weights_sum,
+                               float *depth, float *image, void *stream);
+
+/* Device-side, order-preserving replacement of `rays_alive = rays_alive[rays_alive >= 0]`
+ * (reconstruction/nerf/renderer.py:364).  workspace: ceil(n_alive/256) int32.  n_out: device
+ * int32 receiving the survivor count. */
+TNL_API int tnl_compact_rays(const int32_t *rays_alive, uint32_t n_alive, int32_t *rays_alive_out,
+                             int32_t *n_out, int32_t *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * shencoder: replaces sh_encode_forward of aux_libs/shencoder/src/shencoder.h
+ * (kernel_sh, shencoder.cu:28-355).  degree C in 1..4 (the path uses 4 -> 16 outputs);
+ * returns hipErrorInvalidValue for C > 4 or D != 3.  dy_dx may be NULL (it is on the path).
+ * ------------------------------------------------------------------------------------------- */
+TNL_API int tnl_sh_encode_forward(const float *inputs, float *outputs, uint32_t B, uint32_t D,
+                                  uint32_t C, float *dy_dx, void *stream);
+/* shencoder.cu:359-382 (kernel_sh_backward) */
+TNL_API int tnl_sh_encode_backward(const float *grad, const float *inputs, uint32_t B, uint32_t D,
+                                   uint32_t C, const float *dy_dx, float *grad_inputs, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Wavelet triplane: replaces the torch / pytorch_wavelets operator chain of
+ * reconstruction/triplaneencoder/triplane_encoder.py (build_planes :364-405, sample_from_planes_aux
+ * :314-332).  wave: 0 haar, 1 bior2.2, 2 bior4.4, 3 bior2.6, 4 bior6.8 (:174-180).
+ * ------------------------------------------------------------------------------------------- */
+
+/* One inverse-DWT level: x:[S,n,n], yh:[S,3,n,n] -> out:[S,2n,2n]; computes
+ * idwt((pad(2*x), [pad(yh)])) of triplane_encoder.py:379,392-394 (pytorch_wavelets.DWTInverse,
+ * mode='zero').  S = 3*channels slices (depthwise). */
+TNL_API int tnl_idwt_level_forward(const float *x, const float *yh, uint32_t S, uint32_t n,
+                                   int wave, float *out, void *stream);
+
+/* Adjoint of the above (autograd of SFB2D + pad + 2*): dout:[S,2n,2n] -> dx:[S,n,n], dyh:[S,3,n,n] */
+TNL_API int tnl_idwt_level_backward(const float *dout, uint32_t S, uint32_t n, int wave, float *dx,
+                                    float *dyh, void *stream);
+
+/* Layout change between the reference's (3,C,R,R) planes ("channel-major") and the sampler's
+ * texel-major [3,R,R,C] storage.  half_out != 0 stores fp16 (e = 2), else fp32 (e = 4). */
+TNL_API int tnl_planes_to_texel_major(const float *planes_cm, uint32_t C, uint32_t R, int half_out,
+                                      void *planes_tm, void *stream);
+/* [3,R,R,C] fp32 gradient -> (3,C,R,R) fp32 */
+TNL_API int tnl_planes_to_channel_major(const float *grad_tm, uint32_t C, uint32_t R, float *grad_cm,
+                                        void *stream);
+
+/* TriPlaneVolume.forward (triplane_encoder.py:523-530, :314-332): xyz:[N,3] -> feats:[N,3C] fp32,
+ * feature index plane*C + c; planes_tm texel-major (fp16 if half_in). */
+TNL_API int tnl_triplane_sample_forward(const void *planes_tm, int half_in, const float *xyz,
+                                        float bound, uint32_t N, uint32_t C, uint32_t R, float *feats,
+                                        void *stream);
+/* VJP w.r.t. the planes (torch grid_sampler_2d_backward): atomically accumulates into
+ * grad_tm:[3,R,R,C] fp32, which the caller zero-fills. */
+TNL_API int tnl_triplane_sample_backward(const float *grad_feats, const float *xyz, float bound,
+                                         uint32_t N, uint32_t C, uint32_t R, float *grad_tm,
+                                         void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused field: NeRFNetwork.forward (reconstruction/nerf/network.py:118-147) = triplane lookup
+ * + sigma MLP + trunc_exp (activation.py:5-17) + SH-4 + colour MLP + sigmoid, fp16 MFMA with
+ * fp32 accumulation (the reference runs its nn.Linear layers under autocast(fp16)).
+ * Weights are fp32 masters in the nn.Linear layout [out,in]:
+ *   W0:[Hd,3C] W1:[16,Hd] W2:[Hc,31] W3:[Hc,Hc] W4:[3,Hc],  Hd,Hc in {64,128}, C in {16,32,48}.
+ * tnl_field_pack converts them to the kernel's fp16 fragment order (call once per optimiser step).
+ * ------------------------------------------------------------------------------------------- */
+TNL_API uint32_t tnl_field_packed_bytes(uint32_t C, uint32_t Hd, uint32_t Hc);
+TNL_API int tnl_field_pack(const float *W0, const float *W1, const float *W2, const float *W3,
+                           const float *W4, uint32_t C, uint32_t Hd, uint32_t Hc, void *packed,
+                           void *stream);
+/* sigma:[M] rgb:[M,3] fp32.  feats_save (fp16 [M,3C], may be NULL) keeps the interpolated
+ * features for the backward pass. */
+TNL_API int tnl_field_forward(const void *planes_tm, int half_in, const float *xyz, const float *dirs,
+                              float bound, uint32_t M, uint32_t C, uint32_t R, uint32_t Hd,
+                              uint32_t Hc, const void *packed, float *sigma, float *rgb,
+                              void *feats_save, void *stream);
+/* grad_sigma:[M], grad_rgb:[M,3] -> grad_tm:[3,R,R,C] fp32 (atomic, caller zero-fills) and
+ * gradW:[Hd*3C + 16*Hd + Hc*31 + Hc*Hc + 3*Hc] fp32 in nn.Linear layout, concatenated W0..W4
+ * (accumulated atomically, caller zero-fills).  grad_scale multiplies incoming gradients
+ * (GradScaler); workspace bytes from tnl_field_backward_workspace. */
+TNL_API uint32_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint32_t Hc);
+TNL_API int tnl_field_backward(const float *grad_sigma, const float *grad_rgb, const float *sigma,
+                               const float *rgb, const void *feats_save, const float *xyz,
+                               const float *dirs, float bound, uint32_t M, uint32_t C, uint32_t R,
+                               uint32_t Hd, uint32_t Hc, const void *packed, float *grad_tm,
+                               float *gradW, void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused optimiser for the wavelet coefficients: torch.optim.Adam(betas, eps, no weight decay)
+ * (reconstruction/main_nerf.py:119) with the wavelet L1 regulariser's gradient
+ * (reconstruction/nerf/utils.py:639-655) and GradScaler's unscale folded in:
+ *   g = grad * inv_scale + l1_coef * sign(p) ;  m,v,p <- Adam(g) ;  abs_sum += sum |p_old|.
+ * step_size = lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t).  If found_inf[0] != 0 nothing
+ * is updated (GradScaler.step skip).  grad may be zeroed afterwards (zero_grad != 0).
+ * ------------------------------------------------------------------------------------------- */
+TNL_API int tnl_adam_l1_step(float *p, float *grad, float *m, float *v, uint64_t n, float step_size,
+                             float bias2_sqrt, float beta1, float beta2, float eps, float inv_scale,
+                             float l1_coef, const float *found_inf, float *abs_sum, int zero_grad,
+                             void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRINERFLET_HIP_H */

@@ -1,0 +1,73 @@
+"""Seeded synthetic inputs shared by the parity tests and bench.py.
+
+numpy only: usable by the oracle-side and the GPU-side of a test alike.
+"""
+import numpy as np
+
+
+def sphere_bitfield(H=128, cascades=2, bound=1.5, r_out=0.8, r_in=0.0):
+    """Analytic occupancy: cell occupied iff its centre radius is in [r_in, r_out].
+    Layout = density_bitfield of the reference: bit (cas*H^3 + morton3D(x,y,z))."""
+    idx = np.arange(H, dtype=np.uint32)
+
+    def expand(v):
+        v = (v * np.uint32(0x00010001)) & np.uint32(0xFF0000FF)
+        v = (v * np.uint32(0x00000101)) & np.uint32(0x0F00F00F)
+        v = (v * np.uint32(0x00000011)) & np.uint32(0xC30C30C3)
+        v = (v * np.uint32(0x00000005)) & np.uint32(0x49249249)
+        return v
+
+    ex = expand(idx)
+    mort = (ex[:, None, None] | (ex[None, :, None] << 1) | (ex[None, None, :] << 2)).astype(np.int64)
+    bits = np.zeros(cascades * H ** 3, np.uint8)
+    for cas in range(cascades):
+        b = min(2.0 ** cas, bound)
+        c = ((idx.astype(np.float64) + 0.5) / H * 2 - 1) * b
+        rr = np.sqrt(c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2)
+        occ = (rr <= r_out) & (rr >= r_in)
+        bits[cas * H ** 3 + mort.reshape(-1)] = occ.reshape(-1)
+    return np.packbits(bits.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+
+
+def hemisphere_poses(n, radius=4.0311, seed=0):
+    """n camera-to-world matrices on the upper hemisphere looking at the origin, in the NGP frame
+    (provider.py:23-31 nerf_matrix_to_ngp with scale=1, offset=0 is folded in: it permutes axes only,
+    which a camera set drawn uniformly on the hemisphere absorbs)."""
+    rng = np.random.default_rng(seed)
+    poses = np.zeros((n, 4, 4), np.float32)
+    for i in range(n):
+        v = rng.standard_normal(3)
+        v /= np.linalg.norm(v)
+        v[1] = abs(v[1])  # y up in the NGP frame
+        c = v * radius
+        fwd = -v  # camera looks at the origin (+z forward, matches get_rays' zs = +1)
+        up = np.array([0.0, 1.0, 0.0])
+        right = np.cross(up, fwd)
+        right /= np.linalg.norm(right) + 1e-12
+        up2 = np.cross(fwd, right)
+        poses[i, :3, 0], poses[i, :3, 1], poses[i, :3, 2], poses[i, :3, 3] = right, up2, fwd, c
+        poses[i, 3, 3] = 1
+    return poses
+
+
+def get_rays(poses, pix, H=800, W=800, camera_angle_x=0.6911):
+    """get_rays semantics (reconstruction/nerf/utils.py:65-149): pixel centre +0.5, normalised dirs,
+    rays_d = dirs @ R^T, rays_o = t.  pix: [N,2] = (camera index, flat pixel index)."""
+    fl = W / (2 * np.tan(camera_angle_x / 2))
+    cam, p = pix[:, 0], pix[:, 1]
+    i = (p % W).astype(np.float32) + 0.5
+    j = (p // W).astype(np.float32) + 0.5
+    d = np.stack([(i - W / 2) / fl, (j - H / 2) / fl, np.ones_like(i)], -1).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    R = poses[cam, :3, :3]
+    rays_d = np.einsum("nij,nj->ni", R, d).astype(np.float32)
+    rays_o = poses[cam, :3, 3].astype(np.float32)
+    return rays_o, rays_d
+
+
+def training_rays(N, n_cams=100, seed=0, H=800, W=800):
+    poses = hemisphere_poses(n_cams, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    flat = rng.choice(n_cams * H * W, size=N, replace=False)
+    pix = np.stack([flat // (H * W), flat % (H * W)], -1)
+    return get_rays(poses, pix, H, W)

@@ -1,0 +1,190 @@
+"""GPU parity of the raymarching / shencoder kernels against the CPU oracle (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from tests import scene
+
+pytestmark = pytest.mark.gpu
+
+BOUND, CAS, HG = 1.5, 2, 128
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.fixture(scope="module")
+def rays(cuda):
+    o, d = scene.training_rays(4096, n_cams=8, seed=3)
+    # a few rays that miss the box and axis-parallel rays (rd = inf)
+    d[:4] = np.array([[0, 1, 0], [1, 0, 0], [0, 0, -1], [0.6, 0.8, 0.0]], np.float32)
+    o[4:8] += 10.0
+    aabb = np.array([-BOUND] * 3 + [BOUND] * 3, np.float32)
+    nears, fars = cref.near_far_from_aabb(o, d, aabb, 0.2)
+    return o, d, aabb, nears, fars
+
+
+def test_near_far(cuda, rays):
+    from trinerflet_amd import raymarching
+    o, d, aabb, nears, fars = rays
+    n, f = raymarching.near_far_from_aabb(_t(o, cuda), _t(d, cuda), _t(aabb, cuda), 0.2)
+    assert np.array_equal(n.cpu().numpy(), nears) and np.array_equal(f.cpu().numpy(), fars)
+
+
+def test_morton_roundtrip_and_packbits(cuda):
+    from trinerflet_amd import raymarching
+    g = np.random.default_rng(0)
+    coords = g.integers(0, 128, (100000, 3)).astype(np.int32)
+    idx = raymarching.morton3D(_t(coords, cuda))
+    assert np.array_equal(idx.cpu().numpy(), cref.morton3D(coords))
+    back = raymarching.morton3D_invert(idx)
+    assert np.array_equal(back.cpu().numpy(), coords)
+    # all 128^3 codes: a permutation (checksum) -- SURVEY 8(c) F-GRID
+    ax = torch.arange(128, dtype=torch.int32, device=cuda)
+    full = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    codes = raymarching.morton3D(full).long()
+    assert torch.equal(torch.sort(codes).values, torch.arange(128 ** 3, device=cuda))
+    for n in (128 ** 3 * 2, 8 * 37):  # vector path and ragged tail path
+        grid = g.standard_normal(n).astype(np.float32).reshape(1, -1)
+        bf = raymarching.packbits(_t(grid, cuda), 0.1)
+        assert np.array_equal(bf.cpu().numpy(), cref.packbits(grid, 0.1))
+
+
+@pytest.mark.parametrize("shell", [False, True])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_march_train_exact(cuda, rays, shell, perturb):
+    from trinerflet_amd import raymarching
+    o, d, aabb, nears, fars = rays
+    bf = scene.sphere_bitfield(HG, CAS, BOUND, 0.8, 0.7 if shell else 0.0)
+    N = o.shape[0]
+    noises = np.random.default_rng(5).random(N).astype(np.float32) if perturb else np.zeros(N, np.float32)
+    M_full = N * 1024
+    xr, dr, lr, rr, cr = cref.march_rays_train(o, d, BOUND, bf, CAS, HG, nears, fars, noises, M_full)
+    total = int(cr[0])
+    assert total > 0
+    for M in (M_full, total // 2):  # second case exercises the overflow drop rule (raymarching.cu:422)
+        if M != M_full:
+            xr, dr, lr, rr, cr = cref.march_rays_train(o, d, BOUND, bf, CAS, HG, nears, fars, noises, M)
+        counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+        # mean_count = M - align  -> the wrapper rounds up past the next multiple (raymarching.py:200-203)
+        xyzs, dirs, deltas, rays_t = raymarching.march_rays_train(
+            _t(o, cuda), _t(d, cuda), BOUND, _t(bf, cuda), CAS, HG, _t(nears, cuda), _t(fars, cuda), counter,
+            -1 if M == M_full else M, perturb, -1, M == M_full, 0, 1024, _t(noises, cuda))
+        assert np.array_equal(counter.cpu().numpy(), cr)            # bit-exact counts
+        assert np.array_equal(rays_t.cpu().numpy(), rr)             # ids, offsets, num_steps
+        m = xyzs.shape[0]
+        assert np.array_equal(xyzs.cpu().numpy(), xr[:m])           # bit-exact sample positions
+        assert np.array_equal(dirs.cpu().numpy(), dr[:m])
+        assert np.array_equal(deltas.cpu().numpy(), lr[:m])
+
+
+def _samples(cuda, rays, seed=0):
+    o, d, aabb, nears, fars = rays
+    bf = scene.sphere_bitfield(HG, CAS, BOUND, 0.8, 0.0)
+    N = o.shape[0]
+    noises = np.random.default_rng(5).random(N).astype(np.float32)
+    xr, dr, lr, rr, cr = cref.march_rays_train(o, d, BOUND, bf, CAS, HG, nears, fars, noises, N * 1024)
+    M = int(cr[0])
+    M += 128 - M % 128
+    g = np.random.default_rng(seed)
+    sig = np.exp(g.standard_normal(M) * 2.0).astype(np.float32)  # wide range: early stops and faint rays
+    rgb = g.random((M, 3)).astype(np.float32)
+    return sig, rgb, lr[:M], rr, N, M
+
+
+def test_composite_train_fwd_bwd(cuda, rays):
+    from trinerflet_amd import raymarching
+    sig, rgb, deltas, rr, N, M = _samples(cuda, rays)
+    rr = rr.copy()
+    rr[5, 1] = M  # an overflowing ray: outputs must be zero, no gradient
+    ws, dep, img = cref.composite_rays_train_forward(sig, rgb, deltas, rr, 1e-4)
+    s_t = _t(sig, cuda).requires_grad_(True)
+    c_t = _t(rgb, cuda).requires_grad_(True)
+    ws_t, dep_t, img_t = raymarching.composite_rays_train(s_t, c_t, _t(deltas, cuda), _t(rr, cuda), 1e-4)
+    # fp32 tolerance: wavefront scan vs serial recurrence, __expf on both
+    np.testing.assert_allclose(ws_t.detach().cpu().numpy(), ws, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(img_t.detach().cpu().numpy(), img, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dep_t.detach().cpu().numpy(), dep, rtol=5e-5, atol=1e-5)
+    g = np.random.default_rng(1)
+    gws = g.standard_normal(N).astype(np.float32)
+    gimg = g.standard_normal((N, 3)).astype(np.float32)
+    gs, gc = cref.composite_rays_train_backward(gws, gimg, sig, rgb, deltas, rr, ws, img, 1e-4)
+    (ws_t * _t(gws, cuda)).sum().add((img_t * _t(gimg, cuda)).sum()).backward()
+    np.testing.assert_allclose(c_t.grad.cpu().numpy(), gc, rtol=2e-5, atol=2e-6)
+    # grad_sigma has cancellation (T*rgb - (C_final - C)); compare with an absolute scale
+    scale = np.abs(gs).max()
+    np.testing.assert_allclose(s_t.grad.cpu().numpy(), gs, rtol=1e-3, atol=2e-5 * scale)
+
+
+def test_inference_loop(cuda, rays):
+    """run_cuda's eval branch (renderer.py:324-374) with the GPU kernels vs the oracle, same sigma/rgb field."""
+    from trinerflet_amd import raymarching
+    o, d, aabb, nears, fars = rays
+    bf = scene.sphere_bitfield(HG, CAS, BOUND, 0.8, 0.6)
+    N = 1024
+    o, d, nears, fars = o[:N], d[:N], nears[:N], fars[:N]
+
+    def field(x):  # deterministic analytic field evaluated identically on both sides (float32 numpy)
+        s = (8.0 * np.exp(-4.0 * (x ** 2).sum(-1))).astype(np.float32)
+        c = (0.5 + 0.5 * np.sin(3.0 * x)).astype(np.float32)
+        return s, c
+
+    # oracle
+    ws, dep, img = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    alive = np.arange(N, dtype=np.int32)
+    rt = nears.copy()
+    # gpu
+    ws_g, dep_g, img_g = (torch.zeros(N, device=cuda), torch.zeros(N, device=cuda), torch.zeros(N, 3, device=cuda))
+    alive_g = torch.arange(N, dtype=torch.int32, device=cuda)
+    rt_g = _t(nears, cuda).clone()
+    o_g, d_g, bf_g, n_g, f_g = _t(o, cuda), _t(d, cuda), _t(bf, cuda), _t(nears, cuda), _t(fars, cuda)
+    step = 0
+    while step < 1024:
+        n_alive = alive.shape[0]
+        assert alive_g.shape[0] == n_alive
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        x, dd, dl = cref.march_rays(n_alive, n_step, alive, rt, o, d, BOUND, bf, CAS, HG, nears, fars,
+                                    np.zeros(n_alive, np.float32), 128)
+        xg, dg, lg = raymarching.march_rays(n_alive, n_step, alive_g, rt_g, o_g, d_g, BOUND, bf_g, CAS, HG, n_g, f_g,
+                                            128, False, 0, 1024)
+        assert np.array_equal(xg.cpu().numpy(), x) and np.array_equal(lg.cpu().numpy(), dl)
+        s, c = field(x)
+        cref.composite_rays(n_alive, n_step, alive, rt, s, c, dl, ws, dep, img, 1e-4)
+        raymarching.composite_rays(n_alive, n_step, alive_g, rt_g, _t(s, cuda), _t(c, cuda), lg, ws_g, dep_g, img_g, 1e-4)
+        compacted, n_out = raymarching.compact_rays(alive_g)
+        alive = alive[alive >= 0]
+        assert int(n_out.item()) == alive.shape[0]
+        alive_g = compacted[: alive.shape[0]]
+        assert np.array_equal(alive_g.cpu().numpy(), alive)        # bit-exact surviving ray ids, in order
+        step += n_step
+    np.testing.assert_allclose(img_g.cpu().numpy(), img, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ws_g.cpu().numpy(), ws, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dep_g.cpu().numpy(), dep, rtol=1e-4, atol=1e-5)
+
+
+def test_sh(cuda):
+    from trinerflet_amd.shencoder import SHEncoder
+    g = np.random.default_rng(2)
+    d = g.standard_normal((1000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    enc = SHEncoder(3, 4)
+    out = enc(_t(d, cuda))
+    np.testing.assert_allclose(out.cpu().numpy(), cref.sh4(d), rtol=1e-6, atol=1e-7)
+    # dy_dx path (unused on the hot path): finite differences in float64 of the oracle polynomial
+    dt = _t(d, cuda).requires_grad_(True)
+    w = _t(g.standard_normal((1000, 16)).astype(np.float32), cuda)
+    (enc(dt) * w).sum().backward()
+    eps = 1e-3
+    num = np.zeros_like(d)
+    for k in range(3):
+        dp, dm = d.copy(), d.copy()
+        dp[:, k] += eps
+        dm[:, k] -= eps
+        num[:, k] = ((cref.sh4(dp).astype(np.float64) - cref.sh4(dm)) * w.cpu().numpy()).sum(-1) / (2 * eps)
+    np.testing.assert_allclose(dt.grad.cpu().numpy(), num, rtol=2e-2, atol=2e-2)
+    with pytest.raises(NotImplementedError):
+        SHEncoder(3, 5)(_t(d, cuda))

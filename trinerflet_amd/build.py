@@ -1,0 +1,60 @@
+"""Builds libtrinerflet_hip.so (gfx950) in-tree with hipcc.  `python -m trinerflet_amd.build`.
+
+One object per csrc/*.hip (so an edit recompiles one file), linked into
+trinerflet_amd/libtrinerflet_hip.so, which is the C-ABI library declared in include/trinerflet_hip.h.
+"""
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "libtrinerflet_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
+          "-Wall", "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include")]
+# the marching kernels must not contract a*b+c on their own: bit-exact sample counts (see raymarch.hip)
+PER_FILE = {"raymarch.hip": ["-ffp-contract=off"]}
+
+
+def _newer(src, dst, extra=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in (src, *extra))
+
+
+def build(verbose=False, force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or _newer(s, o, headers):
+            jobs.append([HIPCC, *COMMON, *PER_FILE.get(os.path.basename(s), []), "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True, force="--force" in sys.argv))

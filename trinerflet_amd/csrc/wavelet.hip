@@ -1,0 +1,374 @@
+// wavelet.hip -- multiscale inverse DWT of the triplane coefficients and its adjoint (gfx950).
+//
+// Replaces the pytorch_wavelets.DWTInverse + F.pad + 2* chain of
+// reconstruction/triplaneencoder/triplane_encoder.py:364-405 (three grouped conv_transpose2d pairs
+// per level, each materialising a full intermediate) with ONE LDS-tiled kernel per level:
+//   * a workgroup owns a 64x64 output tile of one (plane, channel) slice; the four coefficient
+//     bands of the 32x32 input tile (+ halo L/4) are staged in LDS once,
+//   * the separable synthesis runs column pass -> LDS -> row pass entirely on chip, register-blocked
+//     (each thread produces 8 outputs from a 12-sample window: ~6 FMA per LDS read),
+//   * polyphase form: even outputs use even taps, odd outputs odd taps; the taps are compile-time
+//     constants per wavelet so zero taps (bior6.8 rec_lo has 7 of 18) cost nothing,
+//   * the zero-padding of mode='zero' and of F.pad is the bounds check of the tile load.
+// The adjoint (autograd of SFB2D: analysis with the same rec_* taps, then crop and 2*) mirrors it:
+// an 80x80 fine tile -> row pass -> column pass -> four 32x32 coarse bands.
+//
+// Closed form (verified against pywt.idwt2(mode='zero')): K = (L-2)/2,
+//   out[o] = sum_j lo[j]*g0[o-2j+K] + hi[j]*g1[o-2j+K].
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/trinerflet_hip.h"
+
+namespace {
+
+struct WTaps {
+  int L;
+  float g0[18];
+  float g1[18];
+};
+
+// pywt.Wavelet(name).rec_lo / rec_hi rounded to float32 (pytorch_wavelets keeps float32 buffers)
+__host__ __device__ constexpr WTaps wtaps(int w) {
+  switch (w) {
+    case 0:
+      return WTaps{2, {0.7071067811865476f, 0.7071067811865476f}, {0.7071067811865476f, -0.7071067811865476f}};
+    case 1:
+      return WTaps{6,
+                   {0.f, 0.3535533905932738f, 0.7071067811865476f, 0.3535533905932738f, 0.f, 0.f},
+                   {0.f, 0.1767766952966369f, 0.3535533905932738f, -1.0606601717798212f, 0.3535533905932738f,
+                    0.1767766952966369f}};
+    case 2:
+      return WTaps{10,
+                   {0.f, -0.06453888262869706f, -0.04068941760916406f, 0.41809227322161724f, 0.7884856164055829f,
+                    0.41809227322161724f, -0.04068941760916406f, -0.06453888262869706f, 0.f, 0.f},
+                   {0.f, -0.03782845550726404f, -0.023849465019556843f, 0.11062440441843718f, 0.37740285561283066f,
+                    -0.8526986790088938f, 0.37740285561283066f, 0.11062440441843718f, -0.023849465019556843f,
+                    -0.03782845550726404f}};
+    case 3:
+      return WTaps{14,
+                   {0.f, 0.f, 0.f, 0.f, 0.f, 0.3535533905932738f, 0.7071067811865476f, 0.3535533905932738f, 0.f, 0.f,
+                    0.f, 0.f, 0.f, 0.f},
+                   {0.f, 0.006905339660024878f, 0.013810679320049757f, -0.04695630968816917f, -0.1077232986963881f,
+                    0.16987135563661201f, 0.4474660099696121f, -0.966747552403483f, 0.4474660099696121f,
+                    0.16987135563661201f, -0.1077232986963881f, -0.04695630968816917f, 0.013810679320049757f,
+                    0.006905339660024878f}};
+    default:
+      return WTaps{18,
+                   {0.f, 0.f, 0.f, 0.014426282505624435f, 0.014467504896790148f, -0.07872200106262882f,
+                    -0.04036797903033992f, 0.41784910915027457f, 0.7589077294536541f, 0.41784910915027457f,
+                    -0.04036797903033992f, -0.07872200106262882f, 0.014467504896790148f, 0.014426282505624435f, 0.f,
+                    0.f, 0.f, 0.f},
+                   {0.f, -0.0019088317364812906f, -0.0019142861290887667f, 0.016990639867602342f,
+                    0.01193456527972926f, -0.04973290349094079f, -0.07726317316720414f, 0.09405920349573646f,
+                    0.4207962846098268f, -0.8259229974584023f, 0.4207962846098268f, 0.09405920349573646f,
+                    -0.07726317316720414f, -0.04973290349094079f, 0.01193456527972926f, 0.016990639867602342f,
+                    -0.0019142861290887667f, -0.0019088317364812906f}};
+  }
+}
+
+constexpr int TI = 32;   // coarse tile edge
+constexpr int RM = 4;    // coarse samples per thread-run
+constexpr int NT = 256;  // threads per workgroup
+
+// ---------------------------------------------------------------------------------------------
+// forward: x:[S][n][n], yh:[S][3][n][n] -> out:[S][2n][2n]
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(NT)
+k_idwt_fwd(const float* __restrict__ x, const float* __restrict__ yh, int n, float* __restrict__ out) {
+  constexpr WTaps T = wtaps(W);
+  constexpr int L = T.L, K = (L - 2) / 2, HW = L / 4;
+  constexpr int TIH = TI + 2 * HW;  // staged input edge
+  constexpr int LS = TIH + 1;       // LDS row stride (odd: conflict-free column walks)
+  constexpr int WIN = RM + 2 * HW;
+  __shared__ float band[4][TIH][LS];
+  __shared__ float mid[2][2 * TI][LS];
+
+  const int s = blockIdx.z;
+  const int a_r = blockIdx.y * TI, a_c = blockIdx.x * TI;  // coarse tile origin
+  const size_t nn = (size_t)n * n;
+  const float* ll = x + (size_t)s * nn;
+  const float* hb = yh + (size_t)s * 3 * nn;
+
+  // stage the four bands (zero outside [0,n): the zero-mode padding); ll carries the 2* of :379
+  for (int idx = threadIdx.x; idx < 4 * TIH * TIH; idx += NT) {
+    const int b = idx / (TIH * TIH), rem = idx - b * TIH * TIH;
+    const int r = rem / TIH, c = rem - r * TIH;
+    const int gr = a_r - HW + r, gc = a_c - HW + c;
+    float v = 0.f;
+    if (gr >= 0 && gr < n && gc >= 0 && gc < n) {
+      const size_t off = (size_t)gr * n + gc;
+      v = b == 0 ? 2.0f * ll[off] : hb[(size_t)(b - 1) * nn + off];
+    }
+    band[b][r][c] = v;
+  }
+  __syncthreads();
+
+  // column pass (synthesis along H): lo = syn(ll, lh), hi = syn(hl, hh)
+  for (int u = threadIdx.x; u < TIH * (TI / RM); u += NT) {
+    const int c = u % TIH, m0 = (u / TIH) * RM;
+    float w0[WIN], w1[WIN], w2[WIN], w3[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; i++) {
+      w0[i] = band[0][m0 + i][c]; w1[i] = band[1][m0 + i][c];
+      w2[i] = band[2][m0 + i][c]; w3[i] = band[3][m0 + i][c];
+    }
+#pragma unroll
+    for (int m = 0; m < RM; m++) {
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        float lo = 0.f, hi = 0.f;
+#pragma unroll
+        for (int d = -HW; d <= HW; d++) {
+          constexpr int dummy = 0; (void)dummy;
+          const int k = e + K - 2 * d;
+          if (k >= 0 && k < L) {
+            const float t0 = T.g0[k], t1 = T.g1[k];
+            if (t0 != 0.f) { lo = fmaf(w0[m + d + HW], t0, lo); hi = fmaf(w2[m + d + HW], t0, hi); }
+            if (t1 != 0.f) { lo = fmaf(w1[m + d + HW], t1, lo); hi = fmaf(w3[m + d + HW], t1, hi); }
+          }
+        }
+        mid[0][2 * (m0 + m) + e][c] = lo;
+        mid[1][2 * (m0 + m) + e][c] = hi;
+      }
+    }
+  }
+  __syncthreads();
+
+  // row pass (synthesis along W) + store; a thread owns 2*RM consecutive outputs of one row
+  const int m2 = 2 * n;
+  float* dst = out + (size_t)s * m2 * m2;
+  for (int u = threadIdx.x; u < 2 * TI * (TI / RM); u += NT) {
+    const int run = u % (TI / RM), r = u / (TI / RM);
+    const int m0 = run * RM;
+    float wl[WIN], wh[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; i++) { wl[i] = mid[0][r][m0 + i]; wh[i] = mid[1][r][m0 + i]; }
+    float o[2 * RM];
+#pragma unroll
+    for (int m = 0; m < RM; m++) {
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int d = -HW; d <= HW; d++) {
+          const int k = e + K - 2 * d;
+          if (k >= 0 && k < L) {
+            const float t0 = T.g0[k], t1 = T.g1[k];
+            if (t0 != 0.f) acc = fmaf(wl[m + d + HW], t0, acc);
+            if (t1 != 0.f) acc = fmaf(wh[m + d + HW], t1, acc);
+          }
+        }
+        o[2 * m + e] = acc;
+      }
+    }
+    const int gr = 2 * a_r + r, gc = 2 * (a_c + m0);
+    if (gr < m2) {
+      float* p = dst + (size_t)gr * m2 + gc;
+      if (gc + 2 * RM <= m2 && (m2 & 3) == 0) {
+        reinterpret_cast<float4*>(p)[0] = make_float4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<float4*>(p)[1] = make_float4(o[4], o[5], o[6], o[7]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2 * RM; i++)
+          if (gc + i < m2) p[i] = o[i];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adjoint: dout:[S][2n][2n] -> dx:[S][n][n] (includes the 2*), dyh:[S][3][n][n]
+//   d_lo[j] = sum_k dout[2j-K+k]*g0[k],  d_hi[j] = sum_k dout[2j-K+k]*g1[k]
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(NT)
+k_idwt_bwd(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh) {
+  constexpr WTaps T = wtaps(W);
+  constexpr int L = T.L, K = (L - 2) / 2;
+  constexpr int FT = 2 * TI + L - 2;  // fine tile edge
+  constexpr int FS = FT + 1;
+  constexpr int LS = TI + 1;
+  constexpr int WIN = 2 * RM + L - 2;
+  __shared__ float fine[FT][FS];
+  __shared__ float mid[2][FT][LS];
+
+  const int s = blockIdx.z;
+  const int a_r = blockIdx.y * TI, a_c = blockIdx.x * TI;
+  const int m2 = 2 * n;
+  const float* src = dout + (size_t)s * m2 * m2;
+  for (int idx = threadIdx.x; idx < FT * FT; idx += NT) {
+    const int r = idx / FT, c = idx - r * FT;
+    const int gr = 2 * a_r - K + r, gc = 2 * a_c - K + c;
+    fine[r][c] = (gr >= 0 && gr < m2 && gc >= 0 && gc < m2) ? src[(size_t)gr * m2 + gc] : 0.f;
+  }
+  __syncthreads();
+
+  // row pass (analysis along W)
+  for (int u = threadIdx.x; u < FT * (TI / RM); u += NT) {
+    const int r = u % FT, j0 = (u / FT) * RM;
+    float w[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; i++) w[i] = fine[r][2 * j0 + i];
+#pragma unroll
+    for (int j = 0; j < RM; j++) {
+      float lo = 0.f, hi = 0.f;
+#pragma unroll
+      for (int k = 0; k < L; k++) {
+        const float t0 = T.g0[k], t1 = T.g1[k];
+        if (t0 != 0.f) lo = fmaf(w[2 * j + k], t0, lo);
+        if (t1 != 0.f) hi = fmaf(w[2 * j + k], t1, hi);
+      }
+      mid[0][r][j0 + j] = lo;
+      mid[1][r][j0 + j] = hi;
+    }
+  }
+  __syncthreads();
+
+  // column pass (analysis along H) + store of the four coarse bands
+  const size_t nn = (size_t)n * n;
+  float* o_ll = dx + (size_t)s * nn;
+  float* o_h = dyh + (size_t)s * 3 * nn;
+  for (int u = threadIdx.x; u < TI * (TI / RM); u += NT) {
+    const int c = u % TI, j0 = (u / TI) * RM;
+    float wl[WIN], wh[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; i++) { wl[i] = mid[0][2 * j0 + i][c]; wh[i] = mid[1][2 * j0 + i][c]; }
+    const int gc = a_c + c;
+#pragma unroll
+    for (int j = 0; j < RM; j++) {
+      float a = 0.f, b = 0.f, cc = 0.f, d = 0.f;
+#pragma unroll
+      for (int k = 0; k < L; k++) {
+        const float t0 = T.g0[k], t1 = T.g1[k];
+        if (t0 != 0.f) { a = fmaf(wl[2 * j + k], t0, a); cc = fmaf(wh[2 * j + k], t0, cc); }
+        if (t1 != 0.f) { b = fmaf(wl[2 * j + k], t1, b); d = fmaf(wh[2 * j + k], t1, d); }
+      }
+      const int gr = a_r + j0 + j;
+      if (gr < n && gc < n) {
+        const size_t off = (size_t)gr * n + gc;
+        o_ll[off] = 2.0f * a;
+        o_h[off] = b;
+        o_h[nn + off] = cc;
+        o_h[2 * nn + off] = d;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout changes: (3,C,R,R) fp32 <-> [3,R,R,C] (texel-major, fp16 or fp32)
+// One workgroup moves a 64-texel row segment for all channels through LDS, so both the read of
+// each channel row (256 B) and the write of the texel block (64*C*e B) are contiguous.
+// ---------------------------------------------------------------------------------------------
+constexpr int TX = 64;
+
+template <bool HALF>
+__global__ void __launch_bounds__(NT)
+k_to_texel_major(const float* __restrict__ cm, int C, int R, void* __restrict__ tm) {
+  extern __shared__ float tile[];  // [C][TX+1]
+  const int p = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * TX;
+  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
+    const int c = idx / TX, xx = idx - c * TX;
+    tile[c * (TX + 1) + xx] = (x0 + xx < R) ? cm[(((size_t)p * C + c) * R + y) * R + x0 + xx] : 0.f;
+  }
+  __syncthreads();
+  const size_t base = (((size_t)p * R + y) * R + x0) * C;
+  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
+    const int xx = idx / C, c = idx - xx * C;
+    if (x0 + xx < R) {
+      const float v = tile[c * (TX + 1) + xx];
+      if (HALF) reinterpret_cast<__half*>(tm)[base + idx] = __float2half(v);
+      else reinterpret_cast<float*>(tm)[base + idx] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(NT)
+k_to_channel_major(const float* __restrict__ tm, int C, int R, float* __restrict__ cm) {
+  extern __shared__ float tile[];  // [C][TX+1]
+  const int p = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * TX;
+  const size_t base = (((size_t)p * R + y) * R + x0) * C;
+  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
+    const int xx = idx / C, c = idx - xx * C;
+    tile[c * (TX + 1) + xx] = (x0 + xx < R) ? tm[base + idx] : 0.f;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
+    const int c = idx / TX, xx = idx - c * TX;
+    if (x0 + xx < R) cm[(((size_t)p * C + c) * R + y) * R + x0 + xx] = tile[c * (TX + 1) + xx];
+  }
+}
+
+inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+template <int W>
+int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_idwt_fwd<W>, dim3(cdiv(n, TI), cdiv(n, TI), S), dim3(NT), 0, st, x, yh, (int)n, out);
+  return (int)hipGetLastError();
+}
+template <int W>
+int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh, hipStream_t st) {
+  hipLaunchKernelGGL(k_idwt_bwd<W>, dim3(cdiv(n, TI), cdiv(n, TI), S), dim3(NT), 0, st, dout, (int)n, dx, dyh);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int tnl_idwt_level_forward(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, float* out,
+                           void* stream) {
+  if (S == 0 || n == 0) return 0;
+  if (S > 65535) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  switch (wave) {
+    case 0: return launch_fwd<0>(x, yh, S, n, out, st);
+    case 1: return launch_fwd<1>(x, yh, S, n, out, st);
+    case 2: return launch_fwd<2>(x, yh, S, n, out, st);
+    case 3: return launch_fwd<3>(x, yh, S, n, out, st);
+    case 4: return launch_fwd<4>(x, yh, S, n, out, st);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
+int tnl_idwt_level_backward(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
+                            void* stream) {
+  if (S == 0 || n == 0) return 0;
+  if (S > 65535) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  switch (wave) {
+    case 0: return launch_bwd<0>(dout, S, n, dx, dyh, st);
+    case 1: return launch_bwd<1>(dout, S, n, dx, dyh, st);
+    case 2: return launch_bwd<2>(dout, S, n, dx, dyh, st);
+    case 3: return launch_bwd<3>(dout, S, n, dx, dyh, st);
+    case 4: return launch_bwd<4>(dout, S, n, dx, dyh, st);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
+int tnl_planes_to_texel_major(const float* planes_cm, uint32_t C, uint32_t R, int half_out, void* planes_tm,
+                              void* stream) {
+  if (C == 0 || R == 0) return 0;
+  const dim3 grid(cdiv(R, TX), R, 3);
+  const size_t lds = (size_t)C * (TX + 1) * sizeof(float);
+  if (half_out)
+    hipLaunchKernelGGL(k_to_texel_major<true>, grid, dim3(NT), lds, (hipStream_t)stream, planes_cm, (int)C, (int)R,
+                       planes_tm);
+  else
+    hipLaunchKernelGGL(k_to_texel_major<false>, grid, dim3(NT), lds, (hipStream_t)stream, planes_cm, (int)C, (int)R,
+                       planes_tm);
+  return (int)hipGetLastError();
+}
+
+int tnl_planes_to_channel_major(const float* grad_tm, uint32_t C, uint32_t R, float* grad_cm, void* stream) {
+  if (C == 0 || R == 0) return 0;
+  const dim3 grid(cdiv(R, TX), R, 3);
+  const size_t lds = (size_t)C * (TX + 1) * sizeof(float);
+  hipLaunchKernelGGL(k_to_channel_major, grid, dim3(NT), lds, (hipStream_t)stream, grad_tm, (int)C, (int)R, grad_cm);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

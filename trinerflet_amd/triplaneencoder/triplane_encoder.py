@@ -1,0 +1,327 @@
+"""TriPlaneVolume -- mirror of reconstruction/triplaneencoder/triplane_encoder.py (reference) whose
+arithmetic runs in libtrinerflet_hip.so.
+
+Same constructor signature, parameter names/shapes (state-dict compatible: `planes_features`,
+`planes_features_wavelet_coefs.{i}`, `plane_axes`, `plane_normals`, `idwt.*`) and public methods:
+forward(coordinates, bound), get_planes(max_res, max_scale, get_all_resolutions), reset_cahce() [sic],
+get_wavelet_features(), get_wavelet_features_upscaled(), get_lbound_scale(), sample_from_planes(),
+get_params().
+
+What differs underneath (MI355X-first):
+  * build_planes (:364-405) = one LDS-tiled HIP kernel per wavelet level (csrc/wavelet.hip) instead of
+    3 conv_transpose2d pairs + 2 F.pad copies per level; its autograd is the adjoint kernel.
+  * sampling reads a texel-major [3,R,R,C] copy of the planes (fp16 by default = the "e=2" fast mode of
+    SURVEY.md 8(d); `plane_dtype=torch.float32` is the train-parity mode) so a texel's channels are one
+    contiguous segment; get_planes() still returns the reference-shaped (3,C,R,R) fp32 tensor.
+Options no README configuration uses (learn_rotation_axis, lbound_auto_scale, upscale_*,
+apply_activation_on_features, two_planes_per_axis, inner_multi_res_scale_current != 1) raise
+NotImplementedError: SURVEY.md 8(f) rank 4, out of this tier.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .. import _lib as L
+from . import utils
+
+WAVELET_IDS = {'haar': 0, 'bior2.2': 1, 'bior4.4': 2, 'bior2.6': 3, 'bior6.8': 4}
+# triplane_encoder.py:174-180
+PAD_DICT = {'bior6.8': 4, 'bior2.6': 3, 'bior4.4': 2, 'bior2.2': 1, 'haar': 0}
+# pywt.Wavelet(w).rec_lo / rec_hi, only used to fill the `idwt.*` buffers for state-dict compatibility
+_REC = {
+    'haar': ([0.7071067811865476, 0.7071067811865476], [0.7071067811865476, -0.7071067811865476]),
+    'bior2.2': ([0, 0.3535533905932738, 0.7071067811865476, 0.3535533905932738, 0, 0],
+                [0, 0.1767766952966369, 0.3535533905932738, -1.0606601717798212, 0.3535533905932738,
+                 0.1767766952966369]),
+    'bior4.4': ([0, -0.06453888262869706, -0.04068941760916406, 0.41809227322161724, 0.7884856164055829,
+                 0.41809227322161724, -0.04068941760916406, -0.06453888262869706, 0, 0],
+                [0, -0.03782845550726404, -0.023849465019556843, 0.11062440441843718, 0.37740285561283066,
+                 -0.8526986790088938, 0.37740285561283066, 0.11062440441843718, -0.023849465019556843,
+                 -0.03782845550726404]),
+    'bior2.6': ([0, 0, 0, 0, 0, 0.3535533905932738, 0.7071067811865476, 0.3535533905932738, 0, 0, 0, 0, 0, 0],
+                [0, 0.006905339660024878, 0.013810679320049757, -0.04695630968816917, -0.1077232986963881,
+                 0.16987135563661201, 0.4474660099696121, -0.966747552403483, 0.4474660099696121,
+                 0.16987135563661201, -0.1077232986963881, -0.04695630968816917, 0.013810679320049757,
+                 0.006905339660024878]),
+    'bior6.8': ([0, 0, 0, 0.014426282505624435, 0.014467504896790148, -0.07872200106262882,
+                 -0.04036797903033992, 0.41784910915027457, 0.7589077294536541, 0.41784910915027457,
+                 -0.04036797903033992, -0.07872200106262882, 0.014467504896790148, 0.014426282505624435,
+                 0, 0, 0, 0],
+                [0, -0.0019088317364812906, -0.0019142861290887667, 0.016990639867602342, 0.01193456527972926,
+                 -0.04973290349094079, -0.07726317316720414, 0.09405920349573646, 0.4207962846098268,
+                 -0.8259229974584023, 0.4207962846098268, 0.09405920349573646, -0.07726317316720414,
+                 -0.04973290349094079, 0.01193456527972926, 0.016990639867602342, -0.0019142861290887667,
+                 -0.0019088317364812906]),
+}
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd wrappers of the C ABI
+# ------------------------------------------------------------------------------------------------
+class _IDWTLevel(Function):
+    """x:(3,C,n,n), yh:(3,C,3,n,n) -> (3,C,2n,2n) = idwt((pad(2x),[pad(yh)])) (triplane_encoder.py:379-394)."""
+
+    @staticmethod
+    def forward(ctx, x, yh, wave_id):
+        L.require_cuda(x, yh)
+        x = x.to(torch.float32).contiguous()
+        yh = yh.to(torch.float32).contiguous()
+        P, C, n = x.shape[0], x.shape[1], x.shape[-1]
+        out = torch.empty(P, C, 2 * n, 2 * n, dtype=torch.float32, device=x.device)
+        L.check(L.lib().tnl_idwt_level_forward(L.ptr(x), L.ptr(yh), L.u32(P * C), L.u32(n), L.i32(wave_id),
+                                               L.ptr(out), L.stream()), "idwt_level_forward")
+        ctx.wave_id = wave_id
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.to(torch.float32).contiguous()
+        P, C, n = g.shape[0], g.shape[1], g.shape[-1] // 2
+        dx = torch.empty(P, C, n, n, dtype=torch.float32, device=g.device)
+        dyh = torch.empty(P, C, 3, n, n, dtype=torch.float32, device=g.device)
+        L.check(L.lib().tnl_idwt_level_backward(L.ptr(g), L.u32(P * C), L.u32(n), L.i32(ctx.wave_id), L.ptr(dx),
+                                                L.ptr(dyh), L.stream()), "idwt_level_backward")
+        return dx, dyh, None
+
+
+class _ToTexelMajor(Function):
+    """(3,C,R,R) fp32 -> [3,R,R,C] fp16|fp32 ; backward: fp32 [3,R,R,C] -> (3,C,R,R)."""
+
+    @staticmethod
+    def forward(ctx, planes_cm, half):
+        L.require_cuda(planes_cm)
+        planes_cm = planes_cm.to(torch.float32).contiguous()
+        _, C, R, _ = planes_cm.shape
+        tm = torch.empty(3, R, R, C, dtype=torch.float16 if half else torch.float32, device=planes_cm.device)
+        L.check(L.lib().tnl_planes_to_texel_major(L.ptr(planes_cm), L.u32(C), L.u32(R), L.i32(1 if half else 0),
+                                                  L.ptr(tm), L.stream()), "planes_to_texel_major")
+        return tm
+
+    @staticmethod
+    def backward(ctx, g_tm):
+        g_tm = g_tm.to(torch.float32).contiguous()
+        _, R, _, C = g_tm.shape
+        g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=g_tm.device)
+        L.check(L.lib().tnl_planes_to_channel_major(L.ptr(g_tm), L.u32(C), L.u32(R), L.ptr(g_cm), L.stream()),
+                "planes_to_channel_major")
+        return g_cm, None
+
+
+class _Sample(Function):
+    """planes_tm [3,R,R,C], xyz [N,3] -> feats [N,3C] (triplane_encoder.py:314-332)."""
+
+    @staticmethod
+    def forward(ctx, planes_tm, xyz, bound):
+        L.require_cuda(planes_tm, xyz)
+        xyz = xyz.to(torch.float32).contiguous()
+        _, R, _, C = planes_tm.shape
+        N = xyz.shape[0]
+        feats = torch.empty(N, 3 * C, dtype=torch.float32, device=xyz.device)
+        L.check(L.lib().tnl_triplane_sample_forward(L.ptr(planes_tm), L.i32(int(planes_tm.dtype == torch.float16)),
+                                                    L.ptr(xyz), L.f32(bound), L.u32(N), L.u32(C), L.u32(R),
+                                                    L.ptr(feats), L.stream()), "triplane_sample_forward")
+        ctx.save_for_backward(xyz)
+        ctx.dims = (C, R, float(bound))
+        return feats
+
+    @staticmethod
+    def backward(ctx, g):
+        (xyz,) = ctx.saved_tensors
+        C, R, bound = ctx.dims
+        g = g.to(torch.float32).contiguous()
+        g_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=g.device)
+        L.check(L.lib().tnl_triplane_sample_backward(L.ptr(g), L.ptr(xyz), L.f32(bound), L.u32(xyz.shape[0]),
+                                                     L.u32(C), L.u32(R), L.ptr(g_tm), L.stream()),
+                "triplane_sample_backward")
+        return g_tm, None, None
+
+
+class _IDWTBuffers(nn.Module):
+    """Holds pytorch_wavelets.DWTInverse's filter buffers (g0_col, g1_col, g0_row, g1_row) so that
+    reference checkpoints (`encoder.idwt.*` keys) load and save unchanged.  Not used for compute."""
+
+    def __init__(self, wave):
+        super().__init__()
+        lo, hi = _REC[wave]
+        g0 = torch.tensor(lo, dtype=torch.float32)
+        g1 = torch.tensor(hi, dtype=torch.float32)
+        self.register_buffer('g0_col', g0.reshape(1, 1, -1, 1))
+        self.register_buffer('g1_col', g1.reshape(1, 1, -1, 1))
+        self.register_buffer('g0_row', g0.reshape(1, 1, 1, -1))
+        self.register_buffer('g1_row', g1.reshape(1, 1, 1, -1))
+
+
+class TriPlaneVolume(torch.nn.Module):
+    def __init__(self, number_of_features=3, plane_resolution=224, init_sigma=0.1, lbound=1,
+                 viewdir_plane_resolution=32,
+                 two_planes_per_axis=False,
+                 planes_features=None, viewdir_plane=None, apply_activation_on_features=False,
+                 inner_multi_res_scale=1, inner_multi_res_viewdir_scale=1, viewdir_mode='plane',
+                 inner_multi_res_scale_current=1,
+                 learn_rotation_axis=False,
+                 dropout=0,
+                 wavelet_type='bior6.8',
+                 lbound_auto_scale=False,
+                 upscale_ratio_bound=-1,
+                 upscale_levels=2,
+                 wavelet_base_resolution=0,
+                 plane_dtype=torch.float16,
+                 ):
+        super().__init__()
+        # reference: triplane_encoder.py:27-94
+        unsupported = {
+            'two_planes_per_axis': two_planes_per_axis, 'apply_activation_on_features': apply_activation_on_features,
+            'learn_rotation_axis': learn_rotation_axis, 'lbound_auto_scale': lbound_auto_scale,
+            'upscale_ratio_bound': 0 < upscale_ratio_bound < 1,
+            'inner_multi_res_scale_current != 1': inner_multi_res_scale_current != 1,
+            'wavelet_base_resolution': wavelet_base_resolution > 0,
+        }
+        for name, on in unsupported.items():
+            if on:
+                raise NotImplementedError(f"TriPlaneVolume option `{name}` is outside the MI355X hot-path tier "
+                                          "(SURVEY.md 8(f) rank 4)")
+        self.number_of_features = number_of_features
+        self.plane_resolution = plane_resolution
+        self.init_sigma = init_sigma
+        self.lbound = lbound
+        self.lbound_viewdir = 1
+        self.output_dim = 3 * self.number_of_features
+        self.viewdir_plane_resolution = viewdir_plane_resolution
+        self.two_planes_per_axis = two_planes_per_axis
+        self.apply_activation_on_features = apply_activation_on_features
+        self.plane_dtype = plane_dtype
+
+        # create_subplanes_trivial_base (:250-289): up (x,z | y), front (x,y | z), right (y,z | x)
+        eye = torch.eye(3)
+        plane_axes = torch.stack([torch.cat([eye[:, 0:1], eye[:, 2:]], 1), torch.cat([eye[:, 0:1], eye[:, 1:2]], 1),
+                                  torch.cat([eye[:, 1:2], eye[:, 2:]], 1)], 0)
+        plane_normals = torch.stack([eye[:, 1:2], eye[:, 2:], eye[:, 0:1]], 0)
+        self.register_buffer('plane_axes', plane_axes.clone().detach())
+        self.register_buffer('plane_normals', plane_normals.clone().detach())
+        self.plane_direction = ['up', 'front', 'right']
+
+        self.wavelet_type = wavelet_type
+        self.inner_wavelet_scale = inner_multi_res_scale
+        self.inner_wavelet_viewdir_scale = inner_multi_res_viewdir_scale
+        self.inner_multi_res_scale_current = inner_multi_res_scale_current
+        self.wavelet_base_resolution = wavelet_base_resolution
+        assert self.inner_wavelet_scale >= self.inner_multi_res_scale_current
+
+        self.init_plane_features(planes_features)
+
+        self.learn_rotation_axis = False
+        self.rotation_matrix = None
+        self.dropout = None
+        if (dropout > 0) and (dropout < 1):
+            self.dropout = nn.Dropout(dropout)
+        self.lbound_auto_scale = False
+        self.lbound_scale = None
+        self.upscale_ratio_bound = upscale_ratio_bound
+        self.upscale_levels = upscale_levels
+        self.upscale_enabled = False
+
+    def init_plane_features(self, planes_features):
+        # reference: triplane_encoder.py:155-231.  The reference runs a real forward DWT of a ones tensor only
+        # to learn the coefficient shapes (:188-203); they are (3,C,3,n_i,n_i) with n_i = base * 2^i,
+        # base = plane_resolution / inner_multi_res_scale.
+        R, C = self.plane_resolution, self.number_of_features
+        self.last_used_planes = None
+        self._planes_tm = None
+        if self.inner_wavelet_scale <= 1:
+            if planes_features is None:
+                planes_features = self.init_sigma * torch.randn(3, C, R, R)
+            self.planes_features = nn.Parameter(planes_features.clone().detach())
+            self.planes_features_wavelet_all_level = 0
+            self.planes_features_wavelet_coefs = nn.ParameterList([])
+            self.planes_features_wavelet_pad = 0
+            self.wave_id = -1
+            return
+        if self.wavelet_type not in WAVELET_IDS:
+            raise KeyError(self.wavelet_type)
+        levels = utils.get_levels(self.inner_wavelet_scale)
+        if R % (2 ** levels) != 0:
+            raise ValueError('plane_resolution must be divisible by inner_multi_res_scale')
+        base = R // (2 ** levels)
+        self.wave_id = WAVELET_IDS[self.wavelet_type]
+        self.idwt = _IDWTBuffers(self.wavelet_type)
+        self.planes_features_wavelet_pad = PAD_DICT[self.wavelet_type]
+        self.planes_features_wavelet_yh_shapes = [torch.Size((3, C, 3, base * 2 ** i, base * 2 ** i))
+                                                  for i in range(levels)]
+        if planes_features is None:
+            planes_features = self.init_sigma * torch.randn(3, C, base, base)
+        self.planes_features = nn.Parameter(planes_features.clone().detach())
+        self.planes_features_wavelet_current_level = 0
+        self.planes_features_wavelet_all_level = levels
+        self.planes_features_wavelet_coefs = nn.ParameterList(
+            [nn.Parameter(torch.zeros(s)) for s in self.planes_features_wavelet_yh_shapes])
+
+    def get_wavelet_features(self):
+        return list(self.planes_features_wavelet_coefs) if self.inner_wavelet_scale > 1 else []
+
+    def get_wavelet_features_upscaled(self):
+        return []
+
+    def get_lbound_scale(self):
+        return None
+
+    def build_planes(self, get_all_resolutions=False, max_res=-1, max_scale=-1):
+        # reference: triplane_encoder.py:364-405
+        all_res = []
+        current_scale = 1
+        x = self.planes_features
+        if self.inner_wavelet_scale > 1:
+            for level_idx in range(self.planes_features_wavelet_all_level):
+                if get_all_resolutions:
+                    all_res.append(x)
+                if ((max_res > 0) and (min(x.shape[2:]) >= max_res)) or ((max_scale > 0) and (current_scale >= max_scale)):
+                    break
+                x = _IDWTLevel.apply(x, self.planes_features_wavelet_coefs[level_idx], self.wave_id)
+                current_scale *= 2
+            if get_all_resolutions:
+                all_res.append(x)
+        return x, all_res
+
+    def get_planes(self, max_res=-1, max_scale=-1, get_all_resolutions=False):
+        # reference: triplane_encoder.py:407-439 (note: like the reference, a cached result is returned
+        # regardless of the arguments)
+        if self.last_used_planes is not None:
+            return self.last_used_planes
+        planes, all_res = self.build_planes(get_all_resolutions, max_res, max_scale)
+        self.last_used_planes = planes
+        self._planes_tm = None
+        if get_all_resolutions:
+            return all_res
+        return planes
+
+    def get_planes_texel_major(self):
+        """[3,R,R,C] copy of get_planes() in `plane_dtype`, cached with it (what the samplers read)."""
+        planes = self.get_planes()
+        if self._planes_tm is None:
+            self._planes_tm = _ToTexelMajor.apply(planes, self.plane_dtype == torch.float16)
+        return self._planes_tm
+
+    def reset_cahce(self):
+        self.last_used_planes = None
+        self._planes_tm = None
+
+    def sample_from_planes(self, coordinates, plane_features=None, lbound=None):
+        # reference: triplane_encoder.py:443-484 -> [N, 3, C]
+        if lbound is None:
+            lbound = self.lbound
+        if plane_features is None:
+            tm = self.get_planes_texel_major()
+        else:
+            tm = _ToTexelMajor.apply(plane_features, self.plane_dtype == torch.float16)
+        feats = _Sample.apply(tm, coordinates, float(lbound))
+        return feats.view(coordinates.shape[0], 3, -1)
+
+    def get_params(self, opt_cfg):
+        return self.parameters()
+
+    def forward(self, coordinates, bound):
+        # reference: triplane_encoder.py:523-530
+        sampled_vals = self.sample_from_planes(coordinates, lbound=bound)
+        res = sampled_vals.view(sampled_vals.shape[0], -1)
+        if self.dropout is not None:
+            res = self.dropout(res)
+        return res
