@@ -1,0 +1,317 @@
+// field.hip -- fused NeRF field for gfx950: triplane lookup + sigma MLP + SH-4 + colour MLP.
+//
+// Replaces NeRFNetwork.forward / density of reconstruction/nerf/network.py:118-166 (five cuBLAS
+// GEMMs + grid_sample + SH kernel + cat + elementwise kernels, every [M,64] activation round-tripping
+// HBM) with ONE kernel in which nothing but the inputs (xyz, dirs), the texels and the outputs
+// (sigma, rgb, optional fp16 feature copy for the backward pass) touches memory.
+//
+// One 64-lane wavefront owns 32 samples: lane (r, h) = (sample r, k-half h).
+//  * gather: for every plane and 16-channel k-step the lane loads the 8 channels [16ks+8h, +8) of the
+//    four bilinear corners as one 16-byte word each (texel-major fp16 planes: a texel's C channels are
+//    contiguous, the x+1 corner is the next C*2 bytes), blends them in fp32 and packs 8 halfs: that IS the
+//    MFMA B fragment of layer 0 (see field_common.h) -- no shuffle, no LDS.
+//  * the five layers run as v_mfma_f32_32x32x16_f16 chains in registers (field_common.h "chain layout");
+//    weights are pre-packed fragments staged once per workgroup in LDS and read with ds_read_b128.
+//  * trunc_exp (activation.py:5-17) and sigmoid are applied on the accumulator registers that hold
+//    row 0 (sigma) / rows 0..2 (rgb): lanes with h == 0.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/trinerflet_hip.h"
+#include "field_common.h"
+#include "triplane_common.h"
+
+namespace {
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+constexpr int FWD_THREADS = 256;
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; i++) z[i] = 0.f;
+  return z;
+}
+
+// registers 8s..8s+7 of an accumulator tile -> fp16 fragment (optionally through ReLU)
+template <bool RELU>
+__device__ __forceinline__ half8 acc_to_frag(const f32x16& a, int s) {
+  half8 f;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    float v = s == 0 ? a[j] : a[8 + j];
+    if (RELU) v = fmaxf(v, 0.f);
+    f[j] = (_Float16)v;
+  }
+  return f;
+}
+
+// SH degree 4 (shencoder.cu:50-68): the 8 values [8h, 8h+8) of the 16, as a fragment
+__device__ __forceinline__ half8 sh_frag(float x, float y, float z, int h) {
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  half8 f;
+  if (h == 0) {
+    f[0] = (_Float16)0.28209479177387814f;
+    f[1] = (_Float16)(-0.48860251190291987f * y);
+    f[2] = (_Float16)(0.48860251190291987f * z);
+    f[3] = (_Float16)(-0.48860251190291987f * x);
+    f[4] = (_Float16)(1.0925484305920792f * xy);
+    f[5] = (_Float16)(-1.0925484305920792f * yz);
+    f[6] = (_Float16)(0.94617469575755997f * z2 - 0.31539156525251999f);
+    f[7] = (_Float16)(-1.0925484305920792f * xz);
+  } else {
+    f[0] = (_Float16)(0.54627421529603959f * x2 - 0.54627421529603959f * y2);
+    f[1] = (_Float16)(0.59004358992664352f * y * (-3.0f * x2 + y2));
+    f[2] = (_Float16)(2.8906114426405538f * xy * z);
+    f[3] = (_Float16)(0.45704579946446572f * y * (1.0f - 5.0f * z2));
+    f[4] = (_Float16)(0.3731763325901154f * z * (5.0f * z2 - 3.0f));
+    f[5] = (_Float16)(0.45704579946446572f * x * (1.0f - 5.0f * z2));
+    f[6] = (_Float16)(1.4453057213202769f * z * (x2 - y2));
+    f[7] = (_Float16)(0.59004358992664352f * x * (-x2 + 3.0f * y2));
+  }
+  return f;
+}
+
+// 8 channels [c0, c0+8) of one texel as floats
+template <bool HALFP>
+__device__ __forceinline__ void load8(const void* planes, size_t elem, float (&v)[8]) {
+  if (HALFP) {
+    const half8 t = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(planes) + elem);
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (float)t[j];
+  } else {
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(planes) + elem);
+    const float4 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+
+// bilinear blend of 8 channels of plane p at k-step kk for this lane's sample -> layer-0 B fragment
+template <int C, bool HALFP>
+__device__ __forceinline__ half8 gather_frag(const void* planes, int R, int p, int kk, int h, const TexelTap& t) {
+  const int c0 = 16 * kk + 8 * h;
+  const size_t pb = (size_t)p * R * R;
+  float v00[8], v01[8], v10[8], v11[8];
+  load8<HALFP>(planes, (pb + (size_t)t.y0 * R + t.x0) * C + c0, v00);
+  load8<HALFP>(planes, (pb + (size_t)t.y0 * R + t.x1) * C + c0, v01);
+  load8<HALFP>(planes, (pb + (size_t)t.y1 * R + t.x0) * C + c0, v10);
+  load8<HALFP>(planes, (pb + (size_t)t.y1 * R + t.x1) * C + c0, v11);
+  half8 f;
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    f[j] = (_Float16)(v00[j] * t.w00 + v01[j] * t.w01 + v10[j] * t.w10 + v11[j] * t.w11);
+  return f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the MLP chain on one 32-sample tile, shared by forward and backward-recompute
+// ---------------------------------------------------------------------------------------------
+template <int C, int H>
+struct Chain {
+  using G = FieldGeom<C, H>;
+  half8 h1[G::KH];   // relu(H1) fragments
+  f32x16 o;          // layer-1 output tile: row 0 sigma logit, rows 1..15 geo (regs 0..7)
+  half8 h3[G::KH];
+  half8 h4[G::KH];
+  f32x16 out;        // layer-4 output tile: rows 0..2 rgb logits (lanes h == 0, regs 0..2)
+};
+
+template <int C, int H>
+__device__ __forceinline__ const half8& wfrag(const half8* w, int f, int lane) { return w[f * 64 + lane]; }
+
+// layers 1..4 given acc0 = W0 * F^T ; DENSITY_ONLY stops after layer 1
+template <int C, int H, bool DENSITY_ONLY>
+__device__ __forceinline__ void chain_tail(const half8* w, int lane, int h, f32x16 (&acc0)[H / 32], float dx,
+                                           float dy, float dz, Chain<C, H>& ch) {
+  using G = FieldGeom<C, H>;
+#pragma unroll
+  for (int ks = 0; ks < G::KH; ks++) {
+    ch.h1[ks] = (ks & 1) ? acc_to_frag<true>(acc0[ks >> 1], 1) : acc_to_frag<true>(acc0[ks >> 1], 0);
+  }
+  ch.o = zero16();
+#pragma unroll
+  for (int ks = 0; ks < G::KH; ks++) ch.o = MFMA32(w[(G::F1 + ks) * 64 + lane], ch.h1[ks], ch.o);
+  if (DENSITY_ONLY) return;
+  const half8 shf = sh_frag(dx, dy, dz, h);
+  const half8 geo = acc_to_frag<false>(ch.o, 0);
+  f32x16 acc2[G::OB];
+#pragma unroll
+  for (int ob = 0; ob < G::OB; ob++) {
+    acc2[ob] = MFMA32(w[(G::F2 + 2 * ob) * 64 + lane], shf, zero16());
+    acc2[ob] = MFMA32(w[(G::F2 + 2 * ob + 1) * 64 + lane], geo, acc2[ob]);
+  }
+#pragma unroll
+  for (int ks = 0; ks < G::KH; ks++)
+    ch.h3[ks] = (ks & 1) ? acc_to_frag<true>(acc2[ks >> 1], 1) : acc_to_frag<true>(acc2[ks >> 1], 0);
+  f32x16 acc3[G::OB];
+#pragma unroll
+  for (int ob = 0; ob < G::OB; ob++) {
+    acc3[ob] = zero16();
+#pragma unroll
+    for (int ks = 0; ks < G::KH; ks++) acc3[ob] = MFMA32(w[(G::F3 + ob * G::KH + ks) * 64 + lane], ch.h3[ks], acc3[ob]);
+  }
+#pragma unroll
+  for (int ks = 0; ks < G::KH; ks++)
+    ch.h4[ks] = (ks & 1) ? acc_to_frag<true>(acc3[ks >> 1], 1) : acc_to_frag<true>(acc3[ks >> 1], 0);
+  ch.out = zero16();
+#pragma unroll
+  for (int ks = 0; ks < G::KH; ks++) ch.out = MFMA32(w[(G::F4 + ks) * 64 + lane], ch.h4[ks], ch.out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward kernel
+// ---------------------------------------------------------------------------------------------
+template <int C, int H, bool HALFP, bool DENSITY_ONLY>
+__global__ void __launch_bounds__(FWD_THREADS)
+k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, const float* __restrict__ dirs,
+            float bound, uint32_t M, int R, const half8* __restrict__ packed, float* __restrict__ sigma,
+            float* __restrict__ rgb, _Float16* __restrict__ feats_save) {
+  using G = FieldGeom<C, H>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half8* w = reinterpret_cast<half8*>(smem);
+  constexpr int NFR = DENSITY_ONLY ? G::F2 : G::NF;
+  for (int i = threadIdx.x; i < NFR * 64; i += FWD_THREADS) w[i] = packed[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const uint32_t waves = gridDim.x * (FWD_THREADS / 64);
+  const uint32_t ntiles = (M + 31) / 32;
+  for (uint32_t tile = blockIdx.x * (FWD_THREADS / 64) + (threadIdx.x >> 6); tile < ntiles; tile += waves) {
+    const uint32_t i = tile * 32 + r;
+    const bool valid = i < M;
+    const uint32_t il = valid ? i : M - 1;
+    const float px = xyz[(size_t)il * 3], py = xyz[(size_t)il * 3 + 1], pz = xyz[(size_t)il * 3 + 2];
+    f32x16 acc0[G::OB];
+#pragma unroll
+    for (int ob = 0; ob < G::OB; ob++) acc0[ob] = zero16();
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      TexelTap t;
+      triplane_tap(px, py, pz, bound, R, p, t);
+#pragma unroll
+      for (int kk = 0; kk < C / 16; kk++) {
+        const half8 f = gather_frag<C, HALFP>(planes, R, p, kk, h, t);
+        const int ks = p * (C / 16) + kk;
+        if (feats_save != nullptr && valid)
+          *reinterpret_cast<half8*>(feats_save + (size_t)i * G::F + 16 * ks + 8 * h) = f;
+#pragma unroll
+        for (int ob = 0; ob < G::OB; ob++) acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], f, acc0[ob]);
+      }
+    }
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (!DENSITY_ONLY) {
+      dx = dirs[(size_t)il * 3]; dy = dirs[(size_t)il * 3 + 1]; dz = dirs[(size_t)il * 3 + 2];
+    }
+    Chain<C, H> ch;
+    chain_tail<C, H, DENSITY_ONLY>(w, lane, h, acc0, dx, dy, dz, ch);
+    if (valid && h == 0) {
+      sigma[i] = expf(ch.o[0]);  // trunc_exp forward (activation.py:9-10)
+      if (!DENSITY_ONLY) {
+        rgb[(size_t)i * 3 + 0] = 1.f / (1.f + expf(-ch.out[0]));
+        rgb[(size_t)i * 3 + 1] = 1.f / (1.f + expf(-ch.out[1]));
+        rgb[(size_t)i * 3 + 2] = 1.f / (1.f + expf(-ch.out[2]));
+      }
+    }
+    if (DENSITY_ONLY && rgb != nullptr && valid) {
+      // geo features (rows 1..15 of the layer-1 tile) -> rgb reused as a [M,15] fp32 buffer by density()
+      const half8 dummy = acc_to_frag<false>(ch.o, 0); (void)dummy;
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        const int row = acc_row(g, h);
+        if (row >= 1) rgb[(size_t)i * 15 + row - 1] = ch.o[g];
+      }
+    }
+  }
+}
+
+template <int C, int H>
+__global__ void k_field_pack(const float* __restrict__ W0, const float* __restrict__ W1, const float* __restrict__ W2,
+                             const float* __restrict__ W3, const float* __restrict__ W4,
+                             _Float16* __restrict__ packed) {
+  using G = FieldGeom<C, H>;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G::NTOT * 512) return;
+  const int src = field_pack_source<C, H>(idx);
+  float v = 0.f;
+  if (src >= 0) {
+    if (src < G::OFF1) v = W0[src - G::OFF0];
+    else if (src < G::OFF2) v = W1[src - G::OFF1];
+    else if (src < G::OFF3) v = W2[src - G::OFF2];
+    else if (src < G::OFF4) v = W3[src - G::OFF3];
+    else v = W4[src - G::OFF4];
+  }
+  packed[idx] = (_Float16)v;
+}
+
+template <int C, int H>
+int launch_fwd(const void* planes, int half_in, const float* xyz, const float* dirs, float bound, uint32_t M,
+               uint32_t R, const void* packed, float* sigma, float* rgb, void* feats_save, bool density_only,
+               hipStream_t st) {
+  using G = FieldGeom<C, H>;
+  const uint32_t ntiles = (M + 31) / 32;
+  uint32_t blocks = (ntiles + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  const half8* pk = reinterpret_cast<const half8*>(packed);
+  _Float16* fs = reinterpret_cast<_Float16*>(feats_save);
+#define TNL_LAUNCH(HP, DO)                                                                                        \
+  hipLaunchKernelGGL((k_field_fwd<C, H, HP, DO>), dim3(blocks), dim3(FWD_THREADS), (DO ? G::F2 : G::NF) * 1024, st, \
+                     planes, xyz, dirs, bound, M, (int)R, pk, sigma, rgb, fs)
+  if (density_only) {
+    if (half_in) TNL_LAUNCH(true, true); else TNL_LAUNCH(false, true);
+  } else {
+    if (half_in) TNL_LAUNCH(true, false); else TNL_LAUNCH(false, false);
+  }
+#undef TNL_LAUNCH
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// backward kernels live in field_bwd.hip; these helpers are shared through this header-less pair
+extern "C" {
+
+uint32_t tnl_field_packed_bytes(uint32_t C, uint32_t Hd, uint32_t Hc) {
+  if (Hd != Hc) return 0;
+  if (C == 16 && Hd == 64) return FieldGeom<16, 64>::NTOT * 1024;
+  if (C == 32 && Hd == 64) return FieldGeom<32, 64>::NTOT * 1024;
+  if (C == 48 && Hd == 128) return FieldGeom<48, 128>::NTOT * 1024;
+  return 0;
+}
+
+int tnl_field_pack(const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, uint32_t C,
+                   uint32_t Hd, uint32_t Hc, void* packed, void* stream) {
+  if (Hd != Hc) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  _Float16* pk = reinterpret_cast<_Float16*>(packed);
+#define TNL_PACK(CC, HH)                                                                                      \
+  hipLaunchKernelGGL((k_field_pack<CC, HH>), dim3((FieldGeom<CC, HH>::NTOT * 512 + 255) / 256), dim3(256), 0, st, \
+                     W0, W1, W2, W3, W4, pk)
+  if (C == 16 && Hd == 64) TNL_PACK(16, 64);
+  else if (C == 32 && Hd == 64) TNL_PACK(32, 64);
+  else if (C == 48 && Hd == 128) TNL_PACK(48, 128);
+  else return (int)hipErrorInvalidValue;
+#undef TNL_PACK
+  return (int)hipGetLastError();
+}
+
+// rgb == NULL, or dirs == NULL: density only (NeRFNetwork.density, network.py:149-166); if dirs == NULL and
+// rgb != NULL, rgb receives the 15 geo features per sample ([M,15] fp32).
+int tnl_field_forward(const void* planes_tm, int half_in, const float* xyz, const float* dirs, float bound,
+                      uint32_t M, uint32_t C, uint32_t R, uint32_t Hd, uint32_t Hc, const void* packed,
+                      float* sigma, float* rgb, void* feats_save, void* stream) {
+  if (M == 0) return 0;
+  if (Hd != Hc) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const bool density_only = (dirs == nullptr) || (rgb == nullptr);
+  if (C == 16 && Hd == 64)
+    return launch_fwd<16, 64>(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, st);
+  if (C == 32 && Hd == 64)
+    return launch_fwd<32, 64>(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, st);
+  if (C == 48 && Hd == 128)
+    return launch_fwd<48, 128>(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, st);
+  return (int)hipErrorInvalidValue;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+"""Autograd wrapper of the fused field kernels (csrc/field.hip, csrc/field_bwd.hip).
+
+sigma, rgb = fused_field(planes_tm, xyz, dirs, W0..W4, bound) == NeRFNetwork.forward
+(reconstruction/nerf/network.py:118-147) with the layers in fp16 MFMA / fp32 accumulate.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _lib as L
+
+SUPPORTED = {(16, 64), (32, 64), (48, 128)}
+
+
+def supported(C, Hd, Hc):
+    return Hd == Hc and (C, Hd) in SUPPORTED
+
+
+def pack_weights(W0, W1, W2, W3, W4, C, H):
+    """fp32 nn.Linear weights -> fp16 MFMA fragment buffer (tnl_field_pack)."""
+    lib = L.lib()
+    nbytes = lib.tnl_field_packed_bytes(L.u32(C), L.u32(H), L.u32(H))
+    if nbytes == 0:
+        raise NotImplementedError(f"fused field: unsupported (channels={C}, hidden={H})")
+    packed = torch.empty(nbytes // 2, dtype=torch.float16, device=W0.device)
+    ws = [w.detach().to(torch.float32).contiguous() for w in (W0, W1, W2, W3, W4)]
+    L.check(lib.tnl_field_pack(*[L.ptr(w) for w in ws], L.u32(C), L.u32(H), L.u32(H), L.ptr(packed), L.stream()),
+            "field_pack")
+    return packed
+
+
+def field_forward(planes_tm, xyz, dirs, packed, bound, C, R, H, save_feats=False, geo_out=False):
+    """Raw call.  dirs=None -> density only (returns sigma, geo[M,15] or None, feats)."""
+    M = xyz.shape[0]
+    dev = xyz.device
+    sigma = torch.empty(M, dtype=torch.float32, device=dev)
+    if dirs is None:
+        second = torch.empty(M, 15, dtype=torch.float32, device=dev) if geo_out else None
+    else:
+        second = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    feats = torch.empty(M, 3 * C, dtype=torch.float16, device=dev) if save_feats else None
+    L.check(L.lib().tnl_field_forward(L.ptr(planes_tm), L.i32(int(planes_tm.dtype == torch.float16)), L.ptr(xyz),
+                                      L.ptr(dirs), L.f32(bound), L.u32(M), L.u32(C), L.u32(R), L.u32(H), L.u32(H),
+                                      L.ptr(packed), L.ptr(sigma), L.ptr(second), L.ptr(feats), L.stream()),
+            "field_forward")
+    return sigma, second, feats
+
+
+def field_backward(grad_sigma, grad_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW):
+    """Raw call: accumulates into grad_tm [3,R,R,C] fp32 and gradW (concatenated W0..W4, fp32)."""
+    lib = L.lib()
+    M = xyz.shape[0]
+    nws = lib.tnl_field_backward_workspace(L.u32(M), L.u32(C), L.u32(H), L.u32(H))
+    ws = torch.empty(max(nws, 4), dtype=torch.uint8, device=xyz.device)
+    L.check(lib.tnl_field_backward(L.ptr(grad_sigma), L.ptr(grad_rgb), L.ptr(sigma), L.ptr(rgb), L.ptr(feats),
+                                   L.ptr(xyz), L.ptr(dirs), L.f32(bound), L.u32(M), L.u32(C), L.u32(R), L.u32(H),
+                                   L.u32(H), L.ptr(packed), L.ptr(grad_tm), L.ptr(gradW), L.ptr(ws), L.stream()),
+            "field_backward")
+
+
+class _FusedField(Function):
+    @staticmethod
+    def forward(ctx, planes_tm, xyz, dirs, W0, W1, W2, W3, W4, bound):
+        L.require_cuda(planes_tm, xyz, dirs, W0)
+        _, R, _, C = planes_tm.shape
+        H = W0.shape[0]
+        xyz = xyz.detach().to(torch.float32).contiguous()
+        dirs = dirs.detach().to(torch.float32).contiguous()
+        packed = pack_weights(W0, W1, W2, W3, W4, C, H)
+        need_grad = any(ctx.needs_input_grad)
+        sigma, rgb, feats = field_forward(planes_tm, xyz, dirs, packed, float(bound), C, R, H, save_feats=need_grad)
+        ctx.save_for_backward(xyz, dirs, packed, sigma, rgb, feats)
+        ctx.dims = (C, R, H, float(bound), [tuple(w.shape) for w in (W0, W1, W2, W3, W4)])
+        return sigma, rgb
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb):
+        xyz, dirs, packed, sigma, rgb, feats = ctx.saved_tensors
+        C, R, H, bound, shapes = ctx.dims
+        dev = xyz.device
+        g_sigma = g_sigma.to(torch.float32).contiguous()
+        g_rgb = g_rgb.to(torch.float32).contiguous()
+        grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=dev)
+        nw = sum(a * b for a, b in shapes)
+        gradW = torch.zeros(nw, dtype=torch.float32, device=dev)
+        field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW)
+        gws, off = [], 0
+        for a, b in shapes:
+            gws.append(gradW[off:off + a * b].view(a, b))
+            off += a * b
+        return (grad_tm, None, None, *gws, None)
+
+
+fused_field = _FusedField.apply

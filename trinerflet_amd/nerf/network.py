@@ -1,0 +1,159 @@
+"""NeRFNetwork -- mirror of reconstruction/nerf/network.py (reference): same constructor keywords,
+sub-module names (encoder, encoder_dir, sigma_net.{0,1}, color_net.{0,1,2}: state-dict compatible) and
+methods forward / density / color / get_params.
+
+forward() and density() run the fused HIP field kernel whenever the configuration is one the kernel is
+built for (triplane_wavelet encoder, channels 16/32/48, hidden 64 or 128: every README configuration);
+other shapes take the modular path (HIP lookup + HIP SH + torch nn.Linear), which is also what `color()`
+uses (only NeRFRenderer.run, the non-cuda_ray renderer, calls it).  The background network
+(bg_radius > 0, network.py:79-100) is not on the hot path and raises NotImplementedError.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..activation import trunc_exp
+from ..encoding import get_encoder
+from . import field as _field
+from .renderer import NeRFRenderer
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self,
+                 encoding="triplane_wavelet",
+                 encoding_dir="sphere_harmonics",
+                 encoding_bg="hashgrid",
+                 num_layers=2,
+                 hidden_dim=64,
+                 geo_feat_dim=15,
+                 num_layers_color=3,
+                 hidden_dim_color=64,
+                 num_layers_bg=2,
+                 hidden_dim_bg=64,
+                 bound=1,
+                 density_blob_scale=0,
+                 density_blob_std=0.5,
+                 mlp_weight_decay=0,
+                 nerfacc_renderer=False,
+                 **kwargs,
+                 ):
+        super().__init__(bound, **kwargs)
+        if self.bg_radius > 0:
+            raise NotImplementedError("background network (bg_radius > 0) is outside the hot-path tier")
+        if nerfacc_renderer:
+            raise NotImplementedError("nerfacc renderer is outside the hot-path tier")
+        self.num_layers = num_layers
+        self.hidden_dim = hidden_dim
+        self.geo_feat_dim = geo_feat_dim
+        self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=2048 * bound, bound=bound, **kwargs)
+
+        # sigma network (network.py:37-52): bias-free Linear layers
+        sigma_net = []
+        for l in range(num_layers):
+            in_dim = self.in_dim if l == 0 else hidden_dim
+            out_dim = 1 + self.geo_feat_dim if l == num_layers - 1 else hidden_dim
+            sigma_net.append(nn.Linear(in_dim, out_dim, bias=False))
+        self.sigma_net = nn.ModuleList(sigma_net)
+
+        # colour network (network.py:55-76)
+        self.num_layers_color = num_layers_color
+        self.hidden_dim_color = hidden_dim_color
+        self.encoder_dir, self.in_dim_dir = get_encoder(encoding_dir)
+        color_net = []
+        for l in range(num_layers_color):
+            in_dim = self.in_dim_dir + self.geo_feat_dim if l == 0 else hidden_dim_color
+            out_dim = 3 if l == num_layers_color - 1 else hidden_dim_color
+            color_net.append(nn.Linear(in_dim, out_dim, bias=False))
+        self.color_net = nn.ModuleList(color_net)
+        self.bg_net = None
+
+        self.density_blob_scale = density_blob_scale
+        self.density_blob_std = density_blob_std
+        self.mlp_weight_decay = mlp_weight_decay
+        self.force_modular = False  # tests flip this to compare the two GPU paths
+
+    # ------------------------------------------------------------------------------------------
+    def _fused_ok(self):
+        enc = self.encoder
+        return (not self.force_modular and hasattr(enc, 'get_planes_texel_major') and enc.dropout is None
+                and self.num_layers == 2 and self.num_layers_color == 3 and self.geo_feat_dim == 15
+                and getattr(self.encoder_dir, 'degree', 0) == 4 and self.density_blob_scale <= 1e-5
+                and _field.supported(enc.number_of_features, self.hidden_dim, self.hidden_dim_color))
+
+    def density_op(self, x, density):
+        if self.density_blob_scale > 1e-5:  # network.py:111-117 (x is the ENCODED position there, kept as is)
+            w = self.density_blob_scale * torch.exp(-0.5 * x.pow(2).sum(dim=-1) / self.density_blob_std ** 2)
+            density = density * w
+        return density
+
+    def _sigma_mlp(self, x):
+        h = self.encoder(x, bound=self.bound)
+        enc = h
+        for l in range(self.num_layers):
+            h = self.sigma_net[l](h)
+            if l != self.num_layers - 1:
+                h = F.relu(h, inplace=True)
+        sigma = trunc_exp(self.density_op(enc, h[..., 0]))
+        return sigma, h[..., 1:]
+
+    def _color_mlp(self, d, geo_feat):
+        d = self.encoder_dir(d)
+        h = torch.cat([d, geo_feat.to(d.dtype)], dim=-1)
+        for l in range(self.num_layers_color):
+            h = self.color_net[l](h.to(self.color_net[l].weight.dtype) if not torch.is_autocast_enabled() else h)
+            if l != self.num_layers_color - 1:
+                h = F.relu(h, inplace=True)
+        return torch.sigmoid(h)
+
+    def forward(self, x, d):
+        # x: [N, 3] in [-bound, bound], d: [N, 3] unit directions -> sigma [N], color [N, 3]  (network.py:118-147)
+        if self._fused_ok():
+            tm = self.encoder.get_planes_texel_major()
+            return _field.fused_field(tm, x, d, self.sigma_net[0].weight, self.sigma_net[1].weight,
+                                      self.color_net[0].weight, self.color_net[1].weight, self.color_net[2].weight,
+                                      self.bound)
+        sigma, geo_feat = self._sigma_mlp(x)
+        return sigma, self._color_mlp(d, geo_feat)
+
+    def density(self, x):
+        # network.py:149-166
+        if self._fused_ok() and not torch.is_grad_enabled():
+            enc = self.encoder
+            tm = enc.get_planes_texel_major()
+            packed = _field.pack_weights(self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight,
+                                         self.color_net[1].weight, self.color_net[2].weight, enc.number_of_features,
+                                         self.hidden_dim)
+            x = x.detach().to(torch.float32).contiguous()
+            sigma, geo, _ = _field.field_forward(tm, x, None, packed, float(self.bound), enc.number_of_features,
+                                                 enc.plane_resolution, self.hidden_dim, geo_out=True)
+            return {'sigma': sigma, 'geo_feat': geo}
+        sigma, geo_feat = self._sigma_mlp(x)
+        return {'sigma': sigma, 'geo_feat': geo_feat}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        # network.py:186-214 (masked colour query)
+        if mask is not None:
+            rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
+            if not mask.any():
+                return rgbs
+            d = d[mask]
+            geo_feat = geo_feat[mask]
+        h = self._color_mlp(d, geo_feat)
+        if mask is not None:
+            rgbs[mask] = h.to(rgbs.dtype)
+        else:
+            rgbs = h
+        return rgbs
+
+    def get_params(self, lr):
+        # network.py:217-243
+        params = [
+            {'params': self.encoder.parameters(), 'lr': lr},
+            {'params': self.encoder_dir.parameters(), 'lr': lr},
+        ]
+        extra = {'weight_decay': self.mlp_weight_decay} if self.mlp_weight_decay > 0 else {}
+        params += [
+            {'params': self.sigma_net.parameters(), 'lr': lr, **extra},
+            {'params': self.color_net.parameters(), 'lr': lr, **extra},
+        ]
+        return params

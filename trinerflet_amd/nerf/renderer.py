@@ -1,0 +1,273 @@
+"""NeRFRenderer -- mirror of reconstruction/nerf/renderer.py (reference): same constructor, buffers
+(aabb_train, aabb_infer, density_grid, density_bitfield, step_counter), attributes (cuda_ray, bg_radius,
+mean_count, mean_density, iter_density, local_step) and methods render / run / run_cuda /
+update_extra_state / mark_untrained_grid / reset_extra_state.
+
+The marching, compositing, compaction and field evaluation are HIP kernels (trinerflet_amd.raymarching,
+NeRFNetwork.forward).  The density-grid refresh evaluates cells in Morton order from a cached coordinate
+table instead of the reference's five nested Python loops; its sampling noise comes from torch's RNG
+like the reference, so it is distribution- not bit-identical.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import raymarching
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1,
+                 **kwargs):
+        super().__init__()
+        # reference: renderer.py:62-100
+        self.bound = bound
+        self.cascade = 1 + math.ceil(math.log2(bound))
+        self.grid_size = 128
+        self.density_scale = density_scale
+        self.min_near = min_near
+        self.density_thresh = density_thresh
+        self.bg_radius = bg_radius
+        aabb_train = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
+        self.register_buffer('aabb_train', aabb_train)
+        self.register_buffer('aabb_infer', aabb_train.clone())
+        self.cuda_ray = cuda_ray
+        if cuda_ray:
+            self.register_buffer('density_grid', torch.zeros([self.cascade, self.grid_size ** 3]))
+            self.register_buffer('density_bitfield',
+                                 torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
+            self.mean_density = 0
+            self.iter_density = 0
+            self.register_buffer('step_counter', torch.zeros(16, 2, dtype=torch.int32))
+            self.mean_count = 0
+            self.local_step = 0
+        self._morton_xyz = None  # [H^3, 3] cell coords (float, in [-1,1]) listed in Morton order
+
+    def forward(self, x, d):
+        raise NotImplementedError()
+
+    def density(self, x):
+        raise NotImplementedError()
+
+    def color(self, x, d, mask=None, **kwargs):
+        raise NotImplementedError()
+
+    def reset_extra_state(self):
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
+
+    # ------------------------------------------------------------------------------------------
+    # non-cuda_ray renderer (renderer.py:126-254): uniform steps, torch compositing.  Kept for API
+    # completeness; upsample_steps > 0 (sample_pdf) is not part of any README configuration.
+    # ------------------------------------------------------------------------------------------
+    def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, **kwargs):
+        if upsample_steps > 0:
+            raise NotImplementedError("hierarchical resampling (upsample_steps > 0) is outside the hot-path tier")
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N, device = rays_o.shape[0], rays_o.device
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        nears, fars = nears.unsqueeze(-1), fars.unsqueeze(-1)
+        z_vals = torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0).expand(N, num_steps)
+        z_vals = nears + (fars - nears) * z_vals
+        sample_dist = (fars - nears) / num_steps
+        if perturb:
+            z_vals = z_vals + (torch.rand(z_vals.shape, device=device) - 0.5) * sample_dist
+        xyzs = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z_vals.unsqueeze(-1)
+        xyzs = torch.min(torch.max(xyzs, aabb[:3]), aabb[3:])
+        dens = self.density(xyzs.reshape(-1, 3))
+        sigma = dens['sigma'].view(N, num_steps)
+        geo = dens['geo_feat'].view(N, num_steps, -1)
+        deltas = z_vals[..., 1:] - z_vals[..., :-1]
+        deltas = torch.cat([deltas, sample_dist * torch.ones_like(deltas[..., :1])], dim=-1)
+        alphas = 1 - torch.exp(-deltas * self.density_scale * sigma)
+        alphas_shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
+        weights = alphas * torch.cumprod(alphas_shifted, dim=-1)[..., :-1]
+        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
+        mask = weights > 1e-4
+        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1),
+                          geo_feat=geo.reshape(-1, geo.shape[-1]))
+        rgbs = rgbs.view(N, -1, 3)
+        weights_sum = weights.sum(dim=-1)
+        ori_z_vals = ((z_vals - nears) / (fars - nears)).clamp(0, 1)
+        depth = torch.sum(weights * ori_z_vals, dim=-1)
+        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
+        if bg_color is None:
+            bg_color = 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        return {'depth': depth.view(*prefix), 'image': image.view(*prefix, 3), 'weights_sum': weights_sum}
+
+    # ------------------------------------------------------------------------------------------
+    # cuda_ray renderer (renderer.py:257-381)
+    # ------------------------------------------------------------------------------------------
+    def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
+                 max_steps=1024, T_thresh=1e-4, **kwargs):
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N, device = rays_o.shape[0], rays_o.device
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d,
+                                                     self.aabb_train if self.training else self.aabb_infer,
+                                                     self.min_near)
+        if bg_color is None:
+            bg_color = 1
+        results = {}
+        if self.training:
+            counter = self.step_counter[self.local_step % 16]
+            counter.zero_()
+            self.local_step += 1
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(
+                rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
+                self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
+            sigmas, rgbs = self(xyzs, dirs)
+            sigmas = self.density_scale * sigmas
+            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            image = image.view(*prefix, 3)
+            depth = depth.view(*prefix)
+            results['weights_sum'] = weights_sum
+        else:
+            weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
+            depth = torch.zeros(N, dtype=torch.float32, device=device)
+            image = torch.zeros(N, 3, dtype=torch.float32, device=device)
+            n_alive = N
+            rays_alive = torch.arange(n_alive, dtype=torch.int32, device=device)
+            rays_t = nears.clone()
+            step = 0
+            while step < max_steps:
+                if n_alive <= 0:
+                    break
+                n_step = max(min(N // n_alive, 8), 1)
+                xyzs, dirs, deltas = raymarching.march_rays(
+                    n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield,
+                    self.cascade, self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma,
+                    max_steps)
+                sigmas, rgbs = self(xyzs, dirs)
+                sigmas = self.density_scale * sigmas
+                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum,
+                                           depth, image, T_thresh)
+                # device-side ordered compaction (replaces rays_alive[rays_alive >= 0], renderer.py:364);
+                # the survivor count is the one host read per iteration the reference also pays (:345)
+                rays_alive, n_out = raymarching.compact_rays(rays_alive, n_alive)
+                n_alive = int(n_out.item())
+                step += n_step
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            image = image.view(*prefix, 3)
+            depth = depth.view(*prefix)
+            weights_sum = weights_sum.view(*prefix)
+        results['depth'] = depth
+        results['image'] = image
+        results['weights_sum'] = weights_sum
+        return results
+
+    # ------------------------------------------------------------------------------------------
+    # density grid upkeep
+    # ------------------------------------------------------------------------------------------
+    def _cells(self):
+        """Cell coordinates in [-1,1]^3 (2*c/(H-1) - 1, renderer.py:416,475) listed in Morton order."""
+        if self._morton_xyz is None or self._morton_xyz.device != self.density_bitfield.device:
+            H = self.grid_size
+            idx = torch.arange(H ** 3, dtype=torch.int32, device=self.density_bitfield.device)
+            coords = raymarching.morton3D_invert(idx)
+            self._morton_xyz = 2 * coords.float() / (H - 1) - 1
+        return self._morton_xyz
+
+    @torch.no_grad()
+    def mark_untrained_grid(self, poses, intrinsic, S=64):
+        # reference: renderer.py:383-446 -- a cell is trainable iff some camera sees its centre
+        if not self.cuda_ray:
+            return
+        if isinstance(poses, np.ndarray):
+            poses = torch.from_numpy(poses)
+        fx, fy, cx, cy = intrinsic
+        dev = self.density_grid.device
+        poses = poses.to(dev).float()
+        cells = self._cells()
+        count = torch.zeros_like(self.density_grid)
+        chunk = 64 ** 3
+        for cas in range(self.cascade):
+            bound = min(2 ** cas, self.bound)
+            half_grid_size = bound / self.grid_size
+            for c0 in range(0, cells.shape[0], chunk):
+                world = (cells[c0:c0 + chunk] * (bound - half_grid_size)).unsqueeze(0)
+                for head in range(0, poses.shape[0], S):
+                    P = poses[head:head + S]
+                    cam = (world - P[:, :3, 3].unsqueeze(1)) @ P[:, :3, :3]
+                    mask = (cam[:, :, 2] > 0) \
+                        & (torch.abs(cam[:, :, 0]) < cx / fx * cam[:, :, 2] + half_grid_size * 2) \
+                        & (torch.abs(cam[:, :, 1]) < cy / fy * cam[:, :, 2] + half_grid_size * 2)
+                    count[cas, c0:c0 + chunk] += mask.sum(0)
+        self.density_grid[count == 0] = -1
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        # reference: renderer.py:448-542
+        if not self.cuda_ray:
+            return
+        dev = self.density_bitfield.device
+        H = self.grid_size
+        tmp_grid = -torch.ones_like(self.density_grid)
+        if self.iter_density < 16:  # full refresh: every cell of every cascade
+            cells = self._cells()
+            for cas in range(self.cascade):
+                bound = min(2 ** cas, self.bound)
+                half_grid_size = bound / H
+                xyzs = cells * (bound - half_grid_size)
+                xyzs = xyzs + (torch.rand_like(xyzs) * 2 - 1) * half_grid_size
+                tmp_grid[cas] = self.density(xyzs)['sigma'].reshape(-1).detach().float() * self.density_scale
+        else:  # partial refresh: H^3/4 uniform cells + H^3/4 currently occupied cells per cascade
+            N = H ** 3 // 4
+            for cas in range(self.cascade):
+                coords = torch.randint(0, H, (N, 3), device=dev)
+                indices = raymarching.morton3D(coords).long()
+                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                if occ_indices.shape[0] > 0:
+                    pick = torch.randint(0, occ_indices.shape[0], [N], dtype=torch.long, device=dev)
+                    occ_indices = occ_indices[pick]
+                    occ_coords = raymarching.morton3D_invert(occ_indices)
+                    indices = torch.cat([indices, occ_indices], dim=0)
+                    coords = torch.cat([coords, occ_coords], dim=0)
+                xyzs = 2 * coords.float() / (H - 1) - 1
+                bound = min(2 ** cas, self.bound)
+                half_grid_size = bound / H
+                xyzs = xyzs * (bound - half_grid_size)
+                xyzs = xyzs + (torch.rand_like(xyzs) * 2 - 1) * half_grid_size
+                tmp_grid[cas, indices] = self.density(xyzs)['sigma'].reshape(-1).detach().float() * self.density_scale
+        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
+        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.iter_density += 1
+        density_thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+        total_step = min(16, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0
+
+    def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
+        # reference: renderer.py:545-578
+        _run = self.run_cuda if self.cuda_ray else self.run
+        B, N = rays_o.shape[:2]
+        device = rays_o.device
+        if staged and not self.cuda_ray:
+            depth = torch.empty((B, N), device=device)
+            image = torch.empty((B, N, 3), device=device)
+            for b in range(B):
+                for head in range(0, N, max_ray_batch):
+                    tail = min(head + max_ray_batch, N)
+                    res = _run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
+                    depth[b:b + 1, head:tail] = res['depth']
+                    image[b:b + 1, head:tail] = res['image']
+            return {'depth': depth, 'image': image}
+        return _run(rays_o, rays_d, **kwargs)
