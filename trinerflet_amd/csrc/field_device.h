@@ -1,0 +1,149 @@
+// field_device.h -- device code shared by field.hip (forward) and field_bwd.hip (backward).
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "field_common.h"
+#include "triplane_common.h"
+
+namespace {
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+constexpr int FWD_THREADS = 256;
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; i++) z[i] = 0.f;
+  return z;
+}
+
+// registers 8s..8s+7 of an accumulator tile -> fp16 fragment (optionally through ReLU)
+template <bool RELU>
+__device__ __forceinline__ half8 acc_to_frag(const f32x16& a, int s) {
+  half8 f;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    float v = s == 0 ? a[j] : a[8 + j];
+    if (RELU) v = fmaxf(v, 0.f);
+    f[j] = (_Float16)v;
+  }
+  return f;
+}
+
+// SH degree 4 (shencoder.cu:50-68): the 8 values [8h, 8h+8) of the 16, as a fragment
+__device__ __forceinline__ half8 sh_frag(float x, float y, float z, int h) {
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  half8 f;
+  if (h == 0) {
+    f[0] = (_Float16)0.28209479177387814f;
+    f[1] = (_Float16)(-0.48860251190291987f * y);
+    f[2] = (_Float16)(0.48860251190291987f * z);
+    f[3] = (_Float16)(-0.48860251190291987f * x);
+    f[4] = (_Float16)(1.0925484305920792f * xy);
+    f[5] = (_Float16)(-1.0925484305920792f * yz);
+    f[6] = (_Float16)(0.94617469575755997f * z2 - 0.31539156525251999f);
+    f[7] = (_Float16)(-1.0925484305920792f * xz);
+  } else {
+    f[0] = (_Float16)(0.54627421529603959f * x2 - 0.54627421529603959f * y2);
+    f[1] = (_Float16)(0.59004358992664352f * y * (-3.0f * x2 + y2));
+    f[2] = (_Float16)(2.8906114426405538f * xy * z);
+    f[3] = (_Float16)(0.45704579946446572f * y * (1.0f - 5.0f * z2));
+    f[4] = (_Float16)(0.3731763325901154f * z * (5.0f * z2 - 3.0f));
+    f[5] = (_Float16)(0.45704579946446572f * x * (1.0f - 5.0f * z2));
+    f[6] = (_Float16)(1.4453057213202769f * z * (x2 - y2));
+    f[7] = (_Float16)(0.59004358992664352f * x * (-x2 + 3.0f * y2));
+  }
+  return f;
+}
+
+// 8 channels [c0, c0+8) of one texel as floats
+template <bool HALFP>
+__device__ __forceinline__ void load8(const void* planes, size_t elem, float (&v)[8]) {
+  if (HALFP) {
+    const half8 t = *reinterpret_cast<const half8*>(reinterpret_cast<const _Float16*>(planes) + elem);
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (float)t[j];
+  } else {
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(planes) + elem);
+    const float4 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+
+// bilinear blend of 8 channels of plane p at k-step kk for this lane's sample -> layer-0 B fragment
+template <int C, bool HALFP>
+__device__ __forceinline__ half8 gather_frag(const void* planes, int R, int p, int kk, int h, const TexelTap& t) {
+  const int c0 = 16 * kk + 8 * h;
+  const size_t pb = (size_t)p * R * R;
+  float v00[8], v01[8], v10[8], v11[8];
+  load8<HALFP>(planes, (pb + (size_t)t.y0 * R + t.x0) * C + c0, v00);
+  load8<HALFP>(planes, (pb + (size_t)t.y0 * R + t.x1) * C + c0, v01);
+  load8<HALFP>(planes, (pb + (size_t)t.y1 * R + t.x0) * C + c0, v10);
+  load8<HALFP>(planes, (pb + (size_t)t.y1 * R + t.x1) * C + c0, v11);
+  half8 f;
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    f[j] = (_Float16)(v00[j] * t.w00 + v01[j] * t.w01 + v10[j] * t.w10 + v11[j] * t.w11);
+  return f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the MLP chain on one 32-sample tile, shared by forward and backward-recompute
+// ---------------------------------------------------------------------------------------------
+template <int C, int H>
+struct Chain {
+  using G = FieldGeom<C, H>;
+  half8 h1[G::KH];   // relu(H1) fragments
+  f32x16 o;          // layer-1 output tile: row 0 sigma logit, rows 1..15 geo (regs 0..7)
+  half8 h3[G::KH];
+  half8 h4[G::KH];
+  f32x16 out;        // layer-4 output tile: rows 0..2 rgb logits (lanes h == 0, regs 0..2)
+};
+
+template <int C, int H>
+__device__ __forceinline__ const half8& wfrag(const half8* w, int f, int lane) { return w[f * 64 + lane]; }
+
+// layers 1..4 given acc0 = W0 * F^T ; DENSITY_ONLY stops after layer 1
+template <int C, int H, bool DENSITY_ONLY>
+__device__ __forceinline__ void chain_tail(const half8* w, int lane, int h, f32x16 (&acc0)[H / 32], float dx,
+                                           float dy, float dz, Chain<C, H>& ch) {
+  using G = FieldGeom<C, H>;
+#pragma unroll
+  for (int ks = 0; ks < G::KH; ks++) {
+    ch.h1[ks] = (ks & 1) ? acc_to_frag<true>(acc0[ks >> 1], 1) : acc_to_frag<true>(acc0[ks >> 1], 0);
+  }
+  ch.o = zero16();
+#pragma unroll
+  for (int ks = 0; ks < G::KH; ks++) ch.o = MFMA32(w[(G::F1 + ks) * 64 + lane], ch.h1[ks], ch.o);
+  if (DENSITY_ONLY) return;
+  const half8 shf = sh_frag(dx, dy, dz, h);
+  const half8 geo = acc_to_frag<false>(ch.o, 0);
+  f32x16 acc2[G::OB];
+#pragma unroll
+  for (int ob = 0; ob < G::OB; ob++) {
+    acc2[ob] = MFMA32(w[(G::F2 + 2 * ob) * 64 + lane], shf, zero16());
+    acc2[ob] = MFMA32(w[(G::F2 + 2 * ob + 1) * 64 + lane], geo, acc2[ob]);
+  }
+#pragma unroll
+  for (int ks = 0; ks < G::KH; ks++)
+    ch.h3[ks] = (ks & 1) ? acc_to_frag<true>(acc2[ks >> 1], 1) : acc_to_frag<true>(acc2[ks >> 1], 0);
+  f32x16 acc3[G::OB];
+#pragma unroll
+  for (int ob = 0; ob < G::OB; ob++) {
+    acc3[ob] = zero16();
+#pragma unroll
+    for (int ks = 0; ks < G::KH; ks++) acc3[ob] = MFMA32(w[(G::F3 + ob * G::KH + ks) * 64 + lane], ch.h3[ks], acc3[ob]);
+  }
+#pragma unroll
+  for (int ks = 0; ks < G::KH; ks++)
+    ch.h4[ks] = (ks & 1) ? acc_to_frag<true>(acc3[ks >> 1], 1) : acc_to_frag<true>(acc3[ks >> 1], 0);
+  ch.out = zero16();
+#pragma unroll
+  for (int ks = 0; ks < G::KH; ks++) ch.out = MFMA32(w[(G::F4 + ks) * 64 + lane], ch.h4[ks], ch.out);
+}
+
+
+}  // namespace
