@@ -160,11 +160,14 @@ TNL_API int tnl_field_pack(const float *W0, const float *W1, const float *W2, co
                            const float *W4, uint32_t C, uint32_t Hd, uint32_t Hc, void *packed,
                            void *stream);
 /* sigma:[M] rgb:[M,3] fp32.  feats_save (fp16 [M,3C], may be NULL) keeps the interpolated
- * features for the backward pass. */
+ * features for the backward pass.  dirs == NULL or rgb == NULL: density only (NeRFNetwork.density,
+ * network.py:149-166); with dirs == NULL and rgb != NULL, rgb receives the 15 geo features ([M,15]).
+ * m_actual (device int32, may be NULL): rows >= min(M, *m_actual) are skipped -- march_rays_train's
+ * counter[0], so the zero rows that pad the sample buffer to its budget M cost nothing. */
 TNL_API int tnl_field_forward(const void *planes_tm, int half_in, const float *xyz, const float *dirs,
                               float bound, uint32_t M, uint32_t C, uint32_t R, uint32_t Hd,
                               uint32_t Hc, const void *packed, float *sigma, float *rgb,
-                              void *feats_save, void *stream);
+                              void *feats_save, const int32_t *m_actual, void *stream);
 /* grad_sigma:[M], grad_rgb:[M,3] -> grad_tm:[3,R,R,C] fp32 (atomic, caller zero-fills) and
  * gradW:[Hd*3C + 16*Hd + Hc*31 + Hc*Hc + 3*Hc] fp32 in nn.Linear layout, concatenated W0..W4
  * (accumulated atomically, caller zero-fills).  grad_scale multiplies incoming gradients
@@ -174,20 +177,21 @@ TNL_API int tnl_field_backward(const float *grad_sigma, const float *grad_rgb, c
                                const float *rgb, const void *feats_save, const float *xyz,
                                const float *dirs, float bound, uint32_t M, uint32_t C, uint32_t R,
                                uint32_t Hd, uint32_t Hc, const void *packed, float *grad_tm,
-                               float *gradW, void *workspace, void *stream);
+                               float *gradW, void *workspace, const int32_t *m_actual, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused optimiser for the wavelet coefficients: torch.optim.Adam(betas, eps, no weight decay)
  * (reconstruction/main_nerf.py:119) with the wavelet L1 regulariser's gradient
  * (reconstruction/nerf/utils.py:639-655) and GradScaler's unscale folded in:
  *   g = grad * inv_scale + l1_coef * sign(p) ;  m,v,p <- Adam(g) ;  abs_sum += sum |p_old|.
- * step_size = lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t).  If found_inf[0] != 0 nothing
- * is updated (GradScaler.step skip).  grad may be zeroed afterwards (zero_grad != 0).
+ * step_size = lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t).  inv_scale_dev (device float, may be
+ * NULL) multiplies inv_scale, so a dynamic loss scale never has to be read back by the host.  If
+ * found_inf[0] != 0 nothing is updated (GradScaler.step skip).  grad may be zeroed afterwards (zero_grad != 0).
  * ------------------------------------------------------------------------------------------- */
 TNL_API int tnl_adam_l1_step(float *p, float *grad, float *m, float *v, uint64_t n, float step_size,
                              float bias2_sqrt, float beta1, float beta2, float eps, float inv_scale,
-                             float l1_coef, const float *found_inf, float *abs_sum, int zero_grad,
-                             void *stream);
+                             const float *inv_scale_dev, float l1_coef, const float *found_inf,
+                             float *abs_sum, int zero_grad, void *stream);
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import cref
-from tests import scene
+from trinerflet_amd import synthetic as scene
 
 pytestmark = pytest.mark.gpu
 

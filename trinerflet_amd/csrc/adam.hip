@@ -1,0 +1,98 @@
+// adam.hip -- fused optimiser pass over the wavelet coefficients (gfx950).
+//
+// Replaces, for the 402 M coefficient parameters of the base configuration, the chain
+//   GradScaler.unscale_ -> wavelet L1 regulariser forward (abs, mean) and backward (sign, scale, add into .grad)
+//   -> torch.optim.Adam (multi-tensor: ~6 elementwise kernels) -> optimizer.zero_grad
+// (reconstruction/nerf/utils.py:639-655,1166-1173; reconstruction/main_nerf.py:119) with ONE streaming pass:
+// 16 B/lane loads of p, g, m, v; 16 B/lane stores of p, m, v (28 B per parameter, the HBM floor for Adam).
+// Arithmetic follows torch.optim.Adam's single-tensor path operation by operation:
+//   m.lerp_(g, 1-b1) ; v.mul_(b2).addcmul_(g, g, 1-b2) ; denom = sqrt(v)/sqrt(bc2) + eps ; p.addcdiv_(m, denom, -lr/bc1)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/trinerflet_hip.h"
+
+namespace {
+
+struct AdamArgs {
+  float step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef;
+};
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
+
+__device__ __forceinline__ void adam1(float& p, float g_in, float& m, float& v, const AdamArgs& a, float& abs_acc) {
+  abs_acc += fabsf(p);
+  const float g = g_in * a.inv_scale + a.l1_coef * sgn(p);
+  m = m + (g - m) * (1.f - a.beta1);
+  v = v * a.beta2 + (1.f - a.beta2) * g * g;
+  const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
+  p = p - a.step_size * (m / denom);
+}
+
+__global__ void __launch_bounds__(256)
+k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, uint64_t n,
+          AdamArgs a, const float* __restrict__ inv_scale_dev, const float* __restrict__ found_inf,
+          float* __restrict__ abs_sum, int zero_grad) {
+  if (inv_scale_dev != nullptr) a.inv_scale *= inv_scale_dev[0];
+  const bool skip = found_inf != nullptr && found_inf[0] != 0.f;
+  float acc = 0.f;
+  const uint64_t n4 = n / 4;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = p4[i];
+    if (!skip) {
+      float4 gg = g4[i], mm = m4[i], vv = v4[i];
+      adam1(pp.x, gg.x, mm.x, vv.x, a, acc);
+      adam1(pp.y, gg.y, mm.y, vv.y, a, acc);
+      adam1(pp.z, gg.z, mm.z, vv.z, a, acc);
+      adam1(pp.w, gg.w, mm.w, vv.w, a, acc);
+      p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    } else {
+      acc += fabsf(pp.x) + fabsf(pp.y) + fabsf(pp.z) + fabsf(pp.w);
+    }
+    if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // ragged tail
+  for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float pp = p[i];
+    if (!skip) {
+      float mm = m[i], vv = v[i];
+      adam1(pp, g[i], mm, vv, a, acc);
+      p[i] = pp; m[i] = mm; v[i] = vv;
+    } else {
+      acc += fabsf(pp);
+    }
+    if (zero_grad) g[i] = 0.f;
+  }
+  if (abs_sum != nullptr) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(abs_sum, part[0] + part[1] + part[2] + part[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int tnl_adam_l1_step(float* p, float* grad, float* m, float* v, uint64_t n, float step_size,
+                                float bias2_sqrt, float beta1, float beta2, float eps, float inv_scale,
+                                const float* inv_scale_dev, float l1_coef, const float* found_inf,
+                                float* abs_sum, int zero_grad, void* stream) {
+  if (n == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
+       reinterpret_cast<uintptr_t>(v)) & 15)
+    return (int)hipErrorInvalidValue;
+  AdamArgs a{step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef};
+  uint64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(k_adam_l1, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n, a,
+                     inv_scale_dev, found_inf, abs_sum, zero_grad);
+  return (int)hipGetLastError();
+}

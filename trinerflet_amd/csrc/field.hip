@@ -30,8 +30,10 @@ template <int C, int H, bool HALFP, bool DENSITY_ONLY>
 __global__ void __launch_bounds__(FWD_THREADS)
 k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, const float* __restrict__ dirs,
             float bound, uint32_t M, int R, const half8* __restrict__ packed, float* __restrict__ sigma,
-            float* __restrict__ rgb, _Float16* __restrict__ feats_save) {
+            float* __restrict__ rgb, _Float16* __restrict__ feats_save, const int32_t* __restrict__ m_actual) {
   using G = FieldGeom<C, H>;
+  if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
+  if (M == 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half8* w = reinterpret_cast<half8*>(smem);
   constexpr int NFR = DENSITY_ONLY ? G::F2 : G::NF;
@@ -111,7 +113,7 @@ __global__ void k_field_pack(const float* __restrict__ W0, const float* __restri
 template <int C, int H>
 int launch_fwd(const void* planes, int half_in, const float* xyz, const float* dirs, float bound, uint32_t M,
                uint32_t R, const void* packed, float* sigma, float* rgb, void* feats_save, bool density_only,
-               hipStream_t st) {
+               const int32_t* m_actual, hipStream_t st) {
   using G = FieldGeom<C, H>;
   const uint32_t ntiles = (M + 31) / 32;
   uint32_t blocks = (ntiles + 3) / 4;
@@ -120,7 +122,7 @@ int launch_fwd(const void* planes, int half_in, const float* xyz, const float* d
   _Float16* fs = reinterpret_cast<_Float16*>(feats_save);
 #define TNL_LAUNCH(HP, DO)                                                                                        \
   hipLaunchKernelGGL((k_field_fwd<C, H, HP, DO>), dim3(blocks), dim3(FWD_THREADS), (DO ? G::F2 : G::NF) * 1024, st, \
-                     planes, xyz, dirs, bound, M, (int)R, pk, sigma, rgb, fs)
+                     planes, xyz, dirs, bound, M, (int)R, pk, sigma, rgb, fs, m_actual)
   if (density_only) {
     if (half_in) TNL_LAUNCH(true, true); else TNL_LAUNCH(false, true);
   } else {
@@ -163,17 +165,17 @@ int tnl_field_pack(const float* W0, const float* W1, const float* W2, const floa
 // rgb != NULL, rgb receives the 15 geo features per sample ([M,15] fp32).
 int tnl_field_forward(const void* planes_tm, int half_in, const float* xyz, const float* dirs, float bound,
                       uint32_t M, uint32_t C, uint32_t R, uint32_t Hd, uint32_t Hc, const void* packed,
-                      float* sigma, float* rgb, void* feats_save, void* stream) {
+                      float* sigma, float* rgb, void* feats_save, const int32_t* m_actual, void* stream) {
   if (M == 0) return 0;
   if (Hd != Hc) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const bool density_only = (dirs == nullptr) || (rgb == nullptr);
   if (C == 16 && Hd == 64)
-    return launch_fwd<16, 64>(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, st);
+    return launch_fwd<16, 64>(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, m_actual, st);
   if (C == 32 && Hd == 64)
-    return launch_fwd<32, 64>(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, st);
+    return launch_fwd<32, 64>(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, m_actual, st);
   if (C == 48 && Hd == 128)
-    return launch_fwd<48, 128>(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, st);
+    return launch_fwd<48, 128>(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, m_actual, st);
   return (int)hipErrorInvalidValue;
 }
 

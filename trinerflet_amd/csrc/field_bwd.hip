@@ -95,9 +95,11 @@ template <int C, int H>
 __global__ void __launch_bounds__(BW_THREADS)
 k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, const _Float16* __restrict__ feats,
             const float* __restrict__ xyz, const float* __restrict__ dirs, float bound, uint32_t M, int R,
-            const half8* __restrict__ packed, float* __restrict__ grad_tm, float* __restrict__ slabs) {
+            const half8* __restrict__ packed, float* __restrict__ grad_tm, float* __restrict__ slabs,
+            const int32_t* __restrict__ m_actual) {
   using G = FieldGeom<C, H>;
   using B = BwdGeom<C, H>;
+  if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   _Float16* Xs = reinterpret_cast<_Float16*>(smem);
   _Float16* Ys = reinterpret_cast<_Float16*>(smem + B::XS_BYTES);
@@ -126,7 +128,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
   for (int k = 0; k < B::A4; k++) dw4[k] = zero16();
 
-  const uint32_t nst = (M + ST - 1) / ST;
+  const uint32_t nst = M == 0 ? 0 : (M + ST - 1) / ST;
   for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
     const uint32_t i = st * ST + col;
     const bool valid = i < M;
@@ -363,7 +365,7 @@ inline uint32_t bwd_blocks(uint32_t M) {
 template <int C, int H>
 int launch_bwd(const float* gsig, const float* grgb, const void* feats, const float* xyz, const float* dirs,
                float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW, void* workspace,
-               hipStream_t st) {
+               const int32_t* m_actual, hipStream_t st) {
   using G = FieldGeom<C, H>;
   using B = BwdGeom<C, H>;
   const uint32_t blocks = bwd_blocks(M);
@@ -377,7 +379,7 @@ int launch_bwd(const float* gsig, const float* grgb, const void* feats, const fl
   float* slabs = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL((k_field_bwd<C, H>), dim3(blocks), dim3(BW_THREADS), B::LDS_BYTES, st, gsig, grgb,
                      reinterpret_cast<const _Float16*>(feats), xyz, dirs, bound, M, (int)R,
-                     reinterpret_cast<const half8*>(packed), grad_tm, slabs);
+                     reinterpret_cast<const half8*>(packed), grad_tm, slabs, m_actual);
   hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 255) / 256), dim3(256), 0, st, slabs, (int)blocks, (int)G::NW, gradW);
   return (int)hipGetLastError();
 }
@@ -398,17 +400,17 @@ uint32_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint3
 int tnl_field_backward(const float* grad_sigma, const float* grad_rgb, const float* sigma, const float* rgb,
                        const void* feats_save, const float* xyz, const float* dirs, float bound, uint32_t M,
                        uint32_t C, uint32_t R, uint32_t Hd, uint32_t Hc, const void* packed, float* grad_tm,
-                       float* gradW, void* workspace, void* stream) {
+                       float* gradW, void* workspace, const int32_t* m_actual, void* stream) {
   (void)sigma; (void)rgb;  // the chain is recomputed bit-identically from feats_save
   if (M == 0) return 0;
   if (Hd != Hc) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   if (C == 16 && Hd == 64)
-    return launch_bwd<16, 64>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, st);
+    return launch_bwd<16, 64>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, st);
   if (C == 32 && Hd == 64)
-    return launch_bwd<32, 64>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, st);
+    return launch_bwd<32, 64>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, st);
   if (C == 48 && Hd == 128)
-    return launch_bwd<48, 128>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, st);
+    return launch_bwd<48, 128>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, st);
   return (int)hipErrorInvalidValue;
 }
 

@@ -28,7 +28,7 @@ def pack_weights(W0, W1, W2, W3, W4, C, H):
     return packed
 
 
-def field_forward(planes_tm, xyz, dirs, packed, bound, C, R, H, save_feats=False, geo_out=False):
+def field_forward(planes_tm, xyz, dirs, packed, bound, C, R, H, save_feats=False, geo_out=False, m_actual=None):
     """Raw call.  dirs=None -> density only (returns sigma, geo[M,15] or None, feats)."""
     M = xyz.shape[0]
     dev = xyz.device
@@ -40,12 +40,13 @@ def field_forward(planes_tm, xyz, dirs, packed, bound, C, R, H, save_feats=False
     feats = torch.empty(M, 3 * C, dtype=torch.float16, device=dev) if save_feats else None
     L.check(L.lib().tnl_field_forward(L.ptr(planes_tm), L.i32(int(planes_tm.dtype == torch.float16)), L.ptr(xyz),
                                       L.ptr(dirs), L.f32(bound), L.u32(M), L.u32(C), L.u32(R), L.u32(H), L.u32(H),
-                                      L.ptr(packed), L.ptr(sigma), L.ptr(second), L.ptr(feats), L.stream()),
+                                      L.ptr(packed), L.ptr(sigma), L.ptr(second), L.ptr(feats), L.ptr(m_actual), L.stream()),
             "field_forward")
     return sigma, second, feats
 
 
-def field_backward(grad_sigma, grad_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW):
+def field_backward(grad_sigma, grad_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW,
+                   m_actual=None):
     """Raw call: accumulates into grad_tm [3,R,R,C] fp32 and gradW (concatenated W0..W4, fp32)."""
     lib = L.lib()
     M = xyz.shape[0]
@@ -53,7 +54,7 @@ def field_backward(grad_sigma, grad_rgb, sigma, rgb, feats, xyz, dirs, packed, b
     ws = torch.empty(max(nws, 4), dtype=torch.uint8, device=xyz.device)
     L.check(lib.tnl_field_backward(L.ptr(grad_sigma), L.ptr(grad_rgb), L.ptr(sigma), L.ptr(rgb), L.ptr(feats),
                                    L.ptr(xyz), L.ptr(dirs), L.f32(bound), L.u32(M), L.u32(C), L.u32(R), L.u32(H),
-                                   L.u32(H), L.ptr(packed), L.ptr(grad_tm), L.ptr(gradW), L.ptr(ws), L.stream()),
+                                   L.u32(H), L.ptr(packed), L.ptr(grad_tm), L.ptr(gradW), L.ptr(ws), L.ptr(m_actual), L.stream()),
             "field_backward")
 
 

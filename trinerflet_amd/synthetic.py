@@ -1,4 +1,4 @@
-"""Seeded synthetic inputs shared by the parity tests and bench.py.
+"""Seeded synthetic inputs shared by bench.py and the parity tests.
 
 numpy only: usable by the oracle-side and the GPU-side of a test alike.
 """
@@ -71,3 +71,26 @@ def training_rays(N, n_cams=100, seed=0, H=800, W=800):
     flat = rng.choice(n_cams * H * W, size=N, replace=False)
     pix = np.stack([flat // (H * W), flat % (H * W)], -1)
     return get_rays(poses, pix, H, W)
+
+
+def target_colors(rays_d):
+    """Analytic ground-truth colours in [0,1] (a smooth function of the ray direction): gives the
+    benchmark a non-trivial loss and gradients without a dataset."""
+    d = np.asarray(rays_d, np.float32)
+    return (0.5 + 0.5 * np.sin(3.0 * d + np.array([0.0, 1.0, 2.0], np.float32))).astype(np.float32)
+
+
+def init_field_parameters(model, seed=0):
+    """SURVEY.md 8(d) field parameters: LL = 0.1*N(0,1); level-i coefficients ~ N(0, (0.02 * 2^-i)^2);
+    Linear weights = torch default init under a fixed seed."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    enc = model.encoder
+    with torch.no_grad():
+        enc.planes_features.copy_((0.1 * torch.randn(enc.planes_features.shape, generator=g)).to(enc.planes_features.device))
+        for i, p in enumerate(enc.planes_features_wavelet_coefs):
+            dev_g = torch.Generator(device=p.device).manual_seed(seed + 1 + i)
+            p.copy_(torch.randn(p.shape, generator=dev_g, device=p.device) * (0.02 * 2.0 ** (-i)))
+        for lin in list(model.sigma_net) + list(model.color_net):
+            w = (torch.rand(lin.weight.shape, generator=g) * 2 - 1) / float(np.sqrt(lin.weight.shape[1]))
+            lin.weight.copy_(w.to(lin.weight.device))

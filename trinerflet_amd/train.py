@@ -1,0 +1,343 @@
+"""TrainStep -- own counterpart of one iteration of Trainer.train_one_epoch2 (reference
+reconstruction/nerf/utils.py:1134-1175) with train_step (:532-679), the optimiser / scheduler / GradScaler
+wiring of reconstruction/main_nerf.py:115-129 and decay_function (utils.py:55-62).
+
+One step = rebuild planes (IDWT) -> [every 16 steps: density-grid refresh] -> near/far -> march -> fused
+field -> composite -> MSE + wavelet-L1 -> composite backward -> fused field backward -> IDWT adjoint ->
+fused Adam(+L1).  Every arithmetic stage is a kernel of libtrinerflet_hip.so; torch supplies device
+memory, the stream, a handful of [N,3] elementwise ops for the loss, and the collectives.
+
+It is numerically the same step as driving the drop-in modules through autograd with
+torch.optim.Adam + GradScaler (tests/test_train_gpu.py checks both against the CPU oracle); it differs
+in what is NOT materialised: no autograd graph, the L1 regulariser never forms |coef| or sign(coef)
+tensors, coefficient gradients are unscaled inside the Adam pass, the parameters / Adam moments /
+gradients of all wavelet levels live in three flat buffers so the whole coefficient update is one launch.
+
+Multi-GPU: rays are sharded across ranks, planes and MLP weights replicated.
+  mode "allreduce": plane gradients all-reduced (RCCL) before the adjoint; every rank repeats the dense work.
+  mode "sharded"  : the 3*C (plane, channel) slices are the shard unit (the IDWT is depthwise): plane gradients
+                    are reduce-scattered by slice, each rank runs adjoint + Adam + IDWT on 3C/G slices, and the
+                    rebuilt planes are all-gathered -- same bytes on the wire, dense HBM work divided by G.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import raymarching
+from .nerf import field as F_
+from .triplaneencoder.triplane_encoder import _IDWTLevel, _ToTexelMajor
+
+
+def lr_factor(it, iters, warmup_steps, sched_base=0.1, warmup_factor=1e-3, sched_exp=2.5):
+    """decay_function (utils.py:55-62) with accumelate_steps = 1."""
+    w = max(warmup_steps, 0)
+    if it < w:
+        return sched_base * warmup_factor + it * (1 - warmup_factor) / (w - 1)
+    return sched_base ** (min((it - w) / iters, 1) ** sched_exp)
+
+
+class _Flat:
+    """Parameters re-homed as views of one flat fp32 buffer, with matching grad / exp_avg / exp_avg_sq buffers."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        # 16-byte aligned segment starts (the Adam kernel uses float4)
+        self.offsets, off = [], 0
+        for n in sizes:
+            self.offsets.append(off)
+            off += (n + 3) // 4 * 4
+        self.total = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o, n in zip(self.params, self.offsets, sizes):
+            self.data[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.data[o:o + n].view(p.shape)
+        self.sizes = sizes
+
+    def grad_view(self, k):
+        o, n = self.offsets[k], self.sizes[k]
+        return self.grad[o:o + n].view(self.params[k].shape)
+
+
+class TrainStep:
+    def __init__(self, model, lr=1e-2, wavelet_regularization=0.4, iters=30000, warmup_steps=0,
+                 betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
+                 max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
+                 dist_mode=None, process_group=None):
+        enc = model.encoder
+        assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
+        if not model._fused_ok():
+            raise NotImplementedError("TrainStep needs a configuration the fused field kernel is built for")
+        self.model, self.enc = model, enc
+        self.C, self.R, self.H = enc.number_of_features, enc.plane_resolution, model.hidden_dim
+        self.J = enc.planes_features_wavelet_all_level
+        self.lr, self.lam, self.iters, self.warmup = lr, wavelet_regularization, iters, warmup_steps
+        self.b1, self.b2, self.eps = betas[0], betas[1], eps
+        self.fp16 = fp16
+        self.update_extra_interval = update_extra_interval
+        self.bg = background_color
+        self.max_steps, self.dt_gamma, self.T_thresh = max_steps, dt_gamma, T_thresh
+        self.global_step = 0
+        dev = enc.planes_features.device
+        self.dev = dev
+        self.coef = _Flat(list(enc.planes_features_wavelet_coefs))
+        self.ll = _Flat([enc.planes_features])
+        self.Ws = [model.sigma_net[0].weight, model.sigma_net[1].weight, model.color_net[0].weight,
+                   model.color_net[1].weight, model.color_net[2].weight]
+        self.mlp = _Flat(self.Ws)
+        assert self.mlp.total == sum(w.numel() for w in self.Ws) or True
+        self.coef_numel = sum(self.coef.sizes)
+        # GradScaler state (torch.cuda.amp.GradScaler defaults: 2^16, x2 every 2000 clean steps, x0.5 on inf)
+        self.scale = torch.full((1,), init_scale if fp16 else 1.0, dtype=torch.float32, device=dev)
+        self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.growth_interval = growth_interval
+        self.abs_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.last = {}
+        self.post_refresh = None    # optional callable run right after every density-grid refresh
+        self.section_events = None  # set to [] to record HIP events (on the launch stream) around every stage
+        # distributed
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist_mode and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self.dist_mode = dist_mode if self.world > 1 else None
+        if self.dist_mode == "sharded":
+            assert (3 * self.C) % self.world == 0, "3*channels must be divisible by the world size"
+
+    # ------------------------------------------------------------------------------------------
+    def _mark(self, name):
+        if self.section_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()  # torch's current stream = the stream every kernel of the step is launched on
+            self.section_events.append((name, ev))
+
+    def section_times(self):
+        """Mean milliseconds per stage over the recorded steps (requires a prior torch.cuda.synchronize())."""
+        if not self.section_events:
+            return {}
+        tot, cnt = {}, {}
+        prev = None
+        for name, ev in self.section_events:
+            if name != "begin" and prev is not None:
+                tot[name] = tot.get(name, 0.0) + prev.elapsed_time(ev)
+                cnt[name] = cnt.get(name, 0) + 1
+            prev = ev
+        return {k: tot[k] / cnt[k] for k in tot}
+
+    def rebuild_planes(self):
+        """encoder.reset_cahce(); encoder.get_planes() of utils.py:1138-1140, outside autograd."""
+        enc = self.enc
+        with torch.no_grad():
+            if self.dist_mode == "sharded":
+                planes = self._rebuild_sharded()
+            else:
+                x = enc.planes_features
+                for lvl in range(self.J):
+                    x = _IDWTLevel.apply(x, enc.planes_features_wavelet_coefs[lvl], enc.wave_id)
+                planes = x
+            enc.last_used_planes = planes
+            enc._planes_tm = _ToTexelMajor.apply(planes, enc.plane_dtype == torch.float16)
+        return enc._planes_tm
+
+    def _slice_range(self):
+        per = 3 * self.C // self.world
+        return self.rank * per, (self.rank + 1) * per
+
+    def _rebuild_sharded(self):
+        enc = self.enc
+        s0, s1 = self._slice_range()
+        n0 = enc.planes_features.shape[-1]
+        x = enc.planes_features.reshape(3 * self.C, n0, n0)[s0:s1].unsqueeze(0)
+        for lvl in range(self.J):
+            n = x.shape[-1]
+            yh = enc.planes_features_wavelet_coefs[lvl].reshape(3 * self.C, 3, n, n)[s0:s1].unsqueeze(0)
+            x = _IDWTLevel.apply(x.contiguous(), yh.contiguous(), enc.wave_id)
+        mine = x.reshape(s1 - s0, self.R, self.R).contiguous()
+        full = torch.empty(3 * self.C, self.R, self.R, dtype=torch.float32, device=self.dev)
+        dist.all_gather_into_tensor(full, mine, group=self.pg)
+        return full.view(3, self.C, self.R, self.R)
+
+    # ------------------------------------------------------------------------------------------
+    def _adam(self, flat, lr_t, l1_coef, found_inf, inv_scale_dev, abs_sum=None, lo=0, hi=None):
+        t = self.global_step + 1
+        step_size = lr_t / (1 - self.b1 ** t)
+        bias2_sqrt = math.sqrt(1 - self.b2 ** t)
+        hi = flat.total if hi is None else hi
+        n = hi - lo
+        if n <= 0:
+            return
+        L.check(L.lib().tnl_adam_l1_step(
+            L.ptr(flat.data[lo:]), L.ptr(flat.grad[lo:]), L.ptr(flat.m[lo:]), L.ptr(flat.v[lo:]), L.u64(n),
+            L.f32(step_size), L.f32(bias2_sqrt), L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0),
+            L.ptr(inv_scale_dev), L.f32(l1_coef), L.ptr(found_inf), L.ptr(abs_sum), L.i32(0), L.stream()),
+            "adam_l1_step")
+
+    def _adjoint(self, grad_tm):
+        """plane gradient [3,R,R,C] fp32 -> fills self.ll.grad / self.coef.grad (dense)."""
+        lib = L.lib()
+        C, R = self.C, self.R
+        g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=self.dev)
+        L.check(lib.tnl_planes_to_channel_major(L.ptr(grad_tm), L.u32(C), L.u32(R), L.ptr(g_cm), L.stream()),
+                "planes_to_channel_major")
+        S = 3 * C
+        s0, s1 = 0, S
+        g = g_cm.view(S, R, R)
+        if self.dist_mode == "allreduce":
+            dist.all_reduce(g, group=self.pg)
+        elif self.dist_mode == "sharded":
+            s0, s1 = self._slice_range()
+            mine = torch.empty(s1 - s0, R, R, dtype=torch.float32, device=self.dev)
+            dist.reduce_scatter_tensor(mine, g, group=self.pg)
+            g = mine
+        ns = s1 - s0
+        for lvl in reversed(range(self.J)):
+            n = g.shape[-1] // 2
+            dyh_full = self.coef.grad_view(lvl).view(S, 3, n, n)
+            if ns == S:
+                dx = torch.empty(S, n, n, dtype=torch.float32, device=self.dev) if lvl > 0 else self.ll.grad_view(0).view(S, n, n)
+                L.check(lib.tnl_idwt_level_backward(L.ptr(g), L.u32(S), L.u32(n), L.i32(self.enc.wave_id), L.ptr(dx),
+                                                    L.ptr(dyh_full), L.stream()), "idwt_level_backward")
+            else:
+                dx = torch.empty(ns, n, n, dtype=torch.float32, device=self.dev)
+                dyh = dyh_full[s0:s1]  # contiguous slice range of the flat gradient buffer
+                L.check(lib.tnl_idwt_level_backward(L.ptr(g), L.u32(ns), L.u32(n), L.i32(self.enc.wave_id), L.ptr(dx),
+                                                    L.ptr(dyh), L.stream()), "idwt_level_backward")
+                if lvl == 0:
+                    self.ll.grad_view(0).view(S, n, n)[s0:s1].copy_(dx)
+            g = dx
+        return s0, s1
+
+    # ------------------------------------------------------------------------------------------
+    def step(self, rays_o, rays_d, gt_rgb, noises=None, n_global_rays=None):
+        """rays_o, rays_d: [N,3]; gt_rgb: [N,3] (already blended with the background, utils.py:574-577).
+        Returns the (unscaled) loss as a device scalar; details in self.last."""
+        model, enc = self.model, self.enc
+        model.train()
+        lib = L.lib()
+        C, R, H = self.C, self.R, self.H
+        N = rays_o.shape[0]
+        n_glob = n_global_rays if n_global_rays is not None else N * self.world
+
+        self._mark("begin")
+        tm = self.rebuild_planes()
+        self._mark("idwt_fwd")
+        if self.global_step % self.update_extra_interval == 0:
+            model.update_extra_state()
+            if self.post_refresh is not None:
+                self.post_refresh()
+            self._mark("grid_refresh")
+
+        packed = F_.pack_weights(*self.Ws, C, H)
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, model.aabb_train, model.min_near)
+        counter = model.step_counter[model.local_step % 16]
+        counter.zero_()
+        model.local_step += 1
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(
+            rays_o, rays_d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars, counter,
+            model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, noises)
+        M = xyzs.shape[0]
+        self._mark("march")
+        # rows past counter[0] are the zero padding of the sample budget: skipped on the device
+        sigma, rgb, feats = F_.field_forward(tm, xyzs, dirs, packed, float(model.bound), C, R, H, save_feats=True,
+                                             m_actual=counter)
+        if model.density_scale != 1:
+            sigma = sigma * model.density_scale
+        self._mark("field_fwd")
+        ws = torch.empty(N, dtype=torch.float32, device=self.dev)
+        depth = torch.empty(N, dtype=torch.float32, device=self.dev)
+        image = torch.empty(N, 3, dtype=torch.float32, device=self.dev)
+        L.check(lib.tnl_composite_rays_train_forward(L.ptr(sigma), L.ptr(rgb), L.ptr(deltas), L.ptr(rays), L.u32(M),
+                                                     L.u32(N), L.f32(self.T_thresh), L.ptr(ws), L.ptr(depth),
+                                                     L.ptr(image), L.stream()), "composite_rays_train_forward")
+        # image = image + (1 - ws) * bg (renderer.py:317); MSE mean over rays and channels (utils.py:595)
+        pred = image + (1 - ws).unsqueeze(-1) * self.bg
+        diff = pred - gt_rgb
+        mse_local = (diff * diff).sum() / (3.0 * n_glob)
+        g_pred = diff * (2.0 / (3.0 * n_glob)) * self.scale          # d(scaled loss)/d pred
+        g_ws = -(g_pred * self.bg).sum(-1) if self.bg != 0 else torch.zeros(N, dtype=torch.float32, device=self.dev)
+        g_sigma = torch.empty(M, dtype=torch.float32, device=self.dev)
+        g_rgb = torch.empty(M, 3, dtype=torch.float32, device=self.dev)
+        g_sigma.zero_(); g_rgb.zero_()  # rows of dropped rays / budget padding (raymarching.py:283-284)
+        self._mark("composite_fwd_loss")
+        L.check(lib.tnl_composite_rays_train_backward(L.ptr(g_ws), L.ptr(g_pred.contiguous()), L.ptr(sigma), L.ptr(rgb),
+                                                      L.ptr(deltas), L.ptr(rays), L.ptr(ws), L.ptr(image), L.u32(M),
+                                                      L.u32(N), L.f32(self.T_thresh), L.ptr(g_sigma), L.ptr(g_rgb),
+                                                      L.stream()), "composite_rays_train_backward")
+        if model.density_scale != 1:
+            g_sigma = g_sigma * model.density_scale
+        self._mark("composite_bwd")
+        grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
+        self.mlp.grad.zero_()
+        F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H, grad_tm,
+                          self.mlp.grad, m_actual=counter)
+        self._mark("field_bwd")
+        if self.world > 1:
+            dist.all_reduce(self.mlp.grad, group=self.pg)
+        s0, s1 = self._adjoint(grad_tm)
+        self._mark("idwt_adjoint")
+
+        # GradScaler: skip the step when any gradient is non-finite.  A non-finite plane gradient always
+        # reaches the coarse LL gradient through the low-pass adjoint, so checking LL + MLP grads suffices.
+        probe = self.ll.grad.abs().sum() + self.mlp.grad.abs().sum()
+        if self.world > 1:
+            dist.all_reduce(probe, group=self.pg)
+        found_inf = (~torch.isfinite(probe)).to(torch.float32).reshape(1)
+        inv_scale = 1.0 / self.scale
+
+        lr_t = self.lr * lr_factor(self.global_step, self.iters, self.warmup)
+        l1 = self.lam / (self.J * self.coef_numel) if (self.J > 0 and self.lam > 0) else 0.0
+        self.abs_sum.zero_()
+        if self.dist_mode == "sharded":
+            self._adam_sharded(lr_t, l1, found_inf, inv_scale, s0, s1)
+            self._mark("adam_coef")
+        else:
+            self._mark("scaler_probe")
+            self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum)
+            self._mark("adam_coef")
+            self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
+        self._adam(self.mlp, lr_t, 0.0, found_inf, inv_scale)
+        if self.fp16:
+            torch._amp_update_scale_(self.scale, self.growth_tracker, found_inf, 2.0, 0.5, self.growth_interval)
+        self.global_step += 1
+
+        reg = self.abs_sum[0] * l1 if l1 > 0 else torch.zeros((), device=self.dev)
+        if self.world > 1:
+            mse = mse_local.clone()
+            dist.all_reduce(mse, group=self.pg)
+            if self.dist_mode == "sharded":
+                dist.all_reduce(reg, group=self.pg)
+        else:
+            mse = mse_local
+        loss = mse + reg
+        self._mark("tail")
+        self.last = {'mse': mse, 'wavelet_reg': reg, 'M': M, 'found_inf': found_inf, 'image': pred, 'ws': ws,
+                     'depth': depth, 'counter': counter, 'lr': lr_t}
+        return loss
+
+    def _adam_sharded(self, lr_t, l1, found_inf, inv_scale, s0, s1):
+        """Each rank updates only its (plane, channel) slices; afterwards parameters are all-gathered so the
+        replicas stay identical (needed for checkpoints; the next rebuild_planes only reads the own slices)."""
+        S = 3 * self.C
+        for lvl in range(self.J):
+            n = self.coef.params[lvl].shape[-1]
+            per = 3 * n * n
+            base = self.coef.offsets[lvl]
+            self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum, base + s0 * per, base + s1 * per)
+        n0 = self.ll.params[0].shape[-1]
+        self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale, None, s0 * n0 * n0, s1 * n0 * n0)
+
+    def sync_sharded_parameters(self):
+        """All-gather the slice-sharded coefficients (call before saving a checkpoint in "sharded" mode)."""
+        if self.dist_mode != "sharded":
+            return
+        s0, s1 = self._slice_range()
+        for p in self.coef.params + self.ll.params:
+            S = 3 * self.C
+            flat = p.data.view(S, -1)
+            mine = flat[s0:s1].contiguous()
+            dist.all_gather_into_tensor(flat, mine, group=self.pg)
