@@ -56,13 +56,43 @@ def triplane_features(planes, xyz, bound):
     return s.permute(2, 0, 1, 3).squeeze(-1).reshape(xyz.shape[0], -1)
 
 
-def mlp(feats, dirs, W, fp16=False):
+class _RoundFp16(torch.autograd.Function):
+    """Round the VALUE to fp16 with a straight-through gradient.  (Plain `x.half().float()` must not be used
+    here: autograd of the dtype casts also rounds the GRADIENT to fp16, in unscaled units.)"""
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def round_fp16(x):
+    return _RoundFp16.apply(x)
+
+
+class _RoundGradFp16(torch.autograd.Function):
+    """Identity whose backward rounds the incoming gradient to fp16: the backward GEMMs of an fp16 Linear
+    (torch autocast in the reference, MFMA operands in the kernel) see their dY operand in half precision."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.half().float()
+
+
+def mlp(feats, dirs, W, fp16=False, grad_fp16=False):
     """W = [W0,W1,W2,W3,W4] in nn.Linear layout.  fp16=True rounds Linear inputs and weights to half (the
-    kernel's MFMA operand precision) while accumulating in fp32."""
+    kernel's MFMA operand precision) while accumulating in fp32; grad_fp16=True also rounds every dY."""
     def lin(x, w):
         if fp16:
-            return F.linear(x.half().float(), w.half().float())
-        return F.linear(x, w)
+            y = F.linear(round_fp16(x), round_fp16(w))
+        else:
+            y = F.linear(x, w)
+        return _RoundGradFp16.apply(y) if grad_fp16 else y
     h = torch.relu(lin(feats, W[0]))
     o = lin(h, W[1])
     sigma = _TruncExp.apply(o[:, 0])
@@ -73,9 +103,9 @@ def mlp(feats, dirs, W, fp16=False):
     return sigma, rgb
 
 
-def field(planes, xyz, dirs, W, bound, fp16=False, plane_half=False):
-    p = planes.half().float() if plane_half else planes
-    return mlp(triplane_features(p, xyz, bound), dirs, W, fp16=fp16)
+def field(planes, xyz, dirs, W, bound, fp16=False, plane_half=False, grad_fp16=False):
+    p = round_fp16(planes) if plane_half else planes
+    return mlp(triplane_features(p, xyz, bound), dirs, W, fp16=fp16, grad_fp16=grad_fp16)
 
 
 def synthesis_filters(wave):

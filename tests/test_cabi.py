@@ -1,0 +1,107 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU and exports
+every symbol include/trinerflet_hip.h declares; the Python mirrors expose the reference's names; the product
+path refuses to run without the library or without a HIP device (no CPU fallback)."""
+import ctypes
+import inspect
+import os
+
+import pytest
+import torch
+
+
+def test_library_exports_every_declared_symbol():
+    from trinerflet_amd import _lib, build
+    lib = build.build()
+    h = ctypes.CDLL(lib)
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 27
+    missing = [s for s in declared if not hasattr(h, s)]
+    assert not missing, missing
+    assert h.tnl_abi_version() == 1
+    h.tnl_march_rays_train_workspace.restype = ctypes.c_uint32
+    assert h.tnl_march_rays_train_workspace(ctypes.c_uint32(60000)) >= 60000 + 235
+    h.tnl_field_packed_bytes.restype = ctypes.c_uint32
+    assert h.tnl_field_packed_bytes(32, 64, 64) == 60 * 1024       # 32 forward + 28 transposed fragments
+    assert h.tnl_field_packed_bytes(32, 64, 128) == 0              # unsupported shape -> 0, not a crash
+
+
+def test_reference_api_surface():
+    """Names and argument order of the reference modules."""
+    from trinerflet_amd import raymarching
+    want = {
+        "near_far_from_aabb": ["rays_o", "rays_d", "aabb", "min_near"],
+        "morton3D": ["coords"], "morton3D_invert": ["indices"], "packbits": ["grid", "thresh", "bitfield"],
+        "march_rays_train": ["rays_o", "rays_d", "bound", "density_bitfield", "C", "H", "nears", "fars", "step_counter",
+                             "mean_count", "perturb", "align", "force_all_rays", "dt_gamma", "max_steps"],
+        "composite_rays_train": ["sigmas", "rgbs", "deltas", "rays", "T_thresh"],
+        "march_rays": ["n_alive", "n_step", "rays_alive", "rays_t", "rays_o", "rays_d", "bound", "density_bitfield", "C",
+                       "H", "near", "far", "align", "perturb", "dt_gamma", "max_steps"],
+        "composite_rays": ["n_alive", "n_step", "rays_alive", "rays_t", "sigmas", "rgbs", "deltas", "weights_sum",
+                           "depth", "image", "T_thresh"],
+        "sph_from_ray": ["rays_o", "rays_d", "radius"],
+    }
+    for name, args in want.items():
+        fn = getattr(raymarching, name)
+        cls = fn.__self__
+        got = list(inspect.signature(cls.forward).parameters)[1:]
+        assert got[:len(args)] == args, (name, got)
+    from trinerflet_amd.shencoder import SHEncoder
+    assert SHEncoder(3, 4).output_dim == 16
+    from trinerflet_amd.triplaneencoder.triplane_encoder import TriPlaneVolume
+    vol = TriPlaneVolume(number_of_features=16, plane_resolution=512, inner_multi_res_scale=8)
+    keys = set(vol.state_dict())
+    assert {"planes_features", "plane_axes", "plane_normals", "planes_features_wavelet_coefs.0",
+            "planes_features_wavelet_coefs.2", "idwt.g0_col", "idwt.g1_row"} <= keys
+    assert [tuple(p.shape) for p in vol.planes_features_wavelet_coefs] == [(3, 16, 3, 64, 64), (3, 16, 3, 128, 128),
+                                                                          (3, 16, 3, 256, 256)]
+    assert tuple(vol.planes_features.shape) == (3, 16, 64, 64) and vol.output_dim == 48
+    for m in ("forward", "get_planes", "reset_cahce", "get_wavelet_features", "get_wavelet_features_upscaled",
+              "get_lbound_scale", "sample_from_planes", "get_params"):
+        assert hasattr(vol, m)
+    with pytest.raises(NotImplementedError):
+        TriPlaneVolume(number_of_features=16, plane_resolution=512, inner_multi_res_scale=8, learn_rotation_axis=True)
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    net = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, triplane_channels=16,
+                      triplane_resolution=256, triplane_wavelet_levels=4, density_thresh=10)
+    sd = set(net.state_dict())
+    assert {"sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight", "color_net.2.weight", "aabb_train",
+            "aabb_infer", "density_grid", "density_bitfield", "step_counter", "encoder.planes_features"} <= sd
+    assert net.cascade == 2 and net.grid_size == 128 and net.density_bitfield.numel() == 2 * 128 ** 3 // 8
+    assert tuple(net.color_net[0].weight.shape) == (64, 31) and tuple(net.sigma_net[1].weight.shape) == (16, 64)
+    import trinerflet_amd
+    trinerflet_amd.install_dropin()
+    import raymarching as rm  # noqa: F401  (what reconstruction/nerf/renderer.py:9 imports)
+    from shencoder import SHEncoder as S2  # noqa: F401
+    from triplaneencoder.triplane_encoder import TriPlaneVolume as T2  # noqa: F401
+    from encoding import get_encoder  # noqa: F401
+    assert rm.march_rays_train is raymarching.march_rays_train
+
+
+def test_no_cpu_fallback():
+    """The hot path must fail loudly off-GPU: wrappers refuse CPU tensors, and a missing library raises."""
+    from trinerflet_amd import _lib
+    from trinerflet_amd.shencoder import SHEncoder
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            SHEncoder(3, 4)(torch.randn(4, 3))
+    saved = _lib.LIB_PATH, _lib._lib
+    try:
+        _lib.LIB_PATH, _lib._lib = os.path.join(os.path.dirname(saved[0]), "does_not_exist.so"), None
+        with pytest.raises(_lib.HipLibraryMissing):
+            _lib.lib()
+    finally:
+        _lib.LIB_PATH, _lib._lib = saved
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under trinerflet_amd/ or bench.py's product leg may import it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    for dp, _, files in os.walk(os.path.join(root, "trinerflet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|oracle/_build|trinerflet_oracle", text, re.M):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -74,7 +74,7 @@ def _relerr(a, b):
 def test_field_backward(cuda, C, H, R, M):
     """d(sigma,rgb)/d(planes, W0..W4) of the fused kernel vs torch autograd of the fp32 restatement.
     The kernel rounds MFMA operands (activations, weights and incoming gradients) to fp16, so the comparison
-    is norm-wise: relative L2 error of every gradient tensor below 1e-2 (measured ~1e-3)."""
+    is norm-wise: relative L2 error of every gradient tensor below 5e-3."""
     from trinerflet_amd.nerf import field as gfield
     from trinerflet_amd.triplaneencoder.triplane_encoder import _ToTexelMajor
     planes, xyz, dirs, W, bound = _make(C, H, R, M, seed=11)
@@ -94,9 +94,9 @@ def test_field_backward(cuda, C, H, R, M):
     ((s_g * a.to(cuda)).sum() + (c_g * b.to(cuda)).sum()).backward()
     for k, (wg, wo) in enumerate(zip(W_g, W_o)):
         e = _relerr(wg.grad.cpu().numpy(), wo.grad.numpy().astype(np.float64))
-        assert e < 1e-2, f"dW{k} rel err {e}"
+        assert e < 5e-3, f"dW{k} rel err {e}"
     e = _relerr(pl_g.grad.cpu().numpy(), pl_o.grad.numpy().astype(np.float64))
-    assert e < 1e-2, f"dplanes rel err {e}"
+    assert e < 5e-3, f"dplanes rel err {e}"
     # untouched texels must stay exactly zero
     untouched = (pl_o.grad == 0)
     assert float(pl_g.grad.cpu()[untouched].abs().max()) == 0.0

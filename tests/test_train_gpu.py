@@ -1,0 +1,154 @@
+"""A13: one optimisation step, three ways, at toy size:
+  (1) TrainStep            -- the fused step: raw C-ABI calls, flat buffers, fused Adam+L1
+  (2) drop-in modules      -- NeRFNetwork.render + torch autograd + torch.optim.Adam (how main_nerf.py drives it)
+  (3) CPU oracle           -- torch fp32 + the C oracle for marching/compositing
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref, field as ofield
+from trinerflet_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+C, R, SCALE, H, N, BOUND, LAM = 16, 64, 4, 64, 384, 1.5, 0.2
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _model(dev):
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=BOUND, cuda_ray=True, density_thresh=10, hidden_dim=H,
+                    hidden_dim_color=H, triplane_channels=C, triplane_resolution=R, triplane_wavelet_levels=SCALE,
+                    wavelet_type="bior6.8").to(dev)
+    synthetic.init_field_parameters(m, seed=3)
+    with torch.no_grad():  # larger detail coefficients so the regulariser and the data term both matter
+        for p in m.encoder.planes_features_wavelet_coefs:
+            p.mul_(5.0)
+    return m
+
+
+class _OracleComposite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sig, rgb, deltas, rays):
+        ws, dep, img = cref.composite_rays_train_forward(sig.numpy(), rgb.numpy(), deltas, rays, 1e-4)
+        ctx.save = (sig.numpy().copy(), rgb.numpy().copy(), deltas, rays, ws, img)
+        return torch.from_numpy(ws), torch.from_numpy(img)
+
+    @staticmethod
+    def backward(ctx, gws, gimg):
+        sig, rgb, deltas, rays, ws, img = ctx.save
+        gs, gc = cref.composite_rays_train_backward(gws.numpy(), gimg.numpy(), sig, rgb, deltas, rays, ws, img, 1e-4)
+        return torch.from_numpy(gs), torch.from_numpy(gc), None, None
+
+
+def test_one_step_three_ways(cuda):
+    from trinerflet_amd.train import TrainStep
+    o, d = synthetic.training_rays(N, n_cams=4, seed=7)
+    gt = synthetic.target_colors(d)
+    noise = np.random.default_rng(0).random(N).astype(np.float32)
+    bf = synthetic.sphere_bitfield(128, 2, BOUND, 0.8, 0.55)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+    base = _model(cuda)
+    base.density_bitfield.copy_(t(bf))
+    names = [n for n, _ in base.named_parameters()]
+    init = {n: p.detach().clone() for n, p in base.named_parameters()}
+
+    # ---------------- (3) CPU oracle
+    ll = init["encoder.planes_features"].cpu().clone().requires_grad_(True)
+    coefs = [init[f"encoder.planes_features_wavelet_coefs.{i}"].cpu().clone().requires_grad_(True) for i in range(2)]
+    W = [init[k].cpu().clone().requires_grad_(True) for k in
+         ("sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight", "color_net.1.weight", "color_net.2.weight")]
+    aabb = np.array([-BOUND] * 3 + [BOUND] * 3, np.float32)
+    nears, fars = cref.near_far_from_aabb(o, d, aabb, 0.2)
+    xyz, dirs, deltas, rays, counter = cref.march_rays_train(o, d, BOUND, bf, 2, 128, nears, fars, noise, N * 1024)
+    total = int(counter[0])
+    planes = ofield.build_planes_torch(ll, coefs, "bior6.8")
+    sig, rgb = ofield.field(planes, torch.from_numpy(xyz[:total]), torch.from_numpy(dirs[:total]), W, BOUND, fp16=True,
+                            plane_half=True)
+    ws, img = _OracleComposite.apply(sig, rgb, deltas[:total], rays)
+    mse = ((img - torch.from_numpy(gt)) ** 2).mean()           # background_color = 0
+    reg = ofield.wavelet_reg(coefs, LAM)
+    (mse + reg).backward()
+    g_mse_ll = ll.grad.clone()
+    opt = torch.optim.Adam([ll] + coefs + W, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    opt.step()
+
+    # ---------------- (1) fused step (GradScaler default initial scale 2^16: fp16 backward operands neither underflow nor overflow)
+    m1 = copy.deepcopy(base)
+    ts = TrainStep(m1, lr=1e-2, wavelet_regularization=LAM, iters=1000, warmup_steps=0, fp16=True, init_scale=65536.0,
+                   update_extra_interval=0)  # no density-grid refresh: keep the analytic bitfield
+    m1.mean_count = 0
+    loss1 = ts.step(t(o), t(d), t(gt), noises=t(noise))
+    assert int(ts.last["counter"][0]) == total                      # bit-exact sample count vs the oracle
+    assert abs(float(ts.last["mse"]) - float(mse)) < 2e-3 * float(mse)
+    assert abs(float(ts.last["wavelet_reg"]) - float(reg)) < 1e-5 * float(reg)
+    inv = 1.0 / 65536.0
+    assert _relerr(ts.ll.grad.cpu().numpy() * inv, g_mse_ll.numpy().reshape(-1)) < 1e-2
+
+    # ---------------- (2) drop-in modules + autograd + torch.optim.Adam
+    m2 = copy.deepcopy(base)
+    m2.train()
+    m2.mean_count = 0
+    opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    m2.encoder.reset_cahce(); m2.encoder.get_planes()
+    out = m2.render(t(o)[None], t(d)[None], staged=False, bg_color=0, perturb=True, force_all_rays=False,
+                    noises=t(noise), dt_gamma=0, max_steps=1024)
+    mse2 = ((out["image"][0] - t(gt)) ** 2).mean()
+    wf = m2.encoder.get_wavelet_features()
+    tot = sum(v.numel() for v in wf)
+    reg2 = LAM * sum(v.abs().mean() * (v.numel() / tot) for v in wf) / len(wf)     # utils.py:639-655
+    ((mse2 + reg2) * 65536.0).backward()          # scaler.scale(loss).backward()   (utils.py:1166)
+    for p in m2.parameters():                     # scaler.step(optimizer) unscales first  (:1170)
+        if p.grad is not None:
+            p.grad.mul_(inv)
+    opt2.step()
+    assert abs(float(mse2) - float(ts.last["mse"])) < 1e-5 * float(mse2) + 1e-9
+    assert _relerr(m2.encoder.planes_features.grad.cpu().numpy().reshape(-1), ts.ll.grad.cpu().numpy() * inv) < 2e-3
+
+    # ---------------- parameters after the step: (1) == (2) and both close to (3)
+    p1 = dict(m1.named_parameters())
+    p2 = dict(m2.named_parameters())
+    oracle_new = {"encoder.planes_features": ll, "encoder.planes_features_wavelet_coefs.0": coefs[0],
+                  "encoder.planes_features_wavelet_coefs.1": coefs[1], "sigma_net.0.weight": W[0],
+                  "sigma_net.1.weight": W[1], "color_net.0.weight": W[2], "color_net.1.weight": W[3],
+                  "color_net.2.weight": W[4]}
+    # Adam's first step with eps = 1e-15 is lr * sign(g): an element can only differ between two correct
+    # implementations where its gradient is at rounding-noise level, so the comparison is restricted to elements
+    # whose gradient is significant (> 1e-3 of the tensor's largest); those must agree.
+    for n in names:
+        a, b, c0 = p1[n].detach().cpu().numpy(), p2[n].detach().cpu().numpy(), init[n].cpu().numpy()
+        assert not np.array_equal(a, c0), n                              # it moved
+        g2 = p2[n].grad.detach().cpu().numpy()
+        sig_mask = np.abs(g2) > 1e-3 * np.abs(g2).max()
+        assert sig_mask.mean() > 0.05, n
+        frac12 = np.mean(np.abs(a - b)[sig_mask] > 1e-6)
+        assert frac12 < 1e-3, (n, frac12)
+        go = oracle_new[n].grad.detach().numpy()
+        mask_o = sig_mask & (np.abs(go) > 1e-3 * np.abs(go).max())
+        frac13 = np.mean(np.abs(a - oracle_new[n].detach().numpy())[mask_o] > 1e-6)
+        assert frac13 < 1e-2, (n, frac13)
+
+
+def test_scaler_skips_on_overflow(cuda):
+    """GradScaler semantics: a non-finite gradient leaves parameters untouched and halves the scale."""
+    from trinerflet_amd.train import TrainStep
+    o, d = synthetic.training_rays(N, n_cams=4, seed=7)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    m = _model(cuda)
+    m.density_bitfield.copy_(t(synthetic.sphere_bitfield(128, 2, BOUND, 0.8, 0.55)))
+    ts = TrainStep(m, fp16=True, init_scale=2.0 ** 40, update_extra_interval=0)  # guarantees fp16 overflow
+    m.mean_count = 0
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    ts.step(t(o), t(d), t(synthetic.target_colors(d)))
+    assert float(ts.last["found_inf"]) == 1.0
+    assert float(ts.scale) == 2.0 ** 39
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n

@@ -110,7 +110,9 @@ class NeRFRenderer(nn.Module):
     # cuda_ray renderer (renderer.py:257-381)
     # ------------------------------------------------------------------------------------------
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False,
-                 max_steps=1024, T_thresh=1e-4, **kwargs):
+                 max_steps=1024, T_thresh=1e-4, noises=None, **kwargs):
+        # `noises` ([N] in [0,1), optional) is this build's only extra keyword: an explicit perturbation for
+        # seeded parity runs; None = torch.rand as in the reference
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
@@ -127,7 +129,7 @@ class NeRFRenderer(nn.Module):
             self.local_step += 1
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
-                self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
+                self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps, noises)
             sigmas, rgbs = self(xyzs, dirs)
             sigmas = self.density_scale * sigmas
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)

@@ -226,7 +226,7 @@ class TrainStep:
         self._mark("begin")
         tm = self.rebuild_planes()
         self._mark("idwt_fwd")
-        if self.global_step % self.update_extra_interval == 0:
+        if self.update_extra_interval > 0 and self.global_step % self.update_extra_interval == 0:
             model.update_extra_state()
             if self.post_refresh is not None:
                 self.post_refresh()
