@@ -1,0 +1,74 @@
+"""Collective plumbing of the multi-GPU step; one process per GPU, torch.distributed.
+
+The shard unit of the dense work is the (plane, channel) slice: the inverse DWT is depthwise, so slices are
+independent through IDWT, its adjoint and Adam.  Per step and rank:
+    plane-gradient slices [S,R,R]  --reduce_scatter-->  own S/G slices  -> adjoint -> Adam -> IDWT
+    own plane slices [S/G,R,R]     --all_gather----->   all S slices
+On RCCL (backend "nccl") these are reduce_scatter_tensor / all_gather_into_tensor; on gloo (the CPU tests)
+the same results are produced with all_reduce / all_gather, so the N>1 logic is testable without GPUs.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_rank(pg=None):
+    if not dist.is_available() or not dist.is_initialized():
+        return 1, 0
+    return dist.get_world_size(pg), dist.get_rank(pg)
+
+
+def slice_range(S, world, rank):
+    """Contiguous block of the S (plane, channel) slices owned by `rank` (S % world == 0)."""
+    if S % world != 0:
+        raise ValueError(f"{S} slices cannot be split evenly over {world} ranks")
+    per = S // world
+    return rank * per, (rank + 1) * per
+
+
+def shard_rays(n_total, world, rank):
+    """Contiguous split of a global ray batch (the last rank takes the remainder)."""
+    per = n_total // world
+    start = rank * per
+    end = n_total if rank == world - 1 else start + per
+    return start, end
+
+
+def _native(pg):
+    return dist.get_backend(pg) == "nccl"
+
+
+def reduce_scatter_slices(full, pg=None):
+    """full: [S, ...] on every rank -> sum over ranks of the caller's block [S/G, ...]."""
+    world, rank = world_rank(pg)
+    if world == 1:
+        return full
+    s0, s1 = slice_range(full.shape[0], world, rank)
+    if _native(pg):
+        out = torch.empty((s1 - s0, *full.shape[1:]), dtype=full.dtype, device=full.device)
+        dist.reduce_scatter_tensor(out, full.contiguous(), group=pg)
+        return out
+    tmp = full.clone()
+    dist.all_reduce(tmp, group=pg)
+    return tmp[s0:s1].contiguous()
+
+
+def all_gather_slices(mine, pg=None):
+    """mine: [S/G, ...] -> [S, ...] in rank order."""
+    world, _ = world_rank(pg)
+    if world == 1:
+        return mine
+    mine = mine.contiguous()
+    if _native(pg):
+        out = torch.empty((mine.shape[0] * world, *mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(out, mine, group=pg)
+        return out
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=pg)
+    return torch.cat(parts, 0)
+
+
+def all_reduce_(t, pg=None, op=None):
+    world, _ = world_rank(pg)
+    if world > 1:
+        dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=pg)
+    return t

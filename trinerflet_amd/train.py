@@ -25,6 +25,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from . import distributed as D
 from . import raymarching
 from .nerf import field as F_
 from .triplaneencoder.triplane_encoder import _IDWTLevel, _ToTexelMajor
@@ -145,8 +146,7 @@ class TrainStep:
         return enc._planes_tm
 
     def _slice_range(self):
-        per = 3 * self.C // self.world
-        return self.rank * per, (self.rank + 1) * per
+        return D.slice_range(3 * self.C, self.world, self.rank)
 
     def _rebuild_sharded(self):
         enc = self.enc
@@ -158,9 +158,7 @@ class TrainStep:
             yh = enc.planes_features_wavelet_coefs[lvl].reshape(3 * self.C, 3, n, n)[s0:s1].unsqueeze(0)
             x = _IDWTLevel.apply(x.contiguous(), yh.contiguous(), enc.wave_id)
         mine = x.reshape(s1 - s0, self.R, self.R).contiguous()
-        full = torch.empty(3 * self.C, self.R, self.R, dtype=torch.float32, device=self.dev)
-        dist.all_gather_into_tensor(full, mine, group=self.pg)
-        return full.view(3, self.C, self.R, self.R)
+        return D.all_gather_slices(mine, self.pg).view(3, self.C, self.R, self.R)
 
     # ------------------------------------------------------------------------------------------
     def _adam(self, flat, lr_t, l1_coef, found_inf, inv_scale_dev, abs_sum=None, lo=0, hi=None):
@@ -191,9 +189,7 @@ class TrainStep:
             dist.all_reduce(g, group=self.pg)
         elif self.dist_mode == "sharded":
             s0, s1 = self._slice_range()
-            mine = torch.empty(s1 - s0, R, R, dtype=torch.float32, device=self.dev)
-            dist.reduce_scatter_tensor(mine, g, group=self.pg)
-            g = mine
+            g = D.reduce_scatter_slices(g, self.pg)
         ns = s1 - s0
         for lvl in reversed(range(self.J)):
             n = g.shape[-1] // 2
@@ -339,5 +335,4 @@ class TrainStep:
         for p in self.coef.params + self.ll.params:
             S = 3 * self.C
             flat = p.data.view(S, -1)
-            mine = flat[s0:s1].contiguous()
-            dist.all_gather_into_tensor(flat, mine, group=self.pg)
+            flat.copy_(D.all_gather_slices(flat[s0:s1], self.pg))
