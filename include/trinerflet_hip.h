@@ -124,6 +124,11 @@ TNL_API int tnl_sh_encode_backward(const float *grad, const float *inputs, uint3
 TNL_API int tnl_idwt_level_forward(const float *x, const float *yh, uint32_t S, uint32_t n,
                                    int wave, float *out, void *stream);
 
+/* Same level with an fp16 result (n % 4 == 0): used for the finest level, whose only consumer is the fp16
+ * texel-major sampler copy, so the fp32 planes are never written. */
+TNL_API int tnl_idwt_level_forward_half(const float *x, const float *yh, uint32_t S, uint32_t n,
+                                        int wave, void *out_half, void *stream);
+
 /* Adjoint of the above (autograd of SFB2D + pad + 2*): dout:[S,2n,2n] -> dx:[S,n,n], dyh:[S,3,n,n] */
 TNL_API int tnl_idwt_level_backward(const float *dout, uint32_t S, uint32_t n, int wave, float *dx,
                                     float *dyh, void *stream);
@@ -132,6 +137,9 @@ TNL_API int tnl_idwt_level_backward(const float *dout, uint32_t S, uint32_t n, i
  * texel-major [3,R,R,C] storage.  half_out != 0 stores fp16 (e = 2), else fp32 (e = 4). */
 TNL_API int tnl_planes_to_texel_major(const float *planes_cm, uint32_t C, uint32_t R, int half_out,
                                       void *planes_tm, void *stream);
+/* fp16 (3,C,R,R) -> fp16 [3,R,R,C] (C % 8 == 0, R % 8 == 0) */
+TNL_API int tnl_planes_half_to_texel_major(const void *planes_cm_half, uint32_t C, uint32_t R,
+                                           void *planes_tm_half, void *stream);
 /* [3,R,R,C] fp32 gradient -> (3,C,R,R) fp32 */
 TNL_API int tnl_planes_to_channel_major(const float *grad_tm, uint32_t C, uint32_t R, float *grad_cm,
                                         void *stream);

@@ -127,3 +127,21 @@ def test_sample_vs_oracle_large(cuda):
     ref = cref.triplane_sample_bwd(cot, xyz, bound, C, R)
     got = tm.grad.permute(0, 3, 1, 2).cpu().numpy()
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+
+
+def test_half_finest_level_and_layout(cuda):
+    """TrainStep's fast path: finest level written as fp16 + fp16 layout change == fp32 level, rounded."""
+    from trinerflet_amd.triplaneencoder.triplane_encoder import (_IDWTLevel, WAVELET_IDS, half_to_texel_major,
+                                                                  idwt_level_half)
+    torch.manual_seed(2)
+    for wave, C, n in (("bior6.8", 16, 128), ("bior4.4", 8, 40), ("haar", 8, 64)):
+        x = torch.randn(3, C, n, n, device=cuda) * 0.3
+        yh = torch.randn(3, C, 3, n, n, device=cuda) * 0.2
+        ref = _IDWTLevel.apply(x, yh, WAVELET_IDS[wave])
+        h = idwt_level_half(x, yh, WAVELET_IDS[wave])
+        # identical up to fp32 contraction differences between the two template instantiations: a handful of
+        # exact rounding ties may land on the neighbouring fp16 value
+        d = (h.float() - ref.half().float()).abs()
+        assert h.dtype == torch.float16 and float((d > 0).float().mean()) < 1e-4 and float(d.max()) <= 2 ** -10
+        tm = half_to_texel_major(h)
+        assert torch.equal(tm, h.permute(0, 2, 3, 1).contiguous())

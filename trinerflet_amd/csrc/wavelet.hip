@@ -71,6 +71,7 @@ __host__ __device__ constexpr WTaps wtaps(int w) {
 constexpr int TI = 32;   // coarse tile edge
 constexpr int RM = 4;    // coarse samples per thread-run
 constexpr int NT = 256;  // threads per workgroup
+constexpr int TX = 64;   // texels per layout-change tile
 
 // ---------------------------------------------------------------------------------------------
 // forward: x:[S][n][n], yh:[S][3][n][n] -> out:[S][2n][2n]
@@ -259,11 +260,290 @@ k_idwt_bwd(const float* __restrict__ dout, int n, float* __restrict__ dx, float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pipelined variants (n % 4 == 0): a workgroup walks TPW consecutive tiles along x.  The four bands of
+// tile t+1 are fetched with 16-byte loads into registers while tile t is being computed (the loads stay
+// in flight across the two barriers of the tile), so HBM latency is hidden by the tile's own ~1500 VALU
+// instructions instead of by occupancy.  HALF_OUT writes the level as fp16 (used for the finest level:
+// the sampler's planes are fp16, so the fp32 copy is never materialised).
+// ---------------------------------------------------------------------------------------------
+constexpr int TPW = 8;  // tiles per workgroup walk
+
+template <int W, bool HALF_OUT>
+__global__ void __launch_bounds__(NT)
+k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n, void* __restrict__ out) {
+  constexpr WTaps T = wtaps(W);
+  constexpr int L = T.L, K = (L - 2) / 2, HW = L / 4;
+  constexpr int HWA = HW ? 4 : 0;            // staged halo, 16-byte aligned
+  constexpr int SH = HWA - HW;               // shift between staged and used halo
+  constexpr int TIH = TI + 2 * HWA;
+  constexpr int LSB = TIH + 4;               // band row stride (floats): 16-B aligned rows for b128 writes
+  constexpr int LSM = TIH + 1;               // mid row stride: odd, conflict-free row walks
+  constexpr int NQ = 4 * TIH * (TIH / 4);    // float4 words per tile
+  constexpr int KQ = (NQ + NT - 1) / NT;
+  constexpr int WIN = RM + 2 * HW;
+  __shared__ __attribute__((aligned(16))) float band[4][TIH][LSB];
+  __shared__ float mid[2][2 * TI][LSM];
+
+  const int s = blockIdx.z;
+  const int a_r = blockIdx.y * TI;
+  const int ntx = (n + TI - 1) / TI;
+  const int tx0 = blockIdx.x * TPW, tx1 = min(tx0 + TPW, ntx);
+  const size_t nn = (size_t)n * n;
+  const float* ll = x + (size_t)s * nn;
+  const float* hb = yh + (size_t)s * 3 * nn;
+  const int m2 = 2 * n;
+
+  // tile-independent part of the staging map
+  int qb[KQ], qr[KQ], qc[KQ];
+  bool qv[KQ];
+#pragma unroll
+  for (int k = 0; k < KQ; k++) {
+    const int q = threadIdx.x + NT * k;
+    qv[k] = q < NQ;
+    const int b = q / (TIH * (TIH / 4)), rem = q - b * (TIH * (TIH / 4));
+    qb[k] = b; qr[k] = rem / (TIH / 4); qc[k] = 4 * (rem - (rem / (TIH / 4)) * (TIH / 4));
+  }
+  float4 pre[KQ];
+  auto prefetch = [&](int tx) {
+    const int a_c = tx * TI;
+#pragma unroll
+    for (int k = 0; k < KQ; k++) {
+      const int gr = a_r - HWA + qr[k], gc = a_c - HWA + qc[k];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qv[k] && gr >= 0 && gr < n && gc >= 0 && gc < n) {
+        const float* src = qb[k] == 0 ? ll : hb + (size_t)(qb[k] - 1) * nn;
+        v = *reinterpret_cast<const float4*>(src + (size_t)gr * n + gc);
+        if (qb[k] == 0) { v.x *= 2.f; v.y *= 2.f; v.z *= 2.f; v.w *= 2.f; }
+      }
+      pre[k] = v;
+    }
+  };
+  prefetch(tx0);
+  for (int tx = tx0; tx < tx1; tx++) {
+#pragma unroll
+    for (int k = 0; k < KQ; k++)
+      if (qv[k]) *reinterpret_cast<float4*>(&band[qb[k]][qr[k]][qc[k]]) = pre[k];
+    __syncthreads();
+    if (tx + 1 < tx1) prefetch(tx + 1);
+
+    for (int u = threadIdx.x; u < TIH * (TI / RM); u += NT) {
+      const int c = u % TIH, m0 = (u / TIH) * RM;
+      float w0[WIN], w1[WIN], w2[WIN], w3[WIN];
+#pragma unroll
+      for (int i = 0; i < WIN; i++) {
+        w0[i] = band[0][m0 + i + SH][c]; w1[i] = band[1][m0 + i + SH][c];
+        w2[i] = band[2][m0 + i + SH][c]; w3[i] = band[3][m0 + i + SH][c];
+      }
+#pragma unroll
+      for (int m = 0; m < RM; m++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          float lo = 0.f, hi = 0.f;
+#pragma unroll
+          for (int d = -HW; d <= HW; d++) {
+            const int k = e + K - 2 * d;
+            if (k >= 0 && k < L) {
+              const float t0 = T.g0[k], t1 = T.g1[k];
+              if (t0 != 0.f) { lo = fmaf(w0[m + d + HW], t0, lo); hi = fmaf(w2[m + d + HW], t0, hi); }
+              if (t1 != 0.f) { lo = fmaf(w1[m + d + HW], t1, lo); hi = fmaf(w3[m + d + HW], t1, hi); }
+            }
+          }
+          mid[0][2 * (m0 + m) + e][c] = lo;
+          mid[1][2 * (m0 + m) + e][c] = hi;
+        }
+      }
+    }
+    __syncthreads();
+
+    const int a_c = tx * TI;
+    for (int u = threadIdx.x; u < 2 * TI * (TI / RM); u += NT) {
+      const int run = u % (TI / RM), r = u / (TI / RM);
+      const int m0 = run * RM;
+      float wl[WIN], wh[WIN];
+#pragma unroll
+      for (int i = 0; i < WIN; i++) { wl[i] = mid[0][r][m0 + i + SH]; wh[i] = mid[1][r][m0 + i + SH]; }
+      float o[2 * RM];
+#pragma unroll
+      for (int m = 0; m < RM; m++) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          float acc = 0.f;
+#pragma unroll
+          for (int d = -HW; d <= HW; d++) {
+            const int k = e + K - 2 * d;
+            if (k >= 0 && k < L) {
+              const float t0 = T.g0[k], t1 = T.g1[k];
+              if (t0 != 0.f) acc = fmaf(wl[m + d + HW], t0, acc);
+              if (t1 != 0.f) acc = fmaf(wh[m + d + HW], t1, acc);
+            }
+          }
+          o[2 * m + e] = acc;
+        }
+      }
+      const int gr = 2 * a_r + r, gc = 2 * (a_c + m0);
+      if (gr < m2 && gc < m2) {  // m2 % 8 == 0 and gc % 8 == 0: the 8 outputs are in range together
+        const size_t off = (size_t)s * m2 * m2 + (size_t)gr * m2 + gc;
+        if (HALF_OUT) {
+          typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+          h8 hv;
+#pragma unroll
+          for (int i = 0; i < 8; i++) hv[i] = (_Float16)o[i];
+          *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(out) + off) = hv;
+        } else {
+          float* p = reinterpret_cast<float*>(out) + off;
+          reinterpret_cast<float4*>(p)[0] = make_float4(o[0], o[1], o[2], o[3]);
+          reinterpret_cast<float4*>(p)[1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+      }
+    }
+    // the next iteration's band writes are safe (every thread is past the column pass); its column pass is
+    // separated from this row pass by the barrier that follows those writes
+  }
+}
+
+template <int W>
+__global__ void __launch_bounds__(NT)
+k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh) {
+  constexpr WTaps T = wtaps(W);
+  constexpr int L = T.L, K = (L - 2) / 2;
+  constexpr int KA = (K + 3) / 4 * 4;                 // aligned left halo of the fine tile
+  constexpr int SH = KA - K;
+  constexpr int FT = 2 * TI + L - 2;                  // fine rows
+  constexpr int FTA = (2 * TI + L - 2 + SH + 3) / 4 * 4;  // fine cols staged (16-B aligned start and length)
+  constexpr int FS = FTA + 1;
+  constexpr int LS = TI + 1;
+  constexpr int NQ = FT * (FTA / 4);
+  constexpr int KQ = (NQ + NT - 1) / NT;
+  constexpr int WIN = 2 * RM + L - 2;
+  __shared__ float fine[FT][FS];
+  __shared__ float mid[2][FT][LS];
+
+  const int s = blockIdx.z;
+  const int a_r = blockIdx.y * TI;
+  const int ntx = (n + TI - 1) / TI;
+  const int tx0 = blockIdx.x * TPW, tx1 = min(tx0 + TPW, ntx);
+  const int m2 = 2 * n;
+  const float* src = dout + (size_t)s * m2 * m2;
+  const size_t nn = (size_t)n * n;
+  float* o_ll = dx + (size_t)s * nn;
+  float* o_h = dyh + (size_t)s * 3 * nn;
+
+  int qr[KQ], qc[KQ];
+  bool qv[KQ];
+#pragma unroll
+  for (int k = 0; k < KQ; k++) {
+    const int q = threadIdx.x + NT * k;
+    qv[k] = q < NQ;
+    qr[k] = q / (FTA / 4);
+    qc[k] = 4 * (q - qr[k] * (FTA / 4));
+  }
+  float4 pre[KQ];
+  auto prefetch = [&](int tx) {
+    const int a_c = tx * TI;
+#pragma unroll
+    for (int k = 0; k < KQ; k++) {
+      const int gr = 2 * a_r - K + qr[k], gc = 2 * a_c - KA + qc[k];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qv[k] && gr >= 0 && gr < m2 && gc >= 0 && gc < m2)
+        v = *reinterpret_cast<const float4*>(src + (size_t)gr * m2 + gc);
+      pre[k] = v;
+    }
+  };
+  prefetch(tx0);
+  for (int tx = tx0; tx < tx1; tx++) {
+#pragma unroll
+    for (int k = 0; k < KQ; k++) {
+      if (qv[k]) {
+        float* d = &fine[qr[k]][qc[k]];
+        d[0] = pre[k].x; d[1] = pre[k].y; d[2] = pre[k].z; d[3] = pre[k].w;
+      }
+    }
+    __syncthreads();
+    if (tx + 1 < tx1) prefetch(tx + 1);
+
+    for (int u = threadIdx.x; u < FT * (TI / RM); u += NT) {
+      const int r = u % FT, j0 = (u / FT) * RM;
+      float w[WIN];
+#pragma unroll
+      for (int i = 0; i < WIN; i++) w[i] = fine[r][2 * j0 + i + SH];
+#pragma unroll
+      for (int j = 0; j < RM; j++) {
+        float lo = 0.f, hi = 0.f;
+#pragma unroll
+        for (int k = 0; k < L; k++) {
+          const float t0 = T.g0[k], t1 = T.g1[k];
+          if (t0 != 0.f) lo = fmaf(w[2 * j + k], t0, lo);
+          if (t1 != 0.f) hi = fmaf(w[2 * j + k], t1, hi);
+        }
+        mid[0][r][j0 + j] = lo;
+        mid[1][r][j0 + j] = hi;
+      }
+    }
+    __syncthreads();
+
+    const int a_c = tx * TI;
+    for (int u = threadIdx.x; u < TI * (TI / RM); u += NT) {
+      const int c = u % TI, j0 = (u / TI) * RM;
+      float wl[WIN], wh[WIN];
+#pragma unroll
+      for (int i = 0; i < WIN; i++) { wl[i] = mid[0][2 * j0 + i][c]; wh[i] = mid[1][2 * j0 + i][c]; }
+      const int gc = a_c + c;
+#pragma unroll
+      for (int j = 0; j < RM; j++) {
+        float a = 0.f, b = 0.f, cc = 0.f, d = 0.f;
+#pragma unroll
+        for (int k = 0; k < L; k++) {
+          const float t0 = T.g0[k], t1 = T.g1[k];
+          if (t0 != 0.f) { a = fmaf(wl[2 * j + k], t0, a); cc = fmaf(wh[2 * j + k], t0, cc); }
+          if (t1 != 0.f) { b = fmaf(wl[2 * j + k], t1, b); d = fmaf(wh[2 * j + k], t1, d); }
+        }
+        const int gr = a_r + j0 + j;
+        if (gr < n && gc < n) {
+          const size_t off = (size_t)gr * n + gc;
+          o_ll[off] = 2.0f * a;
+          o_h[off] = b;
+          o_h[nn + off] = cc;
+          o_h[2 * nn + off] = d;
+        }
+      }
+    }
+  }
+}
+
+// fp16 (3,C,R,R) -> fp16 [3,R,R,C]: 16-byte loads along x, 16-byte stores along the channels
+__global__ void __launch_bounds__(NT)
+k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __restrict__ tm) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 tileh[];  // [C][TX + 8]
+  constexpr int LD = TX + 8;
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const int p = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * TX;
+  for (int idx = threadIdx.x; idx < C * (TX / 8); idx += NT) {
+    const int c = idx / (TX / 8), x8 = (idx - c * (TX / 8)) * 8;
+    h8 v;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (_Float16)0.f;
+    if (x0 + x8 < R) v = *reinterpret_cast<const h8*>(cm + (((size_t)p * C + c) * R + y) * R + x0 + x8);
+    *reinterpret_cast<h8*>(&tileh[c * LD + x8]) = v;
+  }
+  __syncthreads();
+  const size_t base = (((size_t)p * R + y) * R + x0) * C;
+  const int CG = C / 8;
+  for (int idx = threadIdx.x; idx < TX * CG; idx += NT) {
+    const int xx = idx / CG, cg = idx - xx * CG;
+    if (x0 + xx < R) {
+      h8 v;
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = tileh[(cg * 8 + j) * LD + xx];
+      *reinterpret_cast<h8*>(tm + base + (size_t)xx * C + cg * 8) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // layout changes: (3,C,R,R) fp32 <-> [3,R,R,C] (texel-major, fp16 or fp32)
 // One workgroup moves a 64-texel row segment for all channels through LDS, so both the read of
 // each channel row (256 B) and the write of the texel block (64*C*e B) are contiguous.
 // ---------------------------------------------------------------------------------------------
-constexpr int TX = 64;
 
 template <bool HALF>
 __global__ void __launch_bounds__(NT)
@@ -305,13 +585,27 @@ k_to_channel_major(const float* __restrict__ tm, int C, int R, float* __restrict
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 template <int W>
-int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(k_idwt_fwd<W>, dim3(cdiv(n, TI), cdiv(n, TI), S), dim3(NT), 0, st, x, yh, (int)n, out);
+int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, void* out, int half_out, hipStream_t st) {
+  if (n % 4 == 0) {
+    const dim3 grid(cdiv(cdiv(n, TI), TPW), cdiv(n, TI), S);
+    if (half_out)
+      hipLaunchKernelGGL((k_idwt_fwd_pipe<W, true>), grid, dim3(NT), 0, st, x, yh, (int)n, out);
+    else
+      hipLaunchKernelGGL((k_idwt_fwd_pipe<W, false>), grid, dim3(NT), 0, st, x, yh, (int)n, out);
+  } else {
+    if (half_out) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_idwt_fwd<W>, dim3(cdiv(n, TI), cdiv(n, TI), S), dim3(NT), 0, st, x, yh, (int)n,
+                       reinterpret_cast<float*>(out));
+  }
   return (int)hipGetLastError();
 }
 template <int W>
 int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh, hipStream_t st) {
-  hipLaunchKernelGGL(k_idwt_bwd<W>, dim3(cdiv(n, TI), cdiv(n, TI), S), dim3(NT), 0, st, dout, (int)n, dx, dyh);
+  if (n % 2 == 0)
+    hipLaunchKernelGGL(k_idwt_bwd_pipe<W>, dim3(cdiv(cdiv(n, TI), TPW), cdiv(n, TI), S), dim3(NT), 0, st, dout,
+                       (int)n, dx, dyh);
+  else
+    hipLaunchKernelGGL(k_idwt_bwd<W>, dim3(cdiv(n, TI), cdiv(n, TI), S), dim3(NT), 0, st, dout, (int)n, dx, dyh);
   return (int)hipGetLastError();
 }
 
@@ -319,19 +613,42 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
 
 extern "C" {
 
-int tnl_idwt_level_forward(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, float* out,
-                           void* stream) {
+static int idwt_forward_any(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, void* out,
+                            int half_out, void* stream) {
   if (S == 0 || n == 0) return 0;
   if (S > 65535) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   switch (wave) {
-    case 0: return launch_fwd<0>(x, yh, S, n, out, st);
-    case 1: return launch_fwd<1>(x, yh, S, n, out, st);
-    case 2: return launch_fwd<2>(x, yh, S, n, out, st);
-    case 3: return launch_fwd<3>(x, yh, S, n, out, st);
-    case 4: return launch_fwd<4>(x, yh, S, n, out, st);
+    case 0: return launch_fwd<0>(x, yh, S, n, out, half_out, st);
+    case 1: return launch_fwd<1>(x, yh, S, n, out, half_out, st);
+    case 2: return launch_fwd<2>(x, yh, S, n, out, half_out, st);
+    case 3: return launch_fwd<3>(x, yh, S, n, out, half_out, st);
+    case 4: return launch_fwd<4>(x, yh, S, n, out, half_out, st);
     default: return (int)hipErrorInvalidValue;
   }
+}
+
+int tnl_idwt_level_forward(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, float* out,
+                           void* stream) {
+  return idwt_forward_any(x, yh, S, n, wave, out, 0, stream);
+}
+
+int tnl_idwt_level_forward_half(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, void* out_half,
+                                void* stream) {
+  if (n % 4 != 0) return (int)hipErrorInvalidValue;
+  return idwt_forward_any(x, yh, S, n, wave, out_half, 1, stream);
+}
+
+int tnl_planes_half_to_texel_major(const void* planes_cm_half, uint32_t C, uint32_t R, void* planes_tm_half,
+                                   void* stream) {
+  if (C == 0 || R == 0) return 0;
+  if (C % 8 != 0 || R % 8 != 0) return (int)hipErrorInvalidValue;
+  const dim3 grid(cdiv(R, TX), R, 3);
+  const size_t lds = (size_t)C * (TX + 8) * sizeof(_Float16);
+  hipLaunchKernelGGL(k_to_texel_major_h, grid, dim3(NT), lds, (hipStream_t)stream,
+                     reinterpret_cast<const _Float16*>(planes_cm_half), (int)C, (int)R,
+                     reinterpret_cast<_Float16*>(planes_tm_half));
+  return (int)hipGetLastError();
 }
 
 int tnl_idwt_level_backward(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,

@@ -28,7 +28,7 @@ from . import _lib as L
 from . import distributed as D
 from . import raymarching
 from .nerf import field as F_
-from .triplaneencoder.triplane_encoder import _IDWTLevel, _ToTexelMajor
+from .triplaneencoder.triplane_encoder import _IDWTLevel, _ToTexelMajor, half_to_texel_major, idwt_level_half
 
 
 def lr_factor(it, iters, warmup_steps, sched_base=0.1, warmup_factor=1e-3, sched_exp=2.5):
@@ -138,11 +138,18 @@ class TrainStep:
                 planes = self._rebuild_sharded()
             else:
                 x = enc.planes_features
+                fast = (self.J > 0 and enc.plane_dtype == torch.float16 and self.C % 8 == 0 and self.R % 16 == 0)
                 for lvl in range(self.J):
-                    x = _IDWTLevel.apply(x, enc.planes_features_wavelet_coefs[lvl], enc.wave_id)
+                    if fast and lvl == self.J - 1:  # finest level written as fp16: the fp32 planes never exist
+                        x = idwt_level_half(x, enc.planes_features_wavelet_coefs[lvl], enc.wave_id)
+                    else:
+                        x = _IDWTLevel.apply(x, enc.planes_features_wavelet_coefs[lvl], enc.wave_id)
                 planes = x
             enc.last_used_planes = planes
-            enc._planes_tm = _ToTexelMajor.apply(planes, enc.plane_dtype == torch.float16)
+            if planes.dtype == torch.float16:
+                enc._planes_tm = half_to_texel_major(planes)
+            else:
+                enc._planes_tm = _ToTexelMajor.apply(planes, enc.plane_dtype == torch.float16)
         return enc._planes_tm
 
     def _slice_range(self):

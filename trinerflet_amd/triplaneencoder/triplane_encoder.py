@@ -84,6 +84,26 @@ class _IDWTLevel(Function):
         return dx, dyh, None
 
 
+def idwt_level_half(x, yh, wave_id):
+    """Finest level straight to fp16 (no autograd): x (3,C,n,n), yh (3,C,3,n,n) fp32 -> (3,C,2n,2n) fp16."""
+    x = x.detach().to(torch.float32).contiguous()
+    yh = yh.detach().to(torch.float32).contiguous()
+    P, C, n = x.shape[0], x.shape[1], x.shape[-1]
+    out = torch.empty(P, C, 2 * n, 2 * n, dtype=torch.float16, device=x.device)
+    L.check(L.lib().tnl_idwt_level_forward_half(L.ptr(x), L.ptr(yh), L.u32(P * C), L.u32(n), L.i32(wave_id),
+                                                L.ptr(out), L.stream()), "idwt_level_forward_half")
+    return out
+
+
+def half_to_texel_major(planes_cm_half):
+    """fp16 (3,C,R,R) -> fp16 [3,R,R,C] (no autograd)."""
+    _, C, R, _ = planes_cm_half.shape
+    tm = torch.empty(3, R, R, C, dtype=torch.float16, device=planes_cm_half.device)
+    L.check(L.lib().tnl_planes_half_to_texel_major(L.ptr(planes_cm_half), L.u32(C), L.u32(R), L.ptr(tm), L.stream()),
+            "planes_half_to_texel_major")
+    return tm
+
+
 class _ToTexelMajor(Function):
     """(3,C,R,R) fp32 -> [3,R,R,C] fp16|fp32 ; backward: fp32 [3,R,R,C] -> (3,C,R,R)."""
 
