@@ -178,14 +178,25 @@ TNL_API int tnl_field_forward(const void *planes_tm, int half_in, const float *x
                               void *feats_save, const int32_t *m_actual, void *stream);
 /* grad_sigma:[M], grad_rgb:[M,3] -> grad_tm:[3,R,R,C] fp32 (atomic, caller zero-fills) and
  * gradW:[Hd*3C + 16*Hd + Hc*31 + Hc*Hc + 3*Hc] fp32 in nn.Linear layout, concatenated W0..W4
- * (accumulated atomically, caller zero-fills).  grad_scale multiplies incoming gradients
- * (GradScaler); workspace bytes from tnl_field_backward_workspace. */
+ * (accumulated, caller zero-fills); workspace bytes from tnl_field_backward_workspace.  sigma / rgb may be
+ * NULL (the chain is recomputed from feats_save). */
 TNL_API uint32_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint32_t Hc);
 TNL_API int tnl_field_backward(const float *grad_sigma, const float *grad_rgb, const float *sigma,
                                const float *rgb, const void *feats_save, const float *xyz,
                                const float *dirs, float bound, uint32_t M, uint32_t C, uint32_t R,
                                uint32_t Hd, uint32_t Hc, const void *packed, float *grad_tm,
-                               float *gradW, void *workspace, const int32_t *m_actual, void *stream);
+                               float *gradW, void *workspace, const int32_t *m_actual, void *dfeat_half,
+                               void *stream);
+
+/* Plane-gradient accumulation without global float atomics (csrc/scatter.hip).  When tnl_field_backward is
+ * given dfeat_half (fp16 [M,3C]) it writes the feature gradient there instead of scattering it; this call
+ * then counting-sorts the samples by 16x16-texel tile per plane and lets one workgroup per tile accumulate
+ * in LDS and store the tile.  EVERY tile of grad_tm:[3,R,R,C] is written (no zero fill needed).  grad_scale
+ * multiplies dfeat.  R % 16 == 0.  Replaces torch grid_sampler_2d_backward + the autograd zero fill. */
+TNL_API uint64_t tnl_plane_grad_binned_workspace(uint32_t M, uint32_t R);
+TNL_API int tnl_plane_grad_binned(const void *dfeat_half, const float *xyz, float bound, uint32_t M,
+                                  const int32_t *m_actual, uint32_t C, uint32_t R, float grad_scale,
+                                  float *grad_tm, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused optimiser for the wavelet coefficients: torch.optim.Adam(betas, eps, no weight decay)

@@ -117,3 +117,42 @@ def test_network_fused_equals_modular(cuda):
     np.testing.assert_allclose(c_f.cpu().numpy(), c_m.cpu().numpy(), rtol=0, atol=3e-3)
     rel = (s_f - s_m).abs() / s_m
     assert float(rel.median()) < 1e-3 and float(rel.max()) < 2e-2
+
+
+@pytest.mark.parametrize("C,H,R,M", [(32, 64, 96, 6000), (16, 64, 64, 2500)])
+def test_binned_plane_gradient_equals_atomic(cuda, C, H, R, M):
+    """TrainStep's atomic-free path (dF as fp16 -> tile-sorted LDS accumulation) against the atomic scatter
+    and the oracle; includes border / out-of-range samples (clamped footprints) and a device-side row count."""
+    from trinerflet_amd.nerf import field as gfield
+    from trinerflet_amd.triplaneencoder.triplane_encoder import _ToTexelMajor
+    planes, xyz, dirs, W, bound = _make(C, H, R, M, seed=21)
+    xyz[:64] *= 1.2                      # outside the box: border clamp
+    xyz[64:80] = torch.tensor([bound, -bound, bound])
+    g = torch.Generator().manual_seed(9)
+    a, b = torch.randn(M, generator=g), torch.randn(M, 3, generator=g)
+    tm = _ToTexelMajor.apply(planes.to(cuda), True)
+    packed = gfield.pack_weights(*[w.to(cuda) for w in W], C, H)
+    xg, dg = xyz.to(cuda), dirs.to(cuda)
+    m_act = torch.tensor([M - 37, 0], dtype=torch.int32, device=cuda)  # rows past the count are ignored
+    s, c, feats = gfield.field_forward(tm, xg, dg, packed, bound, C, R, H, save_feats=True, m_actual=m_act)
+    nW = sum(w.numel() for w in W)
+    g_at, w_at = torch.zeros(3, R, R, C, device=cuda), torch.zeros(nW, device=cuda)
+    gfield.field_backward(a.to(cuda), b.to(cuda), None, None, feats, xg, dg, packed, bound, C, R, H, g_at, w_at,
+                          m_actual=m_act)
+    g_bin = torch.full((3, R, R, C), float("nan"), device=cuda)      # every tile must be overwritten
+    w_bin = torch.zeros(nW, device=cuda)
+    dfeat = torch.empty(M, 3 * C, dtype=torch.float16, device=cuda)
+    gfield.field_backward(a.to(cuda), b.to(cuda), None, None, feats, xg, dg, packed, bound, C, R, H, g_bin, w_bin,
+                          m_actual=m_act, dfeat=dfeat)
+    gfield.plane_grad_binned(dfeat, xg, bound, C, R, g_bin, m_actual=m_act)
+    assert torch.isfinite(g_bin).all()
+    assert torch.equal(w_bin, w_at) or _relerr(w_bin.cpu().numpy(), w_at.cpu().numpy()) < 1e-6
+    assert _relerr(g_bin.cpu().numpy(), g_at.cpu().numpy().astype(np.float64)) < 1e-3   # fp16 rounding of dF
+    assert torch.equal(g_bin == 0, g_at == 0)                                            # same support
+    # oracle: the same samples through torch autograd
+    n = M - 37
+    pl = ofield.round_fp16(planes).requires_grad_(True)
+    so, co = ofield.field(pl, xyz[:n], dirs[:n], W, bound, fp16=True)
+    ((so * a[:n]).sum() + (co * b[:n]).sum()).backward()
+    ref = pl.grad.permute(0, 2, 3, 1).numpy().astype(np.float64)
+    assert _relerr(g_bin.cpu().numpy(), ref) < 5e-3

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(BW_THREADS)
 k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, const _Float16* __restrict__ feats,
             const float* __restrict__ xyz, const float* __restrict__ dirs, float bound, uint32_t M, int R,
             const half8* __restrict__ packed, float* __restrict__ grad_tm, float* __restrict__ slabs,
-            const int32_t* __restrict__ m_actual) {
+            const int32_t* __restrict__ m_actual, _Float16* __restrict__ dfeat) {
   using G = FieldGeom<C, H>;
   using B = BwdGeom<C, H>;
   if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
@@ -282,7 +282,28 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       const int t = wv + 4 * k;
       if (t < B::NT0) dw0[k] = dw_tile(Ys, Xs, t / G::IB0, t % G::IB0, r, h, dw0[k]);
     }
-    // feature gradient dF^T = W0^T dH1^T, staged [sample][feature] fp32 in this wave's LDS region
+    // feature gradient dF^T = W0^T dH1^T
+    if (dfeat != nullptr) {
+      // binned mode: dF leaves as fp16 [M, 3C]; scatter.hip accumulates it per tile without global atomics
+      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int ib = 0; ib < G::IB0; ib++) {
+        f32x16 df = zero16();
+#pragma unroll
+        for (int ks = 0; ks < G::KH; ks++) df = MFMA32(w[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int f0 = 32 * ib + 8 * q + 4 * h;  // registers 4q..4q+3 hold features f0..f0+3
+          if (f0 < G::F && valid) {
+            half4 v;
+            v[0] = (_Float16)df[4 * q]; v[1] = (_Float16)df[4 * q + 1];
+            v[2] = (_Float16)df[4 * q + 2]; v[3] = (_Float16)df[4 * q + 3];
+            *reinterpret_cast<half4*>(dfeat + (size_t)i * G::F + f0) = v;
+          }
+        }
+      }
+    } else {
+    // atomic mode: staged [sample][feature] fp32 in this wave's LDS region
 #pragma unroll
     for (int ib = 0; ib < G::IB0; ib++) {
       f32x16 df = zero16();
@@ -316,6 +337,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
           }
         }
       }
+    }
     }
     __syncthreads();  // Xs/Ys are rewritten by the next super-tile
   }
@@ -365,7 +387,7 @@ inline uint32_t bwd_blocks(uint32_t M) {
 template <int C, int H>
 int launch_bwd(const float* gsig, const float* grgb, const void* feats, const float* xyz, const float* dirs,
                float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW, void* workspace,
-               const int32_t* m_actual, hipStream_t st) {
+               const int32_t* m_actual, void* dfeat, hipStream_t st) {
   using G = FieldGeom<C, H>;
   using B = BwdGeom<C, H>;
   const uint32_t blocks = bwd_blocks(M);
@@ -379,7 +401,7 @@ int launch_bwd(const float* gsig, const float* grgb, const void* feats, const fl
   float* slabs = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL((k_field_bwd<C, H>), dim3(blocks), dim3(BW_THREADS), B::LDS_BYTES, st, gsig, grgb,
                      reinterpret_cast<const _Float16*>(feats), xyz, dirs, bound, M, (int)R,
-                     reinterpret_cast<const half8*>(packed), grad_tm, slabs, m_actual);
+                     reinterpret_cast<const half8*>(packed), grad_tm, slabs, m_actual, reinterpret_cast<_Float16*>(dfeat));
   hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 255) / 256), dim3(256), 0, st, slabs, (int)blocks, (int)G::NW, gradW);
   return (int)hipGetLastError();
 }
@@ -400,17 +422,17 @@ uint32_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint3
 int tnl_field_backward(const float* grad_sigma, const float* grad_rgb, const float* sigma, const float* rgb,
                        const void* feats_save, const float* xyz, const float* dirs, float bound, uint32_t M,
                        uint32_t C, uint32_t R, uint32_t Hd, uint32_t Hc, const void* packed, float* grad_tm,
-                       float* gradW, void* workspace, const int32_t* m_actual, void* stream) {
+                       float* gradW, void* workspace, const int32_t* m_actual, void* dfeat_half, void* stream) {
   (void)sigma; (void)rgb;  // the chain is recomputed bit-identically from feats_save
   if (M == 0) return 0;
   if (Hd != Hc) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   if (C == 16 && Hd == 64)
-    return launch_bwd<16, 64>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, st);
+    return launch_bwd<16, 64>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   if (C == 32 && Hd == 64)
-    return launch_bwd<32, 64>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, st);
+    return launch_bwd<32, 64>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   if (C == 48 && Hd == 128)
-    return launch_bwd<48, 128>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, st);
+    return launch_bwd<48, 128>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   return (int)hipErrorInvalidValue;
 }
 

@@ -46,7 +46,7 @@ def field_forward(planes_tm, xyz, dirs, packed, bound, C, R, H, save_feats=False
 
 
 def field_backward(grad_sigma, grad_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW,
-                   m_actual=None):
+                   m_actual=None, dfeat=None):
     """Raw call: accumulates into grad_tm [3,R,R,C] fp32 and gradW (concatenated W0..W4, fp32)."""
     lib = L.lib()
     M = xyz.shape[0]
@@ -54,7 +54,8 @@ def field_backward(grad_sigma, grad_rgb, sigma, rgb, feats, xyz, dirs, packed, b
     ws = torch.empty(max(nws, 4), dtype=torch.uint8, device=xyz.device)
     L.check(lib.tnl_field_backward(L.ptr(grad_sigma), L.ptr(grad_rgb), L.ptr(sigma), L.ptr(rgb), L.ptr(feats),
                                    L.ptr(xyz), L.ptr(dirs), L.f32(bound), L.u32(M), L.u32(C), L.u32(R), L.u32(H),
-                                   L.u32(H), L.ptr(packed), L.ptr(grad_tm), L.ptr(gradW), L.ptr(ws), L.ptr(m_actual), L.stream()),
+                                   L.u32(H), L.ptr(packed), L.ptr(grad_tm), L.ptr(gradW), L.ptr(ws), L.ptr(m_actual), L.ptr(dfeat),
+                                   L.stream()),
             "field_backward")
 
 
@@ -92,3 +93,17 @@ class _FusedField(Function):
 
 
 fused_field = _FusedField.apply
+
+
+def plane_grad_binned(dfeat, xyz, bound, C, R, grad_tm, m_actual=None, grad_scale=1.0):
+    """fp16 feature gradients [M,3C] -> plane gradient [3,R,R,C] fp32 by tile-sorted LDS accumulation
+    (csrc/scatter.hip); writes every tile of grad_tm."""
+    lib = L.lib()
+    M = xyz.shape[0]
+    nbytes = lib.tnl_plane_grad_binned_workspace(L.u32(M), L.u32(R))
+    if nbytes == 0:
+        raise NotImplementedError("binned plane gradient needs plane_resolution % 16 == 0")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
+    L.check(lib.tnl_plane_grad_binned(L.ptr(dfeat), L.ptr(xyz), L.f32(bound), L.u32(M), L.ptr(m_actual), L.u32(C),
+                                      L.u32(R), L.f32(grad_scale), L.ptr(grad_tm), L.ptr(ws), L.stream()),
+            "plane_grad_binned")

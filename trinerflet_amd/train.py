@@ -70,7 +70,7 @@ class TrainStep:
     def __init__(self, model, lr=1e-2, wavelet_regularization=0.4, iters=30000, warmup_steps=0,
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
-                 dist_mode=None, process_group=None):
+                 dist_mode=None, process_group=None, binned=True):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
@@ -85,6 +85,7 @@ class TrainStep:
         self.bg = background_color
         self.max_steps, self.dt_gamma, self.T_thresh = max_steps, dt_gamma, T_thresh
         self.global_step = 0
+        self.binned = binned
         dev = enc.planes_features.device
         self.dev = dev
         self.coef = _Flat(list(enc.planes_features_wavelet_coefs))
@@ -274,11 +275,21 @@ class TrainStep:
         if model.density_scale != 1:
             g_sigma = g_sigma * model.density_scale
         self._mark("composite_bwd")
-        grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
         self.mlp.grad.zero_()
-        F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H, grad_tm,
-                          self.mlp.grad, m_actual=counter)
-        self._mark("field_bwd")
+        if self.binned and R % 16 == 0:
+            # no global float atomics: dF -> fp16 -> tile-sorted LDS accumulation (csrc/scatter.hip)
+            grad_tm = torch.empty(3, R, R, C, dtype=torch.float32, device=self.dev)
+            dfeat = torch.empty(M, 3 * C, dtype=torch.float16, device=self.dev)
+            F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
+                              grad_tm, self.mlp.grad, m_actual=counter, dfeat=dfeat)
+            self._mark("field_bwd")
+            F_.plane_grad_binned(dfeat, xyzs, float(model.bound), C, R, grad_tm, m_actual=counter)
+            self._mark("plane_grad_binned")
+        else:
+            grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
+            F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
+                              grad_tm, self.mlp.grad, m_actual=counter)
+            self._mark("field_bwd")
         if self.world > 1:
             dist.all_reduce(self.mlp.grad, group=self.pg)
         s0, s1 = self._adjoint(grad_tm)
