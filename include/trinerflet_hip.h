@@ -191,12 +191,14 @@ TNL_API int tnl_field_backward(const float *grad_sigma, const float *grad_rgb, c
 /* Plane-gradient accumulation without global float atomics (csrc/scatter.hip).  When tnl_field_backward is
  * given dfeat_half (fp16 [M,3C]) it writes the feature gradient there instead of scattering it; this call
  * then counting-sorts the samples by 16x16-texel tile per plane and lets one workgroup per tile accumulate
- * in LDS and store the tile.  EVERY tile of grad_tm:[3,R,R,C] is written (no zero fill needed).  grad_scale
- * multiplies dfeat.  R % 16 == 0.  Replaces torch grid_sampler_2d_backward + the autograd zero fill. */
+ * in LDS and store the tile.  EVERY tile of the gradient is written (no zero fill needed): texel-major
+ * [3,R,R,C] if channel_major == 0, the reference's (3,C,R,R) otherwise (the adjoint IDWT reads that directly,
+ * so the layout-change pass disappears).  grad_scale multiplies dfeat.  R % 32 == 0, C in {16,32,48}.
+ * Replaces torch grid_sampler_2d_backward + the autograd zero fill. */
 TNL_API uint64_t tnl_plane_grad_binned_workspace(uint32_t M, uint32_t R);
 TNL_API int tnl_plane_grad_binned(const void *dfeat_half, const float *xyz, float bound, uint32_t M,
                                   const int32_t *m_actual, uint32_t C, uint32_t R, float grad_scale,
-                                  float *grad_tm, void *workspace, void *stream);
+                                  float *grad_out, int channel_major, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused optimiser for the wavelet coefficients: torch.optim.Adam(betas, eps, no weight decay)

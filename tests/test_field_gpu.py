@@ -146,6 +146,9 @@ def test_binned_plane_gradient_equals_atomic(cuda, C, H, R, M):
                           m_actual=m_act, dfeat=dfeat)
     gfield.plane_grad_binned(dfeat, xg, bound, C, R, g_bin, m_actual=m_act)
     assert torch.isfinite(g_bin).all()
+    g_cm = torch.full((3, C, R, R), float("nan"), device=cuda)      # the (3,C,R,R) output the adjoint IDWT reads
+    gfield.plane_grad_binned(dfeat, xg, bound, C, R, g_cm, m_actual=m_act, channel_major=True)
+    assert _relerr(g_cm.permute(0, 2, 3, 1).cpu().numpy(), g_bin.cpu().numpy().astype(np.float64)) < 1e-6
     assert torch.equal(w_bin, w_at) or _relerr(w_bin.cpu().numpy(), w_at.cpu().numpy()) < 1e-6
     assert _relerr(g_bin.cpu().numpy(), g_at.cpu().numpy().astype(np.float64)) < 1e-3   # fp16 rounding of dF
     assert torch.equal(g_bin == 0, g_at == 0)                                            # same support

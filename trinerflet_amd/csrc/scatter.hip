@@ -22,7 +22,8 @@
 
 namespace {
 
-constexpr int TS = 16;  // tile edge in texels
+constexpr int TSX = 32;  // tile width in texels (128-B rows in the channel-major output)
+constexpr int TSY = 8;   // tile height
 constexpr int NT = 256;
 
 struct Foot {  // tiles touched by a bilinear footprint on one plane
@@ -31,8 +32,8 @@ struct Foot {  // tiles touched by a bilinear footprint on one plane
 
 __device__ __forceinline__ Foot footprint(const TexelTap& t) {
   Foot f;
-  f.tx0 = t.x0 / TS; f.ty0 = t.y0 / TS;
-  f.tx1 = t.x1 / TS; f.ty1 = t.y1 / TS;
+  f.tx0 = t.x0 / TSX; f.ty0 = t.y0 / TSY;
+  f.tx1 = t.x1 / TSX; f.ty1 = t.y1 / TSY;
   return f;
 }
 
@@ -46,8 +47,8 @@ __device__ __forceinline__ uint32_t eff_m(uint32_t M, const int32_t* m_actual) {
 // their slot from it -- ~5x fewer atomics for the primary tile; the rare straddle tiles use one atomic each.
 template <bool FILL>
 __global__ void __launch_bounds__(NT)
-k_bin(const float* __restrict__ xyz, float bound, uint32_t M, const int32_t* __restrict__ m_actual, int R, int TN,
-      int* __restrict__ counts_or_cursor, uint32_t* __restrict__ entries) {
+k_bin(const float* __restrict__ xyz, float bound, uint32_t M, const int32_t* __restrict__ m_actual, int R, int TNX,
+      int TNY, int* __restrict__ counts_or_cursor, uint32_t* __restrict__ entries) {
   const uint32_t Me = eff_m(M, m_actual);
   const uint32_t i = blockIdx.x * NT + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -59,9 +60,9 @@ k_bin(const float* __restrict__ xyz, float bound, uint32_t M, const int32_t* __r
     TexelTap t;
     triplane_tap(x, y, z, bound, R, p, t);
     const Foot f = footprint(t);
-    const int base = p * TN * TN;
+    const int base = p * TNX * TNY;
     // primary tile, run-aggregated
-    const int bin0 = live ? base + f.ty0 * TN + f.tx0 : -1 - lane;
+    const int bin0 = live ? base + f.ty0 * TNX + f.tx0 : -1 - lane;
     const int prev = __shfl_up(bin0, 1);
     const bool head = (lane == 0) || (bin0 != prev);
     const unsigned long long hmask = __ballot(head);
@@ -85,7 +86,7 @@ k_bin(const float* __restrict__ xyz, float bound, uint32_t M, const int32_t* __r
         const int tx = (k & 1) ? f.tx1 : f.tx0, ty = (k & 2) ? f.ty1 : f.ty0;
         const bool dup = ((k & 1) && f.tx1 == f.tx0) || ((k & 2) && f.ty1 == f.ty0);
         if (dup) continue;
-        const int bin = base + ty * TN + tx;
+        const int bin = base + ty * TNX + tx;
         if (FILL) entries[atomicAdd(counts_or_cursor + bin, 1)] = i;
         else atomicAdd(counts_or_cursor + bin, 1);
       }
@@ -134,44 +135,78 @@ k_scan_bins(const int* __restrict__ counts, int nb, int* __restrict__ offsets, i
 //      accumulator words.
 template <int C>
 __global__ void __launch_bounds__(NT)
-k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ xyz, float bound, int R, int TN,
-                  const int* __restrict__ offsets, const uint32_t* __restrict__ entries, float grad_scale,
-                  float* __restrict__ grad_tm) {
-  constexpr int NTEX = TS * TS;
+k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ xyz, float bound, int R, int TNX,
+                  int TNY, const int* __restrict__ offsets, const uint32_t* __restrict__ entries, float grad_scale,
+                  float* __restrict__ grad_out, int channel_major) {
+  constexpr int NTEX = TSX * TSY;
   constexpr int TILE_F = NTEX * C;
+  constexpr int CS = C + 1;  // LDS texel stride: odd, so the transposed read of the epilogue is conflict-free
   constexpr int F = 3 * C;
   constexpr int GL = C <= 16 ? 16 : (C <= 32 ? 32 : 64);  // lanes per texel group
   constexpr int NG = NT / GL;                             // texel groups per workgroup
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-  __shared__ __attribute__((aligned(16))) float acc[TILE_F];
+  __shared__ __attribute__((aligned(16))) float acc[NTEX * CS];
   __shared__ __attribute__((aligned(16))) _Float16 gbuf[NT][C];
   __shared__ int hist[NTEX];
   __shared__ int offs[NTEX + 1];
   __shared__ int wsum[4];
   __shared__ __attribute__((aligned(8))) float2 list_qw[4 * NT];  // (record index as int bits, weight)
   const int bin = blockIdx.x;
-  const int p = bin / (TN * TN), rem = bin - p * TN * TN;
-  const int ty = rem / TN, tx = rem - ty * TN;
+  const int p = bin / (TNX * TNY), rem = bin - p * TNX * TNY;
+  const int ty = rem / TNX, tx = rem - ty * TNX;
   const int beg = offsets[bin], end = offsets[bin + 1];
-  float* dst = grad_tm + (((size_t)p * R + (size_t)ty * TS) * R + (size_t)tx * TS) * C;
-  constexpr int ROW_F4 = TS * C / 4;  // float4 per tile row
-  if (beg == end) {                   // untouched tile: this store replaces the zero fill of the gradient
-    for (int q = threadIdx.x; q < TILE_F / 4; q += NT) {
-      const int ry = q / ROW_F4, rq = q - ry * ROW_F4;
-      reinterpret_cast<float4*>(dst + (size_t)ry * R * C)[rq] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int x_lo = tx * TSX, y_lo = ty * TSY;
+  // epilogue store (also used for untouched tiles, whose store replaces the zero fill of the gradient):
+  //   texel-major  [3][R][R][C]: a tile row is TSX*C contiguous floats
+  //   channel-major (3,C,R,R)  : per channel, TSY rows of TSX contiguous floats (128 B)
+  auto store_tile = [&](bool zero) {
+    if (!channel_major) {
+      float* dst = grad_out + (((size_t)p * R + y_lo) * R + x_lo) * C;
+      constexpr int ROW_F4 = TSX * C / 4;
+      for (int q = threadIdx.x; q < TILE_F / 4; q += NT) {
+        const int ry = q / ROW_F4, rq = q - ry * ROW_F4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!zero) {
+          const int f = rq * 4, lx = f / C, c0 = f - lx * C;
+          const float* a = acc + (ry * TSX + lx) * CS + c0;
+          v = make_float4(a[0], a[1], a[2], a[3]);
+        }
+        reinterpret_cast<float4*>(dst + (size_t)ry * R * C)[rq] = v;
+      }
+    } else {
+      constexpr int X4 = TSX / 4;
+      for (int q = threadIdx.x; q < C * TSY * X4; q += NT) {
+        const int ch = q / (TSY * X4), r2 = q - ch * (TSY * X4);
+        const int ry = r2 / X4, lx = (r2 - ry * X4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!zero) {
+          const float* a = acc + (ry * TSX + lx) * CS + ch;
+          v = make_float4(a[0], a[CS], a[2 * CS], a[3 * CS]);
+        }
+        *reinterpret_cast<float4*>(grad_out + (((size_t)p * C + ch) * R + y_lo + ry) * R + x_lo + lx) = v;
+      }
     }
+  };
+  if (beg == end) {
+    store_tile(true);
     return;
   }
   // acc holds only the CURRENT chunk's per-texel sums (plain stores in phase D); the running totals live in
   // registers: thread t owns the accumulator words {j*NT + t}
   constexpr int NACC = TILE_F / NT;
   float racc[NACC];
+  // accumulator word j of thread t: flat index f = j*NT + t -> (texel f / C, channel f % C) -> LDS texel*CS + c
+  int aidx[NACC];
 #pragma unroll
-  for (int j = 0; j < NACC; j++) { racc[j] = 0.f; acc[j * NT + threadIdx.x] = 0.f; }
+  for (int j = 0; j < NACC; j++) {
+    const int f = j * NT + threadIdx.x;
+    aidx[j] = (f / C) * CS + (f % C);
+    racc[j] = 0.f;
+    acc[aidx[j]] = 0.f;
+  }
   hist[threadIdx.x] = 0;  // NT == NTEX
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int grp = threadIdx.x / GL, c = threadIdx.x - grp * GL;
-  const int x_lo = tx * TS, y_lo = ty * TS;
 
   // prefetch registers for one record
   float px = 0.f, py = 0.f, pz = 0.f;
@@ -200,12 +235,12 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
 #pragma unroll
       for (int k = 0; k < C / 8; k++) reinterpret_cast<h8*>(&gbuf[threadIdx.x][0])[k] = pg[k];
       const int lx0 = t.x0 - x_lo, lx1 = t.x1 - x_lo, ly0 = t.y0 - y_lo, ly1 = t.y1 - y_lo;
-      const bool ix0 = (unsigned)lx0 < (unsigned)TS, ix1 = ((unsigned)lx1 < (unsigned)TS) && (t.x1 != t.x0);
-      const bool iy0 = (unsigned)ly0 < (unsigned)TS, iy1 = ((unsigned)ly1 < (unsigned)TS) && (t.y1 != t.y0);
-      key[0] = (iy0 && ix0) ? ly0 * TS + lx0 : -1; wt[0] = t.w00 * grad_scale;
-      key[1] = (iy0 && ix1) ? ly0 * TS + lx1 : -1; wt[1] = t.w01 * grad_scale;
-      key[2] = (iy1 && ix0) ? ly1 * TS + lx0 : -1; wt[2] = t.w10 * grad_scale;
-      key[3] = (iy1 && ix1) ? ly1 * TS + lx1 : -1; wt[3] = t.w11 * grad_scale;
+      const bool ix0 = (unsigned)lx0 < (unsigned)TSX, ix1 = ((unsigned)lx1 < (unsigned)TSX) && (t.x1 != t.x0);
+      const bool iy0 = (unsigned)ly0 < (unsigned)TSY, iy1 = ((unsigned)ly1 < (unsigned)TSY) && (t.y1 != t.y0);
+      key[0] = (iy0 && ix0) ? ly0 * TSX + lx0 : -1; wt[0] = t.w00 * grad_scale;
+      key[1] = (iy0 && ix1) ? ly0 * TSX + lx1 : -1; wt[1] = t.w01 * grad_scale;
+      key[2] = (iy1 && ix0) ? ly1 * TSX + lx0 : -1; wt[2] = t.w10 * grad_scale;
+      key[3] = (iy1 && ix1) ? ly1 * TSX + lx1 : -1; wt[3] = t.w11 * grad_scale;
 #pragma unroll
       for (int k = 0; k < 4; k++) rank[k] = key[k] >= 0 ? atomicAdd(&hist[key[k]], 1) : 0;
     }
@@ -261,7 +296,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
           if (k + u < k1) {
             const int key = __float_as_int(qw[u].x) >> 8;
             if (key != cur) {
-              if (cur >= 0) acc[cur * C + c] = sum;  // each texel is closed once per chunk: a plain store
+              if (cur >= 0) acc[cur * CS + c] = sum;  // each texel is closed once per chunk: a plain store
               sum = 0.f;
               cur = key;
             }
@@ -269,24 +304,22 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
           }
         }
       }
-      if (cur >= 0) acc[cur * C + c] = sum;
+      if (cur >= 0) acc[cur * CS + c] = sum;
     }
     __syncthreads();
     // ---- E: fold the chunk sums into the register totals and clear them (independent LDS reads)
 #pragma unroll
     for (int j = 0; j < NACC; j++) {
-      racc[j] += acc[j * NT + threadIdx.x];
-      acc[j * NT + threadIdx.x] = 0.f;
+      racc[j] += acc[aidx[j]];
+      acc[aidx[j]] = 0.f;
     }
     hist[threadIdx.x] = 0;
   }
-  constexpr int ROW_F = TS * C;  // floats per tile row
+  // totals back to LDS, then the (possibly transposing) coalesced store
 #pragma unroll
-  for (int j = 0; j < NACC; j++) {
-    const int f = j * NT + threadIdx.x;
-    const int ry = f / ROW_F;
-    dst[(size_t)ry * R * C + (f - ry * ROW_F)] = racc[j];
-  }
+  for (int j = 0; j < NACC; j++) acc[aidx[j]] = racc[j];
+  __syncthreads();
+  store_tile(false);
 }
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -295,20 +328,20 @@ inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 extern "C" {
 
-// bytes of scratch: counts, offsets(+1), cursor: 3*TN^2 ints each; entries: 12 * M uint32
+// bytes of scratch: counts, offsets(+1), cursor: one int per (plane, tile) each; entries: 12 * M uint32
 uint64_t tnl_plane_grad_binned_workspace(uint32_t M, uint32_t R) {
-  if (R % TS != 0) return 0;
-  const uint64_t nb = 3ull * (R / TS) * (R / TS);
-  return (3 * nb + 4) * 4 + 12ull * M * 4;
+  if (R % TSX != 0) return 0;
+  const uint64_t nb = 3ull * (R / TSX) * (R / TSY);
+  return (3 * nb + 8) * 4 + 12ull * M * 4;
 }
 
 int tnl_plane_grad_binned(const void* dfeat_half, const float* xyz, float bound, uint32_t M,
-                          const int32_t* m_actual, uint32_t C, uint32_t R, float grad_scale, float* grad_tm,
-                          void* workspace, void* stream) {
-  if (R % TS != 0 || (C != 16 && C != 32 && C != 48)) return (int)hipErrorInvalidValue;
+                          const int32_t* m_actual, uint32_t C, uint32_t R, float grad_scale, float* grad_out,
+                          int channel_major, void* workspace, void* stream) {
+  if (R % TSX != 0 || (C != 16 && C != 32 && C != 48)) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
-  const int TN = R / TS;
-  const int nb = 3 * TN * TN;
+  const int TNX = R / TSX, TNY = R / TSY;
+  const int nb = 3 * TNX * TNY;
   int* counts = reinterpret_cast<int*>(workspace);
   int* offsets = counts + nb + 1;
   int* cursor = offsets + nb + 1;
@@ -316,24 +349,24 @@ int tnl_plane_grad_binned(const void* dfeat_half, const float* xyz, float bound,
   hipError_t e = hipMemsetAsync(counts, 0, (size_t)(nb + 1) * sizeof(int), st);
   if (e != hipSuccess) return (int)e;
   if (M > 0) {
-    hipLaunchKernelGGL(k_bin<false>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TN, counts,
-                       entries);
+    hipLaunchKernelGGL(k_bin<false>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
+                       counts, entries);
   }
   hipLaunchKernelGGL(k_scan_bins, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursor);
   if (M > 0) {
-    hipLaunchKernelGGL(k_bin<true>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TN, cursor,
-                       entries);
+    hipLaunchKernelGGL(k_bin<true>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
+                       cursor, entries);
   }
   const _Float16* df = reinterpret_cast<const _Float16*>(dfeat_half);
   if (C == 16)
-    hipLaunchKernelGGL(k_tile_accumulate<16>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TN, offsets, entries,
-                       grad_scale, grad_tm);
+    hipLaunchKernelGGL(k_tile_accumulate<16>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY, offsets,
+                       entries, grad_scale, grad_out, channel_major);
   else if (C == 32)
-    hipLaunchKernelGGL(k_tile_accumulate<32>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TN, offsets, entries,
-                       grad_scale, grad_tm);
+    hipLaunchKernelGGL(k_tile_accumulate<32>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY, offsets,
+                       entries, grad_scale, grad_out, channel_major);
   else
-    hipLaunchKernelGGL(k_tile_accumulate<48>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TN, offsets, entries,
-                       grad_scale, grad_tm);
+    hipLaunchKernelGGL(k_tile_accumulate<48>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY, offsets,
+                       entries, grad_scale, grad_out, channel_major);
   return (int)hipGetLastError();
 }
 

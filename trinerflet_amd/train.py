@@ -183,13 +183,15 @@ class TrainStep:
             L.ptr(inv_scale_dev), L.f32(l1_coef), L.ptr(found_inf), L.ptr(abs_sum), L.i32(0), L.stream()),
             "adam_l1_step")
 
-    def _adjoint(self, grad_tm):
-        """plane gradient [3,R,R,C] fp32 -> fills self.ll.grad / self.coef.grad (dense)."""
+    def _adjoint(self, grad_tm, g_cm=None):
+        """plane gradient (texel-major [3,R,R,C], or already (3,C,R,R) in g_cm) -> fills self.ll.grad /
+        self.coef.grad (dense)."""
         lib = L.lib()
         C, R = self.C, self.R
-        g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=self.dev)
-        L.check(lib.tnl_planes_to_channel_major(L.ptr(grad_tm), L.u32(C), L.u32(R), L.ptr(g_cm), L.stream()),
-                "planes_to_channel_major")
+        if g_cm is None:
+            g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=self.dev)
+            L.check(lib.tnl_planes_to_channel_major(L.ptr(grad_tm), L.u32(C), L.u32(R), L.ptr(g_cm), L.stream()),
+                    "planes_to_channel_major")
         S = 3 * C
         s0, s1 = 0, S
         g = g_cm.view(S, R, R)
@@ -276,15 +278,18 @@ class TrainStep:
             g_sigma = g_sigma * model.density_scale
         self._mark("composite_bwd")
         self.mlp.grad.zero_()
-        if self.binned and R % 16 == 0:
-            # no global float atomics: dF -> fp16 -> tile-sorted LDS accumulation (csrc/scatter.hip)
-            grad_tm = torch.empty(3, R, R, C, dtype=torch.float32, device=self.dev)
+        g_cm = None
+        if self.binned and R % 32 == 0:
+            # no global float atomics: dF -> fp16 -> tile-sorted LDS accumulation (csrc/scatter.hip), written
+            # straight in the (3,C,R,R) layout the adjoint IDWT reads
+            g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=self.dev)
             dfeat = torch.empty(M, 3 * C, dtype=torch.float16, device=self.dev)
             F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
-                              grad_tm, self.mlp.grad, m_actual=counter, dfeat=dfeat)
+                              g_cm, self.mlp.grad, m_actual=counter, dfeat=dfeat)
             self._mark("field_bwd")
-            F_.plane_grad_binned(dfeat, xyzs, float(model.bound), C, R, grad_tm, m_actual=counter)
+            F_.plane_grad_binned(dfeat, xyzs, float(model.bound), C, R, g_cm, m_actual=counter, channel_major=True)
             self._mark("plane_grad_binned")
+            grad_tm = None
         else:
             grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
             F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
@@ -292,7 +297,7 @@ class TrainStep:
             self._mark("field_bwd")
         if self.world > 1:
             dist.all_reduce(self.mlp.grad, group=self.pg)
-        s0, s1 = self._adjoint(grad_tm)
+        s0, s1 = self._adjoint(grad_tm, g_cm)
         self._mark("idwt_adjoint")
 
         # GradScaler: skip the step when any gradient is non-finite.  A non-finite plane gradient always
