@@ -101,6 +101,8 @@ class TrainStep:
         self.growth_interval = growth_interval
         self.abs_sum = torch.zeros(1, dtype=torch.float32, device=dev)
         self.last = {}
+        self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
+        self._side = None
         self.post_refresh = None    # optional callable run right after every density-grid refresh
         self.section_events = None  # set to [] to record HIP events (on the launch stream) around every stage
         # distributed
@@ -230,22 +232,45 @@ class TrainStep:
         n_glob = n_global_rays if n_global_rays is not None else N * self.world
 
         self._mark("begin")
+        refresh = self.update_extra_interval > 0 and self.global_step % self.update_extra_interval == 0
+
+        def march():
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, model.aabb_train, model.min_near)
+            counter = model.step_counter[model.local_step % 16]
+            counter.zero_()
+            model.local_step += 1
+            out = raymarching.march_rays_train(
+                rays_o, rays_d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars,
+                counter, model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, noises)
+            return (counter, *out)
+
+        # The march (one ray per lane, latency-bound, ~1/8 of the chip's wave slots) depends only on the rays and
+        # the occupancy bitfield, not on the planes: it runs on a side stream underneath the HBM-bound plane
+        # rebuild.  On grid-refresh steps the bitfield changes first, so there the march stays in order.
+        side = None
+        if self.overlap_march and not refresh and model.mean_count > 0:
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            side = self._side
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                marched = march()
+            for t_ in marched:
+                t_.record_stream(main)
         tm = self.rebuild_planes()
         self._mark("idwt_fwd")
-        if self.update_extra_interval > 0 and self.global_step % self.update_extra_interval == 0:
+        if refresh:
             model.update_extra_state()
             if self.post_refresh is not None:
                 self.post_refresh()
             self._mark("grid_refresh")
-
         packed = F_.pack_weights(*self.Ws, C, H)
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, model.aabb_train, model.min_near)
-        counter = model.step_counter[model.local_step % 16]
-        counter.zero_()
-        model.local_step += 1
-        xyzs, dirs, deltas, rays = raymarching.march_rays_train(
-            rays_o, rays_d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars, counter,
-            model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, noises)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            marched = march()
+        counter, xyzs, dirs, deltas, rays = marched
         M = xyzs.shape[0]
         self._mark("march")
         # rows past counter[0] are the zero padding of the sample budget: skipped on the device
