@@ -142,7 +142,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
   constexpr int TILE_F = NTEX * C;
   constexpr int CS = C + 1;  // LDS texel stride: odd, so the transposed read of the epilogue is conflict-free
   constexpr int F = 3 * C;
-  constexpr int GL = C <= 16 ? 16 : (C <= 32 ? 32 : 64);  // lanes per texel group
+  constexpr int GL = C <= 16 ? 4 : (C <= 32 ? 8 : 16);    // lanes per texel group, 4 channels per lane
   constexpr int NG = NT / GL;                             // texel groups per workgroup
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
   __shared__ __attribute__((aligned(16))) float acc[NTEX * CS];
@@ -206,7 +206,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
   }
   hist[threadIdx.x] = 0;  // NT == NTEX
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int grp = threadIdx.x / GL, c = threadIdx.x - grp * GL;
+  const int grp = threadIdx.x / GL, c = 4 * (threadIdx.x - grp * GL);  // first of this lane's 4 channels
 
   // prefetch registers for one record
   float px = 0.f, py = 0.f, pz = 0.f;
@@ -278,33 +278,42 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
     // ---- D: per-texel register reduction (lane = channel), then one add into the owned accumulator words
     if (c < C) {
       // group g owns texels [g*TPG, (g+1)*TPG): its contributions are ONE contiguous run of the sorted list.
-      // Stream it 8 entries at a time (independent list + dF reads), summing in a register and flushing to the
-      // exclusively owned accumulator word whenever the texel changes.
+      // Stream it 8 entries at a time (independent list + dF reads; a lane covers 4 channels = one 8-byte LDS
+      // read), summing in registers and closing a texel with plain stores whenever the key changes.
       constexpr int TPG = NTEX / NG;
+      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
       const int k0 = offs[grp * TPG], k1 = offs[(grp + 1) * TPG];
-      float sum = 0.f;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       int cur = -1;
       for (int k = k0; k < k1; k += 8) {
         float2 qw[8];
-        float g[8];
+        half4 g[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) qw[u] = list_qw[min(k + u, 4 * NT - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; u++) g[u] = (float)gbuf[__float_as_int(qw[u].x) & (NT - 1)][c];
+        for (int u = 0; u < 8; u++) g[u] = *reinterpret_cast<const half4*>(&gbuf[__float_as_int(qw[u].x) & (NT - 1)][c]);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           if (k + u < k1) {
             const int key = __float_as_int(qw[u].x) >> 8;
             if (key != cur) {
-              if (cur >= 0) acc[cur * CS + c] = sum;  // each texel is closed once per chunk: a plain store
-              sum = 0.f;
+              if (cur >= 0) {  // each texel is closed once per chunk: plain stores
+                float* a = acc + cur * CS + c;
+                a[0] = s0; a[1] = s1; a[2] = s2; a[3] = s3;
+              }
+              s0 = s1 = s2 = s3 = 0.f;
               cur = key;
             }
-            sum = fmaf(g[u], qw[u].y, sum);
+            const float w = qw[u].y;
+            s0 = fmaf((float)g[u][0], w, s0); s1 = fmaf((float)g[u][1], w, s1);
+            s2 = fmaf((float)g[u][2], w, s2); s3 = fmaf((float)g[u][3], w, s3);
           }
         }
       }
-      if (cur >= 0) acc[cur * CS + c] = sum;
+      if (cur >= 0) {
+        float* a = acc + cur * CS + c;
+        a[0] = s0; a[1] = s1; a[2] = s2; a[3] = s3;
+      }
     }
     __syncthreads();
     // ---- E: fold the chunk sums into the register totals and clear them (independent LDS reads)
