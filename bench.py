@@ -85,10 +85,12 @@ def cpu_baseline(workload):
     """Reference operator set on the host cores, bounded sample (see oracle/torch_baseline.py)."""
     from oracle import torch_baseline as tb
     C, R, scale, H, N, lam = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
-    # dense part at 1/16 of the plane area (R/4), per-ray part on N/100 rays; both scale linearly
-    Rs, Ns = max(R // 4, 64 * 2), max(N // 100, 64)
-    ss = max(scale // 4, 2)
+    # torch's CPU kernels stop scaling (and then regress) well before the 256 hardware threads of the GPU box's
+    # host: 32 threads measured fastest there (8: 1.38 s, 16: 1.23 s, 32: 1.10 s, 64: 1.92 s for the same sample)
+    cores = min(os.cpu_count() or 1, 32)
+    # dense part at 1/4 of the plane area (R/2), per-ray part on N/10 rays; both scale linearly
+    Rs, Ns = max(R // 2, 64 * 2), max(N // 10, 64)
+    ss = max(scale // 2, 2)
     t = tb.time_step(C, Rs, ss, H, Ns, lam=lam, threads=cores)
     dense = t["dense_s"] * (R / Rs) ** 2
     ray = t["ray_s"] * (N / Ns)
@@ -96,6 +98,16 @@ def cpu_baseline(workload):
             "sample": f"torch-CPU fp32 step: dense part (IDWT fwd+bwd, L1, Adam) at R={Rs} scaled x{(R / Rs) ** 2:.0f}; "
                       f"per-ray part (512 uniform steps/ray, renderer.run semantics) on {Ns} rays scaled x{N / Ns:.0f}; "
                       f"measured dense {t['dense_s']:.2f}s ray {t['ray_s']:.2f}s"}
+
+
+def pmc_traffic(workload, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01d_pmc_adam.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, gfx950 correction applied);
+    null when no profile exists for this configuration."""
+    path = os.path.join(ROOT, "profiles", "r01d_pmc_adam.json")
+    if workload != "base" or world != 1 or not os.path.exists(path):
+        return None
+    return json.load(open(path))["hbm_bytes_per_launch"]
 
 
 def main():
@@ -191,7 +203,8 @@ def main():
                        "sections_ms": {k: round(v, 4) for k, v in sec.items()}},
             "roofline": {"bound": "hbm", "kernel": "k_adam_l1 (fused Adam + wavelet-L1 over the coefficients)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": adam_bytes, "avg_launch_ms": adam_ms},
+                         "traffic": pmc_traffic(args.workload, world), "algorithmic_bytes_per_launch": adam_bytes,
+                         "avg_launch_ms": adam_ms},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
