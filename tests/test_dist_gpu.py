@@ -1,0 +1,91 @@
+"""Two ranks on ONE MI355X (backend gloo, both processes on cuda:0): the ray-sharded TrainStep in both exchange
+modes against the single-process step on the whole batch.  The HIP kernels are the real ones; only the transport
+differs from the 8-GPU run (gloo instead of RCCL -- the RCCL calls themselves are reduce_scatter_tensor /
+all_gather_into_tensor in trinerflet_amd/distributed.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from trinerflet_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+C, R, SCALE, H, N, BOUND, LAM = 16, 64, 4, 64, 512, 1.5, 0.2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _build(dev):
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=BOUND, cuda_ray=True, density_thresh=10, hidden_dim=H,
+                    hidden_dim_color=H, triplane_channels=C, triplane_resolution=R, triplane_wavelet_levels=SCALE,
+                    wavelet_type="bior6.8").to(dev)
+    synthetic.init_field_parameters(m, seed=3)
+    with torch.no_grad():
+        for p in m.encoder.planes_features_wavelet_coefs:
+            p.mul_(5.0)
+    m.density_bitfield.copy_(torch.from_numpy(synthetic.sphere_bitfield(128, 2, BOUND, 0.8, 0.55)).to(dev))
+    m.mean_count = 0
+    return m
+
+
+def _inputs():
+    o, d = synthetic.training_rays(N, n_cams=4, seed=7)
+    noise = np.random.default_rng(0).random(N).astype(np.float32)
+    return o, d, synthetic.target_colors(d), noise
+
+
+def _run(model, mode, lo, hi, n_global, steps=2):
+    from trinerflet_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    o, d, gt, noise = _inputs()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev)
+    ts = TrainStep(model, lr=1e-2, wavelet_regularization=LAM, iters=1000, fp16=True, update_extra_interval=0,
+                   dist_mode=mode)
+    losses = []
+    for _ in range(steps):
+        losses.append(float(ts.step(t(o), t(d), t(gt), noises=t(noise), n_global_rays=n_global)))
+        model.mean_count = 0
+    ts.sync_sharded_parameters()
+    return losses, {k: v.detach().cpu().clone() for k, v in model.named_parameters()}, ts.ll.grad.detach().cpu().clone()
+
+
+def _worker(rank, port, mode, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        torch.cuda.set_device(0)
+        from trinerflet_amd import distributed as D
+        lo, hi = D.shard_rays(N, 2, rank)
+        losses, params, _ = _run(_build(torch.device("cuda:0")), mode, lo, hi, N)
+        out[rank] = (losses, {k: v.numpy() for k, v in params.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+def test_two_ranks_equal_one(cuda, mode):
+    ref_losses, ref_params, ref_g = _run(_build(cuda), None, 0, N, N)
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(port, mode, out), nprocs=2, join=True)
+    assert set(out.keys()) == {0, 1}
+    l0, p0 = out[0]
+    l1, p1 = out[1]
+    assert np.allclose(l0, l1, rtol=1e-6) and np.allclose(l0, ref_losses, rtol=2e-3), (l0, l1, ref_losses)
+    for k in ref_params:
+        assert np.array_equal(p0[k], p1[k]), k                  # replicas stay identical
+        a, b = p0[k], ref_params[k].numpy()
+        # Adam's early steps are sign-like (eps = 1e-15): compare where the parameter moved consistently
+        frac = np.mean(np.abs(a - b) > 2e-3)                     # 2 steps x lr 1e-2: a flipped sign moves 2e-2
+        assert frac < 5e-3, (k, frac)

@@ -159,15 +159,21 @@ class TrainStep:
         return D.slice_range(3 * self.C, self.world, self.rank)
 
     def _rebuild_sharded(self):
+        """IDWT of this rank's (plane, channel) slices, then all-gather of the rebuilt slices -- in fp16 when the
+        sampler's planes are fp16 (half the bytes on the wire)."""
         enc = self.enc
         s0, s1 = self._slice_range()
         n0 = enc.planes_features.shape[-1]
-        x = enc.planes_features.reshape(3 * self.C, n0, n0)[s0:s1].unsqueeze(0)
+        x = enc.planes_features.reshape(3 * self.C, n0, n0)[s0:s1].unsqueeze(0).contiguous()
+        fast = (self.J > 0 and enc.plane_dtype == torch.float16 and self.C % 8 == 0 and self.R % 16 == 0)
         for lvl in range(self.J):
             n = x.shape[-1]
-            yh = enc.planes_features_wavelet_coefs[lvl].reshape(3 * self.C, 3, n, n)[s0:s1].unsqueeze(0)
-            x = _IDWTLevel.apply(x.contiguous(), yh.contiguous(), enc.wave_id)
-        mine = x.reshape(s1 - s0, self.R, self.R).contiguous()
+            yh = enc.planes_features_wavelet_coefs[lvl].reshape(3 * self.C, 3, n, n)[s0:s1].unsqueeze(0).contiguous()
+            if fast and lvl == self.J - 1:
+                x = idwt_level_half(x, yh, enc.wave_id)
+            else:
+                x = _IDWTLevel.apply(x, yh, enc.wave_id)
+        mine = x.reshape(s1 - s0, self.R, self.R)
         return D.all_gather_slices(mine, self.pg).view(3, self.C, self.R, self.R)
 
     # ------------------------------------------------------------------------------------------
