@@ -25,30 +25,33 @@
 
 namespace {
 
-constexpr int BW_THREADS = 256;
-constexpr int BW_WAVES = 4;
-constexpr int ST = 128;       // samples per super-tile
-constexpr int LS = ST + 8;    // LDS row stride in halfs (272 B: 16-B aligned, conflict-free b128 reads)
-
-template <int C, int H>
+// NW waves per workgroup, 32 samples per wave.  Measured: the kernel needs ~480 registers per lane (dW accumulators
+// + the recomputed chain), i.e. one wave per SIMD, and is VALU-issue-bound there; an 8-wave variant capped at 256
+// registers (two waves per SIMD) spills 90 VGPRs to scratch and runs 1.9x SLOWER (2.72 vs 1.46 ms), so NW = 4.
+template <int C, int H, int NW, bool ATOMIC>
 struct BwdGeom {
   using G = FieldGeom<C, H>;
+  static constexpr int BW_WAVES = NW;
+  static constexpr int BW_THREADS = 64 * NW;
+  static constexpr int ST = 32 * NW;      // samples per super-tile
+  static constexpr int LS = ST + 8;       // LDS row stride in halfs (16-B aligned rows)
   static constexpr int XROWS = (32 * G::IB0 > H) ? 32 * G::IB0 : H;
   static constexpr int YROWS = H;
   static constexpr int STAGE_LD = G::F + 1;                       // floats per staged sample row
   static constexpr size_t XS_BYTES = (size_t)XROWS * LS * 2;
   static constexpr size_t YS_BYTES = (size_t)YROWS * LS * 2;
-  static constexpr size_t STAGE_BYTES = (size_t)BW_WAVES * 32 * STAGE_LD * 4;
+  static constexpr size_t STAGE_BYTES = ATOMIC ? (size_t)BW_WAVES * 32 * STAGE_LD * 4 : 0;
   static constexpr size_t W_BYTES = (size_t)G::NTOT * 1024;
   static constexpr size_t BASE_BYTES = XS_BYTES + YS_BYTES + STAGE_BYTES;
   static constexpr bool LDSW = BASE_BYTES + W_BYTES <= 160 * 1024;  // weights cached in LDS when they fit
   static constexpr size_t LDS_BYTES = BASE_BYTES + (LDSW ? W_BYTES : 0);
   static constexpr int NT0 = G::OB * G::IB0, NT1 = G::OB, NT2 = G::OB, NT3 = G::OB * G::OB, NT4 = G::OB;
-  static constexpr int A0 = (NT0 + 3) / 4, A1 = (NT1 + 3) / 4, A2 = (NT2 + 3) / 4, A3 = (NT3 + 3) / 4,
-                       A4 = (NT4 + 3) / 4;
+  static constexpr int A0 = (NT0 + NW - 1) / NW, A1 = (NT1 + NW - 1) / NW, A2 = (NT2 + NW - 1) / NW,
+                       A3 = (NT3 + NW - 1) / NW, A4 = (NT4 + NW - 1) / NW;
 };
 
-// one 32x32 weight-gradient tile: D[out][in] += sum over the 128 staged samples
+// one 32x32 weight-gradient tile: D[out][in] += sum over the staged samples of the super-tile
+template <int ST, int LS>
 __device__ __forceinline__ f32x16 dw_tile(const _Float16* Ys, const _Float16* Xs, int ob, int ib, int r, int h,
                                           f32x16 acc) {
 #pragma unroll
@@ -61,11 +64,13 @@ __device__ __forceinline__ f32x16 dw_tile(const _Float16* Ys, const _Float16* Xs
 }
 
 // publish an accumulator-layout tile (16 rows per lane) as fp16 rows [32*blk + acc_row][col]
+template <int LS>
 __device__ __forceinline__ void put_acc(_Float16* S, int blk, const f32x16& a, int h, int col) {
 #pragma unroll
   for (int g = 0; g < 16; g++) S[(32 * blk + acc_row(g, h)) * LS + col] = (_Float16)a[g];
 }
 // publish a chain fragment of k-step ks: slot (h,j) -> row kslot_feature(ks,h,j)
+template <int LS>
 __device__ __forceinline__ void put_frag(_Float16* S, int ks, const half8& f, int h, int col) {
 #pragma unroll
   for (int j = 0; j < 8; j++) S[kslot_feature(ks, h, j) * LS + col] = f[j];
@@ -91,14 +96,15 @@ __device__ __forceinline__ void slab_tile(float* slab, int off, int out_dim, int
   }
 }
 
-template <int C, int H>
-__global__ void __launch_bounds__(BW_THREADS)
+template <int C, int H, int NW, bool ATOMIC>
+__global__ void __launch_bounds__(64 * NW)
 k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, const _Float16* __restrict__ feats,
             const float* __restrict__ xyz, const float* __restrict__ dirs, float bound, uint32_t M, int R,
             const half8* __restrict__ packed, float* __restrict__ grad_tm, float* __restrict__ slabs,
             const int32_t* __restrict__ m_actual, _Float16* __restrict__ dfeat) {
   using G = FieldGeom<C, H>;
-  using B = BwdGeom<C, H>;
+  using B = BwdGeom<C, H, NW, ATOMIC>;
+  constexpr int BW_THREADS = B::BW_THREADS, ST = B::ST, LS = B::LS;
   if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   _Float16* Xs = reinterpret_cast<_Float16*>(smem);
@@ -114,7 +120,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
   const int col = 32 * wv + r;
-  float* stage = stage_all + (size_t)wv * 32 * B::STAGE_LD;
+  float* stage = stage_all + (size_t)(ATOMIC ? wv : 0) * 32 * B::STAGE_LD;
 
   f32x16 dw0[B::A0], dw1[B::A1], dw2[B::A2], dw3[B::A3], dw4[B::A4];
 #pragma unroll
@@ -168,13 +174,13 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     const half8 dz4f = acc_to_frag<false>(dz4, 0);
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag(Xs, ks, ch.h4[ks], h, col);
-    put_acc(Ys, 0, dz4, h, col);
+    for (int ks = 0; ks < G::KH; ks++) put_frag<LS>(Xs, ks, ch.h4[ks], h, col);
+    put_acc<LS>(Ys, 0, dz4, h, col);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A4; k++) {
-      const int t = wv + 4 * k;
-      if (t < B::NT4) dw4[k] = dw_tile(Ys, Xs, 0, t, r, h, dw4[k]);
+      const int t = wv + NW * k;
+      if (t < B::NT4) dw4[k] = dw_tile<ST, LS>(Ys, Xs, 0, t, r, h, dw4[k]);
     }
     f32x16 d4[G::OB];
     half8 d4f[G::KH];
@@ -189,14 +195,14 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 
     // ---- layer 3
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag(Xs, ks, ch.h3[ks], h, col);
+    for (int ks = 0; ks < G::KH; ks++) put_frag<LS>(Xs, ks, ch.h3[ks], h, col);
 #pragma unroll
-    for (int ib = 0; ib < G::OB; ib++) put_acc(Ys, ib, d4[ib], h, col);
+    for (int ib = 0; ib < G::OB; ib++) put_acc<LS>(Ys, ib, d4[ib], h, col);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A3; k++) {
-      const int t = wv + 4 * k;
-      if (t < B::NT3) dw3[k] = dw_tile(Ys, Xs, t / G::OB, t % G::OB, r, h, dw3[k]);
+      const int t = wv + NW * k;
+      if (t < B::NT3) dw3[k] = dw_tile<ST, LS>(Ys, Xs, t / G::OB, t % G::OB, r, h, dw3[k]);
     }
     f32x16 d3[G::OB];
     half8 d3f[G::KH];
@@ -224,12 +230,12 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       }
     }
 #pragma unroll
-    for (int ib = 0; ib < G::OB; ib++) put_acc(Ys, ib, d3[ib], h, col);
+    for (int ib = 0; ib < G::OB; ib++) put_acc<LS>(Ys, ib, d3[ib], h, col);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A2; k++) {
-      const int t = wv + 4 * k;
-      if (t < B::NT2) dw2[k] = dw_tile(Ys, Xs, t, 0, r, h, dw2[k]);
+      const int t = wv + NW * k;
+      if (t < B::NT2) dw2[k] = dw_tile<ST, LS>(Ys, Xs, t, 0, r, h, dw2[k]);
     }
     f32x16 dzz = zero16();
 #pragma unroll
@@ -243,7 +249,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 
     // ---- layer 1: X = H1, dY = dO (16 rows) + 16 zero rows
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag(Xs, ks, ch.h1[ks], h, col);
+    for (int ks = 0; ks < G::KH; ks++) put_frag<LS>(Xs, ks, ch.h1[ks], h, col);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int rho = kslot_feature(0, h, j);
@@ -253,8 +259,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A1; k++) {
-      const int t = wv + 4 * k;
-      if (t < B::NT1) dw1[k] = dw_tile(Ys, Xs, 0, t, r, h, dw1[k]);
+      const int t = wv + NW * k;
+      if (t < B::NT1) dw1[k] = dw_tile<ST, LS>(Ys, Xs, 0, t, r, h, dw1[k]);
     }
     f32x16 d1[G::OB];
     half8 d1f[G::KH];
@@ -275,15 +281,15 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
         Xs[(16 * ks + 8 * h + j) * LS + col] = ks < G::KS0 ? ff[ks < G::KS0 ? ks : 0][j] : (_Float16)0.f;
     }
 #pragma unroll
-    for (int ib = 0; ib < G::OB; ib++) put_acc(Ys, ib, d1[ib], h, col);
+    for (int ib = 0; ib < G::OB; ib++) put_acc<LS>(Ys, ib, d1[ib], h, col);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A0; k++) {
-      const int t = wv + 4 * k;
-      if (t < B::NT0) dw0[k] = dw_tile(Ys, Xs, t / G::IB0, t % G::IB0, r, h, dw0[k]);
+      const int t = wv + NW * k;
+      if (t < B::NT0) dw0[k] = dw_tile<ST, LS>(Ys, Xs, t / G::IB0, t % G::IB0, r, h, dw0[k]);
     }
     // feature gradient dF^T = W0^T dH1^T
-    if (dfeat != nullptr) {
+    if (!ATOMIC) {
       // binned mode: dF leaves as fp16 [M, 3C]; scatter.hip accumulates it per tile without global atomics
       typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -346,27 +352,27 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   float* slab = slabs + (size_t)blockIdx.x * G::NW;
 #pragma unroll
   for (int k = 0; k < B::A0; k++) {
-    const int t = wv + 4 * k;
+    const int t = wv + NW * k;
     if (t < B::NT0) slab_tile(slab, G::OFF0, H, G::F, t / G::IB0, t % G::IB0, dw0[k], r, h);
   }
 #pragma unroll
   for (int k = 0; k < B::A1; k++) {
-    const int t = wv + 4 * k;
+    const int t = wv + NW * k;
     if (t < B::NT1) slab_tile(slab, G::OFF1, 16, H, 0, t, dw1[k], r, h);
   }
 #pragma unroll
   for (int k = 0; k < B::A2; k++) {
-    const int t = wv + 4 * k;
+    const int t = wv + NW * k;
     if (t < B::NT2) slab_tile(slab, G::OFF2, H, 31, t, 0, dw2[k], r, h);
   }
 #pragma unroll
   for (int k = 0; k < B::A3; k++) {
-    const int t = wv + 4 * k;
+    const int t = wv + NW * k;
     if (t < B::NT3) slab_tile(slab, G::OFF3, H, H, t / G::OB, t % G::OB, dw3[k], r, h);
   }
 #pragma unroll
   for (int k = 0; k < B::A4; k++) {
-    const int t = wv + 4 * k;
+    const int t = wv + NW * k;
     if (t < B::NT4) slab_tile(slab, G::OFF4, 3, H, 0, t, dw4[k], r, h);
   }
 }
@@ -380,30 +386,41 @@ __global__ void k_slab_reduce(const float* __restrict__ slabs, int nslab, int nw
 }
 
 inline uint32_t bwd_blocks(uint32_t M) {
-  uint32_t nst = (M + ST - 1) / ST;
+  uint32_t nst = (M + 127) / 128;
   return nst < 256 ? nst : 256;
 }
 
-template <int C, int H>
-int launch_bwd(const float* gsig, const float* grgb, const void* feats, const float* xyz, const float* dirs,
-               float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW, void* workspace,
-               const int32_t* m_actual, void* dfeat, hipStream_t st) {
+template <int C, int H, int NW, bool ATOMIC>
+int launch_bwd_impl(const float* gsig, const float* grgb, const void* feats, const float* xyz, const float* dirs,
+                    float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW,
+                    void* workspace, const int32_t* m_actual, void* dfeat, hipStream_t st) {
   using G = FieldGeom<C, H>;
-  using B = BwdGeom<C, H>;
+  using B = BwdGeom<C, H, NW, ATOMIC>;
   const uint32_t blocks = bwd_blocks(M);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd<C, H>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd<C, H, NW, ATOMIC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)B::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   float* slabs = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL((k_field_bwd<C, H>), dim3(blocks), dim3(BW_THREADS), B::LDS_BYTES, st, gsig, grgb,
+  hipLaunchKernelGGL((k_field_bwd<C, H, NW, ATOMIC>), dim3(blocks), dim3(B::BW_THREADS), B::LDS_BYTES, st, gsig, grgb,
                      reinterpret_cast<const _Float16*>(feats), xyz, dirs, bound, M, (int)R,
                      reinterpret_cast<const half8*>(packed), grad_tm, slabs, m_actual, reinterpret_cast<_Float16*>(dfeat));
   hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 255) / 256), dim3(256), 0, st, slabs, (int)blocks, (int)G::NW, gradW);
   return (int)hipGetLastError();
+}
+
+template <int C, int H, int NWB>
+int launch_bwd(const float* gsig, const float* grgb, const void* feats, const float* xyz, const float* dirs,
+               float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW, void* workspace,
+               const int32_t* m_actual, void* dfeat, hipStream_t st) {
+  if (dfeat != nullptr)
+    return launch_bwd_impl<C, H, NWB, false>(gsig, grgb, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
+                                             m_actual, dfeat, st);
+  return launch_bwd_impl<C, H, 4, true>(gsig, grgb, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
+                                        m_actual, dfeat, st);
 }
 
 }  // namespace
@@ -428,11 +445,11 @@ int tnl_field_backward(const float* grad_sigma, const float* grad_rgb, const flo
   if (Hd != Hc) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   if (C == 16 && Hd == 64)
-    return launch_bwd<16, 64>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
+    return launch_bwd<16, 64, 4>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   if (C == 32 && Hd == 64)
-    return launch_bwd<32, 64>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
+    return launch_bwd<32, 64, 4>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   if (C == 48 && Hd == 128)
-    return launch_bwd<48, 128>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
+    return launch_bwd<48, 128, 4>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   return (int)hipErrorInvalidValue;
 }
 
