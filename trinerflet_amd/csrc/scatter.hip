@@ -120,19 +120,26 @@ k_scan_bins(const int* __restrict__ counts, int nb, int* __restrict__ offsets, i
   if (threadIdx.x == 1023) offsets[nb] = part[1023];
 }
 
-// pass 4: one workgroup per (plane, tile): accumulate in LDS, store the tile.
+// pass 4: one workgroup per (plane, tile of 32 x 8 texels): accumulate the tile's samples, store the tile.
 //
-// Float LDS atomics are the slow path on this chip (ds_add_f32 measured ~150 cycles per wave-instruction: 9 ms
-// per step), and a read-modify-write chain per record is latency-bound, so the tile is reduced by SORTING:
-// entries are consumed in chunks of 256 records (one thread per record; the next chunk's id, xyz and fp16 dF
-// slice are prefetched into registers while the current chunk is reduced).  Per chunk:
-//   A. each thread computes its record's tap once, stages dF in LDS and ranks its (<= 4) in-tile corner
-//      contributions per texel with an integer LDS atomic (fast path),
-//   B. a 256-entry exclusive scan turns the per-texel counts into offsets,
-//   C. contributions (record index, weight) are written in texel order,
-//   D. each group of C lanes (lane = channel) walks the texels it owns, sums their contributions in a register
-//      -- independent LDS reads, no read-modify-write chain -- and adds the sum to its exclusively owned
-//      accumulator words.
+// The accumulation  acc[(y,x), c] += sum_q rw_q[y] * cw_q[x] * g_q[c]   (bilinear weights are separable:
+// rw = {1-wy, wy} on rows y0,y1 ; cw = {1-wx, wx} on columns x0,x1) is a matrix product over the records q, so
+// it runs on the matrix cores instead of LDS atomics (ds_add_f32 measured ~150 cycles per wave-instruction here:
+// 9 ms per step) or sort-and-reduce passes (6 barriers per 256 records, LDS-latency-bound: 1.7 ms):
+//   per tile row y (one 32-texel block):  D_y[x, c] += A_y[x, q] * G[q, c],   A_y[x, q] = fp16(cw_q[x] * rw_q[y])
+// with v_mfma_f32_32x32x16_f16, fp32 accumulators in registers for the whole tile lifetime (wave w owns rows
+// 2w, 2w+1).  Records are consumed 256 at a time: phase A (one thread per record; the next chunk's id, xyz and
+// fp16 dF slice are prefetched into registers during phase B) computes the tap once and stages dF transposed
+// (gT[c][q]: a B fragment is one 16-byte LDS read), the row weights (rwT[y][q]) and the column taps; phase B is
+// 16 k-steps x 2 rows of MFMA per wave.  Two barriers per chunk, no atomics, deterministic summation order.
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef float f16acc __attribute__((ext_vector_type(16)));
+
+struct __attribute__((aligned(8))) ColTap {
+  short x0, x1;          // tile-local columns, -1 when outside the tile (or the clamped duplicate)
+  _Float16 w0, w1;       // 1 - wx, wx
+};
+
 template <int C>
 __global__ void __launch_bounds__(NT)
 k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ xyz, float bound, int R, int TNX,
@@ -140,195 +147,176 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
                   float* __restrict__ grad_out, int channel_major) {
   constexpr int NTEX = TSX * TSY;
   constexpr int TILE_F = NTEX * C;
-  constexpr int CS = C + 1;  // LDS texel stride: odd, so the transposed read of the epilogue is conflict-free
   constexpr int F = 3 * C;
-  constexpr int GL = C <= 16 ? 4 : (C <= 32 ? 8 : 16);    // lanes per texel group, 4 channels per lane
-  constexpr int NG = NT / GL;                             // texel groups per workgroup
-  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-  __shared__ __attribute__((aligned(16))) float acc[NTEX * CS];
-  __shared__ __attribute__((aligned(16))) _Float16 gbuf[NT][C];
-  __shared__ int hist[NTEX];
-  __shared__ int offs[NTEX + 1];
-  __shared__ int wsum[4];
-  __shared__ __attribute__((aligned(8))) float2 list_qw[4 * NT];  // (record index as int bits, weight)
+  constexpr int NB = (C + 31) / 32;          // 32-channel column blocks
+  constexpr int QS = NT + 8;                 // record stride (halfs) of the transposed stages: 16-B aligned rows
+  constexpr int XS = TSX + 4;                // epilogue staging stride (floats)
+  constexpr size_t STAGE_A = (size_t)(32 * NB + TSY) * QS * 2 + NT * sizeof(ColTap);
+  constexpr size_t STAGE_E = (size_t)4 * 2 * 32 * NB * XS * 4;
+  constexpr size_t LDS_BYTES = STAGE_A > STAGE_E ? STAGE_A : STAGE_E;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+  _Float16* gT = reinterpret_cast<_Float16*>(smem);                 // [32*NB][QS]
+  _Float16* rwT = gT + (size_t)32 * NB * QS;                        // [TSY][QS]
+  ColTap* ctap = reinterpret_cast<ColTap*>(rwT + (size_t)TSY * QS);  // [NT]
+
   const int bin = blockIdx.x;
   const int p = bin / (TNX * TNY), rem = bin - p * TNX * TNY;
   const int ty = rem / TNX, tx = rem - ty * TNX;
   const int beg = offsets[bin], end = offsets[bin + 1];
   const int x_lo = tx * TSX, y_lo = ty * TSY;
-  // epilogue store (also used for untouched tiles, whose store replaces the zero fill of the gradient):
-  //   texel-major  [3][R][R][C]: a tile row is TSX*C contiguous floats
-  //   channel-major (3,C,R,R)  : per channel, TSY rows of TSX contiguous floats (128 B)
-  auto store_tile = [&](bool zero) {
+  if (beg == end) {  // untouched tile: this store replaces the zero fill of the gradient
     if (!channel_major) {
       float* dst = grad_out + (((size_t)p * R + y_lo) * R + x_lo) * C;
       constexpr int ROW_F4 = TSX * C / 4;
       for (int q = threadIdx.x; q < TILE_F / 4; q += NT) {
         const int ry = q / ROW_F4, rq = q - ry * ROW_F4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!zero) {
-          const int f = rq * 4, lx = f / C, c0 = f - lx * C;
-          const float* a = acc + (ry * TSX + lx) * CS + c0;
-          v = make_float4(a[0], a[1], a[2], a[3]);
-        }
-        reinterpret_cast<float4*>(dst + (size_t)ry * R * C)[rq] = v;
+        reinterpret_cast<float4*>(dst + (size_t)ry * R * C)[rq] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
       constexpr int X4 = TSX / 4;
       for (int q = threadIdx.x; q < C * TSY * X4; q += NT) {
         const int ch = q / (TSY * X4), r2 = q - ch * (TSY * X4);
         const int ry = r2 / X4, lx = (r2 - ry * X4) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!zero) {
-          const float* a = acc + (ry * TSX + lx) * CS + ch;
-          v = make_float4(a[0], a[CS], a[2 * CS], a[3 * CS]);
-        }
-        *reinterpret_cast<float4*>(grad_out + (((size_t)p * C + ch) * R + y_lo + ry) * R + x_lo + lx) = v;
+        *reinterpret_cast<float4*>(grad_out + (((size_t)p * C + ch) * R + y_lo + ry) * R + x_lo + lx) =
+            make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-  };
-  if (beg == end) {
-    store_tile(true);
     return;
   }
-  // acc holds only the CURRENT chunk's per-texel sums (plain stores in phase D); the running totals live in
-  // registers: thread t owns the accumulator words {j*NT + t}
-  constexpr int NACC = TILE_F / NT;
-  float racc[NACC];
-  // accumulator word j of thread t: flat index f = j*NT + t -> (texel f / C, channel f % C) -> LDS texel*CS + c
-  int aidx[NACC];
-#pragma unroll
-  for (int j = 0; j < NACC; j++) {
-    const int f = j * NT + threadIdx.x;
-    aidx[j] = (f / C) * CS + (f % C);
-    racc[j] = 0.f;
-    acc[aidx[j]] = 0.f;
-  }
-  hist[threadIdx.x] = 0;  // NT == NTEX
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int grp = threadIdx.x / GL, c = 4 * (threadIdx.x - grp * GL);  // first of this lane's 4 channels
+  const int r = lane & 31, h = lane >> 5;
+
+  f16acc acc[2][NB];
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) acc[b][nb][g] = 0.f;
+  // rows of gT beyond C (C = 16 or 48: the padded half of a column block) stay zero for the whole kernel
+  if (C % 32 != 0) {
+    for (int q = threadIdx.x; q < (32 * NB - C) * QS; q += NT) gT[(size_t)C * QS + q] = (_Float16)0.f;
+  }
 
   // prefetch registers for one record
   float px = 0.f, py = 0.f, pz = 0.f;
-  h8 pg[C / 8];
+  h8v pg[C / 8];
   bool pv = false;
   auto prefetch = [&](int base) {
     pv = base + (int)threadIdx.x < end;
     if (pv) {
       const uint32_t i = entries[base + threadIdx.x];
       px = xyz[(size_t)i * 3]; py = xyz[(size_t)i * 3 + 1]; pz = xyz[(size_t)i * 3 + 2];
-      const h8* src = reinterpret_cast<const h8*>(dfeat + (size_t)i * F + p * C);
+      const h8v* src = reinterpret_cast<const h8v*>(dfeat + (size_t)i * F + p * C);
 #pragma unroll
       for (int k = 0; k < C / 8; k++) pg[k] = src[k];
     }
   };
   prefetch(beg);
   for (int base = beg; base < end; base += NT) {
-    __syncthreads();  // previous chunk fully reduced; acc / hist initialised on the first trip
-    // ---- A: tap, stage dF, rank the in-tile corners
-    int key[4], rank[4];
-    float wt[4];
-    const bool valid = pv;
-    if (valid) {
-      TexelTap t;
-      triplane_tap(px, py, pz, bound, R, p, t);
+    __syncthreads();  // previous chunk's fragments fully read
+    // ---- A: one thread per record
+    {
+      const int q = threadIdx.x;
+      ColTap ct;
+      ct.x0 = -1; ct.x1 = -1; ct.w0 = (_Float16)0.f; ct.w1 = (_Float16)0.f;
+      int ly0 = -1, ly1 = -1;
+      float wy0 = 0.f, wy1 = 0.f;
+      if (pv) {
+        TexelTap t;
+        triplane_tap(px, py, pz, bound, R, p, t);
+        const float wx = t.w01 + t.w11, wy = t.w10 + t.w11;  // weights are (1-wx|wx) x (1-wy|wy)
+        const int lx0 = t.x0 - x_lo, lx1 = t.x1 - x_lo;
+        ly0 = t.y0 - y_lo; ly1 = (t.y1 != t.y0) ? t.y1 - y_lo : -1;
+        if ((unsigned)lx0 < (unsigned)TSX) { ct.x0 = (short)lx0; ct.w0 = (_Float16)(1.f - wx); }
+        if ((unsigned)lx1 < (unsigned)TSX && t.x1 != t.x0) { ct.x1 = (short)lx1; ct.w1 = (_Float16)wx; }
+        wy0 = (1.f - wy) * grad_scale; wy1 = wy * grad_scale;
 #pragma unroll
-      for (int k = 0; k < C / 8; k++) reinterpret_cast<h8*>(&gbuf[threadIdx.x][0])[k] = pg[k];
-      const int lx0 = t.x0 - x_lo, lx1 = t.x1 - x_lo, ly0 = t.y0 - y_lo, ly1 = t.y1 - y_lo;
-      const bool ix0 = (unsigned)lx0 < (unsigned)TSX, ix1 = ((unsigned)lx1 < (unsigned)TSX) && (t.x1 != t.x0);
-      const bool iy0 = (unsigned)ly0 < (unsigned)TSY, iy1 = ((unsigned)ly1 < (unsigned)TSY) && (t.y1 != t.y0);
-      key[0] = (iy0 && ix0) ? ly0 * TSX + lx0 : -1; wt[0] = t.w00 * grad_scale;
-      key[1] = (iy0 && ix1) ? ly0 * TSX + lx1 : -1; wt[1] = t.w01 * grad_scale;
-      key[2] = (iy1 && ix0) ? ly1 * TSX + lx0 : -1; wt[2] = t.w10 * grad_scale;
-      key[3] = (iy1 && ix1) ? ly1 * TSX + lx1 : -1; wt[3] = t.w11 * grad_scale;
+        for (int k = 0; k < C / 8; k++)
 #pragma unroll
-      for (int k = 0; k < 4; k++) rank[k] = key[k] >= 0 ? atomicAdd(&hist[key[k]], 1) : 0;
+          for (int j = 0; j < 8; j++) gT[(size_t)(8 * k + j) * QS + q] = pg[k][j];
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) gT[(size_t)c * QS + q] = (_Float16)0.f;  // 0 * stale NaN would poison the MFMA
+      }
+      ctap[q] = ct;
+#pragma unroll
+      for (int y = 0; y < TSY; y++) rwT[(size_t)y * QS + q] = (_Float16)((y == ly0 ? wy0 : 0.f) + (y == ly1 ? wy1 : 0.f));
     }
     if (base + NT < end) prefetch(base + NT); else pv = false;
     __syncthreads();
-    // ---- B: exclusive scan of the 256 per-texel counts
-    {
-      const int v = hist[threadIdx.x];
-      int incl = v;
+    // ---- B: matrix-core accumulation, wave wv owns tile rows 2wv and 2wv+1
+    const int nks = (min(NT, end - base) + 15) / 16;
+    for (int ks = 0; ks < nks; ks++) {
+      const int q0 = 16 * ks + 8 * h;
+      // column weights of this lane's texel column r for its 8 records
+      float cw[8];
+      const uint4* tp = reinterpret_cast<const uint4*>(ctap + q0);
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int u = __shfl_up(incl, off);
-        if (lane >= off) incl += u;
-      }
-      if (lane == 63) wsum[wv] = incl;
-      __syncthreads();
-      int b = 0;
+      for (int v = 0; v < 4; v++) {
+        const uint4 u = tp[v];  // two records
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-      for (int k = 0; k < 4; k++) if (k < wv) b += wsum[k];
-      offs[threadIdx.x] = b + incl - v;
-      if (threadIdx.x == NT - 1) offs[NTEX] = b + incl;
-    }
-    __syncthreads();
-    // ---- C: contributions in texel order
-    if (valid) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (key[k] >= 0) {
-          const int pos = offs[key[k]] + rank[k];
-          list_qw[pos] = make_float2(__int_as_float((int)threadIdx.x | (key[k] << 8)), wt[k]);
+        for (int e = 0; e < 2; e++) {
+          const int x0 = (short)(w[2 * e] & 0xffffu), x1 = (short)(w[2 * e] >> 16);
+          union { uint32_t u32; _Float16 hh[2]; } cv;
+          cv.u32 = w[2 * e + 1];
+          cw[2 * v + e] = (r == x0 ? (float)cv.hh[0] : 0.f) + (r == x1 ? (float)cv.hh[1] : 0.f);
         }
       }
-    }
-    __syncthreads();
-    // ---- D: per-texel register reduction (lane = channel), then one add into the owned accumulator words
-    if (c < C) {
-      // group g owns texels [g*TPG, (g+1)*TPG): its contributions are ONE contiguous run of the sorted list.
-      // Stream it 8 entries at a time (independent list + dF reads; a lane covers 4 channels = one 8-byte LDS
-      // read), summing in registers and closing a texel with plain stores whenever the key changes.
-      constexpr int TPG = NTEX / NG;
-      typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-      const int k0 = offs[grp * TPG], k1 = offs[(grp + 1) * TPG];
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int cur = -1;
-      for (int k = k0; k < k1; k += 8) {
-        float2 qw[8];
-        half4 g[8];
+      h8v bf[NB];
 #pragma unroll
-        for (int u = 0; u < 8; u++) qw[u] = list_qw[min(k + u, 4 * NT - 1)];
+      for (int nb = 0; nb < NB; nb++) bf[nb] = *reinterpret_cast<const h8v*>(gT + (size_t)(32 * nb + r) * QS + q0);
 #pragma unroll
-        for (int u = 0; u < 8; u++) g[u] = *reinterpret_cast<const half4*>(&gbuf[__float_as_int(qw[u].x) & (NT - 1)][c]);
+      for (int b = 0; b < 2; b++) {
+        const h8v rw = *reinterpret_cast<const h8v*>(rwT + (size_t)(2 * wv + b) * QS + q0);
+        h8v af;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          if (k + u < k1) {
-            const int key = __float_as_int(qw[u].x) >> 8;
-            if (key != cur) {
-              if (cur >= 0) {  // each texel is closed once per chunk: plain stores
-                float* a = acc + cur * CS + c;
-                a[0] = s0; a[1] = s1; a[2] = s2; a[3] = s3;
-              }
-              s0 = s1 = s2 = s3 = 0.f;
-              cur = key;
-            }
-            const float w = qw[u].y;
-            s0 = fmaf((float)g[u][0], w, s0); s1 = fmaf((float)g[u][1], w, s1);
-            s2 = fmaf((float)g[u][2], w, s2); s3 = fmaf((float)g[u][3], w, s3);
-          }
-        }
-      }
-      if (cur >= 0) {
-        float* a = acc + cur * CS + c;
-        a[0] = s0; a[1] = s1; a[2] = s2; a[3] = s3;
+        for (int j = 0; j < 8; j++) af[j] = (_Float16)(cw[j] * (float)rw[j]);
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+          acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[nb], acc[b][nb], 0, 0, 0);
       }
     }
-    __syncthreads();
-    // ---- E: fold the chunk sums into the register totals and clear them (independent LDS reads)
-#pragma unroll
-    for (int j = 0; j < NACC; j++) {
-      racc[j] += acc[aidx[j]];
-      acc[aidx[j]] = 0.f;
-    }
-    hist[threadIdx.x] = 0;
   }
-  // totals back to LDS, then the (possibly transposing) coalesced store
+  // ---- epilogue: D[x = acc_row(g,h)][channel = 32nb + r] of rows 2wv, 2wv+1
+  if (!channel_major) {
 #pragma unroll
-  for (int j = 0; j < NACC; j++) acc[aidx[j]] = racc[j];
-  __syncthreads();
-  store_tile(false);
+    for (int b = 0; b < 2; b++) {
+      float* dst = grad_out + (((size_t)p * R + y_lo + 2 * wv + b) * R + x_lo) * C;
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) {
+        const int c = 32 * nb + r;
+        if (c < C) {
+#pragma unroll
+          for (int g = 0; g < 16; g++) dst[(size_t)((g & 3) + 8 * (g >> 2) + 4 * h) * C + c] = acc[b][nb][g];
+        }
+      }
+    }
+  } else {
+    __syncthreads();  // the staging area aliases gT / rwT / ctap
+    float* stg = reinterpret_cast<float*>(smem) + (size_t)wv * 2 * 32 * NB * XS;
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int g = 0; g < 16; g++)
+          stg[(size_t)((b * NB + nb) * 32 + r) * XS + (g & 3) + 8 * (g >> 2) + 4 * h] = acc[b][nb][g];
+    // a wave reads back only what it wrote: no barrier, but LDS writes must land first
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    constexpr int X4 = TSX / 4;
+    for (int q = lane; q < 2 * 32 * NB * X4; q += 64) {
+      const int row = q / X4, lx = (q - row * X4) * 4;   // row = (b*NB + nb)*32 + channel-in-block
+      const int b = row / (32 * NB), c = row - b * (32 * NB);
+      if (c < C) {
+        const float* a = stg + (size_t)row * XS + lx;
+        *reinterpret_cast<float4*>(grad_out + (((size_t)p * C + c) * R + y_lo + 2 * wv + b) * R + x_lo + lx) =
+            make_float4(a[0], a[1], a[2], a[3]);
+      }
+    }
+  }
 }
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
