@@ -135,10 +135,7 @@ k_scan_bins(const int* __restrict__ counts, int nb, int* __restrict__ offsets, i
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef float f16acc __attribute__((ext_vector_type(16)));
 
-struct __attribute__((aligned(8))) ColTap {
-  short x0, x1;          // tile-local columns, -1 when outside the tile (or the clamped duplicate)
-  _Float16 w0, w1;       // 1 - wx, wx
-};
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
 template <int C>
 __global__ void __launch_bounds__(NT)
@@ -151,13 +148,16 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
   constexpr int NB = (C + 31) / 32;          // 32-channel column blocks
   constexpr int QS = NT + 8;                 // record stride (halfs) of the transposed stages: 16-B aligned rows
   constexpr int XS = TSX + 4;                // epilogue staging stride (floats)
-  constexpr size_t STAGE_A = (size_t)(32 * NB + TSY) * QS * 2 + NT * sizeof(ColTap);
+  constexpr size_t STAGE_A = (size_t)(32 * NB + TSY) * QS * 2 + NT * 4 + NT * 4;
   constexpr size_t STAGE_E = (size_t)4 * 2 * 32 * NB * XS * 4;
   constexpr size_t LDS_BYTES = STAGE_A > STAGE_E ? STAGE_A : STAGE_E;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
   _Float16* gT = reinterpret_cast<_Float16*>(smem);                 // [32*NB][QS]
   _Float16* rwT = gT + (size_t)32 * NB * QS;                        // [TSY][QS]
-  ColTap* ctap = reinterpret_cast<ColTap*>(rwT + (size_t)TSY * QS);  // [NT]
+  // column taps: x0 (int, may be -1: then x0+1 = 0 can still be inside) and the weight pair (1-wx | wx) as half2;
+  // a weight is stored as 0 when its column lies outside the tile, so only x0 is needed to place both
+  int* cx0 = reinterpret_cast<int*>(rwT + (size_t)TSY * QS);          // [NT]
+  h2v* cww = reinterpret_cast<h2v*>(cx0 + NT);                         // [NT]
 
   const int bin = blockIdx.x;
   const int p = bin / (TNX * TNY), rem = bin - p * TNX * TNY;
@@ -218,8 +218,9 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
     // ---- A: one thread per record
     {
       const int q = threadIdx.x;
-      ColTap ct;
-      ct.x0 = -1; ct.x1 = -1; ct.w0 = (_Float16)0.f; ct.w1 = (_Float16)0.f;
+      int tx0 = -100;
+      h2v tw;
+      tw[0] = (_Float16)0.f; tw[1] = (_Float16)0.f;
       int ly0 = -1, ly1 = -1;
       float wy0 = 0.f, wy1 = 0.f;
       if (pv) {
@@ -228,8 +229,9 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
         const float wx = t.w01 + t.w11, wy = t.w10 + t.w11;  // weights are (1-wx|wx) x (1-wy|wy)
         const int lx0 = t.x0 - x_lo, lx1 = t.x1 - x_lo;
         ly0 = t.y0 - y_lo; ly1 = (t.y1 != t.y0) ? t.y1 - y_lo : -1;
-        if ((unsigned)lx0 < (unsigned)TSX) { ct.x0 = (short)lx0; ct.w0 = (_Float16)(1.f - wx); }
-        if ((unsigned)lx1 < (unsigned)TSX && t.x1 != t.x0) { ct.x1 = (short)lx1; ct.w1 = (_Float16)wx; }
+        tx0 = lx0;
+        if ((unsigned)lx0 < (unsigned)TSX) tw[0] = (_Float16)(1.f - wx);
+        if ((unsigned)lx1 < (unsigned)TSX && t.x1 != t.x0) tw[1] = (_Float16)wx;
         wy0 = (1.f - wy) * grad_scale; wy1 = wy * grad_scale;
 #pragma unroll
         for (int k = 0; k < C / 8; k++)
@@ -239,7 +241,8 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < C; c++) gT[(size_t)c * QS + q] = (_Float16)0.f;  // 0 * stale NaN would poison the MFMA
       }
-      ctap[q] = ct;
+      cx0[q] = tx0;
+      cww[q] = tw;
 #pragma unroll
       for (int y = 0; y < TSY; y++) rwT[(size_t)y * QS + q] = (_Float16)((y == ly0 ? wy0 : 0.f) + (y == ly1 ? wy1 : 0.f));
     }
@@ -249,19 +252,17 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
     const int nks = (min(NT, end - base) + 15) / 16;
     for (int ks = 0; ks < nks; ks++) {
       const int q0 = 16 * ks + 8 * h;
-      // column weights of this lane's texel column r for its 8 records
-      float cw[8];
-      const uint4* tp = reinterpret_cast<const uint4*>(ctap + q0);
+      // column weights of this lane's texel column r for its 8 records, kept in fp16: cw = d==0 ? w0 : d==1 ? w1 : 0
+      h8v cw;
+      {
+        const int4 xa = *reinterpret_cast<const int4*>(cx0 + q0), xb = *reinterpret_cast<const int4*>(cx0 + q0 + 4);
+        const h8v wa = *reinterpret_cast<const h8v*>(cww + q0), wb = *reinterpret_cast<const h8v*>(cww + q0 + 4);
+        const int xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const uint4 u = tp[v];  // two records
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-          const int x0 = (short)(w[2 * e] & 0xffffu), x1 = (short)(w[2 * e] >> 16);
-          union { uint32_t u32; _Float16 hh[2]; } cv;
-          cv.u32 = w[2 * e + 1];
-          cw[2 * v + e] = (r == x0 ? (float)cv.hh[0] : 0.f) + (r == x1 ? (float)cv.hh[1] : 0.f);
+        for (int j = 0; j < 8; j++) {
+          const int d = r - xs[j];
+          const _Float16 w0 = j < 4 ? wa[2 * j] : wb[2 * (j - 4)], w1 = j < 4 ? wa[2 * j + 1] : wb[2 * (j - 4) + 1];
+          cw[j] = d == 0 ? w0 : (d == 1 ? w1 : (_Float16)0.f);
         }
       }
       h8v bf[NB];
@@ -270,9 +271,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
 #pragma unroll
       for (int b = 0; b < 2; b++) {
         const h8v rw = *reinterpret_cast<const h8v*>(rwT + (size_t)(2 * wv + b) * QS + q0);
-        h8v af;
-#pragma unroll
-        for (int j = 0; j < 8; j++) af[j] = (_Float16)(cw[j] * (float)rw[j]);
+        const h8v af = cw * rw;  // packed fp16 products (v_pk_mul_f16)
 #pragma unroll
         for (int nb = 0; nb < NB; nb++)
           acc[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf[nb], acc[b][nb], 0, 0, 0);
