@@ -133,6 +133,18 @@ TNL_API int tnl_idwt_level_forward_half(const float *x, const float *yh, uint32_
 TNL_API int tnl_idwt_level_backward(const float *dout, uint32_t S, uint32_t n, int wave, float *dx,
                                     float *dyh, void *stream);
 
+/* The adjoint level fused with the optimiser (tnl_adam_l1_step's arithmetic and arguments): the level's
+ * detail-band gradients are applied to p/m/v:[S,3,n,n] where they are produced and never written; dx:[S,n,n]
+ * receives the low-pass gradient for the next level, or, at the coarsest level, pass dx = NULL and the LL
+ * parameter ll_p/ll_m/ll_v:[S,n,n] (updated without the L1 term).  abs_sum += sum |p_old| of the detail bands.
+ * n % 2 == 0.  Saves the 8 bytes per coefficient of writing and re-reading the gradient. */
+TNL_API int tnl_idwt_level_backward_adam(const float *dout, uint32_t S, uint32_t n, int wave, float *dx,
+                                         float *p, float *m, float *v, float *ll_p, float *ll_m,
+                                         float *ll_v, float step_size, float bias2_sqrt, float beta1,
+                                         float beta2, float eps, float inv_scale,
+                                         const float *inv_scale_dev, float l1_coef,
+                                         const float *found_inf, float *abs_sum, void *stream);
+
 /* Layout change between the reference's (3,C,R,R) planes ("channel-major") and the sampler's
  * texel-major [3,R,R,C] storage.  half_out != 0 stores fp16 (e = 2), else fp32 (e = 4). */
 TNL_API int tnl_planes_to_texel_major(const float *planes_cm, uint32_t C, uint32_t R, int half_out,
@@ -194,11 +206,13 @@ TNL_API int tnl_field_backward(const float *grad_sigma, const float *grad_rgb, c
  * in LDS and store the tile.  EVERY tile of the gradient is written (no zero fill needed): texel-major
  * [3,R,R,C] if channel_major == 0, the reference's (3,C,R,R) otherwise (the adjoint IDWT reads that directly,
  * so the layout-change pass disappears).  grad_scale multiplies dfeat.  R % 32 == 0, C in {16,32,48}.
+ * nonfinite_flag (device int32, may be NULL) is set to 1 if any stored value is inf/nan (GradScaler probe).
  * Replaces torch grid_sampler_2d_backward + the autograd zero fill. */
 TNL_API uint64_t tnl_plane_grad_binned_workspace(uint32_t M, uint32_t R);
 TNL_API int tnl_plane_grad_binned(const void *dfeat_half, const float *xyz, float bound, uint32_t M,
                                   const int32_t *m_actual, uint32_t C, uint32_t R, float grad_scale,
-                                  float *grad_out, int channel_major, void *workspace, void *stream);
+                                  float *grad_out, int channel_major, int32_t *nonfinite_flag,
+                                  void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused optimiser for the wavelet coefficients: torch.optim.Adam(betas, eps, no weight decay)

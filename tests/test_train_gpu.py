@@ -82,9 +82,16 @@ def test_one_step_three_ways(cuda):
     opt.step()
 
     # ---------------- (1) fused step (GradScaler default initial scale 2^16: fp16 backward operands neither underflow nor overflow)
+    # ... with the optional fused form (m1f: Adam inside the adjoint IDWT kernels) and as shipped (separate optimiser
+    # pass, coefficient gradients observable); both must land on the same parameters
+    m1f = copy.deepcopy(base)
+    tsf = TrainStep(m1f, lr=1e-2, wavelet_regularization=LAM, iters=1000, warmup_steps=0, fp16=True, init_scale=65536.0,
+                    update_extra_interval=0, fuse_adam=True)
+    m1f.mean_count = 0
+    tsf.step(t(o), t(d), t(gt), noises=t(noise))
     m1 = copy.deepcopy(base)
     ts = TrainStep(m1, lr=1e-2, wavelet_regularization=LAM, iters=1000, warmup_steps=0, fp16=True, init_scale=65536.0,
-                   update_extra_interval=0)  # no density-grid refresh: keep the analytic bitfield
+                   update_extra_interval=0, fuse_adam=False)  # no density-grid refresh: keep the analytic bitfield
     m1.mean_count = 0
     loss1 = ts.step(t(o), t(d), t(gt), noises=t(noise))
     assert int(ts.last["counter"][0]) == total                      # bit-exact sample count vs the oracle
@@ -116,6 +123,11 @@ def test_one_step_three_ways(cuda):
     # ---------------- parameters after the step: (1) == (2) and both close to (3)
     p1 = dict(m1.named_parameters())
     p2 = dict(m2.named_parameters())
+    assert abs(float(tsf.last["wavelet_reg"]) - float(ts.last["wavelet_reg"])) < 1e-6 * float(ts.last["wavelet_reg"])
+    for n, pf in m1f.named_parameters():   # fused optimiser == separate optimiser pass (same kernels upstream)
+        g2 = p2[n].grad.detach().cpu().numpy()
+        sig = np.abs(g2) > 1e-3 * np.abs(g2).max()
+        assert np.mean(np.abs(pf.detach().cpu().numpy() - p1[n].detach().cpu().numpy())[sig] > 1e-6) < 1e-3, n
     oracle_new = {"encoder.planes_features": ll, "encoder.planes_features_wavelet_coefs.0": coefs[0],
                   "encoder.planes_features_wavelet_coefs.1": coefs[1], "sigma_net.0.weight": W[0],
                   "sigma_net.1.weight": W[1], "color_net.0.weight": W[2], "color_net.1.weight": W[3],

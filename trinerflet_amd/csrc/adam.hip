@@ -11,23 +11,9 @@
 #include <stdint.h>
 
 #include "../../include/trinerflet_hip.h"
+#include "adam_common.h"
 
 namespace {
-
-struct AdamArgs {
-  float step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef;
-};
-
-__device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
-
-__device__ __forceinline__ void adam1(float& p, float g_in, float& m, float& v, const AdamArgs& a, float& abs_acc) {
-  abs_acc += fabsf(p);
-  const float g = g_in * a.inv_scale + a.l1_coef * sgn(p);
-  m = m + (g - m) * (1.f - a.beta1);
-  v = v * a.beta2 + (1.f - a.beta2) * g * g;
-  const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
-  p = p - a.step_size * (m / denom);
-}
 
 __global__ void __launch_bounds__(256)
 k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, uint64_t n,

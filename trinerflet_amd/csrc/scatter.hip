@@ -141,7 +141,7 @@ template <int C>
 __global__ void __launch_bounds__(NT)
 k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ xyz, float bound, int R, int TNX,
                   int TNY, const int* __restrict__ offsets, const uint32_t* __restrict__ entries, float grad_scale,
-                  float* __restrict__ grad_out, int channel_major) {
+                  float* __restrict__ grad_out, int channel_major, int* __restrict__ nonfinite_flag) {
   constexpr int NTEX = TSX * TSY;
   constexpr int TILE_F = NTEX * C;
   constexpr int F = 3 * C;
@@ -279,6 +279,16 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
     }
   }
   // ---- epilogue: D[x = acc_row(g,h)][channel = 32nb + r] of rows 2wv, 2wv+1
+  if (nonfinite_flag != nullptr) {
+    float chk = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) chk += acc[b][nb][g] * 0.f;  // 0 unless some value is inf/nan
+    if (chk != 0.f || chk != chk) *nonfinite_flag = 1;
+  }
   if (!channel_major) {
 #pragma unroll
     for (int b = 0; b < 2; b++) {
@@ -333,7 +343,7 @@ uint64_t tnl_plane_grad_binned_workspace(uint32_t M, uint32_t R) {
 
 int tnl_plane_grad_binned(const void* dfeat_half, const float* xyz, float bound, uint32_t M,
                           const int32_t* m_actual, uint32_t C, uint32_t R, float grad_scale, float* grad_out,
-                          int channel_major, void* workspace, void* stream) {
+                          int channel_major, int32_t* nonfinite_flag, void* workspace, void* stream) {
   if (R % TSX != 0 || (C != 16 && C != 32 && C != 48)) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int TNX = R / TSX, TNY = R / TSY;
@@ -356,13 +366,13 @@ int tnl_plane_grad_binned(const void* dfeat_half, const float* xyz, float bound,
   const _Float16* df = reinterpret_cast<const _Float16*>(dfeat_half);
   if (C == 16)
     hipLaunchKernelGGL(k_tile_accumulate<16>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY, offsets,
-                       entries, grad_scale, grad_out, channel_major);
+                       entries, grad_scale, grad_out, channel_major, nonfinite_flag);
   else if (C == 32)
     hipLaunchKernelGGL(k_tile_accumulate<32>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY, offsets,
-                       entries, grad_scale, grad_out, channel_major);
+                       entries, grad_scale, grad_out, channel_major, nonfinite_flag);
   else
     hipLaunchKernelGGL(k_tile_accumulate<48>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY, offsets,
-                       entries, grad_scale, grad_out, channel_major);
+                       entries, grad_scale, grad_out, channel_major, nonfinite_flag);
   return (int)hipGetLastError();
 }
 

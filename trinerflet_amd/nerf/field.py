@@ -95,7 +95,8 @@ class _FusedField(Function):
 fused_field = _FusedField.apply
 
 
-def plane_grad_binned(dfeat, xyz, bound, C, R, grad_out, m_actual=None, grad_scale=1.0, channel_major=False):
+def plane_grad_binned(dfeat, xyz, bound, C, R, grad_out, m_actual=None, grad_scale=1.0, channel_major=False,
+                      nonfinite_flag=None):
     """fp16 feature gradients [M,3C] -> plane gradient fp32 by tile-sorted LDS accumulation (csrc/scatter.hip):
     [3,R,R,C], or (3,C,R,R) with channel_major=True; writes every tile of grad_out."""
     lib = L.lib()
@@ -105,6 +106,7 @@ def plane_grad_binned(dfeat, xyz, bound, C, R, grad_out, m_actual=None, grad_sca
         raise NotImplementedError("binned plane gradient needs plane_resolution % 32 == 0")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
     L.check(lib.tnl_plane_grad_binned(L.ptr(dfeat), L.ptr(xyz), L.f32(bound), L.u32(M), L.ptr(m_actual), L.u32(C),
-                                      L.u32(R), L.f32(grad_scale), L.ptr(grad_out), L.i32(int(channel_major)), L.ptr(ws),
+                                      L.u32(R), L.f32(grad_scale), L.ptr(grad_out), L.i32(int(channel_major)),
+                                      L.ptr(nonfinite_flag), L.ptr(ws),
                                       L.stream()),
             "plane_grad_binned")

@@ -70,7 +70,7 @@ class TrainStep:
     def __init__(self, model, lr=1e-2, wavelet_regularization=0.4, iters=30000, warmup_steps=0,
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
-                 dist_mode=None, process_group=None, binned=True):
+                 dist_mode=None, process_group=None, binned=True, fuse_adam=False):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
@@ -86,6 +86,10 @@ class TrainStep:
         self.max_steps, self.dt_gamma, self.T_thresh = max_steps, dt_gamma, T_thresh
         self.global_step = 0
         self.binned = binned
+        # fuse_adam: Adam(+L1) applied inside the adjoint IDWT kernels (no coefficient-gradient buffer).  Measured
+        # SLOWER at base (3.8 ms vs 0.95 + 2.03 ms): the epilogue's 4-byte p/m/v accesses are issued late and in
+        # 128-B pieces, while the stand-alone pass streams 16 B/lane at the HBM ceiling.  Kept as an option.
+        self.fuse_adam = fuse_adam
         dev = enc.planes_features.device
         self.dev = dev
         self.coef = _Flat(list(enc.planes_features_wavelet_coefs))
@@ -100,6 +104,7 @@ class TrainStep:
         self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=dev)
         self.growth_interval = growth_interval
         self.abs_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
         self.last = {}
         self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
         self._side = None
@@ -191,9 +196,14 @@ class TrainStep:
             L.ptr(inv_scale_dev), L.f32(l1_coef), L.ptr(found_inf), L.ptr(abs_sum), L.i32(0), L.stream()),
             "adam_l1_step")
 
-    def _adjoint(self, grad_tm, g_cm=None):
-        """plane gradient (texel-major [3,R,R,C], or already (3,C,R,R) in g_cm) -> fills self.ll.grad /
-        self.coef.grad (dense)."""
+    def _adam_scalars(self, lr_t):
+        t = self.global_step + 1
+        return lr_t / (1 - self.b1 ** t), math.sqrt(1 - self.b2 ** t)
+
+    def _adjoint(self, grad_tm, g_cm=None, fuse=None):
+        """plane gradient (texel-major [3,R,R,C], or already (3,C,R,R) in g_cm) -> coefficient / LL gradients.
+        fuse=None: fills self.ll.grad / self.coef.grad (dense).  fuse=(lr_t, l1, found_inf, inv_scale): every
+        level applies Adam(+L1) to its coefficients where their gradients are produced (no gradient buffer)."""
         lib = L.lib()
         C, R = self.C, self.R
         if g_cm is None:
@@ -209,20 +219,31 @@ class TrainStep:
             s0, s1 = self._slice_range()
             g = D.reduce_scatter_slices(g, self.pg)
         ns = s1 - s0
+        if fuse is not None:
+            lr_t, l1, found_inf, inv_scale = fuse
+            step_size, bias2_sqrt = self._adam_scalars(lr_t)
         for lvl in reversed(range(self.J)):
             n = g.shape[-1] // 2
-            dyh_full = self.coef.grad_view(lvl).view(S, 3, n, n)
-            if ns == S:
-                dx = torch.empty(S, n, n, dtype=torch.float32, device=self.dev) if lvl > 0 else self.ll.grad_view(0).view(S, n, n)
-                L.check(lib.tnl_idwt_level_backward(L.ptr(g), L.u32(S), L.u32(n), L.i32(self.enc.wave_id), L.ptr(dx),
-                                                    L.ptr(dyh_full), L.stream()), "idwt_level_backward")
+            per = 3 * n * n
+            dx = torch.empty(ns, n, n, dtype=torch.float32, device=self.dev) if lvl > 0 else None
+            if fuse is not None:
+                o = self.coef.offsets[lvl] + s0 * per
+                cf = self.coef
+                llp = [None, None, None]
+                if lvl == 0:
+                    lo = s0 * n * n
+                    llp = [self.ll.data[lo:], self.ll.m[lo:], self.ll.v[lo:]]
+                L.check(lib.tnl_idwt_level_backward_adam(
+                    L.ptr(g), L.u32(ns), L.u32(n), L.i32(self.enc.wave_id), L.ptr(dx), L.ptr(cf.data[o:]),
+                    L.ptr(cf.m[o:]), L.ptr(cf.v[o:]), L.ptr(llp[0]), L.ptr(llp[1]), L.ptr(llp[2]), L.f32(step_size),
+                    L.f32(bias2_sqrt), L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0), L.ptr(inv_scale),
+                    L.f32(l1), L.ptr(found_inf), L.ptr(self.abs_sum), L.stream()), "idwt_level_backward_adam")
             else:
-                dx = torch.empty(ns, n, n, dtype=torch.float32, device=self.dev)
-                dyh = dyh_full[s0:s1]  # contiguous slice range of the flat gradient buffer
+                dyh = self.coef.grad_view(lvl).view(S, 3, n, n)[s0:s1]  # contiguous slice range of the flat buffer
+                if lvl == 0:
+                    dx = self.ll.grad_view(0).view(S, n, n)[s0:s1]
                 L.check(lib.tnl_idwt_level_backward(L.ptr(g), L.u32(ns), L.u32(n), L.i32(self.enc.wave_id), L.ptr(dx),
                                                     L.ptr(dyh), L.stream()), "idwt_level_backward")
-                if lvl == 0:
-                    self.ll.grad_view(0).view(S, n, n)[s0:s1].copy_(dx)
             g = dx
         return s0, s1
 
@@ -310,46 +331,65 @@ class TrainStep:
         self._mark("composite_bwd")
         self.mlp.grad.zero_()
         g_cm = None
+        lr_t = self.lr * lr_factor(self.global_step, self.iters, self.warmup)
+        l1 = self.lam / (self.J * self.coef_numel) if (self.J > 0 and self.lam > 0) else 0.0
+        inv_scale = 1.0 / self.scale
+        self.abs_sum.zero_()
         if self.binned and R % 32 == 0:
-            # no global float atomics: dF -> fp16 -> tile-sorted LDS accumulation (csrc/scatter.hip), written
+            # no global float atomics: dF -> fp16 -> tile-sorted matrix-core accumulation (csrc/scatter.hip), written
             # straight in the (3,C,R,R) layout the adjoint IDWT reads
             g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=self.dev)
             dfeat = torch.empty(M, 3 * C, dtype=torch.float16, device=self.dev)
             F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
                               g_cm, self.mlp.grad, m_actual=counter, dfeat=dfeat)
             self._mark("field_bwd")
-            F_.plane_grad_binned(dfeat, xyzs, float(model.bound), C, R, g_cm, m_actual=counter, channel_major=True)
+            self.nonfinite.zero_()
+            F_.plane_grad_binned(dfeat, xyzs, float(model.bound), C, R, g_cm, m_actual=counter, channel_major=True,
+                                 nonfinite_flag=self.nonfinite)
             self._mark("plane_grad_binned")
-            grad_tm = None
+            if self.world > 1:
+                dist.all_reduce(self.mlp.grad, group=self.pg)
+            # GradScaler probe BEFORE the dense backward, so that the optimiser can be fused into it: the plane
+            # gradient reports non-finite values through the tile kernel's flag, the MLP gradient is 13.5k floats
+            probe = self.mlp.grad.abs().sum() + torch.where(self.nonfinite[0] != 0, float("inf"), 0.0)
+            if self.world > 1:
+                dist.all_reduce(probe, group=self.pg)
+            found_inf = (~torch.isfinite(probe)).to(torch.float32).reshape(1)
+            self._mark("scaler_probe")
+            if self.fuse_adam:
+                s0, s1 = self._adjoint(None, g_cm, fuse=(lr_t, l1, found_inf, inv_scale))
+                self._mark("idwt_adjoint_adam")
+            else:
+                s0, s1 = self._adjoint(None, g_cm)
+                self._mark("idwt_adjoint")
+                if self.dist_mode == "sharded":
+                    self._adam_sharded(lr_t, l1, found_inf, inv_scale, s0, s1)
+                else:
+                    self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum)
+                    self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
+                self._mark("adam_coef")
         else:
             grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
             F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
                               grad_tm, self.mlp.grad, m_actual=counter)
             self._mark("field_bwd")
-        if self.world > 1:
-            dist.all_reduce(self.mlp.grad, group=self.pg)
-        s0, s1 = self._adjoint(grad_tm, g_cm)
-        self._mark("idwt_adjoint")
-
-        # GradScaler: skip the step when any gradient is non-finite.  A non-finite plane gradient always
-        # reaches the coarse LL gradient through the low-pass adjoint, so checking LL + MLP grads suffices.
-        probe = self.ll.grad.abs().sum() + self.mlp.grad.abs().sum()
-        if self.world > 1:
-            dist.all_reduce(probe, group=self.pg)
-        found_inf = (~torch.isfinite(probe)).to(torch.float32).reshape(1)
-        inv_scale = 1.0 / self.scale
-
-        lr_t = self.lr * lr_factor(self.global_step, self.iters, self.warmup)
-        l1 = self.lam / (self.J * self.coef_numel) if (self.J > 0 and self.lam > 0) else 0.0
-        self.abs_sum.zero_()
-        if self.dist_mode == "sharded":
-            self._adam_sharded(lr_t, l1, found_inf, inv_scale, s0, s1)
-            self._mark("adam_coef")
-        else:
+            if self.world > 1:
+                dist.all_reduce(self.mlp.grad, group=self.pg)
+            s0, s1 = self._adjoint(grad_tm, None)
+            self._mark("idwt_adjoint")
+            # GradScaler: skip the step when any gradient is non-finite.  A non-finite plane gradient always
+            # reaches the coarse LL gradient through the low-pass adjoint, so checking LL + MLP grads suffices.
+            probe = self.ll.grad.abs().sum() + self.mlp.grad.abs().sum()
+            if self.world > 1:
+                dist.all_reduce(probe, group=self.pg)
+            found_inf = (~torch.isfinite(probe)).to(torch.float32).reshape(1)
             self._mark("scaler_probe")
-            self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum)
+            if self.dist_mode == "sharded":
+                self._adam_sharded(lr_t, l1, found_inf, inv_scale, s0, s1)
+            else:
+                self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum)
+                self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
             self._mark("adam_coef")
-            self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
         self._adam(self.mlp, lr_t, 0.0, found_inf, inv_scale)
         if self.fp16:
             torch._amp_update_scale_(self.scale, self.growth_tracker, found_inf, 2.0, 0.5, self.growth_interval)
