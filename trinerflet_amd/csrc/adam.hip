@@ -23,12 +23,16 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
   const bool skip = found_inf != nullptr && found_inf[0] != 0.f;
   float acc = 0.f;
   const uint64_t n4 = n / 4;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   float4* p4 = reinterpret_cast<float4*>(p);
   float4* g4 = reinterpret_cast<float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m);
   float4* v4 = reinterpret_cast<float4*>(v);
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  // each workgroup streams ONE contiguous chunk of the arrays (DRAM-page / TLB locality: a grid-stride walk would
+  // have every wave touch addresses 16 MB apart on each trip)
+  // (A/B in one process at 402 M parameters: 2.255 ms chunked vs 2.45 ms grid-stride)
+  const uint64_t chunk = (n4 + gridDim.x - 1) / gridDim.x;
+  const uint64_t c0 = (uint64_t)blockIdx.x * chunk, c1 = min(c0 + chunk, n4);
+  for (uint64_t i = c0 + threadIdx.x; i < c1; i += blockDim.x) {
     float4 pp = p4[i];
     if (!skip) {
       float4 gg = g4[i], mm = m4[i], vv = v4[i];
@@ -42,6 +46,7 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
     }
     if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   // ragged tail
   for (uint64_t i = n4 * 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float pp = p[i];
