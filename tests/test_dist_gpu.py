@@ -72,6 +72,36 @@ def _worker(rank, port, mode, out):
         dist.destroy_process_group()
 
 
+def _refresh_worker(rank, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        from trinerflet_amd.train import TrainStep
+        from trinerflet_amd import distributed as D
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        torch.manual_seed(100 + rank)                       # different jitter streams on purpose
+        m = _build(dev)
+        o, d, gt, noise = _inputs()
+        lo, hi = D.shard_rays(N, 2, rank)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev)
+        ts = TrainStep(m, fp16=True, update_extra_interval=1, dist_mode="sharded")
+        ts.step(t(o), t(d), t(gt), noises=t(noise), n_global_rays=N)
+        out[rank] = (m.density_grid.cpu().numpy(), m.density_bitfield.cpu().numpy(), m.mean_density)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grid_refresh_is_replicated(cuda):
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_refresh_worker, args=(port, out), nprocs=2, join=True)
+    g0, b0, m0 = out[0]
+    g1, b1, m1 = out[1]
+    assert np.array_equal(g0, g1) and np.array_equal(b0, b1) and m0 == m1 and b0.any()
+
+
 @pytest.mark.parametrize("mode", ["sharded", "allreduce"])
 def test_two_ranks_equal_one(cuda, mode):
     ref_losses, ref_params, ref_g = _run(_build(cuda), None, 0, N, N)

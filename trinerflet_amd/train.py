@@ -289,6 +289,14 @@ class TrainStep:
         self._mark("idwt_fwd")
         if refresh:
             model.update_extra_state()
+            if self.world > 1:
+                # the refresh draws its in-cell jitter from each rank's RNG: keep the replicas' occupancy identical
+                # by adopting rank 0's grid (16 MB + 0.5 MB every `update_extra_interval` steps)
+                dist.broadcast(model.density_grid, 0, group=self.pg)
+                dist.broadcast(model.density_bitfield, 0, group=self.pg)
+                md = torch.tensor([float(model.mean_density)], device=self.dev)
+                dist.broadcast(md, 0, group=self.pg)
+                model.mean_density = float(md.item())
             if self.post_refresh is not None:
                 self.post_refresh()
             self._mark("grid_refresh")
