@@ -72,20 +72,19 @@ k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, cons
     Chain<C, H> ch;
     chain_tail<C, H, DENSITY_ONLY>(w, lane, h, acc0, dx, dy, dz, ch);
     if (valid && h == 0) {
-      sigma[i] = expf(ch.o[0]);  // trunc_exp forward (activation.py:9-10)
+      sigma[i] = expf(ch.o8[0]);  // trunc_exp forward (activation.py:9-10)
       if (!DENSITY_ONLY) {
-        rgb[(size_t)i * 3 + 0] = 1.f / (1.f + expf(-ch.out[0]));
-        rgb[(size_t)i * 3 + 1] = 1.f / (1.f + expf(-ch.out[1]));
-        rgb[(size_t)i * 3 + 2] = 1.f / (1.f + expf(-ch.out[2]));
+        rgb[(size_t)i * 3 + 0] = 1.f / (1.f + expf(-ch.rgbl[0]));
+        rgb[(size_t)i * 3 + 1] = 1.f / (1.f + expf(-ch.rgbl[1]));
+        rgb[(size_t)i * 3 + 2] = 1.f / (1.f + expf(-ch.rgbl[2]));
       }
     }
     if (DENSITY_ONLY && rgb != nullptr && valid) {
       // geo features (rows 1..15 of the layer-1 tile) -> rgb reused as a [M,15] fp32 buffer by density()
-      const half8 dummy = acc_to_frag<false>(ch.o, 0); (void)dummy;
 #pragma unroll
       for (int g = 0; g < 8; g++) {
         const int row = acc_row(g, h);
-        if (row >= 1) rgb[(size_t)i * 15 + row - 1] = ch.o[g];
+        if (row >= 1) rgb[(size_t)i * 15 + row - 1] = ch.o8[g];
       }
     }
   }

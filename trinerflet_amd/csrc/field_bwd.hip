@@ -146,19 +146,18 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
                 g_c2 = valid ? grgb[(size_t)i * 3 + 2] : 0.f;
 
     // ---- recompute the forward chain from the saved fp16 features
-    half8 ff[G::KS0];
     f32x16 acc0[G::OB];
 #pragma unroll
     for (int ob = 0; ob < G::OB; ob++) acc0[ob] = zero16();
 #pragma unroll
     for (int ks = 0; ks < G::KS0; ks++) {
-      ff[ks] = *reinterpret_cast<const half8*>(feats + (size_t)il * G::F + 16 * ks + 8 * h);
+      half8 fk = *reinterpret_cast<const half8*>(feats + (size_t)il * G::F + 16 * ks + 8 * h);
       if (!valid) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) ff[ks][j] = (_Float16)0.f;
+        for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
       }
 #pragma unroll
-      for (int ob = 0; ob < G::OB; ob++) acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], ff[ks], acc0[ob]);
+      for (int ob = 0; ob < G::OB; ob++) acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], fk, acc0[ob]);
     }
     Chain<C, H> ch;
     chain_tail<C, H, false>(w, lane, h, acc0, dx, dy, dz, ch);
@@ -166,8 +165,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     // ---- layer 4: dZ4 = drgb * rgb * (1 - rgb) on rows 0..2 (lanes h == 0)
     f32x16 dz4 = zero16();
     if (h == 0) {
-      const float c0 = 1.f / (1.f + expf(-ch.out[0])), c1 = 1.f / (1.f + expf(-ch.out[1])),
-                  c2 = 1.f / (1.f + expf(-ch.out[2]));
+      const float c0 = 1.f / (1.f + expf(-ch.rgbl[0])), c1 = 1.f / (1.f + expf(-ch.rgbl[1])),
+                  c2 = 1.f / (1.f + expf(-ch.rgbl[2]));
       dz4[0] = g_c0 * c0 * (1.f - c0);
       dz4[1] = g_c1 * c1 * (1.f - c1);
       dz4[2] = g_c2 * c2 * (1.f - c2);
@@ -220,7 +219,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     // ---- layer 2: X = z = [SH(16) | geo(15) | 0]
     {
       const half8 shf = sh_frag(dx, dy, dz, h);
-      const half8 geo = acc_to_frag<false>(ch.o, 0);
+      half8 geo;
+#pragma unroll
+      for (int j = 0; j < 8; j++) geo[j] = (_Float16)ch.o8[j];
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         Xs[(8 * h + j) * LS + col] = shf[j];
@@ -241,7 +242,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) dzz = MFMA32(w[(G::T2 + ks) * 64 + lane], d3f[ks], dzz);
     // dO fragment: slots rho = 0..14 <- d geo (rows 16..30 of dz = regs 8..15); slot rho = 15 <- d logit
-    const float logit = __shfl(ch.o[0], r);  // row 0 lives in lanes h == 0
+    const float logit = __shfl(ch.o8[0], r);  // row 0 lives in lanes h == 0
     const float dlogit = g_s * expf(fminf(fmaxf(logit, -15.f), 15.f));  // trunc_exp backward (activation.py:14-17)
     half8 dof = acc_to_frag<false>(dzz, 1);
     if (h == 1) dof[7] = (_Float16)dlogit;
@@ -273,12 +274,16 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     __syncthreads();
 
-    // ---- layer 0: X = F (natural k order), rows F..32*IB0-1 zero
+    // ---- layer 0: X = F (natural k order), rows F..32*IB0-1 zero.  The features are re-read here (L2-hot)
+    // rather than kept in 4*KS0 registers through the whole backward chain.
 #pragma unroll
     for (int ks = 0; ks < 2 * G::IB0; ks++) {
+      half8 fk;
 #pragma unroll
-      for (int j = 0; j < 8; j++)
-        Xs[(16 * ks + 8 * h + j) * LS + col] = ks < G::KS0 ? ff[ks < G::KS0 ? ks : 0][j] : (_Float16)0.f;
+      for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
+      if (ks < G::KS0 && valid) fk = *reinterpret_cast<const half8*>(feats + (size_t)il * G::F + 16 * ks + 8 * h);
+#pragma unroll
+      for (int j = 0; j < 8; j++) Xs[(16 * ks + 8 * h + j) * LS + col] = fk[j];
     }
 #pragma unroll
     for (int ib = 0; ib < G::OB; ib++) put_acc<LS>(Ys, ib, d1[ib], h, col);

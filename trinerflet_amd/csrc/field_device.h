@@ -97,10 +97,10 @@ template <int C, int H>
 struct Chain {
   using G = FieldGeom<C, H>;
   half8 h1[G::KH];   // relu(H1) fragments
-  f32x16 o;          // layer-1 output tile: row 0 sigma logit, rows 1..15 geo (regs 0..7)
+  float o8[8];       // layer-1 output tile, registers 0..7: rows {0..3, 8..11} + 4h (row 0 = sigma logit, 1..15 geo)
   half8 h3[G::KH];
   half8 h4[G::KH];
-  f32x16 out;        // layer-4 output tile: rows 0..2 rgb logits (lanes h == 0, regs 0..2)
+  float rgbl[3];     // layer-4 output rows 0..2 (rgb logits; meaningful on lanes h == 0)
 };
 
 template <int C, int H>
@@ -115,12 +115,14 @@ __device__ __forceinline__ void chain_tail(const half8* w, int lane, int h, f32x
   for (int ks = 0; ks < G::KH; ks++) {
     ch.h1[ks] = (ks & 1) ? acc_to_frag<true>(acc0[ks >> 1], 1) : acc_to_frag<true>(acc0[ks >> 1], 0);
   }
-  ch.o = zero16();
+  f32x16 o = zero16();
 #pragma unroll
-  for (int ks = 0; ks < G::KH; ks++) ch.o = MFMA32(w[(G::F1 + ks) * 64 + lane], ch.h1[ks], ch.o);
+  for (int ks = 0; ks < G::KH; ks++) o = MFMA32(w[(G::F1 + ks) * 64 + lane], ch.h1[ks], o);
+#pragma unroll
+  for (int g = 0; g < 8; g++) ch.o8[g] = o[g];
   if (DENSITY_ONLY) return;
   const half8 shf = sh_frag(dx, dy, dz, h);
-  const half8 geo = acc_to_frag<false>(ch.o, 0);
+  const half8 geo = acc_to_frag<false>(o, 0);
   f32x16 acc2[G::OB];
 #pragma unroll
   for (int ob = 0; ob < G::OB; ob++) {
@@ -140,9 +142,10 @@ __device__ __forceinline__ void chain_tail(const half8* w, int lane, int h, f32x
 #pragma unroll
   for (int ks = 0; ks < G::KH; ks++)
     ch.h4[ks] = (ks & 1) ? acc_to_frag<true>(acc3[ks >> 1], 1) : acc_to_frag<true>(acc3[ks >> 1], 0);
-  ch.out = zero16();
+  f32x16 out = zero16();
 #pragma unroll
-  for (int ks = 0; ks < G::KH; ks++) ch.out = MFMA32(w[(G::F4 + ks) * 64 + lane], ch.h4[ks], ch.out);
+  for (int ks = 0; ks < G::KH; ks++) out = MFMA32(w[(G::F4 + ks) * 64 + lane], ch.h4[ks], out);
+  ch.rgbl[0] = out[0]; ch.rgbl[1] = out[1]; ch.rgbl[2] = out[2];
 }
 
 
