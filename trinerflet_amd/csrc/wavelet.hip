@@ -568,8 +568,11 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
 // fp16 (3,C,R,R) -> fp16 [3,R,R,C]: 16-byte loads along x, 16-byte stores along the channels
 __global__ void __launch_bounds__(NT)
 k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __restrict__ tm) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 tileh[];  // [C][TX + 8]
+  extern __shared__ __attribute__((aligned(16))) _Float16 tileh[];  // [C][TX + 8] + 8 halfs of shift per 8 channels
   constexpr int LD = TX + 8;
+  // row of channel c starts at c*LD + (c/8)*8: the extra 16 bytes per channel group put the four groups that one
+  // transposed read touches on different banks (8*LD halfs = 288 dwords = 0 mod 32 otherwise: measured 67 % of
+  // the LDS cycles were bank conflicts)
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
   const int p = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * TX;
   for (int idx = threadIdx.x; idx < C * (TX / 8); idx += NT) {
@@ -578,7 +581,7 @@ k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __re
 #pragma unroll
     for (int i = 0; i < 8; i++) v[i] = (_Float16)0.f;
     if (x0 + x8 < R) v = *reinterpret_cast<const h8*>(cm + (((size_t)p * C + c) * R + y) * R + x0 + x8);
-    *reinterpret_cast<h8*>(&tileh[c * LD + x8]) = v;
+    *reinterpret_cast<h8*>(&tileh[c * LD + (c >> 3) * 8 + x8]) = v;
   }
   __syncthreads();
   const size_t base = (((size_t)p * R + y) * R + x0) * C;
@@ -588,52 +591,9 @@ k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __re
     if (x0 + xx < R) {
       h8 v;
 #pragma unroll
-      for (int j = 0; j < 8; j++) v[j] = tileh[(cg * 8 + j) * LD + xx];
+      for (int j = 0; j < 8; j++) v[j] = tileh[(cg * 8 + j) * LD + cg * 8 + xx];
       *reinterpret_cast<h8*>(tm + base + (size_t)xx * C + cg * 8) = v;
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// layout changes: (3,C,R,R) fp32 <-> [3,R,R,C] (texel-major, fp16 or fp32)
-// One workgroup moves a 64-texel row segment for all channels through LDS, so both the read of
-// each channel row (256 B) and the write of the texel block (64*C*e B) are contiguous.
-// ---------------------------------------------------------------------------------------------
-
-template <bool HALF>
-__global__ void __launch_bounds__(NT)
-k_to_texel_major(const float* __restrict__ cm, int C, int R, void* __restrict__ tm) {
-  extern __shared__ float tile[];  // [C][TX+1]
-  const int p = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * TX;
-  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
-    const int c = idx / TX, xx = idx - c * TX;
-    tile[c * (TX + 1) + xx] = (x0 + xx < R) ? cm[(((size_t)p * C + c) * R + y) * R + x0 + xx] : 0.f;
-  }
-  __syncthreads();
-  const size_t base = (((size_t)p * R + y) * R + x0) * C;
-  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
-    const int xx = idx / C, c = idx - xx * C;
-    if (x0 + xx < R) {
-      const float v = tile[c * (TX + 1) + xx];
-      if (HALF) reinterpret_cast<__half*>(tm)[base + idx] = __float2half(v);
-      else reinterpret_cast<float*>(tm)[base + idx] = v;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(NT)
-k_to_channel_major(const float* __restrict__ tm, int C, int R, float* __restrict__ cm) {
-  extern __shared__ float tile[];  // [C][TX+1]
-  const int p = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * TX;
-  const size_t base = (((size_t)p * R + y) * R + x0) * C;
-  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
-    const int xx = idx / C, c = idx - xx * C;
-    tile[c * (TX + 1) + xx] = (x0 + xx < R) ? tm[base + idx] : 0.f;
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
-    const int c = idx / TX, xx = idx - c * TX;
-    if (x0 + xx < R) cm[(((size_t)p * C + c) * R + y) * R + x0 + xx] = tile[c * (TX + 1) + xx];
   }
 }
 
@@ -699,7 +659,7 @@ int tnl_planes_half_to_texel_major(const void* planes_cm_half, uint32_t C, uint3
   if (C == 0 || R == 0) return 0;
   if (C % 8 != 0 || R % 8 != 0) return (int)hipErrorInvalidValue;
   const dim3 grid(cdiv(R, TX), R, 3);
-  const size_t lds = (size_t)C * (TX + 8) * sizeof(_Float16);
+  const size_t lds = ((size_t)C * (TX + 8) + (C / 8) * 8) * sizeof(_Float16);
   hipLaunchKernelGGL(k_to_texel_major_h, grid, dim3(NT), lds, (hipStream_t)stream,
                      reinterpret_cast<const _Float16*>(planes_cm_half), (int)C, (int)R,
                      reinterpret_cast<_Float16*>(planes_tm_half));
