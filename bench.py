@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--workload", default="base", choices=sorted(WORKLOADS))
     ap.add_argument("--dist-mode", default="sharded", choices=["sharded", "allreduce"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the measured configuration); gloo only to dry-run the N>1 code on one GPU")
+    ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (dry-run with --backend gloo)")
     ap.add_argument("--sections", action="store_true", help="print a per-section time breakdown to stderr")
     args = ap.parse_args()
 
@@ -126,11 +129,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from trinerflet_amd import build as tbuild
