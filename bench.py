@@ -102,9 +102,9 @@ def cpu_baseline(workload):
 
 def pmc_traffic(workload, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01d_pmc_adam.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, gfx950 correction applied);
+    (profiles/r01f_pmc_adam.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, gfx950 correction applied);
     null when no profile exists for this configuration."""
-    path = os.path.join(ROOT, "profiles", "r01d_pmc_adam.json")
+    path = os.path.join(ROOT, "profiles", "r01f_pmc_adam.json")
     if workload != "base" or world != 1 or not os.path.exists(path):
         return None
     return json.load(open(path))["hbm_bytes_per_launch"]
