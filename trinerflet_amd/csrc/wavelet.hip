@@ -269,9 +269,18 @@ k_idwt_bwd(const float* __restrict__ dout, int n, float* __restrict__ dx, float*
 // ---------------------------------------------------------------------------------------------
 constexpr int TPW = 8;  // tiles per workgroup walk
 
+// Region of interest of the FINE grid of a level, per plane (slice s belongs to plane s / spp): origin (ox, oy) and
+// common size rw x rh, all multiples of 64.  rw == 0 means the whole plane.  With a ROI the fine-side array
+// (forward output / adjoint input) is COMPACT: [S][rh][rw].  TrainStep derives the ROI from the occupancy grid:
+// texels no sample can touch are neither rebuilt nor transposed, their gradient is neither stored nor read.
+struct Roi {
+  int ox[3], oy[3];
+  int rw, rh, spp;
+};
+
 template <int W, bool HALF_OUT>
 __global__ void __launch_bounds__(NT)
-k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n, void* __restrict__ out) {
+k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n, void* __restrict__ out, Roi roi) {
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2, HW = L / 4;
   constexpr int HWA = HW ? 4 : 0;            // staged halo, 16-byte aligned
@@ -286,13 +295,17 @@ k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n
   __shared__ float mid[2][2 * TI][LSM];
 
   const int s = blockIdx.z;
-  const int a_r = blockIdx.y * TI;
-  const int ntx = (n + TI - 1) / TI;
+  const int m2 = 2 * n;
+  const int pl = roi.rw ? s / roi.spp : 0;
+  const int fox = roi.rw ? roi.ox[pl] : 0, foy = roi.rw ? roi.oy[pl] : 0;   // fine-grid origin of the tile walk
+  const int orow = roi.rw ? roi.rw : m2;                                     // output row stride
+  const size_t oplane = roi.rw ? (size_t)roi.rh * roi.rw : (size_t)m2 * m2;  // output slice stride
+  const int a_r = foy / 2 + blockIdx.y * TI;
+  const int ntx = roi.rw ? roi.rw / (2 * TI) : (n + TI - 1) / TI;
   const int tx0 = blockIdx.x * TPW, tx1 = min(tx0 + TPW, ntx);
   const size_t nn = (size_t)n * n;
   const float* ll = x + (size_t)s * nn;
   const float* hb = yh + (size_t)s * 3 * nn;
-  const int m2 = 2 * n;
 
   // tile-independent part of the staging map
   int qb[KQ], qr[KQ], qc[KQ];
@@ -306,7 +319,7 @@ k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n
   }
   float4 pre[KQ];
   auto prefetch = [&](int tx) {
-    const int a_c = tx * TI;
+    const int a_c = fox / 2 + tx * TI;
 #pragma unroll
     for (int k = 0; k < KQ; k++) {
       const int gr = a_r - HWA + qr[k], gc = a_c - HWA + qc[k];
@@ -356,7 +369,7 @@ k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n
     }
     __syncthreads();
 
-    const int a_c = tx * TI;
+    const int a_c = fox / 2 + tx * TI;
     for (int u = threadIdx.x; u < 2 * TI * (TI / RM); u += NT) {
       const int run = u % (TI / RM), r = u / (TI / RM);
       const int m0 = run * RM;
@@ -383,7 +396,7 @@ k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n
       }
       const int gr = 2 * a_r + r, gc = 2 * (a_c + m0);
       if (gr < m2 && gc < m2) {  // m2 % 8 == 0 and gc % 8 == 0: the 8 outputs are in range together
-        const size_t off = (size_t)s * m2 * m2 + (size_t)gr * m2 + gc;
+        const size_t off = (size_t)s * oplane + (size_t)(gr - foy) * orow + (gc - fox);
         if (HALF_OUT) {
           typedef _Float16 h8 __attribute__((ext_vector_type(8)));
           h8 hv;
@@ -416,7 +429,8 @@ struct FuseAdam {
 
 template <int W, bool FUSE>
 __global__ void __launch_bounds__(NT)
-k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh, FuseAdam fa) {
+k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh, FuseAdam fa,
+                Roi roi) {
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2;
   constexpr int KA = (K + 3) / 4 * 4;                 // aligned left halo of the fine tile
@@ -436,7 +450,11 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
   const int ntx = (n + TI - 1) / TI;
   const int tx0 = blockIdx.x * TPW, tx1 = min(tx0 + TPW, ntx);
   const int m2 = 2 * n;
-  const float* src = dout + (size_t)s * m2 * m2;
+  const int pl = roi.rw ? s / roi.spp : 0;
+  // fine-side input: compact ROI window [oy, oy+rh) x [ox, ox+rw) (zero outside), or the whole plane
+  const int fox = roi.rw ? roi.ox[pl] : 0, foy = roi.rw ? roi.oy[pl] : 0;
+  const int fw = roi.rw ? roi.rw : m2, fh = roi.rw ? roi.rh : m2;
+  const float* src = dout + (size_t)s * fh * fw;
   const size_t nn = (size_t)n * n;
   float* o_ll = dx + (size_t)s * nn;
   float* o_h = dyh + (size_t)s * 3 * nn;
@@ -461,15 +479,34 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
     const int a_c = tx * TI;
 #pragma unroll
     for (int k = 0; k < KQ; k++) {
-      const int gr = 2 * a_r - K + qr[k], gc = 2 * a_c - KA + qc[k];
+      const int gr = 2 * a_r - K + qr[k] - foy, gc = 2 * a_c - KA + qc[k] - fox;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (qv[k] && gr >= 0 && gr < m2 && gc >= 0 && gc < m2)
-        v = *reinterpret_cast<const float4*>(src + (size_t)gr * m2 + gc);
+      if (qv[k] && gr >= 0 && gr < fh && gc >= 0 && gc < fw)
+        v = *reinterpret_cast<const float4*>(src + (size_t)gr * fw + gc);
       pre[k] = v;
     }
   };
-  prefetch(tx0);
+  // does the fine support of tile tx intersect the input window?  (uniform over the workgroup)
+  auto hits = [&](int tx) {
+    const int r0 = 2 * a_r - K, c0 = 2 * tx * TI - KA;
+    return r0 < foy + fh && r0 + FT > foy && c0 < fox + fw && c0 + FTA > fox;
+  };
+  if (hits(tx0)) prefetch(tx0);
   for (int tx = tx0; tx < tx1; tx++) {
+    if (!hits(tx)) {
+      // nothing of the gradient reaches this tile: its four coarse outputs are exactly zero
+      if (tx + 1 < tx1 && hits(tx + 1)) prefetch(tx + 1);
+      if (!FUSE) {
+        for (int u = threadIdx.x; u < TI * TI; u += NT) {
+          const int gr = a_r + u / TI, gc = tx * TI + (u % TI);
+          if (gr < n && gc < n) {
+            const size_t off = (size_t)gr * n + gc;
+            o_ll[off] = 0.f; o_h[off] = 0.f; o_h[nn + off] = 0.f; o_h[2 * nn + off] = 0.f;
+          }
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < KQ; k++) {
       if (qv[k]) {
@@ -478,7 +515,7 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
       }
     }
     __syncthreads();
-    if (tx + 1 < tx1) prefetch(tx + 1);
+    if (tx + 1 < tx1 && hits(tx + 1)) prefetch(tx + 1);
 
     for (int u = threadIdx.x; u < FT * (TI / RM); u += NT) {
       const int r = u % FT, j0 = (u / FT) * RM;
@@ -567,20 +604,24 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
 
 // fp16 (3,C,R,R) -> fp16 [3,R,R,C]: 16-byte loads along x, 16-byte stores along the channels
 __global__ void __launch_bounds__(NT)
-k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __restrict__ tm) {
+k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __restrict__ tm, Roi roi) {
   extern __shared__ __attribute__((aligned(16))) _Float16 tileh[];  // [C][TX + 8] + 8 halfs of shift per 8 channels
   constexpr int LD = TX + 8;
   // row of channel c starts at c*LD + (c/8)*8: the extra 16 bytes per channel group put the four groups that one
   // transposed read touches on different banks (8*LD halfs = 288 dwords = 0 mod 32 otherwise: measured 67 % of
   // the LDS cycles were bank conflicts)
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-  const int p = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * TX;
+  // source: (3,C,R,R), or the compact ROI window [3*C][rh][rw]; destination: always the full [3,R,R,C] array
+  const int p = blockIdx.z;
+  const int sw = roi.rw ? roi.rw : R, shh = roi.rw ? roi.rh : R;
+  const int ys = blockIdx.y, xs0 = blockIdx.x * TX;                  // source coordinates
+  const int y = ys + (roi.rw ? roi.oy[p] : 0), x0 = xs0 + (roi.rw ? roi.ox[p] : 0);
   for (int idx = threadIdx.x; idx < C * (TX / 8); idx += NT) {
     const int c = idx / (TX / 8), x8 = (idx - c * (TX / 8)) * 8;
     h8 v;
 #pragma unroll
     for (int i = 0; i < 8; i++) v[i] = (_Float16)0.f;
-    if (x0 + x8 < R) v = *reinterpret_cast<const h8*>(cm + (((size_t)p * C + c) * R + y) * R + x0 + x8);
+    if (xs0 + x8 < sw) v = *reinterpret_cast<const h8*>(cm + (((size_t)p * C + c) * shh + ys) * sw + xs0 + x8);
     *reinterpret_cast<h8*>(&tileh[c * LD + (c >> 3) * 8 + x8]) = v;
   }
   __syncthreads();
@@ -597,17 +638,63 @@ k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// layout changes: (3,C,R,R) fp32 <-> [3,R,R,C] (texel-major, fp16 or fp32)
+// One workgroup moves a 64-texel row segment for all channels through LDS, so both the read of
+// each channel row (256 B) and the write of the texel block (64*C*e B) are contiguous.
+// ---------------------------------------------------------------------------------------------
+
+template <bool HALF>
+__global__ void __launch_bounds__(NT)
+k_to_texel_major(const float* __restrict__ cm, int C, int R, void* __restrict__ tm) {
+  extern __shared__ float tile[];  // [C][TX+1]
+  const int p = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * TX;
+  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
+    const int c = idx / TX, xx = idx - c * TX;
+    tile[c * (TX + 1) + xx] = (x0 + xx < R) ? cm[(((size_t)p * C + c) * R + y) * R + x0 + xx] : 0.f;
+  }
+  __syncthreads();
+  const size_t base = (((size_t)p * R + y) * R + x0) * C;
+  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
+    const int xx = idx / C, c = idx - xx * C;
+    if (x0 + xx < R) {
+      const float v = tile[c * (TX + 1) + xx];
+      if (HALF) reinterpret_cast<__half*>(tm)[base + idx] = __float2half(v);
+      else reinterpret_cast<float*>(tm)[base + idx] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(NT)
+k_to_channel_major(const float* __restrict__ tm, int C, int R, float* __restrict__ cm) {
+  extern __shared__ float tile[];  // [C][TX+1]
+  const int p = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * TX;
+  const size_t base = (((size_t)p * R + y) * R + x0) * C;
+  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
+    const int xx = idx / C, c = idx - xx * C;
+    tile[c * (TX + 1) + xx] = (x0 + xx < R) ? tm[base + idx] : 0.f;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
+    const int c = idx / TX, xx = idx - c * TX;
+    if (x0 + xx < R) cm[(((size_t)p * C + c) * R + y) * R + x0 + xx] = tile[c * (TX + 1) + xx];
+  }
+}
+
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 template <int W>
-int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, void* out, int half_out, hipStream_t st) {
+int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, void* out, int half_out, hipStream_t st,
+               Roi roi = Roi{}) {
   if (n % 4 == 0) {
-    const dim3 grid(cdiv(cdiv(n, TI), TPW), cdiv(n, TI), S);
+    const dim3 grid = roi.rw ? dim3(cdiv(roi.rw / (2 * TI), TPW), roi.rh / (2 * TI), S)
+                             : dim3(cdiv(cdiv(n, TI), TPW), cdiv(n, TI), S);
     if (half_out)
-      hipLaunchKernelGGL((k_idwt_fwd_pipe<W, true>), grid, dim3(NT), 0, st, x, yh, (int)n, out);
+      hipLaunchKernelGGL((k_idwt_fwd_pipe<W, true>), grid, dim3(NT), 0, st, x, yh, (int)n, out, roi);
     else
-      hipLaunchKernelGGL((k_idwt_fwd_pipe<W, false>), grid, dim3(NT), 0, st, x, yh, (int)n, out);
+      hipLaunchKernelGGL((k_idwt_fwd_pipe<W, false>), grid, dim3(NT), 0, st, x, yh, (int)n, out, roi);
   } else {
+    if (roi.rw) return (int)hipErrorInvalidValue;
     if (half_out) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_idwt_fwd<W>, dim3(cdiv(n, TI), cdiv(n, TI), S), dim3(NT), 0, st, x, yh, (int)n,
                        reinterpret_cast<float*>(out));
@@ -615,10 +702,12 @@ int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, void* ou
   return (int)hipGetLastError();
 }
 template <int W>
-int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh, hipStream_t st) {
+int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh, hipStream_t st, Roi roi = Roi{}) {
   if (n % 2 == 0)
     hipLaunchKernelGGL((k_idwt_bwd_pipe<W, false>), dim3(cdiv(cdiv(n, TI), TPW), cdiv(n, TI), S), dim3(NT), 0, st, dout,
-                       (int)n, dx, dyh, FuseAdam{});
+                       (int)n, dx, dyh, FuseAdam{}, roi);
+  else if (roi.rw)
+    return (int)hipErrorInvalidValue;
   else
     hipLaunchKernelGGL(k_idwt_bwd<W>, dim3(cdiv(n, TI), cdiv(n, TI), S), dim3(NT), 0, st, dout, (int)n, dx, dyh);
   return (int)hipGetLastError();
@@ -628,17 +717,34 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
 
 extern "C" {
 
+// roi: host array {ox0,ox1,ox2, oy0,oy1,oy2, rw, rh} in fine-grid texels (multiples of 64), or NULL
+static bool make_roi(const int32_t* r, uint32_t S, uint32_t fine_n, Roi& roi) {
+  roi = Roi{};
+  if (r == nullptr) return true;
+  if (S % 3 != 0) return false;
+  for (int p = 0; p < 3; p++) { roi.ox[p] = r[p]; roi.oy[p] = r[3 + p]; }
+  roi.rw = r[6]; roi.rh = r[7]; roi.spp = (int)(S / 3);
+  if (roi.rw <= 0 || roi.rh <= 0 || roi.rw % 64 || roi.rh % 64) return false;
+  for (int p = 0; p < 3; p++)
+    if (roi.ox[p] < 0 || roi.oy[p] < 0 || roi.ox[p] % 64 || roi.oy[p] % 64 || roi.ox[p] + roi.rw > (int)fine_n ||
+        roi.oy[p] + roi.rh > (int)fine_n)
+      return false;
+  return true;
+}
+
 static int idwt_forward_any(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, void* out,
-                            int half_out, void* stream) {
+                            int half_out, void* stream, const int32_t* roi_host = nullptr) {
+  Roi roi;
+  if (!make_roi(roi_host, S, 2 * n, roi)) return (int)hipErrorInvalidValue;
   if (S == 0 || n == 0) return 0;
   if (S > 65535) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   switch (wave) {
-    case 0: return launch_fwd<0>(x, yh, S, n, out, half_out, st);
-    case 1: return launch_fwd<1>(x, yh, S, n, out, half_out, st);
-    case 2: return launch_fwd<2>(x, yh, S, n, out, half_out, st);
-    case 3: return launch_fwd<3>(x, yh, S, n, out, half_out, st);
-    case 4: return launch_fwd<4>(x, yh, S, n, out, half_out, st);
+    case 0: return launch_fwd<0>(x, yh, S, n, out, half_out, st, roi);
+    case 1: return launch_fwd<1>(x, yh, S, n, out, half_out, st, roi);
+    case 2: return launch_fwd<2>(x, yh, S, n, out, half_out, st, roi);
+    case 3: return launch_fwd<3>(x, yh, S, n, out, half_out, st, roi);
+    case 4: return launch_fwd<4>(x, yh, S, n, out, half_out, st, roi);
     default: return (int)hipErrorInvalidValue;
   }
 }
@@ -654,29 +760,65 @@ int tnl_idwt_level_forward_half(const float* x, const float* yh, uint32_t S, uin
   return idwt_forward_any(x, yh, S, n, wave, out_half, 1, stream);
 }
 
+int tnl_idwt_level_forward_half_roi(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, void* out_half,
+                                    const int32_t* roi, void* stream) {
+  if (n % 4 != 0) return (int)hipErrorInvalidValue;
+  return idwt_forward_any(x, yh, S, n, wave, out_half, 1, stream, roi);
+}
+
+static int planes_half_to_tm(const void* planes_cm_half, uint32_t C, uint32_t R, void* planes_tm_half,
+                             const int32_t* roi_host, void* stream);
+
+int tnl_planes_half_to_texel_major_roi(const void* planes_roi_half, uint32_t C, uint32_t R, void* planes_tm_half,
+                                       const int32_t* roi, void* stream) {
+  return planes_half_to_tm(planes_roi_half, C, R, planes_tm_half, roi, stream);
+}
+
 int tnl_planes_half_to_texel_major(const void* planes_cm_half, uint32_t C, uint32_t R, void* planes_tm_half,
                                    void* stream) {
+  return planes_half_to_tm(planes_cm_half, C, R, planes_tm_half, nullptr, stream);
+}
+
+static int planes_half_to_tm(const void* planes_cm_half, uint32_t C, uint32_t R, void* planes_tm_half,
+                             const int32_t* roi_host, void* stream) {
   if (C == 0 || R == 0) return 0;
   if (C % 8 != 0 || R % 8 != 0) return (int)hipErrorInvalidValue;
-  const dim3 grid(cdiv(R, TX), R, 3);
+  Roi roi;
+  if (!make_roi(roi_host, 3 * C, R, roi)) return (int)hipErrorInvalidValue;
+  const dim3 grid = roi.rw ? dim3(roi.rw / TX, roi.rh, 3) : dim3(cdiv(R, TX), R, 3);
   const size_t lds = ((size_t)C * (TX + 8) + (C / 8) * 8) * sizeof(_Float16);
   hipLaunchKernelGGL(k_to_texel_major_h, grid, dim3(NT), lds, (hipStream_t)stream,
                      reinterpret_cast<const _Float16*>(planes_cm_half), (int)C, (int)R,
-                     reinterpret_cast<_Float16*>(planes_tm_half));
+                     reinterpret_cast<_Float16*>(planes_tm_half), roi);
   return (int)hipGetLastError();
 }
 
+static int idwt_backward_any(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
+                             const int32_t* roi_host, void* stream);
+
 int tnl_idwt_level_backward(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
                             void* stream) {
+  return idwt_backward_any(dout, S, n, wave, dx, dyh, nullptr, stream);
+}
+
+int tnl_idwt_level_backward_roi(const float* dout_roi, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
+                                const int32_t* roi, void* stream) {
+  return idwt_backward_any(dout_roi, S, n, wave, dx, dyh, roi, stream);
+}
+
+static int idwt_backward_any(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
+                             const int32_t* roi_host, void* stream) {
   if (S == 0 || n == 0) return 0;
   if (S > 65535) return (int)hipErrorInvalidValue;
+  Roi roi;
+  if (!make_roi(roi_host, S, 2 * n, roi)) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   switch (wave) {
-    case 0: return launch_bwd<0>(dout, S, n, dx, dyh, st);
-    case 1: return launch_bwd<1>(dout, S, n, dx, dyh, st);
-    case 2: return launch_bwd<2>(dout, S, n, dx, dyh, st);
-    case 3: return launch_bwd<3>(dout, S, n, dx, dyh, st);
-    case 4: return launch_bwd<4>(dout, S, n, dx, dyh, st);
+    case 0: return launch_bwd<0>(dout, S, n, dx, dyh, st, roi);
+    case 1: return launch_bwd<1>(dout, S, n, dx, dyh, st, roi);
+    case 2: return launch_bwd<2>(dout, S, n, dx, dyh, st, roi);
+    case 3: return launch_bwd<3>(dout, S, n, dx, dyh, st, roi);
+    case 4: return launch_bwd<4>(dout, S, n, dx, dyh, st, roi);
     default: return (int)hipErrorInvalidValue;
   }
 }
@@ -692,7 +834,7 @@ int tnl_idwt_level_backward_adam(const float* dout, uint32_t S, uint32_t n, int 
   const dim3 grid(cdiv(cdiv(n, TI), TPW), cdiv(n, TI), S);
   hipStream_t st = (hipStream_t)stream;
 #define TNL_BWD_ADAM(WW) \
-  hipLaunchKernelGGL((k_idwt_bwd_pipe<WW, true>), grid, dim3(NT), 0, st, dout, (int)n, dx, (float*)nullptr, fa)
+  hipLaunchKernelGGL((k_idwt_bwd_pipe<WW, true>), grid, dim3(NT), 0, st, dout, (int)n, dx, (float*)nullptr, fa, Roi{})
   switch (wave) {
     case 0: TNL_BWD_ADAM(0); break;
     case 1: TNL_BWD_ADAM(1); break;
