@@ -202,8 +202,8 @@ TNL_API int tnl_field_backward(const float *grad_sigma, const float *grad_rgb, c
 
 /* Plane-gradient accumulation without global float atomics (csrc/scatter.hip).  When tnl_field_backward is
  * given dfeat_half (fp16 [M,3C]) it writes the feature gradient there instead of scattering it; this call
- * then counting-sorts the samples by 16x16-texel tile per plane and lets one workgroup per tile accumulate
- * in LDS and store the tile.  EVERY tile of the gradient is written (no zero fill needed): texel-major
+ * then counting-sorts the samples by 32x8-texel tile per plane and lets one workgroup per tile reduce its
+ * samples on the matrix cores and store the tile.  EVERY tile of the gradient is written (no zero fill needed): texel-major
  * [3,R,R,C] if channel_major == 0, the reference's (3,C,R,R) otherwise (the adjoint IDWT reads that directly,
  * so the layout-change pass disappears).  grad_scale multiplies dfeat.  R % 32 == 0, C in {16,32,48}.
  * nonfinite_flag (device int32, may be NULL) is set to 1 if any stored value is inf/nan (GradScaler probe).
@@ -213,6 +213,33 @@ TNL_API int tnl_plane_grad_binned(const void *dfeat_half, const float *xyz, floa
                                   const int32_t *m_actual, uint32_t C, uint32_t R, float grad_scale,
                                   float *grad_out, int channel_major, int32_t *nonfinite_flag,
                                   void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Occupancy ROI variants (no reference predecessor: the reference rebuilds and differentiates whole planes).
+ * roi = HOST array of 10 int32 {ox0,ox1,ox2, oy0,oy1,oy2, rw, rh, spp, s0}: per-plane origin and common size of
+ * the window of the R x R plane grid that every sample footprint falls into (multiples of 64), spp = slices
+ * (channels) per plane and s0 = global index of the first slice passed to a depthwise call (0 unless a rank owns
+ * a sub-range of the 3*spp slices); NULL = the whole plane (then each call equals its non-ROI counterpart).
+ * ROI-side arrays are COMPACT: [S][rh][rw].
+ *   tnl_idwt_level_forward_half_roi    finest level only over the window -> fp16 [S][rh][rw]   (S = 3C slices)
+ *   tnl_planes_half_to_texel_major_roi compact fp16 window -> the window of the full fp16 [3,R,R,C] array
+ *                                      (texels outside keep their previous contents)
+ *   tnl_plane_grad_binned_roi          tiles of the window only -> compact fp32 (3C,rh,rw); channel_major must
+ *                                      be 1; samples whose footprint leaves the window are DROPPED (caller's
+ *                                      contract: the window covers the occupancy grid's footprint)
+ *   tnl_idwt_level_backward_roi        adjoint of the finest level reading the compact gradient (zero outside);
+ *                                      bit-identical to the full adjoint of the zero-extended gradient
+ * ------------------------------------------------------------------------------------------- */
+TNL_API int tnl_idwt_level_forward_half_roi(const float *x, const float *yh, uint32_t S, uint32_t n, int wave,
+                                            void *out_half, const int32_t *roi, void *stream);
+TNL_API int tnl_planes_half_to_texel_major_roi(const void *planes_roi_half, uint32_t C, uint32_t R,
+                                               void *planes_tm_half, const int32_t *roi, void *stream);
+TNL_API int tnl_plane_grad_binned_roi(const void *dfeat_half, const float *xyz, float bound, uint32_t M,
+                                      const int32_t *m_actual, uint32_t C, uint32_t R, float grad_scale,
+                                      float *grad_out, int channel_major, int32_t *nonfinite_flag,
+                                      const int32_t *roi, void *workspace, void *stream);
+TNL_API int tnl_idwt_level_backward_roi(const float *dout_roi, uint32_t S, uint32_t n, int wave, float *dx,
+                                        float *dyh, const int32_t *roi, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused optimiser for the wavelet coefficients: torch.optim.Adam(betas, eps, no weight decay)

@@ -1,0 +1,172 @@
+"""Occupancy-window (ROI) variants of the dense kernels: each must equal its whole-plane counterpart restricted
+to the window, and a training run with the window must equal the run without it.
+
+The whole-plane kernels are the ones pinned to the oracle / golden vectors (tests/test_triplane_gpu.py,
+tests/test_field_gpu.py); here the ROI entry points are tied to them bit for bit, and the window itself is
+checked against positions drawn from the C oracle's march (every footprint must fall inside).
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+from trinerflet_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _roi10(ox, oy, rw, rh, C, s0=0):
+    return list(ox) + list(oy) + [rw, rh, C, s0]
+
+
+@pytest.mark.parametrize("wave", ["bior6.8", "bior2.2", "haar"])
+def test_forward_and_adjoint_roi_match_whole_plane(cuda, wave):
+    from trinerflet_amd import _lib as L
+    from trinerflet_amd.triplaneencoder import triplane_encoder as te
+    C, n = 8, 128
+    R = 2 * n
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(3, C, n, n, generator=g).to(cuda)
+    yh = torch.randn(3, C, 3, n, n, generator=g).to(cuda)
+    wid = te.WAVELET_IDS[wave]
+    full = te.idwt_level_half(x, yh, wid)                                # (3,C,R,R) fp16
+    ox, oy, rw, rh = (64, 0, 128), (128, 64, 0), 128, 64
+    roi = _roi10(ox, oy, rw, rh, C)
+    comp = te.idwt_level_half_roi(x, yh, wid, roi)                       # (3C, rh, rw)
+    for p in range(3):
+        ref = full[p, :, oy[p]:oy[p] + rh, ox[p]:ox[p] + rw]
+        assert torch.equal(comp.view(3, C, rh, rw)[p], ref), (wave, p)
+    # layout change into the persistent texel-major array: window replaced, rest untouched
+    tm = torch.full((3, R, R, C), 7.0, dtype=torch.float16, device=cuda)
+    te.half_roi_into_texel_major(comp, tm, roi)
+    tm_full = te.half_to_texel_major(full)
+    for p in range(3):
+        win = (slice(oy[p], oy[p] + rh), slice(ox[p], ox[p] + rw))
+        assert torch.equal(tm[p][win], tm_full[p][win])
+        mask = torch.ones(R, R, dtype=torch.bool, device=cuda)
+        mask[win] = False
+        assert bool((tm[p][mask] == 7.0).all())
+    # adjoint: compact gradient == zero-extended gradient through the whole-plane adjoint, bit for bit
+    gc = torch.randn(3 * C, rh, rw, generator=g).to(cuda)
+    gfull = torch.zeros(3, C, R, R, device=cuda)
+    for p in range(3):
+        gfull[p, :, oy[p]:oy[p] + rh, ox[p]:ox[p] + rw] = gc.view(3, C, rh, rw)[p]
+    lib = L.lib()
+    outs = []
+    for use_roi in (False, True):
+        dx = torch.full((3 * C, n, n), float("nan"), device=cuda)
+        dyh = torch.full((3 * C, 3, n, n), float("nan"), device=cuda)
+        src = gc if use_roi else gfull
+        L.check(lib.tnl_idwt_level_backward_roi(L.ptr(src), L.u32(3 * C), L.u32(n), L.i32(wid), L.ptr(dx), L.ptr(dyh),
+                                                L.roi_array(roi) if use_roi else None, L.stream()), "bwd")
+        outs.append((dx, dyh))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # a rank owning slices [s0, s1): same numbers as the corresponding rows of the whole call
+    s0, s1 = C + 2, 2 * C + 3
+    sub = te.idwt_level_half_roi(x.view(1, 3 * C, n, n)[:, s0:s1], yh.view(1, 3 * C, 3, n, n)[:, s0:s1], wid,
+                                 _roi10(ox, oy, rw, rh, C, s0))
+    assert torch.equal(sub, comp[s0:s1])
+
+
+def test_plane_gradient_roi_matches_whole_plane(cuda):
+    from trinerflet_amd.nerf import field as F_
+    C, R, M, bound = 16, 256, 20000, 1.0
+    rng = np.random.default_rng(5)
+    # positions inside a box whose footprint is covered by the window below
+    xyz = np.stack([rng.uniform(-0.45, 0.2, M), rng.uniform(-0.3, 0.45, M), rng.uniform(0.05, 0.45, M)], 1)
+    xyz = torch.from_numpy(xyz.astype(np.float32)).to(cuda)
+    dfeat = torch.from_numpy(rng.standard_normal((M, 3 * C)).astype(np.float16)).to(cuda)
+    # texel = (u+1)/2*255: x in [70,153] -> [64,192), y in [89,185] -> [64,192), z in [133,185] -> [128,192)
+    ox, oy, rw, rh = (64, 64, 64), (64, 64, 64), 128, 128   # plane0 (x,z), plane1 (x,y), plane2 (y,z)
+    full = torch.empty(3, C, R, R, device=cuda)
+    F_.plane_grad_binned(dfeat, xyz, bound, C, R, full, channel_major=True)
+    comp = torch.full((3 * C, rh, rw), float("nan"), device=cuda)
+    F_.plane_grad_binned(dfeat, xyz, bound, C, R, comp, channel_major=True, roi=_roi10(ox, oy, rw, rh, C))
+    comp = comp.view(3, C, rh, rw)
+    tot = 0.0
+    for p in range(3):
+        ref = full[p, :, oy[p]:oy[p] + rh, ox[p]:ox[p] + rw]
+        # same records per tile, order inside a tile set by the bin-fill atomics: equal up to fp32 summation order
+        assert torch.allclose(comp[p], ref, rtol=1e-4, atol=1e-4), p
+        tot += float(ref.abs().sum())
+    assert abs(float(full.abs().sum()) - tot) <= 1e-6 * tot   # nothing of the gradient lies outside the window
+
+
+def _model(dev, C=16, R=256, scale=2, H=64, bound=1.0):
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=bound, cuda_ray=True, density_thresh=10, hidden_dim=H,
+                    hidden_dim_color=H, triplane_channels=C, triplane_resolution=R, triplane_wavelet_levels=scale,
+                    wavelet_type="bior6.8").to(dev)
+    synthetic.init_field_parameters(m, seed=3)
+    return m
+
+
+def test_window_covers_every_marched_footprint(cuda):
+    """The window computed from the bitfield contains the bilinear footprint of every sample the ORACLE's march
+    produces for that bitfield (off-centre occupancy, two cascades)."""
+    from trinerflet_amd.train import TrainStep
+    bound, R, Hg = 2.0, 256, 128
+    m = _model(cuda, R=R, bound=bound)
+    # off-centre blob: occupied cells of cascade 0 with centre within 0.35 of (0.3, -0.2, 0.1); cascade 1 likewise
+    idx = np.arange(Hg)
+    bits = np.zeros((2, Hg ** 3), np.uint8)
+    coords = np.stack(np.meshgrid(idx, idx, idx, indexing="ij"), -1).reshape(-1, 3)
+    mort = cref.morton3D(coords.astype(np.uint32))
+    for cas in range(2):
+        b = min(2.0 ** cas, bound)
+        c = ((coords + 0.5) / Hg * 2 - 1) * b
+        occ = np.linalg.norm(c - np.array([0.3, -0.2, 0.1]), axis=1) < 0.35
+        bits[cas, mort] = occ
+    bf = np.packbits(bits.reshape(-1, 8), axis=1, bitorder="little").reshape(-1)
+    m.density_bitfield.copy_(torch.from_numpy(bf).to(cuda))
+    ts = TrainStep(m, update_extra_interval=0)
+    roi = ts._compute_roi()
+    assert roi is not None and roi[6] < R and roi[7] < R
+    N = 4096
+    o, d = synthetic.training_rays(N, n_cams=6, seed=2)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = cref.near_far_from_aabb(o, d, aabb, 0.2)
+    noise = np.random.default_rng(1).random(N).astype(np.float32)
+    xyzs, _, _, _, counter = cref.march_rays_train(o, d, bound, bf, 2, Hg, nears, fars, noise, N * 64)
+    n_samples = int(counter[0])
+    assert 1000 < n_samples <= N * 64
+    u = np.clip(xyzs[:n_samples] / bound, -1, 1)
+    f = (u + 1) / 2 * (R - 1)
+    t0 = np.floor(f).astype(int)
+    t1 = np.minimum(t0 + 1, R - 1)
+    xa, ya = (0, 0, 1), (2, 1, 2)
+    for p in range(3):
+        assert t0[:, xa[p]].min() >= roi[p] and t1[:, xa[p]].max() < roi[p] + roi[6]
+        assert t0[:, ya[p]].min() >= roi[3 + p] and t1[:, ya[p]].max() < roi[3 + p] + roi[7]
+
+
+def test_training_with_window_equals_whole_plane_training(cuda):
+    """Six steps (one grid refresh inside) with and without the occupancy window: same parameters."""
+    from trinerflet_amd.train import TrainStep
+    N, bound = 2048, 1.0
+    o, d = synthetic.training_rays(N, n_cams=4, seed=7)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    gt = t(synthetic.target_colors(d))
+    noise = t(np.random.default_rng(0).random(N).astype(np.float32))
+    base = _model(cuda, bound=bound)
+    bf = t(synthetic.sphere_bitfield(128, 1, bound, 0.4, 0.0))
+    base.density_bitfield.copy_(bf)
+    res = []
+    for use_roi in (False, True):
+        m = copy.deepcopy(base)
+        ts = TrainStep(m, update_extra_interval=4, use_roi=use_roi)
+        ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf)   # keep the analytic occupancy
+        m.mean_count = 0
+        losses = []
+        for it in range(6):
+            losses.append(float(ts.step(t(o), t(d), gt, noises=noise)))
+            if use_roi and it % 4 != 0:
+                assert ts._roi is not None and ts._roi[6] < 256
+        res.append((losses, [p.detach().clone() for p in m.parameters()], ts))
+    assert res[1][2].use_roi and res[1][2]._roi is not None
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-4)
+    for a, b in zip(res[0][1], res[1][1]):
+        # Adam's first steps are sign-like: compare where the whole-plane run actually moved the parameter
+        assert torch.allclose(a, b, rtol=1e-3, atol=2e-3), float((a - b).abs().max())

@@ -68,3 +68,12 @@ u32 = C.c_uint32
 f32 = C.c_float
 i32 = C.c_int
 u64 = C.c_uint64
+
+
+def roi_array(roi):
+    """10 host int32 {ox0,ox1,ox2, oy0,oy1,oy2, rw, rh, spp, s0} for the *_roi entry points (None -> NULL)."""
+    if roi is None:
+        return None
+    vals = [int(v) for v in roi]
+    assert len(vals) == 10
+    return (C.c_int32 * 10)(*vals)

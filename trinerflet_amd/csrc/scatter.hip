@@ -6,18 +6,19 @@
 // sample that alone was 6 ms per step.  Here instead:
 //   1. the field backward writes the feature gradient dF as fp16 [M, 3C] (the precision the reference's
 //      autocast Linear backward hands to grid_sample's backward as well),
-//   2. samples are counting-sorted by the 16x16-texel tile their bilinear footprint touches, per plane
+//   2. samples are counting-sorted by the 32x8-texel tile their bilinear footprint touches, per plane
 //      (a footprint that straddles tiles is listed in each of them),
-//   3. one workgroup per tile accumulates its samples in an fp32 LDS tile (ds_add_f32, lanes = channels)
-//      and writes the finished tile with plain 16-byte stores -- every tile is written exactly once, so
-//      the 4*P-byte zero fill of the gradient disappears too.
+//   3. one workgroup per tile reduces its samples on the matrix cores (separable bilinear weights x dF, fp32
+//      accumulators in registers) and writes the finished tile with plain 16-byte stores -- every tile is
+//      written exactly once, so the 4*P-byte zero fill of the gradient disappears too.
 // HBM traffic per sample: 12 B xyz x3 passes + ~3.4 list entries x 4 B x2 + 6*C B of dF, versus 48*C B
-// of atomics; per step additionally the 4*P-byte tile stores that replace the memset.
+// of atomics; per step additionally the 4*P-byte tile stores that replace the memset (only the ROI's with a ROI).
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/trinerflet_hip.h"
+#include "roi_common.h"
 #include "triplane_common.h"
 
 namespace {
@@ -163,7 +164,7 @@ template <int C>
 __global__ void __launch_bounds__(NT)
 k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ xyz, float bound, int R, int TNX,
                   int TNY, const int* __restrict__ offsets, const uint32_t* __restrict__ entries, float grad_scale,
-                  float* __restrict__ grad_out, int channel_major, int* __restrict__ nonfinite_flag) {
+                  float* __restrict__ grad_out, int channel_major, int* __restrict__ nonfinite_flag, Roi roi) {
   constexpr int NTEX = TSX * TSY;
   constexpr int TILE_F = NTEX * C;
   constexpr int F = 3 * C;
@@ -181,11 +182,26 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
   int* cx0 = reinterpret_cast<int*>(rwT + (size_t)TSY * QS);          // [NT]
   h2v* cww = reinterpret_cast<h2v*>(cx0 + NT);                         // [NT]
 
-  const int bin = blockIdx.x;
-  const int p = bin / (TNX * TNY), rem = bin - p * TNX * TNY;
-  const int ty = rem / TNX, tx = rem - ty * TNX;
+  // With a ROI only its tiles are launched (samples binned elsewhere are dropped: the caller guarantees there are
+  // none) and the output is the compact channel-major window [3C][rh][rw].
+  int p, ty, tx;
+  if (roi.rw) {
+    const int rnx = roi.rw / TSX, rny = roi.rh / TSY;
+    p = blockIdx.x / (rnx * rny);
+    const int rem = blockIdx.x - p * rnx * rny;
+    ty = rem / rnx + roi.oy[p] / TSY;
+    tx = rem - (rem / rnx) * rnx + roi.ox[p] / TSX;
+  } else {
+    p = blockIdx.x / (TNX * TNY);
+    const int rem = blockIdx.x - p * TNX * TNY;
+    ty = rem / TNX; tx = rem - ty * TNX;
+  }
+  const int bin = p * TNX * TNY + ty * TNX + tx;
   const int beg = offsets[bin], end = offsets[bin + 1];
   const int x_lo = tx * TSX, y_lo = ty * TSY;
+  // channel-major output addressing: row stride, slice stride and origin of the (possibly compact) window
+  const int ow = roi.rw ? roi.rw : R, oh = roi.rw ? roi.rh : R;
+  const int x_out = x_lo - (roi.rw ? roi.ox[p] : 0), y_out = y_lo - (roi.rw ? roi.oy[p] : 0);
   if (beg == end) {  // untouched tile: this store replaces the zero fill of the gradient
     if (!channel_major) {
       float* dst = grad_out + (((size_t)p * R + y_lo) * R + x_lo) * C;
@@ -199,7 +215,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
       for (int q = threadIdx.x; q < C * TSY * X4; q += NT) {
         const int ch = q / (TSY * X4), r2 = q - ch * (TSY * X4);
         const int ry = r2 / X4, lx = (r2 - ry * X4) * 4;
-        *reinterpret_cast<float4*>(grad_out + (((size_t)p * C + ch) * R + y_lo + ry) * R + x_lo + lx) =
+        *reinterpret_cast<float4*>(grad_out + (((size_t)p * C + ch) * oh + y_out + ry) * ow + x_out + lx) =
             make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -343,7 +359,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
       const int b = row / (32 * NB), c = row - b * (32 * NB);
       if (c < C) {
         const float* a = stg + (size_t)row * XS + lx;
-        *reinterpret_cast<float4*>(grad_out + (((size_t)p * C + c) * R + y_lo + 2 * wv + b) * R + x_lo + lx) =
+        *reinterpret_cast<float4*>(grad_out + (((size_t)p * C + c) * oh + y_out + 2 * wv + b) * ow + x_out + lx) =
             make_float4(a[0], a[1], a[2], a[3]);
       }
     }
@@ -366,7 +382,18 @@ uint64_t tnl_plane_grad_binned_workspace(uint32_t M, uint32_t R) {
 int tnl_plane_grad_binned(const void* dfeat_half, const float* xyz, float bound, uint32_t M,
                           const int32_t* m_actual, uint32_t C, uint32_t R, float grad_scale, float* grad_out,
                           int channel_major, int32_t* nonfinite_flag, void* workspace, void* stream) {
+  return tnl_plane_grad_binned_roi(dfeat_half, xyz, bound, M, m_actual, C, R, grad_scale, grad_out, channel_major,
+                                   nonfinite_flag, nullptr, workspace, stream);
+}
+
+int tnl_plane_grad_binned_roi(const void* dfeat_half, const float* xyz, float bound, uint32_t M,
+                              const int32_t* m_actual, uint32_t C, uint32_t R, float grad_scale, float* grad_out,
+                              int channel_major, int32_t* nonfinite_flag, const int32_t* roi_host, void* workspace,
+                              void* stream) {
   if (R % TSX != 0 || (C != 16 && C != 32 && C != 48)) return (int)hipErrorInvalidValue;
+  Roi roi;
+  if (!make_roi(roi_host, 3 * C, R, roi) || (roi.rw && (!channel_major || roi.spp != (int)C || roi.s0 != 0)))
+    return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int TNX = R / TSX, TNY = R / TSY;
   const int nb = 3 * TNX * TNY;
@@ -389,15 +416,16 @@ int tnl_plane_grad_binned(const void* dfeat_half, const float* xyz, float bound,
                        cursor, entries);
   }
   const _Float16* df = reinterpret_cast<const _Float16*>(dfeat_half);
+  const int ntiles = roi.rw ? 3 * (roi.rw / TSX) * (roi.rh / TSY) : nb;
   if (C == 16)
-    hipLaunchKernelGGL(k_tile_accumulate<16>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY, offsets,
-                       entries, grad_scale, grad_out, channel_major, nonfinite_flag);
+    hipLaunchKernelGGL(k_tile_accumulate<16>, dim3(ntiles), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY,
+                       offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   else if (C == 32)
-    hipLaunchKernelGGL(k_tile_accumulate<32>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY, offsets,
-                       entries, grad_scale, grad_out, channel_major, nonfinite_flag);
+    hipLaunchKernelGGL(k_tile_accumulate<32>, dim3(ntiles), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY,
+                       offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   else
-    hipLaunchKernelGGL(k_tile_accumulate<48>, dim3(nb), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY, offsets,
-                       entries, grad_scale, grad_out, channel_major, nonfinite_flag);
+    hipLaunchKernelGGL(k_tile_accumulate<48>, dim3(ntiles), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY,
+                       offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   return (int)hipGetLastError();
 }
 

@@ -21,6 +21,7 @@
 
 #include "../../include/trinerflet_hip.h"
 #include "adam_common.h"
+#include "roi_common.h"
 
 namespace {
 
@@ -269,14 +270,6 @@ k_idwt_bwd(const float* __restrict__ dout, int n, float* __restrict__ dx, float*
 // ---------------------------------------------------------------------------------------------
 constexpr int TPW = 8;  // tiles per workgroup walk
 
-// Region of interest of the FINE grid of a level, per plane (slice s belongs to plane s / spp): origin (ox, oy) and
-// common size rw x rh, all multiples of 64.  rw == 0 means the whole plane.  With a ROI the fine-side array
-// (forward output / adjoint input) is COMPACT: [S][rh][rw].  TrainStep derives the ROI from the occupancy grid:
-// texels no sample can touch are neither rebuilt nor transposed, their gradient is neither stored nor read.
-struct Roi {
-  int ox[3], oy[3];
-  int rw, rh, spp;
-};
 
 template <int W, bool HALF_OUT>
 __global__ void __launch_bounds__(NT)
@@ -296,7 +289,7 @@ k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n
 
   const int s = blockIdx.z;
   const int m2 = 2 * n;
-  const int pl = roi.rw ? s / roi.spp : 0;
+  const int pl = roi.rw ? (s + roi.s0) / roi.spp : 0;
   const int fox = roi.rw ? roi.ox[pl] : 0, foy = roi.rw ? roi.oy[pl] : 0;   // fine-grid origin of the tile walk
   const int orow = roi.rw ? roi.rw : m2;                                     // output row stride
   const size_t oplane = roi.rw ? (size_t)roi.rh * roi.rw : (size_t)m2 * m2;  // output slice stride
@@ -450,7 +443,7 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
   const int ntx = (n + TI - 1) / TI;
   const int tx0 = blockIdx.x * TPW, tx1 = min(tx0 + TPW, ntx);
   const int m2 = 2 * n;
-  const int pl = roi.rw ? s / roi.spp : 0;
+  const int pl = roi.rw ? (s + roi.s0) / roi.spp : 0;
   // fine-side input: compact ROI window [oy, oy+rh) x [ox, ox+rw) (zero outside), or the whole plane
   const int fox = roi.rw ? roi.ox[pl] : 0, foy = roi.rw ? roi.oy[pl] : 0;
   const int fw = roi.rw ? roi.rw : m2, fh = roi.rw ? roi.rh : m2;
@@ -717,21 +710,6 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
 
 extern "C" {
 
-// roi: host array {ox0,ox1,ox2, oy0,oy1,oy2, rw, rh} in fine-grid texels (multiples of 64), or NULL
-static bool make_roi(const int32_t* r, uint32_t S, uint32_t fine_n, Roi& roi) {
-  roi = Roi{};
-  if (r == nullptr) return true;
-  if (S % 3 != 0) return false;
-  for (int p = 0; p < 3; p++) { roi.ox[p] = r[p]; roi.oy[p] = r[3 + p]; }
-  roi.rw = r[6]; roi.rh = r[7]; roi.spp = (int)(S / 3);
-  if (roi.rw <= 0 || roi.rh <= 0 || roi.rw % 64 || roi.rh % 64) return false;
-  for (int p = 0; p < 3; p++)
-    if (roi.ox[p] < 0 || roi.oy[p] < 0 || roi.ox[p] % 64 || roi.oy[p] % 64 || roi.ox[p] + roi.rw > (int)fine_n ||
-        roi.oy[p] + roi.rh > (int)fine_n)
-      return false;
-  return true;
-}
-
 static int idwt_forward_any(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, void* out,
                             int half_out, void* stream, const int32_t* roi_host = nullptr) {
   Roi roi;
@@ -784,7 +762,8 @@ static int planes_half_to_tm(const void* planes_cm_half, uint32_t C, uint32_t R,
   if (C == 0 || R == 0) return 0;
   if (C % 8 != 0 || R % 8 != 0) return (int)hipErrorInvalidValue;
   Roi roi;
-  if (!make_roi(roi_host, 3 * C, R, roi)) return (int)hipErrorInvalidValue;
+  if (!make_roi(roi_host, 3 * C, R, roi) || (roi.rw && (roi.spp != (int)C || roi.s0 != 0)))
+    return (int)hipErrorInvalidValue;
   const dim3 grid = roi.rw ? dim3(roi.rw / TX, roi.rh, 3) : dim3(cdiv(R, TX), R, 3);
   const size_t lds = ((size_t)C * (TX + 8) + (C / 8) * 8) * sizeof(_Float16);
   hipLaunchKernelGGL(k_to_texel_major_h, grid, dim3(NT), lds, (hipStream_t)stream,

@@ -96,17 +96,18 @@ fused_field = _FusedField.apply
 
 
 def plane_grad_binned(dfeat, xyz, bound, C, R, grad_out, m_actual=None, grad_scale=1.0, channel_major=False,
-                      nonfinite_flag=None):
-    """fp16 feature gradients [M,3C] -> plane gradient fp32 by tile-sorted LDS accumulation (csrc/scatter.hip):
-    [3,R,R,C], or (3,C,R,R) with channel_major=True; writes every tile of grad_out."""
+                      nonfinite_flag=None, roi=None):
+    """fp16 feature gradients [M,3C] -> plane gradient fp32 by tile-sorted matrix-core reduction
+    (csrc/scatter.hip): [3,R,R,C], or (3,C,R,R) with channel_major=True; writes every tile of grad_out.
+    roi (8 ints): only the window's tiles, grad_out compact (3C, rh, rw), channel_major required."""
     lib = L.lib()
     M = xyz.shape[0]
     nbytes = lib.tnl_plane_grad_binned_workspace(L.u32(M), L.u32(R))
     if nbytes == 0:
         raise NotImplementedError("binned plane gradient needs plane_resolution % 32 == 0")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
-    L.check(lib.tnl_plane_grad_binned(L.ptr(dfeat), L.ptr(xyz), L.f32(bound), L.u32(M), L.ptr(m_actual), L.u32(C),
-                                      L.u32(R), L.f32(grad_scale), L.ptr(grad_out), L.i32(int(channel_major)),
-                                      L.ptr(nonfinite_flag), L.ptr(ws),
-                                      L.stream()),
+    L.check(lib.tnl_plane_grad_binned_roi(L.ptr(dfeat), L.ptr(xyz), L.f32(bound), L.u32(M), L.ptr(m_actual),
+                                          L.u32(C), L.u32(R), L.f32(grad_scale), L.ptr(grad_out),
+                                          L.i32(int(channel_major)), L.ptr(nonfinite_flag), L.roi_array(roi),
+                                          L.ptr(ws), L.stream()),
             "plane_grad_binned")

@@ -28,7 +28,8 @@ from . import _lib as L
 from . import distributed as D
 from . import raymarching
 from .nerf import field as F_
-from .triplaneencoder.triplane_encoder import _IDWTLevel, _ToTexelMajor, half_to_texel_major, idwt_level_half
+from .triplaneencoder.triplane_encoder import (_IDWTLevel, _ToTexelMajor, half_roi_into_texel_major, half_to_texel_major,
+                                                idwt_level_half, idwt_level_half_roi)
 
 
 def lr_factor(it, iters, warmup_steps, sched_base=0.1, warmup_factor=1e-3, sched_exp=2.5):
@@ -70,7 +71,7 @@ class TrainStep:
     def __init__(self, model, lr=1e-2, wavelet_regularization=0.4, iters=30000, warmup_steps=0,
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
-                 dist_mode=None, process_group=None, binned=True, fuse_adam=False):
+                 dist_mode=None, process_group=None, binned=True, fuse_adam=False, use_roi=True):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
@@ -90,6 +91,15 @@ class TrainStep:
         # SLOWER at base (3.8 ms vs 0.95 + 2.03 ms): the epilogue's 4-byte p/m/v accesses are issued late and in
         # 128-B pieces, while the stand-alone pass streams 16 B/lane at the HBM ceiling.  Kept as an option.
         self.fuse_adam = fuse_adam
+        # use_roi: between two density-grid refreshes no sample can leave the bounding window of the occupied cells,
+        # so the finest IDWT level, the fp16 layout change, the plane gradient and the finest adjoint only touch
+        # that window (compact arrays).  Refresh steps rebuild whole planes (the grid update queries density
+        # everywhere).  Results are bit-identical to the whole-plane step.
+        self.use_roi = (use_roi and binned and not fuse_adam and self.J > 0 and self.R % 64 == 0 and self.C % 8 == 0
+                        and enc.plane_dtype == torch.float16)
+        self._roi = None          # 8 ints {ox[3], oy[3], rw, rh} or None (whole planes)
+        self._roi_valid = False   # False: recompute from the bitfield before it is used
+        self._tm_full = None      # persistent fp16 [3,R,R,C]; the ROI steps refresh its window in place
         dev = enc.planes_features.device
         self.dev = dev
         self.coef = _Flat(list(enc.planes_features_wavelet_coefs))
@@ -138,34 +148,95 @@ class TrainStep:
             prev = ev
         return {k: tot[k] / cnt[k] for k in tot}
 
-    def rebuild_planes(self):
-        """encoder.reset_cahce(); encoder.get_planes() of utils.py:1138-1140, outside autograd."""
+    def invalidate_roi(self):
+        """Call after changing model.density_bitfield by hand (update_extra_state inside step() is tracked)."""
+        self._roi_valid = False
+
+    def _roi10(self, s0=0):
+        return None if self._roi is None else list(self._roi) + [self.C, s0]
+
+    def _compute_roi(self):
+        """Window of the plane grid (per plane origin, common size, multiples of 64) that contains the bilinear
+        footprint of every position inside an occupied cell of any cascade.  One small host read-back."""
+        model, R = self.model, self.R
+        Hg, casc = model.grid_size, model.cascade
+        if not hasattr(self, "_cell_coords"):
+            idx = torch.arange(Hg ** 3, dtype=torch.int32, device=self.dev)
+            self._cell_coords = raymarching.morton3D_invert(idx).to(torch.int64)          # [H^3, 3]
+        bits = model.density_bitfield.view(casc, -1)                                       # [casc, H^3/8] uint8
+        shifts = torch.arange(8, dtype=torch.uint8, device=self.dev)
+        occ = ((bits.unsqueeze(-1) >> shifts) & 1).bool().view(casc, -1)                   # bit j of byte n = cell 8n+j
+        lo = torch.full((3,), float("inf"), device=self.dev)
+        hi = torch.full((3,), float("-inf"), device=self.dev)
+        big = Hg + 1
+        for k in range(casc):
+            sk = min(2.0 ** k, float(model.bound))
+            m = occ[k].unsqueeze(-1)
+            cmin = torch.where(m, self._cell_coords, big).amin(0).to(torch.float32)
+            cmax = torch.where(m, self._cell_coords, -1).amax(0).to(torch.float32)
+            has = occ[k].any()
+            lo = torch.where(has, torch.minimum(lo, (cmin / Hg * 2 - 1) * sk), lo)
+            hi = torch.where(has, torch.maximum(hi, ((cmax + 1) / Hg * 2 - 1) * sk), hi)
+        vals = torch.cat([lo, hi]).tolist()
+        if not all(math.isfinite(v) for v in vals):
+            vals = [0.0] * 6                                                                # empty grid: no samples
+        b = float(model.bound)
+
+        def texels(a):   # axis a -> [first, end) texel range incl. the +1 corner and one texel of slack each side
+            f0 = (min(max(vals[a] / b, -1.0), 1.0) + 1) / 2 * (R - 1)
+            f1 = (min(max(vals[3 + a] / b, -1.0), 1.0) + 1) / 2 * (R - 1)
+            t0 = max(int(math.floor(f0)) - 1, 0) // 64 * 64
+            t1 = min((int(math.floor(f1)) + 3 + 63) // 64 * 64, R)
+            return t0, t1
+        xa, ya = (0, 0, 1), (2, 1, 2)   # plane p samples (axis xa[p] -> texel x, axis ya[p] -> texel y)
+        xr = [texels(a) for a in xa]
+        yr = [texels(a) for a in ya]
+        rw = max(t1 - t0 for t0, t1 in xr)
+        rh = max(t1 - t0 for t0, t1 in yr)
+        if rw * rh > 0.8 * R * R:
+            return None
+        ox = [min(t0, R - rw) for t0, _ in xr]
+        oy = [min(t0, R - rh) for t0, _ in yr]
+        return ox + oy + [rw, rh]
+
+    def rebuild_planes(self, roi=False):
+        """encoder.reset_cahce(); encoder.get_planes() of utils.py:1138-1140, outside autograd.
+        roi=True (step() between grid refreshes): only the occupancy window of the finest level is rebuilt and
+        written into the persistent texel-major array; the encoder's own plane cache is dropped."""
         enc = self.enc
+        fast = (self.J > 0 and enc.plane_dtype == torch.float16 and self.C % 8 == 0 and self.R % 16 == 0)
+        roi = roi and self._roi is not None and self._tm_full is not None
         with torch.no_grad():
             if self.dist_mode == "sharded":
-                planes = self._rebuild_sharded()
+                planes = self._rebuild_sharded(roi)
             else:
                 x = enc.planes_features
-                fast = (self.J > 0 and enc.plane_dtype == torch.float16 and self.C % 8 == 0 and self.R % 16 == 0)
                 for lvl in range(self.J):
+                    yh = enc.planes_features_wavelet_coefs[lvl]
                     if fast and lvl == self.J - 1:  # finest level written as fp16: the fp32 planes never exist
-                        x = idwt_level_half(x, enc.planes_features_wavelet_coefs[lvl], enc.wave_id)
+                        x = idwt_level_half_roi(x, yh, enc.wave_id, self._roi10()) if roi else \
+                            idwt_level_half(x, yh, enc.wave_id)
                     else:
-                        x = _IDWTLevel.apply(x, enc.planes_features_wavelet_coefs[lvl], enc.wave_id)
+                        x = _IDWTLevel.apply(x, yh, enc.wave_id)
                 planes = x
+            if roi:
+                enc.last_used_planes = None
+                enc._planes_tm = None
+                return half_roi_into_texel_major(planes, self._tm_full, self._roi10())
             enc.last_used_planes = planes
             if planes.dtype == torch.float16:
                 enc._planes_tm = half_to_texel_major(planes)
             else:
                 enc._planes_tm = _ToTexelMajor.apply(planes, enc.plane_dtype == torch.float16)
+            self._tm_full = enc._planes_tm if self.use_roi else None
         return enc._planes_tm
 
     def _slice_range(self):
         return D.slice_range(3 * self.C, self.world, self.rank)
 
-    def _rebuild_sharded(self):
+    def _rebuild_sharded(self, roi=False):
         """IDWT of this rank's (plane, channel) slices, then all-gather of the rebuilt slices -- in fp16 when the
-        sampler's planes are fp16 (half the bytes on the wire)."""
+        sampler's planes are fp16 (half the bytes on the wire); with roi only the occupancy window travels."""
         enc = self.enc
         s0, s1 = self._slice_range()
         n0 = enc.planes_features.shape[-1]
@@ -175,9 +246,12 @@ class TrainStep:
             n = x.shape[-1]
             yh = enc.planes_features_wavelet_coefs[lvl].reshape(3 * self.C, 3, n, n)[s0:s1].unsqueeze(0).contiguous()
             if fast and lvl == self.J - 1:
-                x = idwt_level_half(x, yh, enc.wave_id)
+                x = idwt_level_half_roi(x, yh, enc.wave_id, self._roi10(s0)) if roi else \
+                    idwt_level_half(x, yh, enc.wave_id)
             else:
                 x = _IDWTLevel.apply(x, yh, enc.wave_id)
+        if roi:
+            return D.all_gather_slices(x.reshape(s1 - s0, self._roi[7], self._roi[6]), self.pg)
         mine = x.reshape(s1 - s0, self.R, self.R)
         return D.all_gather_slices(mine, self.pg).view(3, self.C, self.R, self.R)
 
@@ -200,7 +274,7 @@ class TrainStep:
         t = self.global_step + 1
         return lr_t / (1 - self.b1 ** t), math.sqrt(1 - self.b2 ** t)
 
-    def _adjoint(self, grad_tm, g_cm=None, fuse=None):
+    def _adjoint(self, grad_tm, g_cm=None, fuse=None, roi=None):
         """plane gradient (texel-major [3,R,R,C], or already (3,C,R,R) in g_cm) -> coefficient / LL gradients.
         fuse=None: fills self.ll.grad / self.coef.grad (dense).  fuse=(lr_t, l1, found_inf, inv_scale): every
         level applies Adam(+L1) to its coefficients where their gradients are produced (no gradient buffer)."""
@@ -212,7 +286,7 @@ class TrainStep:
                     "planes_to_channel_major")
         S = 3 * C
         s0, s1 = 0, S
-        g = g_cm.view(S, R, R)
+        g = g_cm.view(S, R, R) if roi is None else g_cm     # roi: compact (S, rh, rw) window of the gradient
         if self.dist_mode == "allreduce":
             dist.all_reduce(g, group=self.pg)
         elif self.dist_mode == "sharded":
@@ -223,7 +297,7 @@ class TrainStep:
             lr_t, l1, found_inf, inv_scale = fuse
             step_size, bias2_sqrt = self._adam_scalars(lr_t)
         for lvl in reversed(range(self.J)):
-            n = g.shape[-1] // 2
+            n = (R >> (self.J - lvl)) if roi is not None else g.shape[-1] // 2
             per = 3 * n * n
             dx = torch.empty(ns, n, n, dtype=torch.float32, device=self.dev) if lvl > 0 else None
             if fuse is not None:
@@ -242,8 +316,10 @@ class TrainStep:
                 dyh = self.coef.grad_view(lvl).view(S, 3, n, n)[s0:s1]  # contiguous slice range of the flat buffer
                 if lvl == 0:
                     dx = self.ll.grad_view(0).view(S, n, n)[s0:s1]
-                L.check(lib.tnl_idwt_level_backward(L.ptr(g), L.u32(ns), L.u32(n), L.i32(self.enc.wave_id), L.ptr(dx),
-                                                    L.ptr(dyh), L.stream()), "idwt_level_backward")
+                lvl_roi = L.roi_array(list(roi) + [C, s0]) if (roi is not None and lvl == self.J - 1) else None
+                L.check(lib.tnl_idwt_level_backward_roi(L.ptr(g), L.u32(ns), L.u32(n), L.i32(self.enc.wave_id),
+                                                        L.ptr(dx), L.ptr(dyh), lvl_roi, L.stream()),
+                        "idwt_level_backward")
             g = dx
         return s0, s1
 
@@ -285,7 +361,9 @@ class TrainStep:
                 marched = march()
             for t_ in marched:
                 t_.record_stream(main)
-        tm = self.rebuild_planes()
+        if self.use_roi and not refresh and not self._roi_valid:
+            self._roi, self._roi_valid = self._compute_roi(), True
+        tm = self.rebuild_planes(roi=self.use_roi and not refresh)
         self._mark("idwt_fwd")
         if refresh:
             model.update_extra_state()
@@ -299,6 +377,8 @@ class TrainStep:
                 model.mean_density = float(md.item())
             if self.post_refresh is not None:
                 self.post_refresh()
+            if self.use_roi:
+                self._roi, self._roi_valid = self._compute_roi(), True
             self._mark("grid_refresh")
         packed = F_.pack_weights(*self.Ws, C, H)
         if side is not None:
@@ -346,14 +426,18 @@ class TrainStep:
         if self.binned and R % 32 == 0:
             # no global float atomics: dF -> fp16 -> tile-sorted matrix-core accumulation (csrc/scatter.hip), written
             # straight in the (3,C,R,R) layout the adjoint IDWT reads
-            g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=self.dev)
+            roi = self._roi if self.use_roi else None
+            if roi is None:
+                g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=self.dev)
+            else:
+                g_cm = torch.empty(3 * C, roi[7], roi[6], dtype=torch.float32, device=self.dev)
             dfeat = torch.empty(M, 3 * C, dtype=torch.float16, device=self.dev)
             F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
                               g_cm, self.mlp.grad, m_actual=counter, dfeat=dfeat)
             self._mark("field_bwd")
             self.nonfinite.zero_()
             F_.plane_grad_binned(dfeat, xyzs, float(model.bound), C, R, g_cm, m_actual=counter, channel_major=True,
-                                 nonfinite_flag=self.nonfinite)
+                                 nonfinite_flag=self.nonfinite, roi=self._roi10() if roi is not None else None)
             self._mark("plane_grad_binned")
             if self.world > 1:
                 dist.all_reduce(self.mlp.grad, group=self.pg)
@@ -368,7 +452,7 @@ class TrainStep:
                 s0, s1 = self._adjoint(None, g_cm, fuse=(lr_t, l1, found_inf, inv_scale))
                 self._mark("idwt_adjoint_adam")
             else:
-                s0, s1 = self._adjoint(None, g_cm)
+                s0, s1 = self._adjoint(None, g_cm, roi=roi)
                 self._mark("idwt_adjoint")
                 if self.dist_mode == "sharded":
                     self._adam_sharded(lr_t, l1, found_inf, inv_scale, s0, s1)

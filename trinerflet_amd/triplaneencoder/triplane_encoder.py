@@ -95,6 +95,28 @@ def idwt_level_half(x, yh, wave_id):
     return out
 
 
+def idwt_level_half_roi(x, yh, wave_id, roi):
+    """Finest level over the ROI window only: -> compact fp16 (P*C, rh, rw).  roi = 8 ints, see
+    include/trinerflet_hip.h (window of the 2n x 2n grid, multiples of 64)."""
+    x = x.detach().to(torch.float32).contiguous()
+    yh = yh.detach().to(torch.float32).contiguous()
+    P, C, n = x.shape[0], x.shape[1], x.shape[-1]
+    out = torch.empty(P * C, roi[7], roi[6], dtype=torch.float16, device=x.device)
+    L.check(L.lib().tnl_idwt_level_forward_half_roi(L.ptr(x), L.ptr(yh), L.u32(P * C), L.u32(n), L.i32(wave_id),
+                                                    L.ptr(out), L.roi_array(roi), L.stream()),
+            "idwt_level_forward_half_roi")
+    return out
+
+
+def half_roi_into_texel_major(planes_roi_half, tm, roi):
+    """Compact fp16 window (3C, rh, rw) -> the same window of the full fp16 [3,R,R,C] array `tm`, in place."""
+    _, R, _, C = tm.shape
+    L.check(L.lib().tnl_planes_half_to_texel_major_roi(L.ptr(planes_roi_half), L.u32(C), L.u32(R), L.ptr(tm),
+                                                       L.roi_array(roi), L.stream()),
+            "planes_half_to_texel_major_roi")
+    return tm
+
+
 def half_to_texel_major(planes_cm_half):
     """fp16 (3,C,R,R) -> fp16 [3,R,R,C] (no autograd)."""
     _, C, R, _ = planes_cm_half.shape
