@@ -254,6 +254,33 @@ TNL_API int tnl_adam_l1_step(float *p, float *grad, float *m, float *v, uint64_t
                              float bias2_sqrt, float beta1, float beta2, float eps, float inv_scale,
                              const float *inv_scale_dev, float l1_coef, const float *found_inf,
                              float *abs_sum, int zero_grad, void *stream);
+/* Same update with the bias corrections taken from a DEVICE counter: opt_step_dev[0] = number of optimiser steps
+ * taken so far (torch.optim.Adam's `step` state, which GradScaler.step leaves unchanged on a skipped iteration,
+ * torch/amp/grad_scaler.py); t = opt_step_dev[0] + 1, step_size = lr / (1 - beta1^t), bias2_sqrt =
+ * sqrt(1 - beta2^t) evaluated in double on the device.  The caller advances the counter by (1 - found_inf). */
+TNL_API int tnl_adam_l1_step_dev(float *p, float *grad, float *m, float *v, uint64_t n, float lr,
+                                 const float *opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
+                                 const float *inv_scale_dev, float l1_coef, const float *found_inf,
+                                 float *abs_sum, int zero_grad, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Ray batches from a device-resident pixel pool.  One launch replaces get_rays over whole
+ * images (reconstruction/nerf/utils.py:65-149), shuffle_data (CPU randperm + gather of every tensor, :228-236),
+ * select_batch (slice + H2D, :238-243) and the background blend of train_step / eval_step (:559-577, :690-695).
+ *   poses [B,4,4] fp32 cam2world (device); intrinsics_host = {fx, fy, cx, cy} (HOST); images [B,H,W,channels]
+ *   fp32 in [0,1] or uint8 (images_u8 != 0: value / 255), channels 3 or 4, may be NULL when gt_rgb is NULL.
+ *   Pixel of ray n:  pix[n] if pix != NULL (device int64, b*H*W + y*W + x);  else g = first + n and
+ *   perm_total == 0 ? g : permute(g)  with perm_total = B*H*W and the epoch's perm_key (tnl_permute_index: a keyed
+ *   bijection of [0, total), so consecutive batches of one epoch partition the pool like shuffle_data's randperm).
+ *   gt_rgb (may be NULL) = rgb*a + bg*(1-a) for 4 channels (bg = bg_rand[n] if bg_rand != NULL else bg_color),
+ *   rgb for 3.  pix_out (may be NULL) receives the pixel ids.
+ * ------------------------------------------------------------------------------------------- */
+TNL_API uint64_t tnl_permute_index(uint64_t g, uint64_t total, uint64_t key);
+TNL_API int tnl_ray_batch(const float *poses, const float *intrinsics_host, uint32_t B, uint32_t H, uint32_t W,
+                          const void *images, int channels, int images_u8, const int64_t *pix, uint64_t first,
+                          uint64_t perm_total, uint64_t perm_key, uint32_t N, float bg_color,
+                          const float *bg_rand, float *rays_o, float *rays_d, float *gt_rgb, int64_t *pix_out,
+                          void *stream);
 
 #ifdef __cplusplus
 }

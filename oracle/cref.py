@@ -249,3 +249,23 @@ def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, we
                              _p(rays_t, C.c_float), _p(sigmas, C.c_float), _p(rgbs, C.c_float),
                              _p(deltas, C.c_float), _p(weights_sum, C.c_float), _p(depth, C.c_float),
                              _p(image, C.c_float))
+
+
+def get_rays(poses, intrinsics, H, W, pix):
+    """utils.py:65-149 for flat pixel ids pix[n] = b*H*W + y*W + x -> rays_o, rays_d [N,3]."""
+    poses = _f32(poses).reshape(-1, 16)
+    intrinsics = _f32(intrinsics)
+    pix = np.ascontiguousarray(pix, np.int64)
+    N = pix.shape[0]
+    rays_o = np.empty((N, 3), np.float32)
+    rays_d = np.empty((N, 3), np.float32)
+    lib().orc_get_rays(_p(poses, C.c_float), _p(intrinsics, C.c_float), C.c_uint32(H), C.c_uint32(W),
+                       _p(pix, C.c_int64), C.c_uint64(N), _p(rays_o, C.c_float), _p(rays_d, C.c_float))
+    return rays_o, rays_d
+
+
+def permute_index(g, total, key):
+    f = lib().orc_permute_index
+    f.restype = C.c_uint64
+    return np.array([f(C.c_uint64(int(v)), C.c_uint64(int(total)), C.c_uint64(int(key))) for v in np.atleast_1d(g)],
+                    np.int64)

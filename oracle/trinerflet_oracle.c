@@ -605,3 +605,51 @@ ORC_API void orc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thres
     image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
   }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Ray generation for flat pixel ids (8(f) rank 2).  reconstruction/nerf/utils.py:65-149 (get_rays):
+ *   i = x + 0.5, j = y + 0.5 ; dir = ((i-cx)/fx, (j-cy)/fy, 1) / |.| ; rays_d = dir @ R^T ; rays_o = t.
+ * pix[n] = b*H*W + y*W + x (the flattened [B, H*W] index of shuffle_data, utils.py:228-236).
+ * ------------------------------------------------------------------------------------------- */
+ORC_API void orc_get_rays(const float *poses, const float *intrinsics, uint32_t H, uint32_t W,
+                          const int64_t *pix, uint64_t N, float *rays_o, float *rays_d) {
+  const float fx = intrinsics[0], fy = intrinsics[1], cx = intrinsics[2], cy = intrinsics[3];
+  const uint64_t HW = (uint64_t)H * W;
+  for (uint64_t n = 0; n < N; n++) {
+    const uint64_t b = (uint64_t)pix[n] / HW, p = (uint64_t)pix[n] % HW;
+    const float i = (float)(p % W) + 0.5f, j = (float)(p / W) + 0.5f;
+    const float xs = (i - cx) / fx, ys = (j - cy) / fy, zs = 1.0f;
+    const float nrm = sqrtf(xs * xs + ys * ys + zs * zs);
+    const float d[3] = {xs / nrm, ys / nrm, zs / nrm};
+    const float *P = poses + 16 * b;
+    for (int k = 0; k < 3; k++) {
+      rays_d[3 * n + k] = d[0] * P[4 * k + 0] + d[1] * P[4 * k + 1] + d[2] * P[4 * k + 2];
+      rays_o[3 * n + k] = P[4 * k + 3];
+    }
+  }
+}
+
+/* Keyed bijection of [0, total) used instead of a materialised torch.randperm (utils.py:230): balanced Feistel
+ * network over the next even power of two, cycle-walked into range.  Own construction (no reference
+ * counterpart beyond "a uniform random permutation per epoch"); restated here so the device version can be
+ * checked value for value. */
+static uint32_t feistel_f_(uint32_t x, uint64_t key, uint32_t round) {
+  uint32_t h = x * 0x9E3779B1u + (uint32_t)(key >> (16 * (round & 3))) + round * 0x85EBCA6Bu;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+ORC_API uint64_t orc_permute_index(uint64_t g, uint64_t total, uint64_t key) {
+  uint32_t half = 1;
+  while ((1ull << (2 * half)) < total) half++;
+  const uint32_t mask = (uint32_t)((1ull << half) - 1);
+  uint64_t v = g;
+  do {
+    uint32_t l = (uint32_t)(v >> half) & mask, r = (uint32_t)v & mask;
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t t = l ^ (feistel_f_(r, key, k) & mask);
+      l = r; r = t;
+    }
+    v = ((uint64_t)l << half) | r;
+  } while (v >= total);
+  return v;
+}

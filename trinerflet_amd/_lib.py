@@ -31,8 +31,9 @@ def lib():
         for name in ("tnl_march_rays_train_workspace", "tnl_field_packed_bytes", "tnl_field_backward_workspace"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_uint32
-        if hasattr(_lib, "tnl_plane_grad_binned_workspace"):
-            _lib.tnl_plane_grad_binned_workspace.restype = C.c_uint64
+        for name in ("tnl_plane_grad_binned_workspace", "tnl_permute_index"):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = C.c_uint64
     return _lib
 
 

@@ -18,7 +18,7 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include")]
 # the marching kernels must not contract a*b+c on their own: bit-exact sample counts (see raymarch.hip)
-PER_FILE = {"raymarch.hip": ["-ffp-contract=off"]}
+PER_FILE = {"raymarch.hip": ["-ffp-contract=off"], "rays.hip": ["-ffp-contract=off"]}
 
 
 def _newer(src, dst, extra=()):

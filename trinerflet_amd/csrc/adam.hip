@@ -18,7 +18,21 @@ namespace {
 __global__ void __launch_bounds__(256)
 k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, uint64_t n,
           AdamArgs a, const float* __restrict__ inv_scale_dev, const float* __restrict__ found_inf,
-          float* __restrict__ abs_sum, int zero_grad) {
+          float* __restrict__ abs_sum, int zero_grad, const float* __restrict__ opt_step_dev) {
+  if (opt_step_dev != nullptr) {
+    // a.step_size carries the learning rate; the bias corrections come from the DEVICE count of optimiser steps
+    // actually taken (torch.optim.Adam's per-parameter `step`, which GradScaler.step does not advance on a skipped
+    // iteration) -- so the host never has to read found_inf back
+    __shared__ float bc[2];
+    if (threadIdx.x == 0) {
+      const double t = (double)opt_step_dev[0] + 1.0;
+      bc[0] = (float)((double)a.step_size / (1.0 - pow((double)a.beta1, t)));
+      bc[1] = (float)sqrt(1.0 - pow((double)a.beta2, t));
+    }
+    __syncthreads();
+    a.step_size = bc[0];
+    a.bias2_sqrt = bc[1];
+  }
   if (inv_scale_dev != nullptr) a.inv_scale *= inv_scale_dev[0];
   const bool skip = found_inf != nullptr && found_inf[0] != 0.f;
   float acc = 0.f;
@@ -71,10 +85,10 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
 
 }  // namespace
 
-extern "C" int tnl_adam_l1_step(float* p, float* grad, float* m, float* v, uint64_t n, float step_size,
-                                float bias2_sqrt, float beta1, float beta2, float eps, float inv_scale,
-                                const float* inv_scale_dev, float l1_coef, const float* found_inf,
-                                float* abs_sum, int zero_grad, void* stream) {
+static int adam_launch(float* p, float* grad, float* m, float* v, uint64_t n, float step_size, float bias2_sqrt,
+                       float beta1, float beta2, float eps, float inv_scale, const float* inv_scale_dev,
+                       float l1_coef, const float* found_inf, float* abs_sum, int zero_grad,
+                       const float* opt_step_dev, void* stream) {
   if (n == 0) return 0;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
        reinterpret_cast<uintptr_t>(v)) & 15)
@@ -84,6 +98,23 @@ extern "C" int tnl_adam_l1_step(float* p, float* grad, float* m, float* v, uint6
   if (blocks > 4096) blocks = 4096;
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL(k_adam_l1, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n, a,
-                     inv_scale_dev, found_inf, abs_sum, zero_grad);
+                     inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev);
   return (int)hipGetLastError();
+}
+
+extern "C" int tnl_adam_l1_step(float* p, float* grad, float* m, float* v, uint64_t n, float step_size,
+                                float bias2_sqrt, float beta1, float beta2, float eps, float inv_scale,
+                                const float* inv_scale_dev, float l1_coef, const float* found_inf,
+                                float* abs_sum, int zero_grad, void* stream) {
+  return adam_launch(p, grad, m, v, n, step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, inv_scale_dev, l1_coef,
+                     found_inf, abs_sum, zero_grad, nullptr, stream);
+}
+
+extern "C" int tnl_adam_l1_step_dev(float* p, float* grad, float* m, float* v, uint64_t n, float lr,
+                                    const float* opt_step_dev, float beta1, float beta2, float eps,
+                                    float inv_scale, const float* inv_scale_dev, float l1_coef,
+                                    const float* found_inf, float* abs_sum, int zero_grad, void* stream) {
+  if (opt_step_dev == nullptr) return (int)hipErrorInvalidValue;
+  return adam_launch(p, grad, m, v, n, lr, 1.0f, beta1, beta2, eps, inv_scale, inv_scale_dev, l1_coef, found_inf,
+                     abs_sum, zero_grad, opt_step_dev, stream);
 }

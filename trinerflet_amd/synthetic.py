@@ -80,6 +80,30 @@ def target_colors(rays_d):
     return (0.5 + 0.5 * np.sin(3.0 * d + np.array([0.0, 1.0, 2.0], np.float32))).astype(np.float32)
 
 
+def sphere_scene_rgba(rays_o, rays_d, radius=0.6):
+    """Analytic scene for end-to-end runs without a dataset: an opaque sphere shaded by its normal
+    (rgb = 0.5 + 0.5 n) with alpha = 1 where the ray hits it, 0 elsewhere -> [N,4] like a Blender RGBA pixel."""
+    o, d = np.asarray(rays_o, np.float64), np.asarray(rays_d, np.float64)
+    b = (o * d).sum(-1)
+    disc = b * b - ((o * o).sum(-1) - radius ** 2)
+    hit = disc > 0
+    t = -b - np.sqrt(np.clip(disc, 0, None))
+    n = (o + t[:, None] * d) / radius
+    rgb = (0.5 + 0.5 * n) * hit[:, None]
+    return np.concatenate([rgb, hit[:, None].astype(np.float64)], -1).astype(np.float32)
+
+
+def sphere_dataset(n_cams=8, H=64, W=64, seed=0, radius=0.6, camera_angle_x=0.6911):
+    """(poses [B,4,4], intrinsics (fx,fy,cx,cy), images [B,H,W,4]) of the analytic sphere scene: the arrays a
+    Blender-style provider hands to the trainer (provider.py:269-281 intrinsics from camera_angle_x)."""
+    poses = hemisphere_poses(n_cams, seed=seed)
+    fl = W / (2 * np.tan(camera_angle_x / 2))
+    pix = np.stack([np.repeat(np.arange(n_cams), H * W), np.tile(np.arange(H * W), n_cams)], -1)
+    o, d = get_rays(poses, pix, H, W, camera_angle_x)
+    images = sphere_scene_rgba(o, d, radius).reshape(n_cams, H, W, 4)
+    return poses, (fl, fl, W / 2, H / 2), images
+
+
 def init_field_parameters(model, seed=0):
     """SURVEY.md 8(d) field parameters: LL = 0.1*N(0,1); level-i coefficients ~ N(0, (0.02 * 2^-i)^2);
     Linear weights = torch default init under a fixed seed."""

@@ -113,6 +113,7 @@ class TrainStep:
         self.scale = torch.full((1,), init_scale if fp16 else 1.0, dtype=torch.float32, device=dev)
         self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=dev)
         self.growth_interval = growth_interval
+        self.opt_steps = torch.zeros(1, dtype=torch.float32, device=dev)   # optimiser steps taken (skips excluded)
         self.abs_sum = torch.zeros(1, dtype=torch.float32, device=dev)
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
         self.last = {}
@@ -162,21 +163,18 @@ class TrainStep:
         Hg, casc = model.grid_size, model.cascade
         if not hasattr(self, "_cell_coords"):
             idx = torch.arange(Hg ** 3, dtype=torch.int32, device=self.dev)
-            self._cell_coords = raymarching.morton3D_invert(idx).to(torch.int64)          # [H^3, 3]
+            self._cell_coords = raymarching.morton3D_invert(idx).t().contiguous()         # [3, H^3] int32
         bits = model.density_bitfield.view(casc, -1)                                       # [casc, H^3/8] uint8
         shifts = torch.arange(8, dtype=torch.uint8, device=self.dev)
-        occ = ((bits.unsqueeze(-1) >> shifts) & 1).bool().view(casc, -1)                   # bit j of byte n = cell 8n+j
-        lo = torch.full((3,), float("inf"), device=self.dev)
-        hi = torch.full((3,), float("-inf"), device=self.dev)
-        big = Hg + 1
-        for k in range(casc):
-            sk = min(2.0 ** k, float(model.bound))
-            m = occ[k].unsqueeze(-1)
-            cmin = torch.where(m, self._cell_coords, big).amin(0).to(torch.float32)
-            cmax = torch.where(m, self._cell_coords, -1).amax(0).to(torch.float32)
-            has = occ[k].any()
-            lo = torch.where(has, torch.minimum(lo, (cmin / Hg * 2 - 1) * sk), lo)
-            hi = torch.where(has, torch.maximum(hi, ((cmax + 1) / Hg * 2 - 1) * sk), hi)
+        occ = ((bits.unsqueeze(-1) >> shifts) & 1).bool().view(casc, 1, -1)               # bit j of byte n = cell 8n+j
+        cc = self._cell_coords.unsqueeze(0)
+        cmin = torch.where(occ, cc, Hg + 1).amin(-1).to(torch.float32)                     # [casc, 3] (row reductions)
+        cmax = torch.where(occ, cc, -1).amax(-1).to(torch.float32)
+        sk = torch.tensor([[min(2.0 ** k, float(model.bound))] for k in range(casc)], device=self.dev)
+        has = cmax[:, :1] >= 0
+        inf = float("inf")
+        lo = torch.where(has, (cmin / Hg * 2 - 1) * sk, inf).amin(0)
+        hi = torch.where(has, ((cmax + 1) / Hg * 2 - 1) * sk, -inf).amax(0)
         vals = torch.cat([lo, hi]).tolist()
         if not all(math.isfinite(v) for v in vals):
             vals = [0.0] * 6                                                                # empty grid: no samples
@@ -257,20 +255,21 @@ class TrainStep:
 
     # ------------------------------------------------------------------------------------------
     def _adam(self, flat, lr_t, l1_coef, found_inf, inv_scale_dev, abs_sum=None, lo=0, hi=None):
-        t = self.global_step + 1
-        step_size = lr_t / (1 - self.b1 ** t)
-        bias2_sqrt = math.sqrt(1 - self.b2 ** t)
+        # bias corrections from the device-side count of steps actually taken (self.opt_steps): GradScaler.step does
+        # not advance torch.optim.Adam's `step` on a skipped iteration, and the host never reads found_inf
         hi = flat.total if hi is None else hi
         n = hi - lo
         if n <= 0:
             return
-        L.check(L.lib().tnl_adam_l1_step(
+        L.check(L.lib().tnl_adam_l1_step_dev(
             L.ptr(flat.data[lo:]), L.ptr(flat.grad[lo:]), L.ptr(flat.m[lo:]), L.ptr(flat.v[lo:]), L.u64(n),
-            L.f32(step_size), L.f32(bias2_sqrt), L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0),
+            L.f32(lr_t), L.ptr(self.opt_steps), L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0),
             L.ptr(inv_scale_dev), L.f32(l1_coef), L.ptr(found_inf), L.ptr(abs_sum), L.i32(0), L.stream()),
             "adam_l1_step")
 
     def _adam_scalars(self, lr_t):
+        # fuse_adam path only: host-side bias correction from the iteration count (equal to the device count unless
+        # GradScaler skipped a step)
         t = self.global_step + 1
         return lr_t / (1 - self.b1 ** t), math.sqrt(1 - self.b2 ** t)
 
@@ -324,9 +323,10 @@ class TrainStep:
         return s0, s1
 
     # ------------------------------------------------------------------------------------------
-    def step(self, rays_o, rays_d, gt_rgb, noises=None, n_global_rays=None):
+    def step(self, rays_o, rays_d, gt_rgb, noises=None, n_global_rays=None, bg_color=None):
         """rays_o, rays_d: [N,3]; gt_rgb: [N,3] (already blended with the background, utils.py:574-577).
-        Returns the (unscaled) loss as a device scalar; details in self.last."""
+        bg_color: None (the constructor's background_color) or a per-ray [N,3] tensor (--train_rand_bg,
+        utils.py:568-570).  Returns the (unscaled) loss as a device scalar; details in self.last."""
         model, enc = self.model, self.enc
         model.train()
         lib = L.lib()
@@ -401,11 +401,15 @@ class TrainStep:
                                                      L.u32(N), L.f32(self.T_thresh), L.ptr(ws), L.ptr(depth),
                                                      L.ptr(image), L.stream()), "composite_rays_train_forward")
         # image = image + (1 - ws) * bg (renderer.py:317); MSE mean over rays and channels (utils.py:595)
-        pred = image + (1 - ws).unsqueeze(-1) * self.bg
+        bg = self.bg if bg_color is None else bg_color
+        pred = image + (1 - ws).unsqueeze(-1) * bg
         diff = pred - gt_rgb
         mse_local = (diff * diff).sum() / (3.0 * n_glob)
         g_pred = diff * (2.0 / (3.0 * n_glob)) * self.scale          # d(scaled loss)/d pred
-        g_ws = -(g_pred * self.bg).sum(-1) if self.bg != 0 else torch.zeros(N, dtype=torch.float32, device=self.dev)
+        if torch.is_tensor(bg) or bg != 0:
+            g_ws = -(g_pred * bg).sum(-1)
+        else:
+            g_ws = torch.zeros(N, dtype=torch.float32, device=self.dev)
         g_sigma = torch.empty(M, dtype=torch.float32, device=self.dev)
         g_rgb = torch.empty(M, 3, dtype=torch.float32, device=self.dev)
         g_sigma.zero_(); g_rgb.zero_()  # rows of dropped rays / budget padding (raymarching.py:283-284)
@@ -483,6 +487,7 @@ class TrainStep:
                 self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
             self._mark("adam_coef")
         self._adam(self.mlp, lr_t, 0.0, found_inf, inv_scale)
+        self.opt_steps += 1.0 - found_inf
         if self.fp16:
             torch._amp_update_scale_(self.scale, self.growth_tracker, found_inf, 2.0, 0.5, self.growth_interval)
         self.global_step += 1

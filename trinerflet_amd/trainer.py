@@ -1,0 +1,409 @@
+"""Trainer -- the loop around TrainStep.
+
+Counterpart of the reference's `Trainer` (reconstruction/nerf/utils.py:375-530 ctor, :762-816 train,
+:1116-1228 train_one_epoch2, :1229-1388 evaluate_one_epoch / test, :1390-1532 save/load_checkpoint) and of the
+stage loop of reconstruction/main_nerf.py:168-205, restricted to what the README configurations run
+(`--fp16 --cuda_ray --triplane_wavelet --ckpt latest_model --ema_decay -1 --fast_training`):
+
+  * one epoch = every pixel of the pool once, in a fresh random order, `num_rays` at a time (RayPool: the
+    permutation and the ray generation happen on the device);
+  * one iteration = TrainStep.step (planes rebuild, grid refresh every `update_extra_interval`, render, loss, fused
+    backward, Adam, GradScaler update, LambdaLR(decay_function));
+  * checkpoints are the reference's `.pth` dictionaries: keys epoch / global_step / stats / mean_count /
+    mean_density / model [/ optimizer / lr_scheduler / scaler when full], the model under the reference's
+    state-dict names, the optimiser as a torch.optim.Adam state_dict over `model.get_params(lr)` -- a checkpoint
+    written here loads in the reference's Trainer and vice versa;
+  * `use_checkpoint="latest_model"` loads the newest checkpoint's model with strict=False: moving to the next
+    resolution keeps LL and the existing wavelet levels and starts the new finest level at zero (main_nerf.py's
+    stage hand-off);
+  * evaluation renders whole images (renderer eval branch), accumulates PSNR per image as PSNRMeter does, on the
+    device, images striped over the ranks when torch.distributed is initialised.
+
+Not here (out of scope): tensorboard, EMA, LPIPS/SSIM, video/mesh export, the GUI, error maps,
+patch sampling, CLIP loss.
+"""
+import glob
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .train import TrainStep, lr_factor
+
+
+class PSNRMeter:
+    """utils.py:245-282: per update -10*log10(mean((pred-truth)^2)); measure() = mean over updates.  The running
+    sum stays on the device (one read-back in measure())."""
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.V = None
+        self.N = 0
+
+    def update(self, preds, truths):
+        mse = ((preds.to(torch.float32) - truths.to(torch.float32)) ** 2).mean()
+        psnr = -10.0 * torch.log10(mse)
+        self.V = psnr if self.V is None else self.V + psnr
+        self.N += 1
+
+    def state(self, device):
+        v = torch.zeros((), device=device, dtype=torch.float64) if self.V is None else self.V.to(torch.float64)
+        return torch.stack([v, torch.tensor(float(self.N), device=device, dtype=torch.float64)])
+
+    def measure(self):
+        return float(self.V) / self.N
+
+    def report(self):
+        return f"PSNR = {self.measure():.6f}"
+
+
+class Trainer:
+    def __init__(self, name, model, workspace=None, lr=1e-2, iters=30000, warmup_steps=0, num_rays=4096,
+                 wavelet_regularization=0.0, background_color=0.0, train_rand_bg=False, fp16=True,
+                 update_extra_interval=16, max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, use_checkpoint="latest",
+                 max_keep_ckpt=2, eval_interval=1, fast_training=False, seed=0, dist_mode=None, process_group=None,
+                 mute=True, train_step_kwargs=None):
+        self.name, self.model, self.workspace = name, model, workspace
+        self.lr, self.iters, self.warmup_steps, self.num_rays = lr, iters, warmup_steps, num_rays
+        self.background_color, self.train_rand_bg = background_color, train_rand_bg
+        self.fp16 = fp16
+        self.max_steps, self.dt_gamma, self.T_thresh = max_steps, dt_gamma, T_thresh
+        self.max_keep_ckpt, self.eval_interval, self.fast_training = max_keep_ckpt, eval_interval, fast_training
+        self.seed, self.mute = seed, mute
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.device = next(model.parameters()).device
+        self.epoch = 0
+        self.stats = {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
+        self.ckpt_path = None
+        if workspace is not None:
+            os.makedirs(workspace, exist_ok=True)
+            self.ckpt_path = os.path.join(workspace, "checkpoints")
+            os.makedirs(self.ckpt_path, exist_ok=True)
+        # checkpoint to start from (utils.py:468-488) -- BEFORE TrainStep re-homes the parameters in flat buffers
+        self._pending_full = None
+        if self.ckpt_path is not None:
+            if use_checkpoint == "scratch":
+                pass
+            elif use_checkpoint == "latest":
+                self._pending_full = self.load_checkpoint(model_only=False, _defer_optimizer=True)
+            elif use_checkpoint == "latest_model":
+                self.load_checkpoint(model_only=True)
+            elif use_checkpoint:
+                self._pending_full = self.load_checkpoint(use_checkpoint, model_only=False, _defer_optimizer=True)
+        kw = dict(train_step_kwargs or {})
+        self.ts = TrainStep(model, lr=lr, wavelet_regularization=wavelet_regularization, iters=iters,
+                            warmup_steps=warmup_steps, fp16=fp16, update_extra_interval=update_extra_interval,
+                            background_color=background_color, max_steps=max_steps, dt_gamma=dt_gamma,
+                            T_thresh=T_thresh, dist_mode=dist_mode if self.world > 1 else None,
+                            process_group=process_group, **kw)
+        if self._pending_full is not None:
+            self._restore_training_state(self._pending_full)
+            self._pending_full = None
+
+    # ----------------------------------------------------------------------------------------------------------
+    @property
+    def global_step(self):
+        return self.ts.global_step
+
+    def log(self, *a):
+        if not self.mute and self.rank == 0:
+            print(*a)
+
+    # ----------------------------------------------------------------------------------------------------------
+    # training (utils.py:762-816, :1116-1228)
+    # ----------------------------------------------------------------------------------------------------------
+    def max_epochs_for(self, pool):
+        """main_nerf.py:147-148: ceil((iters + max(warmup, 0)) / steps_per_epoch)."""
+        return int(math.ceil((self.iters + max(self.warmup_steps, 0)) / (pool.total / self.num_rays)))
+
+    def train(self, train_pool, valid_pool=None, max_epochs=None, mark_untrained=True):
+        if max_epochs is None:
+            max_epochs = self.max_epochs_for(train_pool)
+        if mark_untrained and self.model.cuda_ray:                                  # utils.py:768-770
+            self.model.mark_untrained_grid(train_pool.poses, train_pool.intrinsics)
+            self.ts.invalidate_roi()
+        if not self.fast_training and valid_pool is not None:
+            self.evaluate_one_epoch(valid_pool)
+        t_train = 0.0
+        for epoch in range(self.epoch + 1, max_epochs + 1):
+            t0 = time.time()
+            self.epoch = epoch
+            self.train_one_epoch(train_pool)
+            torch.cuda.synchronize()
+            t_train += time.time() - t0
+            self.log(f"epoch {epoch} time: {time.time() - t0:.2f}[s]")
+            if not self.fast_training and self.workspace is not None and epoch % self.eval_interval == 0:
+                if valid_pool is not None:
+                    self.evaluate_one_epoch(valid_pool)
+                self.save_checkpoint(full=True)
+        self.log(f"training time: {t_train:.2f}[s]")
+        if self.workspace is not None:
+            self.save_checkpoint(full=True, remove_old=False)
+        return t_train
+
+    def train_one_epoch(self, pool):
+        """train_one_epoch2: a fresh permutation of every pixel, ceil(total/num_rays) iterations (the last batch is
+        short); each rank of a multi-GPU job takes its contiguous share of every batch."""
+        model = self.model
+        model.train()
+        model.local_step = 0
+        pool.shuffle(self.seed * 1000003 + self.epoch)
+        steps = pool.steps_per_epoch(self.num_rays)
+        total = torch.zeros((), dtype=torch.float32, device=self.device)
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(self.seed * 7919 + self.epoch)
+        for batch_idx in range(steps):
+            data = pool.batch(batch_idx, self.num_rays, bg_color=self.background_color)
+            n = data["rays_o"].shape[0]
+            bg = None
+            if self.train_rand_bg and pool.channels == 4:                           # utils.py:568-570
+                bg = torch.rand(n, 3, device=self.device, generator=gen)
+                data = pool.batch(batch_idx, self.num_rays, bg_rand=bg)
+            o, d, gt = data["rays_o"], data["rays_d"], data["gt_rgb"]
+            if self.world > 1:                                                      # rays sharded across ranks
+                lo, hi = n * self.rank // self.world, n * (self.rank + 1) // self.world
+                o, d, gt = o[lo:hi], d[lo:hi], gt[lo:hi]
+                bg = bg[lo:hi] if bg is not None else None
+            loss = self.ts.step(o, d, gt, n_global_rays=n, bg_color=bg)
+            total += loss.detach()
+        avg = float(total) / steps                                                  # the epoch's only read-back
+        self.stats["loss"].append(avg)
+        self.log(f"==> Finished Epoch {self.epoch}, loss {avg:.6f}")
+        return avg
+
+    # ----------------------------------------------------------------------------------------------------------
+    # evaluation (utils.py:681-735 eval_step / test_step, :1229-1388 evaluate_one_epoch / test)
+    # ----------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def render_image(self, pool, index, max_steps=None, perturb=False):
+        """All rays of one pose through the renderer's inference branch -> (pred [H,W,3], depth [H,W], gt or None)."""
+        model = self.model
+        was_training = model.training
+        model.eval()
+        self.model.encoder.reset_cahce()      # the training loop only refreshes the occupancy window of the planes
+        data = pool.image_rays(index, bg_color=self.background_color)
+        out = model.render(data["rays_o"].unsqueeze(0), data["rays_d"].unsqueeze(0), staged=True,
+                           bg_color=self.background_color, perturb=perturb, dt_gamma=self.dt_gamma,
+                           max_steps=max_steps or self.max_steps)
+        H, W = pool.H, pool.W
+        pred = out["image"].reshape(H, W, 3)
+        depth = out["depth"].reshape(H, W)
+        gt = data["gt_rgb"].reshape(H, W, 3) if data["gt_rgb"] is not None else None
+        if was_training:
+            model.train()
+        return pred, depth, gt
+
+    def evaluate_one_epoch(self, pool, max_steps=None):
+        """PSNR over the pool's images (PSNRMeter: mean of per-image PSNRs) and the mean MSE 'loss'; images are
+        striped over the ranks and the two sums all-reduced."""
+        meter = PSNRMeter()
+        loss = torch.zeros((), dtype=torch.float64, device=self.device)
+        for i in range(self.rank, pool.B, self.world):
+            pred, _, gt = self.render_image(pool, i, max_steps=max_steps)
+            meter.update(pred, gt)
+            loss += ((pred - gt) ** 2).mean().to(torch.float64)
+        acc = torch.cat([meter.state(self.device), loss.reshape(1)])
+        if self.world > 1:
+            dist.all_reduce(acc, group=self.pg)
+        psnr = float(acc[0] / acc[1])
+        avg_loss = float(acc[2] / acc[1])
+        self.stats["valid_loss"].append(avg_loss)
+        self.stats["results"].append(avg_loss)                                      # utils.py:1340-1350 keeps the loss
+        self.log(f"++> Evaluate epoch {self.epoch}: PSNR = {psnr:.6f}")
+        return {"PSNR": psnr, "loss": avg_loss}
+
+    evaluate = evaluate_one_epoch
+
+    def test(self, pool, save_path=None, max_steps=None):
+        """Render every pose (test_step); returns [B,H,W,3] uint8 on the host and, if a path is given, writes
+        binary PPMs there (the reference writes PNG + MP4 through cv2 / imageio, which this build does not carry)."""
+        frames = []
+        for i in range(pool.B):
+            pred, _, _ = self.render_image(pool, i, max_steps=max_steps)
+            frames.append((pred.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy())
+        frames = np.stack(frames)
+        if save_path is not None and self.rank == 0:
+            os.makedirs(save_path, exist_ok=True)
+            for i, f in enumerate(frames):
+                with open(os.path.join(save_path, f"{self.name}_{i:04d}_rgb.ppm"), "wb") as fh:
+                    fh.write(f"P6 {f.shape[1]} {f.shape[0]} 255\n".encode())
+                    fh.write(f.tobytes())
+        return frames
+
+    # ----------------------------------------------------------------------------------------------------------
+    # checkpoints (utils.py:1390-1532)
+    # ----------------------------------------------------------------------------------------------------------
+    def _torch_optimizer(self):
+        """A torch.optim.Adam over model.get_params(lr) (main_nerf.py:119) carrying TrainStep's moments -- only to
+        read / write the reference's optimiser state_dict layout."""
+        opt = torch.optim.Adam(self.model.get_params(self.lr), betas=(self.ts.b1, self.ts.b2), eps=self.ts.eps)
+        return opt
+
+    def _flat_slots(self):
+        """parameter -> (flat buffer, segment index) for every parameter TrainStep owns."""
+        slots = {}
+        for flat in (self.ts.ll, self.ts.coef, self.ts.mlp):
+            for k, p in enumerate(flat.params):
+                slots[id(p)] = (flat, k)
+        return slots
+
+    def optimizer_state_dict(self):
+        self.ts.sync_sharded_parameters()
+        opt = self._torch_optimizer()
+        slots = self._flat_slots()
+        step = self.ts.opt_steps.detach().to("cpu", torch.float32).reshape(())
+        for group in opt.param_groups:
+            group["lr"] = self.lr * lr_factor(self.global_step, self.iters, self.warmup_steps)
+            group["initial_lr"] = self.lr
+            for p in group["params"]:
+                flat, k = slots[id(p)]
+                o, n = flat.offsets[k], flat.sizes[k]
+                opt.state[p] = {"step": step.clone(), "exp_avg": flat.m[o:o + n].view(p.shape).clone(),
+                                "exp_avg_sq": flat.v[o:o + n].view(p.shape).clone()}
+        return opt.state_dict()
+
+    def load_optimizer_state_dict(self, sd):
+        opt = self._torch_optimizer()
+        opt.load_state_dict(sd)
+        slots = self._flat_slots()
+        step = None
+        for group in opt.param_groups:
+            for p in group["params"]:
+                st = opt.state.get(p)
+                if not st:
+                    continue
+                flat, k = slots[id(p)]
+                o, n = flat.offsets[k], flat.sizes[k]
+                flat.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                flat.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                step = float(st["step"])
+        if step is not None:
+            self.ts.opt_steps.fill_(step)
+
+    def scheduler_state_dict(self):
+        """state_dict() of the LambdaLR(decay_function) the reference steps once per iteration
+        (main_nerf.py:129, utils.py:1173), positioned at the current iteration -- produced by a real torch scheduler
+        so the layout is this torch version's."""
+        it = self.global_step
+        opt = self._torch_optimizer()
+        sched = torch.optim.lr_scheduler.LambdaLR(
+            opt, lambda k: lr_factor(k, self.iters, self.warmup_steps))
+        sched.last_epoch = it
+        sched._step_count = it + 1
+        sched._last_lr = [self.lr * lr_factor(it, self.iters, self.warmup_steps)] * len(opt.param_groups)
+        return sched.state_dict()
+
+    def scaler_state_dict(self):
+        """torch.cuda.amp.GradScaler.state_dict() layout."""
+        if not self.fp16:
+            return {}
+        return {"scale": float(self.ts.scale), "growth_factor": 2.0, "backoff_factor": 0.5,
+                "growth_interval": self.ts.growth_interval, "_growth_tracker": int(self.ts.growth_tracker)}
+
+    def save_checkpoint(self, name=None, full=False, remove_old=True):
+        if self.ckpt_path is None:
+            raise RuntimeError("Trainer was built without a workspace")
+        self.ts.sync_sharded_parameters()
+        if self.rank != 0:
+            return None
+        if name is None:
+            name = f"{self.name}_ep{self.epoch:04d}"
+        state = {"epoch": self.epoch, "global_step": self.global_step, "stats": self.stats}
+        if self.model.cuda_ray:
+            state["mean_count"] = self.model.mean_count
+            state["mean_density"] = self.model.mean_density
+        if full:
+            state["optimizer"] = self.optimizer_state_dict()
+            state["lr_scheduler"] = self.scheduler_state_dict()
+            state["scaler"] = self.scaler_state_dict()
+        state["model"] = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        path = os.path.join(self.ckpt_path, f"{name}.pth")
+        if remove_old:
+            self.stats["checkpoints"].append(path)
+            if len(self.stats["checkpoints"]) > self.max_keep_ckpt:
+                old = self.stats["checkpoints"].pop(0)
+                if os.path.exists(old):
+                    os.remove(old)
+        torch.save(state, path)
+        return path
+
+    def load_checkpoint(self, checkpoint=None, model_only=False, _defer_optimizer=False):
+        if checkpoint is None:
+            found = sorted(glob.glob(os.path.join(self.ckpt_path, f"{self.name}_ep*.pth")))
+            if not found:
+                self.log("[WARN] No checkpoint found, model randomly initialized.")
+                return None
+            checkpoint = found[-1]
+        ckpt = torch.load(checkpoint, map_location=self.device, weights_only=False)
+        if "model" not in ckpt:
+            self._load_model_state(ckpt, strict=True)
+            return None
+        self._load_model_state(ckpt["model"], strict=False)
+        if self.model.cuda_ray:
+            self.model.mean_count = ckpt.get("mean_count", self.model.mean_count)
+            self.model.mean_density = ckpt.get("mean_density", self.model.mean_density)
+        if model_only:
+            return None
+        self.stats = ckpt["stats"]
+        self.epoch = ckpt["epoch"]
+        if _defer_optimizer:
+            return ckpt
+        self._restore_training_state(ckpt)
+        return None
+
+    def _load_model_state(self, sd, strict):
+        """load_state_dict with the reference's tolerance (strict=False: missing new wavelet levels stay at their
+        zero init, utils.py:1481) plus a shape filter: a tensor whose shape changed with the resolution is skipped
+        with a warning instead of raising."""
+        own = self.model.state_dict()
+        ok = {k: v for k, v in sd.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}
+        skipped = [k for k in sd if k not in ok]
+        missing, unexpected = self.model.load_state_dict(ok, strict=False)
+        if strict and (missing or skipped):
+            raise RuntimeError(f"checkpoint does not match the model: missing {missing}, skipped {skipped}")
+        if missing:
+            self.log(f"[WARN] missing keys: {missing}")
+        if skipped:
+            self.log(f"[WARN] unexpected / reshaped keys: {skipped}")
+        if hasattr(self, "ts"):
+            self.ts.invalidate_roi()
+        self.model.encoder.reset_cahce()
+
+    def _restore_training_state(self, ckpt):
+        self.ts.global_step = int(ckpt.get("global_step", 0))
+        if "optimizer" in ckpt:
+            try:
+                self.load_optimizer_state_dict(ckpt["optimizer"])
+            except Exception as e:   # utils.py:1511-1517: a stage with new shapes keeps a fresh optimiser
+                self.log("[WARN] Failed to load optimizer.", str(e))
+        sc = ckpt.get("scaler") or {}
+        if self.fp16 and "scale" in sc:
+            self.ts.scale.fill_(float(sc["scale"]))
+            self.ts.growth_tracker.fill_(int(sc.get("_growth_tracker", 0)))
+
+
+def train_stages(make_model, make_pools, stages, workspace, name="trinerflet", **common):
+    """The stage loop of main_nerf.py:168-205: every stage builds a fresh model at its own resolution / wavelet
+    depth and a fresh Trainer with `--ckpt latest_model`, so it starts from the previous stage's planes (new
+    finest level zero), a new optimiser, scaler and schedule.  `stages` is a list of dicts with the per-stage
+    options (iters, num_rays, triplane_resolution, triplane_wavelet_levels, warmup_steps, lr,
+    wavelet_regularization); `make_model(stage)` and `make_pools(stage)` supply the model and
+    (train_pool, valid_pool).  Returns the last Trainer."""
+    trainer = None
+    for stage in stages:
+        model = make_model(stage)
+        train_pool, valid_pool = make_pools(stage)
+        opts = dict(common)
+        for k in ("iters", "num_rays", "warmup_steps", "lr", "wavelet_regularization"):
+            if k in stage:
+                opts[k] = stage[k]
+        trainer = Trainer(name, model, workspace=workspace, use_checkpoint="latest_model", **opts)
+        trainer.train(train_pool, valid_pool)
+    return trainer
