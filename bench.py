@@ -71,14 +71,16 @@ def make_batches(n_batches, N, rank, device):
     return out
 
 
-def one_step(model, ts, bitfield, batch, mean_count):
+def one_step(model, ts, bitfield, batch, mean_count, next_batch=None):
     o, d, gt, noise = batch
 
     def reimpose():  # analytic occupancy re-imposed after the (timed) refresh; fixed sample budget
         model.density_bitfield.copy_(bitfield)
         model.mean_count = mean_count
     ts.post_refresh = reimpose
-    return ts.step(o, d, gt, noises=noise)
+    # the following batch (a loader has it ready) lets its march start underneath this step's kernels
+    nxt = None if next_batch is None else (next_batch[0], next_batch[1], next_batch[3])
+    return ts.step(o, d, gt, noises=noise, next_rays=nxt)
 
 
 def cpu_baseline(workload):
@@ -165,8 +167,9 @@ def main():
         mean_count = int(mc.item())
     model.mean_count = mean_count
 
+    nb = len(batches)
     for i in range(args.warmup):
-        one_step(model, ts, bitfield, batches[i % len(batches)], mean_count)
+        one_step(model, ts, bitfield, batches[i % nb], mean_count, batches[(i + 1) % nb])
 
     ts.section_events = [] if True else None
     if world > 1:
@@ -175,7 +178,7 @@ def main():
     t0 = time.perf_counter()
     samples = 0
     for i in range(args.steps):
-        one_step(model, ts, bitfield, batches[i % len(batches)], mean_count)
+        one_step(model, ts, bitfield, batches[(args.warmup + i) % nb], mean_count, batches[(args.warmup + i + 1) % nb])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

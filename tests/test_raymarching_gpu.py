@@ -80,6 +80,28 @@ def test_march_train_exact(cuda, rays, shell, perturb):
         assert np.array_equal(deltas.cpu().numpy(), lr[:m])
 
 
+def test_march_with_unaligned_bitfield(cuda, rays):
+    """The 64-bit cached occupancy lookups need an 8-byte aligned bitfield; any other pointer takes the byte-wise
+    path.  Same samples either way (and both equal the oracle's, see test_march_train_exact)."""
+    from trinerflet_amd import raymarching
+    o, d, aabb, nears, fars = rays
+    bf = scene.sphere_bitfield(HG, CAS, BOUND, 0.8, 0.7)
+    N = o.shape[0]
+    noises = _t(np.random.default_rng(5).random(N).astype(np.float32), cuda)
+    holder = torch.zeros(bf.size + 8, dtype=torch.uint8, device=cuda)
+    outs = []
+    for shift in (0, 3):
+        view = holder[shift:shift + bf.size]
+        view.copy_(_t(bf, cuda))
+        assert view.data_ptr() % 8 == (holder.data_ptr() + shift) % 8
+        counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+        out = raymarching.march_rays_train(_t(o, cuda), _t(d, cuda), BOUND, view, CAS, HG, _t(nears, cuda),
+                                           _t(fars, cuda), counter, -1, True, -1, True, 0, 1024, noises)
+        outs.append([t.clone() for t in out] + [counter.clone()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def _samples(cuda, rays, seed=0):
     o, d, aabb, nears, fars = rays
     bf = scene.sphere_bitfield(HG, CAS, BOUND, 0.8, 0.0)

@@ -81,11 +81,18 @@ __device__ __forceinline__ void march_init(MarchCtx& m, const float* o, const fl
   m.Hf = (float)H; m.Cf = (float)C; m.H = H; m.grid = grid;
 }
 
-template <bool WRITE>
+// Occupancy lookups go through a one-entry register cache of 64 consecutive bits: in Morton order that is an aligned
+// 4x4x4 block of cells, so successive tests of a ray (samples dt apart inside a cell, neighbouring cells while
+// skipping) mostly hit the cached word.  The loop is a chain of dependent global loads otherwise (one wave per SIMD:
+// nothing hides their latency); with the cache only every ~10th test loads.  Needs the bitfield 8-byte aligned
+// (WIDE); the byte-wise path is kept for arbitrary pointers.  Results are identical.
+template <bool WRITE, bool WIDE>
 __device__ __forceinline__ uint32_t march_run(const MarchCtx& m, float& t, float far, uint32_t limit,
                                               float* xyzs, float* dirs, float* deltas) {
   float last_t = t;
   uint32_t step = 0;
+  uint32_t cached_blk = 0xffffffffu;
+  unsigned long long cached_bits = 0ull;
   while (t < far && step < limit) {
     const float x = clampf_(fmaf(t, m.dx, m.ox), -m.bound, m.bound);
     const float y = clampf_(fmaf(t, m.dy, m.oy), -m.bound, m.bound);
@@ -98,7 +105,17 @@ __device__ __forceinline__ uint32_t march_run(const MarchCtx& m, float& t, float
     const int ny = (int)clampf_(0.5f * fmaf(y, mip_rbound, 1.0f) * m.Hf, 0.0f, (float)(m.H - 1));
     const int nz = (int)clampf_(0.5f * fmaf(z, mip_rbound, 1.0f) * m.Hf, 0.0f, (float)(m.H - 1));
     const uint32_t index = (uint32_t)((float)level * m.H3) + morton3D_(nx, ny, nz);
-    const bool occ = m.grid[index >> 3] & (1u << (index & 7u));
+    bool occ;
+    if (WIDE) {
+      const uint32_t blk = index >> 6;
+      if (blk != cached_blk) {
+        cached_bits = reinterpret_cast<const unsigned long long*>(m.grid)[blk];
+        cached_blk = blk;
+      }
+      occ = (cached_bits >> (index & 63u)) & 1ull;
+    } else {
+      occ = m.grid[index >> 3] & (1u << (index & 7u));
+    }
     if (occ) {
       if (WRITE) {
         xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
@@ -244,6 +261,7 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* smem4, int* total
   return base + incl - v;
 }
 
+template <bool WIDE>
 __global__ void __launch_bounds__(MARCH_BLOCK)
 k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                     const uint8_t* __restrict__ grid, float bound, float dt_gamma, uint32_t max_steps,
@@ -258,7 +276,7 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
     march_init(m, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
     float t = nears[n];
     t = fmaf(clampf_(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
-    ns = (int)march_run<false>(m, t, fars[n], max_steps, nullptr, nullptr, nullptr);
+    ns = (int)march_run<false, WIDE>(m, t, fars[n], max_steps, nullptr, nullptr, nullptr);
     num_steps_out[n] = ns;
   }
   int total;
@@ -266,6 +284,7 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
+template <bool WIDE>
 __global__ void __launch_bounds__(MARCH_BLOCK)
 k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                     const uint8_t* __restrict__ grid, float bound, float dt_gamma, uint32_t max_steps,
@@ -299,7 +318,7 @@ k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ 
   march_init(m, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
   float t = nears[n];
   t = fmaf(clampf_(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
-  march_run<true>(m, t, fars[n], (uint32_t)ns, xyzs + (size_t)off * 3, dirs + (size_t)off * 3,
+  march_run<true, WIDE>(m, t, fars[n], (uint32_t)ns, xyzs + (size_t)off * 3, dirs + (size_t)off * 3,
                   deltas + (size_t)off * 2);
 }
 
@@ -461,6 +480,7 @@ k_composite_train_bwd(const float* __restrict__ grad_weights_sum, const float* _
 // ---------------------------------------------------------------------------------------------
 // inference
 // ---------------------------------------------------------------------------------------------
+template <bool WIDE>
 __global__ void k_march_rays(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
                              const float* __restrict__ rays_t, const float* __restrict__ rays_o,
                              const float* __restrict__ rays_d, float bound, float dt_gamma,
@@ -475,7 +495,7 @@ __global__ void k_march_rays(uint32_t n_alive, uint32_t n_step, const int* __res
   march_init(m, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
   float t = rays_t[index];
   t = fmaf(clampf_(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
-  march_run<true>(m, t, fars[index], n_step, xyzs + (size_t)n * n_step * 3, dirs + (size_t)n * n_step * 3,
+  march_run<true, WIDE>(m, t, fars[index], n_step, xyzs + (size_t)n * n_step * 3, dirs + (size_t)n * n_step * 3,
                   deltas + (size_t)n * n_step * 2);
 }
 
@@ -612,6 +632,11 @@ inline int launch_status() { return (int)hipGetLastError(); }
 
 }  // namespace
 
+// the 64-bit cached lookups need an 8-byte aligned bitfield whose bit count is a multiple of 64
+static inline bool wide_bitfield(const uint8_t* grid, uint32_t C, uint32_t H) {
+  return (reinterpret_cast<uintptr_t>(grid) & 7) == 0 && ((uint64_t)C * H * H * H) % 64 == 0;
+}
+
 extern "C" {
 
 int tnl_abi_version(void) { return 1; }
@@ -663,11 +688,19 @@ int tnl_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
   int* num_steps = workspace;
   int* block_sums = workspace + N;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_march_train_count, dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
-                     max_steps, N, C, H, nears, fars, noises, num_steps, block_sums);
-  hipLaunchKernelGGL(k_march_train_write, dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound, dt_gamma,
-                     max_steps, N, C, H, M, nears, fars, noises, num_steps, block_sums, counter, xyzs, dirs, deltas,
-                     rays);
+  if (wide_bitfield(grid, C, H)) {
+    hipLaunchKernelGGL(k_march_train_count<true>, dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
+                       dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums);
+    hipLaunchKernelGGL(k_march_train_write<true>, dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
+                       dt_gamma, max_steps, N, C, H, M, nears, fars, noises, num_steps, block_sums, counter, xyzs,
+                       dirs, deltas, rays);
+  } else {
+    hipLaunchKernelGGL(k_march_train_count<false>, dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
+                       dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums);
+    hipLaunchKernelGGL(k_march_train_write<false>, dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
+                       dt_gamma, max_steps, N, C, H, M, nears, fars, noises, num_steps, block_sums, counter, xyzs,
+                       dirs, deltas, rays);
+  }
   hipLaunchKernelGGL(k_march_train_finalize, dim3(1), dim3(MARCH_BLOCK), 0, st, block_sums, nb, N, counter);
   return launch_status();
 }
@@ -698,9 +731,14 @@ int tnl_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,
                    float* xyzs, float* dirs, float* deltas, const float* noises, void* stream) {
   (void)nears;
   if (n_alive == 0) return 0;
-  hipLaunchKernelGGL(k_march_rays, dim3(cdiv(n_alive, 128)), dim3(128), 0, (hipStream_t)stream, n_alive, n_step,
-                     rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs,
-                     deltas, noises);
+  if (wide_bitfield(grid, C, H))
+    hipLaunchKernelGGL(k_march_rays<true>, dim3(cdiv(n_alive, 128)), dim3(128), 0, (hipStream_t)stream, n_alive,
+                       n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs,
+                       dirs, deltas, noises);
+  else
+    hipLaunchKernelGGL(k_march_rays<false>, dim3(cdiv(n_alive, 128)), dim3(128), 0, (hipStream_t)stream, n_alive,
+                       n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs,
+                       dirs, deltas, noises);
   return launch_status();
 }
 

@@ -119,6 +119,7 @@ class TrainStep:
         self.last = {}
         self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
         self._side = None
+        self._prefetched = None     # (key, marched tensors) of a march started for the following call
         self.post_refresh = None    # optional callable run right after every density-grid refresh
         self.section_events = None  # set to [] to record HIP events (on the launch stream) around every stage
         # distributed
@@ -323,10 +324,13 @@ class TrainStep:
         return s0, s1
 
     # ------------------------------------------------------------------------------------------
-    def step(self, rays_o, rays_d, gt_rgb, noises=None, n_global_rays=None, bg_color=None):
+    def step(self, rays_o, rays_d, gt_rgb, noises=None, n_global_rays=None, bg_color=None, next_rays=None):
         """rays_o, rays_d: [N,3]; gt_rgb: [N,3] (already blended with the background, utils.py:574-577).
         bg_color: None (the constructor's background_color) or a per-ray [N,3] tensor (--train_rand_bg,
-        utils.py:568-570).  Returns the (unscaled) loss as a device scalar; details in self.last."""
+        utils.py:568-570).  next_rays: optional (rays_o, rays_d[, noises]) of the FOLLOWING call: its march is
+        then started on the side stream underneath this step's field / gradient / optimiser kernels (the march
+        reads only rays and the occupancy bitfield), and the next call picks it up if it is given the same
+        tensors.  Returns the (unscaled) loss as a device scalar; details in self.last."""
         model, enc = self.model, self.enc
         model.train()
         lib = L.lib()
@@ -337,30 +341,36 @@ class TrainStep:
         self._mark("begin")
         refresh = self.update_extra_interval > 0 and self.global_step % self.update_extra_interval == 0
 
-        def march():
-            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, model.aabb_train, model.min_near)
+        def march(o=rays_o, d=rays_d, nz=noises):
+            nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_train, model.min_near)
             counter = model.step_counter[model.local_step % 16]
             counter.zero_()
             model.local_step += 1
             out = raymarching.march_rays_train(
-                rays_o, rays_d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars,
-                counter, model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, noises)
+                o, d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars,
+                counter, model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, nz)
             return (counter, *out)
+
+        def march_on_side(*a):
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                out = march(*a)
+            for t_ in out:
+                t_.record_stream(main)
+            return out
 
         # The march (one ray per lane, latency-bound, ~1/8 of the chip's wave slots) depends only on the rays and
         # the occupancy bitfield, not on the planes: it runs on a side stream underneath the HBM-bound plane
         # rebuild.  On grid-refresh steps the bitfield changes first, so there the march stays in order.
         side = None
-        if self.overlap_march and not refresh and model.mean_count > 0:
-            main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            side = self._side
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                marched = march()
-            for t_ in marched:
-                t_.record_stream(main)
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and not refresh and pre[0] == (rays_o.data_ptr(), rays_d.data_ptr(), N):
+            marched, side = pre[1], self._side          # started during the previous call
+        elif self.overlap_march and not refresh and model.mean_count > 0:
+            marched, side = march_on_side(), self._side
         if self.use_roi and not refresh and not self._roi_valid:
             self._roi, self._roi_valid = self._compute_roi(), True
         tm = self.rebuild_planes(roi=self.use_roi and not refresh)
@@ -388,6 +398,11 @@ class TrainStep:
         counter, xyzs, dirs, deltas, rays = marched
         M = xyzs.shape[0]
         self._mark("march")
+        next_refresh = self.update_extra_interval > 0 and (self.global_step + 1) % self.update_extra_interval == 0
+        if next_rays is not None and self.overlap_march and not next_refresh and model.mean_count > 0:
+            no, nd = next_rays[0], next_rays[1]
+            nn = next_rays[2] if len(next_rays) > 2 else None
+            self._prefetched = ((no.data_ptr(), nd.data_ptr(), no.shape[0]), march_on_side(no, nd, nn))
         # rows past counter[0] are the zero padding of the sample budget: skipped on the device
         sigma, rgb, feats = F_.field_forward(tm, xyzs, dirs, packed, float(model.bound), C, R, H, save_feats=True,
                                              m_actual=counter)

@@ -159,7 +159,8 @@ class Trainer:
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         gen = torch.Generator(device=self.device)
         gen.manual_seed(self.seed * 7919 + self.epoch)
-        for batch_idx in range(steps):
+
+        def fetch(batch_idx):
             data = pool.batch(batch_idx, self.num_rays, bg_color=self.background_color)
             n = data["rays_o"].shape[0]
             bg = None
@@ -169,10 +170,19 @@ class Trainer:
             o, d, gt = data["rays_o"], data["rays_d"], data["gt_rgb"]
             if self.world > 1:                                                      # rays sharded across ranks
                 lo, hi = n * self.rank // self.world, n * (self.rank + 1) // self.world
-                o, d, gt = o[lo:hi], d[lo:hi], gt[lo:hi]
+                o, d, gt = o[lo:hi].contiguous(), d[lo:hi].contiguous(), gt[lo:hi].contiguous()
                 bg = bg[lo:hi] if bg is not None else None
-            loss = self.ts.step(o, d, gt, n_global_rays=n, bg_color=bg)
+            return o, d, gt, bg, n
+
+        cur = fetch(0)
+        for batch_idx in range(steps):
+            # the next batch is one cheap launch: having it now lets TrainStep march it underneath this step
+            nxt = fetch(batch_idx + 1) if batch_idx + 1 < steps else None
+            o, d, gt, bg, n = cur
+            loss = self.ts.step(o, d, gt, n_global_rays=n, bg_color=bg,
+                                next_rays=None if nxt is None else (nxt[0], nxt[1]))
             total += loss.detach()
+            cur = nxt
         avg = float(total) / steps                                                  # the epoch's only read-back
         self.stats["loss"].append(avg)
         self.log(f"==> Finished Epoch {self.epoch}, loss {avg:.6f}")
