@@ -214,6 +214,15 @@ TNL_API int tnl_plane_grad_binned(const void *dfeat_half, const float *xyz, floa
                                   float *grad_out, int channel_major, int32_t *nonfinite_flag,
                                   void *workspace, void *stream);
 
+/* The two halves of tnl_plane_grad_binned[_roi], for callers that overlap them: _sort (counting sort of the samples
+ * by plane tile) needs only the positions and can run as soon as the march has produced them, on another stream;
+ * _reduce consumes the sorted workspace together with dfeat.  Same workspace size and contents contract. */
+TNL_API int tnl_plane_grad_sort(const float *xyz, float bound, uint32_t M, const int32_t *m_actual, uint32_t R,
+                                void *workspace, void *stream);
+TNL_API int tnl_plane_grad_reduce(const void *dfeat_half, const float *xyz, float bound, uint32_t C, uint32_t R,
+                                  float grad_scale, float *grad_out, int channel_major, int32_t *nonfinite_flag,
+                                  const int32_t *roi, const void *workspace, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Occupancy ROI variants (no reference predecessor: the reference rebuilds and differentiates whole planes).
  * roi = HOST array of 10 int32 {ox0,ox1,ox2, oy0,oy1,oy2, rw, rh, spp, s0}: per-plane origin and common size of

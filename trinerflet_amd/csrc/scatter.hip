@@ -386,37 +386,63 @@ int tnl_plane_grad_binned(const void* dfeat_half, const float* xyz, float bound,
                                    nonfinite_flag, nullptr, workspace, stream);
 }
 
-int tnl_plane_grad_binned_roi(const void* dfeat_half, const float* xyz, float bound, uint32_t M,
-                              const int32_t* m_actual, uint32_t C, uint32_t R, float grad_scale, float* grad_out,
-                              int channel_major, int32_t* nonfinite_flag, const int32_t* roi_host, void* workspace,
-                              void* stream) {
+struct SortWs {
+  int *counts, *offsets, *cursor, *block_tot;
+  uint32_t* entries;
+  int nb, nblk;
+};
+
+static SortWs sort_ws(void* workspace, uint32_t R) {
+  SortWs w;
+  const int TNX = R / TSX, TNY = R / TSY;
+  w.nb = 3 * TNX * TNY;
+  w.nblk = (w.nb + 1023) / 1024;
+  w.counts = reinterpret_cast<int*>(workspace);
+  w.offsets = w.counts + w.nb + 1;
+  w.cursor = w.offsets + w.nb + 1;
+  w.block_tot = w.cursor + w.nb + 1;  // nblk ints, inside the slack before the entry list (see workspace())
+  w.entries = reinterpret_cast<uint32_t*>(w.cursor + w.nb + 2 + w.nblk + 8);
+  return w;
+}
+
+// Part 1 (needs only the sample positions): counting sort of the samples by (plane, tile).  TrainStep runs it on
+// the march's side stream, so it is off the critical path of the step.
+int tnl_plane_grad_sort(const float* xyz, float bound, uint32_t M, const int32_t* m_actual, uint32_t R,
+                        void* workspace, void* stream) {
+  if (R % TSX != 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const int TNX = R / TSX, TNY = R / TSY;
+  const SortWs w = sort_ws(workspace, R);
+  hipError_t e = hipMemsetAsync(w.counts, 0, (size_t)(w.nb + 1) * sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  if (M > 0) {
+    hipLaunchKernelGGL(k_bin<false>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
+                       w.counts, w.entries);
+  }
+  hipLaunchKernelGGL(k_scan_local, dim3(w.nblk), dim3(1024), 0, st, w.counts, w.nb, w.offsets, w.block_tot);
+  hipLaunchKernelGGL(k_scan_fix, dim3(w.nblk), dim3(1024), 0, st, w.nb, w.nblk, w.block_tot, w.offsets, w.cursor);
+  if (M > 0) {
+    hipLaunchKernelGGL(k_bin<true>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
+                       w.cursor, w.entries);
+  }
+  return (int)hipGetLastError();
+}
+
+// Part 2: one workgroup per (plane, tile) reduces the tile's sorted samples on the matrix cores.
+int tnl_plane_grad_reduce(const void* dfeat_half, const float* xyz, float bound, uint32_t C, uint32_t R,
+                          float grad_scale, float* grad_out, int channel_major, int32_t* nonfinite_flag,
+                          const int32_t* roi_host, const void* workspace, void* stream) {
   if (R % TSX != 0 || (C != 16 && C != 32 && C != 48)) return (int)hipErrorInvalidValue;
   Roi roi;
   if (!make_roi(roi_host, 3 * C, R, roi) || (roi.rw && (!channel_major || roi.spp != (int)C || roi.s0 != 0)))
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int TNX = R / TSX, TNY = R / TSY;
-  const int nb = 3 * TNX * TNY;
-  int* counts = reinterpret_cast<int*>(workspace);
-  int* offsets = counts + nb + 1;
-  int* cursor = offsets + nb + 1;
-  uint32_t* entries = reinterpret_cast<uint32_t*>(cursor + nb + 2 + (nb + 1023) / 1024 + 8);
-  hipError_t e = hipMemsetAsync(counts, 0, (size_t)(nb + 1) * sizeof(int), st);
-  if (e != hipSuccess) return (int)e;
-  if (M > 0) {
-    hipLaunchKernelGGL(k_bin<false>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
-                       counts, entries);
-  }
-  const int nblk = (nb + 1023) / 1024;
-  int* block_tot = cursor + nb + 1;  // nblk ints, inside the 8-int slack + before the entry list (see workspace())
-  hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(1024), 0, st, counts, nb, offsets, block_tot);
-  hipLaunchKernelGGL(k_scan_fix, dim3(nblk), dim3(1024), 0, st, nb, nblk, block_tot, offsets, cursor);
-  if (M > 0) {
-    hipLaunchKernelGGL(k_bin<true>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
-                       cursor, entries);
-  }
+  const SortWs w = sort_ws(const_cast<void*>(workspace), R);
+  const int* offsets = w.offsets;
+  const uint32_t* entries = w.entries;
   const _Float16* df = reinterpret_cast<const _Float16*>(dfeat_half);
-  const int ntiles = roi.rw ? 3 * (roi.rw / TSX) * (roi.rh / TSY) : nb;
+  const int ntiles = roi.rw ? 3 * (roi.rw / TSX) * (roi.rh / TSY) : w.nb;
   if (C == 16)
     hipLaunchKernelGGL(k_tile_accumulate<16>, dim3(ntiles), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY,
                        offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
@@ -427,6 +453,17 @@ int tnl_plane_grad_binned_roi(const void* dfeat_half, const float* xyz, float bo
     hipLaunchKernelGGL(k_tile_accumulate<48>, dim3(ntiles), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY,
                        offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   return (int)hipGetLastError();
+}
+
+int tnl_plane_grad_binned_roi(const void* dfeat_half, const float* xyz, float bound, uint32_t M,
+                              const int32_t* m_actual, uint32_t C, uint32_t R, float grad_scale, float* grad_out,
+                              int channel_major, int32_t* nonfinite_flag, const int32_t* roi_host, void* workspace,
+                              void* stream) {
+  if (R % TSX != 0 || (C != 16 && C != 32 && C != 48)) return (int)hipErrorInvalidValue;
+  const int e = tnl_plane_grad_sort(xyz, bound, M, m_actual, R, workspace, stream);
+  if (e != 0) return e;
+  return tnl_plane_grad_reduce(dfeat_half, xyz, bound, C, R, grad_scale, grad_out, channel_major, nonfinite_flag,
+                               roi_host, workspace, stream);
 }
 
 }  // extern "C"

@@ -95,6 +95,30 @@ class _FusedField(Function):
 fused_field = _FusedField.apply
 
 
+def plane_grad_sort(xyz, bound, R, m_actual=None):
+    """First half of plane_grad_binned: counting sort of the samples by plane tile (positions only).  Returns the
+    workspace tensor plane_grad_reduce consumes."""
+    lib = L.lib()
+    M = xyz.shape[0]
+    nbytes = lib.tnl_plane_grad_binned_workspace(L.u32(M), L.u32(R))
+    if nbytes == 0:
+        raise NotImplementedError("binned plane gradient needs plane_resolution % 32 == 0")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
+    L.check(lib.tnl_plane_grad_sort(L.ptr(xyz), L.f32(bound), L.u32(M), L.ptr(m_actual), L.u32(R), L.ptr(ws),
+                                    L.stream()), "plane_grad_sort")
+    return ws
+
+
+def plane_grad_reduce(ws, dfeat, xyz, bound, C, R, grad_out, grad_scale=1.0, channel_major=False, nonfinite_flag=None,
+                      roi=None):
+    """Second half: per-tile matrix-core reduction of dfeat over the sorted samples in `ws`."""
+    L.check(L.lib().tnl_plane_grad_reduce(L.ptr(dfeat), L.ptr(xyz), L.f32(bound), L.u32(C), L.u32(R),
+                                          L.f32(grad_scale), L.ptr(grad_out), L.i32(int(channel_major)),
+                                          L.ptr(nonfinite_flag), L.roi_array(roi), L.ptr(ws), L.stream()),
+            "plane_grad_reduce")
+    return grad_out
+
+
 def plane_grad_binned(dfeat, xyz, bound, C, R, grad_out, m_actual=None, grad_scale=1.0, channel_major=False,
                       nonfinite_flag=None, roi=None):
     """fp16 feature gradients [M,3C] -> plane gradient fp32 by tile-sorted matrix-core reduction

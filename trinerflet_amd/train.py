@@ -349,7 +349,10 @@ class TrainStep:
             out = raymarching.march_rays_train(
                 o, d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars,
                 counter, model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, nz)
-            return (counter, *out)
+            # the tile sort of the plane gradient needs only the positions: it rides with the march (side stream)
+            sort_ws = F_.plane_grad_sort(out[0], float(model.bound), R, counter) if (self.binned and R % 32 == 0) \
+                else torch.empty(0, device=self.dev)
+            return (counter, *out, sort_ws)
 
         def march_on_side(*a):
             main = torch.cuda.current_stream()
@@ -395,14 +398,9 @@ class TrainStep:
             torch.cuda.current_stream().wait_stream(side)
         else:
             marched = march()
-        counter, xyzs, dirs, deltas, rays = marched
+        counter, xyzs, dirs, deltas, rays, sort_ws = marched
         M = xyzs.shape[0]
         self._mark("march")
-        next_refresh = self.update_extra_interval > 0 and (self.global_step + 1) % self.update_extra_interval == 0
-        if next_rays is not None and self.overlap_march and not next_refresh and model.mean_count > 0:
-            no, nd = next_rays[0], next_rays[1]
-            nn = next_rays[2] if len(next_rays) > 2 else None
-            self._prefetched = ((no.data_ptr(), nd.data_ptr(), no.shape[0]), march_on_side(no, nd, nn))
         # rows past counter[0] are the zero padding of the sample budget: skipped on the device
         sigma, rgb, feats = F_.field_forward(tm, xyzs, dirs, packed, float(model.bound), C, R, H, save_feats=True,
                                              m_actual=counter)
@@ -454,8 +452,13 @@ class TrainStep:
             F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
                               g_cm, self.mlp.grad, m_actual=counter, dfeat=dfeat)
             self._mark("field_bwd")
+            # The following batch's march + tile sort (ALU/latency-bound, few waves) start here, underneath the
+            # HBM-bound tail of the step (tile reduction, adjoint IDWT; in the multi-GPU modes the collectives).
+            # Measured at base: started before the MFMA field kernels it costs them the same 0.5 ms; started under
+            # Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms stay exposed.
+            self._prefetch_next(next_rays, march_on_side)
             self.nonfinite.zero_()
-            F_.plane_grad_binned(dfeat, xyzs, float(model.bound), C, R, g_cm, m_actual=counter, channel_major=True,
+            F_.plane_grad_reduce(sort_ws, dfeat, xyzs, float(model.bound), C, R, g_cm, channel_major=True,
                                  nonfinite_flag=self.nonfinite, roi=self._roi10() if roi is not None else None)
             self._mark("plane_grad_binned")
             if self.world > 1:
@@ -484,6 +487,11 @@ class TrainStep:
             F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
                               grad_tm, self.mlp.grad, m_actual=counter)
             self._mark("field_bwd")
+            # The following batch's march + tile sort (ALU/latency-bound, few waves) start here, underneath the
+            # HBM-bound tail of the step (tile reduction, adjoint IDWT; in the multi-GPU modes the collectives).
+            # Measured at base: started before the MFMA field kernels it costs them the same 0.5 ms; started under
+            # Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms stay exposed.
+            self._prefetch_next(next_rays, march_on_side)
             if self.world > 1:
                 dist.all_reduce(self.mlp.grad, group=self.pg)
             s0, s1 = self._adjoint(grad_tm, None)
@@ -520,6 +528,15 @@ class TrainStep:
         self.last = {'mse': mse, 'wavelet_reg': reg, 'M': M, 'found_inf': found_inf, 'image': pred, 'ws': ws,
                      'depth': depth, 'counter': counter, 'lr': lr_t}
         return loss
+
+    def _prefetch_next(self, next_rays, march_on_side):
+        model = self.model
+        next_refresh = self.update_extra_interval > 0 and (self.global_step + 1) % self.update_extra_interval == 0
+        if next_rays is None or not self.overlap_march or next_refresh or model.mean_count <= 0:
+            return
+        no, nd = next_rays[0], next_rays[1]
+        nn = next_rays[2] if len(next_rays) > 2 else None
+        self._prefetched = ((no.data_ptr(), nd.data_ptr(), no.shape[0]), march_on_side(no, nd, nn))
 
     def _adam_sharded(self, lr_t, l1, found_inf, inv_scale, s0, s1):
         """Each rank updates only its (plane, channel) slices; afterwards parameters are all-gathered so the
