@@ -62,7 +62,7 @@ def make_batches(n_batches, N, rank, device):
     poses = synthetic.hemisphere_poses(100, seed=0)
     for b in range(n_batches):
         rng = np.random.default_rng(1000 * rank + b)
-        flat = rng.choice(100 * 800 * 800, size=N, replace=False)
+        flat = rng.permutation(np.unique(rng.integers(0, 100 * 800 * 800, size=N + N // 8 + 16)))[:N]  # distinct pixels
         pix = np.stack([flat // (800 * 800), flat % (800 * 800)], -1)
         o, d = synthetic.get_rays(poses, pix)
         noise = rng.random(N).astype(np.float32)
@@ -103,10 +103,10 @@ def cpu_baseline(workload):
 
 
 def pmc_traffic(workload, world):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01f_pmc_adam.json: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, gfx950 correction applied);
-    null when no profile exists for this configuration."""
-    path = os.path.join(ROOT, "profiles", "r01f_pmc_adam.json")
+    """HBM bytes of the step's k_adam_l1 launches from the committed rocprofv3 PMC passes
+    (profiles/r01h_pmc_adam.json, made by tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate --pmc runs,
+    gfx950 correction applied); null when no profile exists for this configuration."""
+    path = os.path.join(ROOT, "profiles", "r01h_pmc_adam.json")
     if workload != "base" or world != 1 or not os.path.exists(path):
         return None
     return json.load(open(path))["hbm_bytes_per_launch"]
@@ -194,7 +194,20 @@ def main():
     samples_per_step = float(np.mean(counts))
     P_coef = ts.coef_numel if ts.dist_mode != "sharded" else ts.coef_numel // world
     adam_ms = sec.get("adam_coef", float("nan"))
-    adam_bytes = 28.0 * P_coef
+    # algorithmic bytes of the step's Adam launches (one per wavelet level + LL): 16 B read (p, g, m, v) + 12 B
+    # written (p, m, v) per coefficient; with the gradient-support chain g is neither stored nor read outside each
+    # level's rectangle (24 B there).  TrainStep._rects holds the rectangles of the last non-refresh step.
+    S_own = (3 * ts.C) // (world if ts.dist_mode == "sharded" else 1)
+    rects = ts._rects if (ts._rect_ok and ts._roi is not None and all(r is not None for r in ts._rects)) else None
+    adam_bytes, n_launch = 0.0, 0
+    for lvl in range(ts.J):
+        n_l = ts.coef.params[lvl].shape[-1]
+        inside = rects[lvl][6] * rects[lvl][7] if rects is not None else n_l * n_l
+        adam_bytes += S_own * 3 * (24.0 * n_l * n_l + 4.0 * inside)
+        n_launch += 1
+    n_ll = ts.ll.params[0].shape[-1]
+    adam_bytes += S_own * (24.0 * n_ll * n_ll + 4.0 * (rects[0][6] * rects[0][7] if rects is not None else n_ll * n_ll))
+    n_launch += 1
     achieved = adam_bytes / (adam_ms * 1e-3) / 1e9 if adam_ms == adam_ms and adam_ms > 0 else float("nan")
 
     if rank == 0:
@@ -212,10 +225,14 @@ def main():
                        "sample_budget_M": mean_count, "parallelism": f"ray-dp{world}" + (f"+{args.dist_mode}" if world > 1 else ""),
                        "samples_per_sec": samples_per_step * world * args.steps / elapsed,
                        "sections_ms": {k: round(v, 4) for k, v in sec.items()}},
-            "roofline": {"bound": "hbm", "kernel": "k_adam_l1 (fused Adam + wavelet-L1 over the coefficients)",
+            "roofline": {"bound": "hbm", "kernel": "k_adam_l1 (fused Adam + wavelet-L1), the step's launches over all "
+                                                   "wavelet levels + LL taken together",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload, world), "algorithmic_bytes_per_launch": adam_bytes,
-                         "avg_launch_ms": adam_ms},
+                         "avg_launch_ms": adam_ms, "launches_per_step": n_launch,
+                         "note": "achieved = algorithmic bytes of the step's k_adam_l1 launches / their summed duration "
+                                 "(HIP events on the launch stream); 8000 GB/s is the spec peak, a float4 copy "
+                                 "reaches 6290 GB/s on MI355X (MI355X_MICROARCH.md)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)

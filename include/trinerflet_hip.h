@@ -291,6 +291,26 @@ TNL_API int tnl_ray_batch(const float *poses, const float *intrinsics_host, uint
                           const float *bg_rand, float *rays_o, float *rays_d, float *gt_rgb, int64_t *pix_out,
                           void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Gradient-support chain (no reference predecessor).  With an occupancy window the plane gradient is zero outside
+ * it, so every level's coefficient gradient is zero outside the rectangle of coarse tiles the window reaches:
+ *   tnl_idwt_level_backward_win  adjoint of one level whose fine-side input is valid only inside `win` (10 ints as
+ *       for the *_roi calls; strided = 0: compact [S][rh][rw] array, 1: full-size array, window multiples of 4).
+ *       If out_rect (HOST, 8 ints: ox[3], oy[3], w, h in coarse coordinates) is given it receives the rectangle of
+ *       reachable tiles (common size over the planes) and NOTHING is stored outside it -- dx / dyh keep their old
+ *       contents there; the next (coarser) level takes out_rect as its strided window.
+ *   tnl_adam_l1_step_rect        tnl_adam_l1_step_dev over one level [S][bands][n][n] (n a power of two) that
+ *       reads the gradient only inside the rectangle and uses 0 outside (24 instead of 28 bytes per coefficient).
+ * Together: bit-identical to the whole-plane adjoint + Adam, without storing or re-reading the zeros.
+ * ------------------------------------------------------------------------------------------- */
+TNL_API int tnl_idwt_level_backward_win(const float *dout, uint32_t S, uint32_t n, int wave, float *dx, float *dyh,
+                                        const int32_t *win, int strided, int32_t *out_rect, void *stream);
+TNL_API int tnl_adam_l1_step_rect(float *p, float *grad, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n,
+                                  uint32_t spp, uint32_t s0, const int32_t *rect, float lr,
+                                  const float *opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
+                                  const float *inv_scale_dev, float l1_coef, const float *found_inf,
+                                  float *abs_sum, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

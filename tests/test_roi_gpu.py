@@ -94,7 +94,95 @@ def test_plane_gradient_roi_matches_whole_plane(cuda):
     assert abs(float(full.abs().sum()) - tot) <= 1e-6 * tot   # nothing of the gradient lies outside the window
 
 
-def _model(dev, C=16, R=256, scale=2, H=64, bound=1.0):
+def test_support_chain_adjoint_and_rect_adam_match_dense(cuda):
+    """Windowed adjoint over two levels (compact window -> rectangle -> strided window -> rectangle) equals the
+    whole-plane adjoint of the zero-extended gradient inside the rectangles and leaves everything outside untouched;
+    Adam that takes g = 0 outside a rectangle equals plain Adam on the zero-filled gradient, bit for bit."""
+    import ctypes
+    from trinerflet_amd import _lib as L
+    lib = L.lib()
+    C, n1, wid = 8, 64, 4                     # levels: 64 -> 128 -> 256 (fine)
+    S, R = 3 * C, 4 * n1
+    g = torch.Generator(device="cpu").manual_seed(2)
+    ox, oy, rw, rh = (64, 0, 128), (128, 64, 0), 64, 128
+    gc = torch.randn(S, rh, rw, generator=g).to(cuda)
+    gfull = torch.zeros(3, C, R, R, device=cuda)
+    for p in range(3):
+        gfull[p, :, oy[p]:oy[p] + rh, ox[p]:ox[p] + rw] = gc.view(3, C, rh, rw)[p]
+    # dense reference chain
+    ref = []
+    src = gfull.view(S, R, R)
+    for n in (2 * n1, n1):
+        dx = torch.empty(S, n, n, device=cuda)
+        dyh = torch.empty(S, 3, n, n, device=cuda)
+        L.check(lib.tnl_idwt_level_backward(L.ptr(src), L.u32(S), L.u32(n), L.i32(wid), L.ptr(dx), L.ptr(dyh),
+                                            L.stream()), "bwd")
+        ref.append((dx, dyh))
+        src = dx
+    # windowed chain
+    win, strided, src = _roi10(ox, oy, rw, rh, C), 0, gc
+    out = []
+    for lvl, n in enumerate((2 * n1, n1)):
+        dx = torch.full((S, n, n), 123.0, device=cuda)
+        dyh = torch.full((S, 3, n, n), 123.0, device=cuda)
+        rect = (ctypes.c_int32 * 8)()
+        L.check(lib.tnl_idwt_level_backward_win(L.ptr(src), L.u32(S), L.u32(n), L.i32(wid), L.ptr(dx), L.ptr(dyh),
+                                                L.roi_array(win), L.i32(strided), rect, L.stream()), "bwd_win")
+        rect = list(rect)
+        out.append((dx, dyh, rect))
+        assert rect[6] % 32 == 0 and rect[7] % 32 == 0 and (rect[6] < n or rect[7] < n or lvl == 1)
+        for p in range(3):
+            ys, xs = slice(rect[3 + p], rect[3 + p] + rect[7]), slice(rect[p], rect[p] + rect[6])
+            sl = slice(p * C, (p + 1) * C)
+            assert torch.equal(dx[sl, ys, xs], ref[lvl][0][sl, ys, xs])
+            assert torch.equal(dyh[sl, :, ys, xs], ref[lvl][1][sl, :, ys, xs])
+            mask = torch.ones(n, n, dtype=torch.bool, device=cuda)
+            mask[ys, xs] = False
+            assert bool((dx[sl][:, mask] == 123.0).all()) and bool((dyh[sl][:, :, mask] == 123.0).all())
+            # ... and the dense result really is zero there
+            assert float(ref[lvl][0][sl][:, mask].abs().sum()) == 0 and float(ref[lvl][1][sl][:, :, mask].abs().sum()) == 0
+        win, strided, src = rect + [C, 0], 1, dx
+    # Adam: rectangle-aware on the stale-outside gradient == plain on the dense gradient
+    dyh_w, rect = out[0][1], out[0][2]
+    n = 2 * n1
+    p0 = torch.randn(S * 3 * n * n, generator=g).to(cuda)
+    m0 = torch.randn(S * 3 * n * n, generator=g).to(cuda) * 1e-3
+    v0 = torch.rand(S * 3 * n * n, generator=g).to(cuda) * 1e-6
+    steps = torch.full((1,), 4.0, device=cuda)
+    found = torch.zeros(1, device=cuda)
+    res = []
+    for use_rect in (False, True):
+        p_, m_, v_ = p0.clone(), m0.clone(), v0.clone()
+        gbuf = (dyh_w if use_rect else ref[0][1]).reshape(-1).clone()
+        abs_sum = torch.zeros(1, device=cuda)
+        if use_rect:
+            L.check(lib.tnl_adam_l1_step_rect(L.ptr(p_), L.ptr(gbuf), L.ptr(m_), L.ptr(v_), L.u32(S), L.u32(3), L.u32(n),
+                                              L.u32(C), L.u32(0), (ctypes.c_int32 * 8)(*rect), L.f32(1e-2), L.ptr(steps),
+                                              L.f32(0.9), L.f32(0.99), L.f32(1e-15), L.f32(0.5), None, L.f32(1e-4),
+                                              L.ptr(found), L.ptr(abs_sum), L.stream()), "adam_rect")
+        else:
+            L.check(lib.tnl_adam_l1_step_dev(L.ptr(p_), L.ptr(gbuf), L.ptr(m_), L.ptr(v_), L.u64(p_.numel()), L.f32(1e-2),
+                                             L.ptr(steps), L.f32(0.9), L.f32(0.99), L.f32(1e-15), L.f32(0.5), None,
+                                             L.f32(1e-4), L.ptr(found), L.ptr(abs_sum), L.i32(0), L.stream()), "adam")
+        res.append((p_, m_, v_, abs_sum))
+    for k, (a, b) in enumerate(zip(*res)):
+        if k < 3:
+            assert torch.equal(a, b), ("pmv"[k], float((a - b).abs().max()), int((a != b).sum()))
+        else:
+            assert torch.allclose(a, b, rtol=1e-5)      # sum of |p|: float atomics, order-dependent
+    # a rank that owns slices [s0, s1): same rows
+    s0, s1 = C - 2, 2 * C + 1
+    per = 3 * n * n
+    p_, m_, v_ = (t[s0 * per:s1 * per].clone() for t in (p0, m0, v0))
+    gbuf = dyh_w.reshape(-1)[s0 * per:s1 * per].clone()
+    L.check(lib.tnl_adam_l1_step_rect(L.ptr(p_), L.ptr(gbuf), L.ptr(m_), L.ptr(v_), L.u32(s1 - s0), L.u32(3), L.u32(n),
+                                      L.u32(C), L.u32(s0), (ctypes.c_int32 * 8)(*rect), L.f32(1e-2), L.ptr(steps),
+                                      L.f32(0.9), L.f32(0.99), L.f32(1e-15), L.f32(0.5), None, L.f32(1e-4), L.ptr(found),
+                                      None, L.stream()), "adam_rect")
+    assert torch.equal(p_, res[0][0][s0 * per:s1 * per]) and torch.equal(v_, res[0][2][s0 * per:s1 * per])
+
+
+def _model(dev, C=16, R=256, scale=4, H=64, bound=1.0):
     from trinerflet_amd.nerf.network import NeRFNetwork
     m = NeRFNetwork(encoding="triplane_wavelet", bound=bound, cuda_ray=True, density_thresh=10, hidden_dim=H,
                     hidden_dim_color=H, triplane_channels=C, triplane_resolution=R, triplane_wavelet_levels=scale,
@@ -166,6 +254,7 @@ def test_training_with_window_equals_whole_plane_training(cuda):
                 assert ts._roi is not None and ts._roi[6] < 256
         res.append((losses, [p.detach().clone() for p in m.parameters()], ts))
     assert res[1][2].use_roi and res[1][2]._roi is not None
+    assert res[1][2]._rect_ok and all(r is not None for r in res[1][2]._rects)   # the support chain was active
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-4)
     for a, b in zip(res[0][1], res[1][1]):
         # Adam's first steps are sign-like: compare where the whole-plane run actually moved the parameter

@@ -15,10 +15,19 @@
 
 namespace {
 
+// Gradient support of one wavelet level laid out [S][bands][n][n] (n a power of two): per plane a rectangle of the
+// n x n grid outside which the gradient is identically zero and is NOT stored -- the adjoint IDWT skipped those tiles
+// (tnl_idwt_level_backward_win).  Elements outside read g = 0 instead of the (stale) buffer: 24 B instead of 28.
+struct AdamRect {
+  int rx[3], ry[3], rw, rh;
+  int log2n, bands, spp, s0;
+};
+
+template <bool RECT>
 __global__ void __launch_bounds__(256)
 k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, uint64_t n,
           AdamArgs a, const float* __restrict__ inv_scale_dev, const float* __restrict__ found_inf,
-          float* __restrict__ abs_sum, int zero_grad, const float* __restrict__ opt_step_dev) {
+          float* __restrict__ abs_sum, int zero_grad, const float* __restrict__ opt_step_dev, AdamRect rc) {
   if (opt_step_dev != nullptr) {
     // a.step_size carries the learning rate; the bias corrections come from the DEVICE count of optimiser steps
     // actually taken (torch.optim.Adam's per-parameter `step`, which GradScaler.step does not advance on a skipped
@@ -49,7 +58,19 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
   for (uint64_t i = c0 + threadIdx.x; i < c1; i += blockDim.x) {
     float4 pp = p4[i];
     if (!skip) {
-      float4 gg = g4[i], mm = m4[i], vv = v4[i];
+      float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+      bool inside = true;
+      if (RECT) {
+        const uint64_t e = i * 4;
+        const int nm = (1 << rc.log2n) - 1;
+        const int c = (int)(e & nm), r = (int)((e >> rc.log2n) & nm);
+        const uint32_t sb = (uint32_t)(e >> (2 * rc.log2n));                      // slice * bands + band (< 2^15)
+        const int sl = (int)(rc.bands == 3 ? (sb * 0xAAABu) >> 17 : sb) + rc.s0;  // exact sb / 3 for sb < 98304
+        const int pl = sl >= 2 * rc.spp ? 2 : (sl >= rc.spp ? 1 : 0);
+        inside = c >= rc.rx[pl] && c < rc.rx[pl] + rc.rw && r >= rc.ry[pl] && r < rc.ry[pl] + rc.rh;
+      }
+      if (inside) gg = g4[i];
+      float4 mm = m4[i], vv = v4[i];
       adam1(pp.x, gg.x, mm.x, vv.x, a, acc);
       adam1(pp.y, gg.y, mm.y, vv.y, a, acc);
       adam1(pp.z, gg.z, mm.z, vv.z, a, acc);
@@ -88,7 +109,7 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
 static int adam_launch(float* p, float* grad, float* m, float* v, uint64_t n, float step_size, float bias2_sqrt,
                        float beta1, float beta2, float eps, float inv_scale, const float* inv_scale_dev,
                        float l1_coef, const float* found_inf, float* abs_sum, int zero_grad,
-                       const float* opt_step_dev, void* stream) {
+                       const float* opt_step_dev, void* stream, const AdamRect* rect = nullptr) {
   if (n == 0) return 0;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
        reinterpret_cast<uintptr_t>(v)) & 15)
@@ -97,8 +118,12 @@ static int adam_launch(float* p, float* grad, float* m, float* v, uint64_t n, fl
   uint64_t blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(k_adam_l1, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n, a,
-                     inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev);
+  if (rect != nullptr)
+    hipLaunchKernelGGL(k_adam_l1<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n, a,
+                       inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, *rect);
+  else
+    hipLaunchKernelGGL(k_adam_l1<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n, a,
+                       inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, AdamRect{});
   return (int)hipGetLastError();
 }
 
@@ -117,4 +142,28 @@ extern "C" int tnl_adam_l1_step_dev(float* p, float* grad, float* m, float* v, u
   if (opt_step_dev == nullptr) return (int)hipErrorInvalidValue;
   return adam_launch(p, grad, m, v, n, lr, 1.0f, beta1, beta2, eps, inv_scale, inv_scale_dev, l1_coef, found_inf,
                      abs_sum, zero_grad, opt_step_dev, stream);
+}
+
+// One wavelet level [S][bands][n][n] whose gradient is stored only inside a per-plane rectangle (rect_host: ox[3],
+// oy[3], w, h in the level's own n x n coordinates, as returned by tnl_idwt_level_backward_win; multiples of 4).
+extern "C" int tnl_adam_l1_step_rect(float* p, float* grad, float* m, float* v, uint32_t S, uint32_t bands, uint32_t n,
+                                     uint32_t spp, uint32_t s0, const int32_t* rect_host, float lr,
+                                     const float* opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
+                                     const float* inv_scale_dev, float l1_coef, const float* found_inf,
+                                     float* abs_sum, void* stream) {
+  if (opt_step_dev == nullptr || rect_host == nullptr || n == 0 || (n & (n - 1)) != 0 || n % 4 != 0 || bands == 0 ||
+      spp == 0)
+    return (int)hipErrorInvalidValue;
+  AdamRect rc;
+  for (int k = 0; k < 3; k++) { rc.rx[k] = rect_host[k]; rc.ry[k] = rect_host[3 + k]; }
+  rc.rw = rect_host[6]; rc.rh = rect_host[7];
+  if (rc.rw % 4 != 0) return (int)hipErrorInvalidValue;
+  for (int k = 0; k < 3; k++)
+    if (rc.rx[k] % 4 != 0 || rc.rx[k] < 0 || rc.ry[k] < 0 || rc.rx[k] + rc.rw > (int)n || rc.ry[k] + rc.rh > (int)n)
+      return (int)hipErrorInvalidValue;
+  rc.log2n = 0;
+  while ((1u << rc.log2n) < n) rc.log2n++;
+  rc.bands = (int)bands; rc.spp = (int)spp; rc.s0 = (int)s0;
+  return adam_launch(p, grad, m, v, (uint64_t)S * bands * n * n, lr, 1.0f, beta1, beta2, eps, inv_scale, inv_scale_dev,
+                     l1_coef, found_inf, abs_sum, 0, opt_step_dev, stream, &rc);
 }

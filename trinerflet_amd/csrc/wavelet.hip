@@ -423,7 +423,7 @@ struct FuseAdam {
 template <int W, bool FUSE>
 __global__ void __launch_bounds__(NT)
 k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh, FuseAdam fa,
-                Roi roi) {
+                Roi roi, Roi orect) {
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2;
   constexpr int KA = (K + 3) / 4 * 4;                 // aligned left halo of the fine tile
@@ -447,7 +447,12 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
   // fine-side input: compact ROI window [oy, oy+rh) x [ox, ox+rw) (zero outside), or the whole plane
   const int fox = roi.rw ? roi.ox[pl] : 0, foy = roi.rw ? roi.oy[pl] : 0;
   const int fw = roi.rw ? roi.rw : m2, fh = roi.rw ? roi.rh : m2;
-  const float* src = dout + (size_t)s * fh * fw;
+  const int sw = (roi.rw && !roi.strided) ? roi.rw : m2;                 // row stride of the input array
+  const int sox = roi.strided ? 0 : fox, soy = roi.strided ? 0 : foy;   // array origin in fine coordinates
+  const float* src = dout + (size_t)s * (roi.strided ? (size_t)m2 * m2 : (size_t)fh * fw);
+  // output rectangle (coarse coordinates): tiles outside it are not written at all -- the caller knows they are zero
+  const bool has_or = orect.rw != 0;
+  const int orx = has_or ? orect.ox[pl] : 0, ory = has_or ? orect.oy[pl] : 0;
   const size_t nn = (size_t)n * n;
   float* o_ll = dx + (size_t)s * nn;
   float* o_h = dyh + (size_t)s * 3 * nn;
@@ -472,10 +477,11 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
     const int a_c = tx * TI;
 #pragma unroll
     for (int k = 0; k < KQ; k++) {
-      const int gr = 2 * a_r - K + qr[k] - foy, gc = 2 * a_c - KA + qc[k] - fox;
+      const int ar = 2 * a_r - K + qr[k], ac = 2 * a_c - KA + qc[k];      // absolute fine coordinates
+      const int gr = ar - foy, gc = ac - fox;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (qv[k] && gr >= 0 && gr < fh && gc >= 0 && gc < fw)
-        v = *reinterpret_cast<const float4*>(src + (size_t)gr * fw + gc);
+        v = *reinterpret_cast<const float4*>(src + (size_t)(ar - soy) * sw + (ac - sox));
       pre[k] = v;
     }
   };
@@ -484,11 +490,13 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
     const int r0 = 2 * a_r - K, c0 = 2 * tx * TI - KA;
     return r0 < foy + fh && r0 + FT > foy && c0 < fox + fw && c0 + FTA > fox;
   };
+  if (has_or && (a_r < ory || a_r >= ory + orect.rh)) return;            // whole tile row outside the rectangle
   if (hits(tx0)) prefetch(tx0);
   for (int tx = tx0; tx < tx1; tx++) {
     if (!hits(tx)) {
       // nothing of the gradient reaches this tile: its four coarse outputs are exactly zero
       if (tx + 1 < tx1 && hits(tx + 1)) prefetch(tx + 1);
+      if (has_or && (tx * TI < orx || tx * TI >= orx + orect.rw)) continue;   // outside: not even stored
       if (!FUSE) {
         for (int u = threadIdx.x; u < TI * TI; u += NT) {
           const int gr = a_r + u / TI, gc = tx * TI + (u % TI);
@@ -695,10 +703,47 @@ int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, void* ou
   return (int)hipGetLastError();
 }
 template <int W>
-int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh, hipStream_t st, Roi roi = Roi{}) {
+int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh, hipStream_t st, Roi roi = Roi{},
+               int32_t* out_rect = nullptr) {
+  Roi orect{};
+  if (out_rect != nullptr) {
+    // Tiles of coarse outputs the input window reaches (same test as the kernel's hits()), per plane, then grown to a
+    // common size: inside the rectangle every tile is written (computed or zero), outside nothing is.
+    if (n % 2 != 0 || n % TI != 0) return (int)hipErrorInvalidValue;
+    constexpr WTaps T = wtaps(W);
+    constexpr int L = T.L, K = (L - 2) / 2, KA = (K + 3) / 4 * 4, SH = KA - K;
+    constexpr int FT = 2 * TI + L - 2, FTA = (2 * TI + L - 2 + SH + 3) / 4 * 4;
+    const int nt = (int)n / TI;
+    int lo[2][3], hi[2][3];
+    for (int p = 0; p < 3; p++) {
+      const int wo[2] = {roi.rw ? roi.ox[p] : 0, roi.rw ? roi.oy[p] : 0};
+      const int we[2] = {roi.rw ? roi.rw : 2 * (int)n, roi.rw ? roi.rh : 2 * (int)n};
+      const int ka[2] = {KA, K}, ft[2] = {FTA, FT};
+      for (int d = 0; d < 2; d++) {
+        lo[d][p] = nt; hi[d][p] = -1;
+        for (int t = 0; t < nt; t++) {
+          const int c0 = 2 * t * TI - ka[d];
+          if (c0 < wo[d] + we[d] && c0 + ft[d] > wo[d]) { lo[d][p] = t < lo[d][p] ? t : lo[d][p]; hi[d][p] = t; }
+        }
+        if (hi[d][p] < 0) { lo[d][p] = 0; hi[d][p] = 0; }
+      }
+    }
+    int ext[2] = {0, 0};
+    for (int d = 0; d < 2; d++)
+      for (int p = 0; p < 3; p++) ext[d] = (hi[d][p] - lo[d][p] + 1) > ext[d] ? (hi[d][p] - lo[d][p] + 1) : ext[d];
+    for (int p = 0; p < 3; p++) {
+      orect.ox[p] = TI * (lo[0][p] + ext[0] > nt ? nt - ext[0] : lo[0][p]);
+      orect.oy[p] = TI * (lo[1][p] + ext[1] > nt ? nt - ext[1] : lo[1][p]);
+      out_rect[p] = orect.ox[p]; out_rect[3 + p] = orect.oy[p];
+    }
+    orect.rw = TI * ext[0]; orect.rh = TI * ext[1];
+    out_rect[6] = orect.rw; out_rect[7] = orect.rh;
+    orect.spp = roi.rw ? roi.spp : (int)(S / 3);
+    orect.s0 = roi.s0;
+  }
   if (n % 2 == 0)
     hipLaunchKernelGGL((k_idwt_bwd_pipe<W, false>), dim3(cdiv(cdiv(n, TI), TPW), cdiv(n, TI), S), dim3(NT), 0, st, dout,
-                       (int)n, dx, dyh, FuseAdam{}, roi);
+                       (int)n, dx, dyh, FuseAdam{}, roi, orect);
   else if (roi.rw)
     return (int)hipErrorInvalidValue;
   else
@@ -773,7 +818,7 @@ static int planes_half_to_tm(const void* planes_cm_half, uint32_t C, uint32_t R,
 }
 
 static int idwt_backward_any(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
-                             const int32_t* roi_host, void* stream);
+                             const int32_t* roi_host, void* stream, int strided = 0, int32_t* out_rect = nullptr);
 
 int tnl_idwt_level_backward(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
                             void* stream) {
@@ -785,19 +830,26 @@ int tnl_idwt_level_backward_roi(const float* dout_roi, uint32_t S, uint32_t n, i
   return idwt_backward_any(dout_roi, S, n, wave, dx, dyh, roi, stream);
 }
 
+int tnl_idwt_level_backward_win(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
+                                const int32_t* win, int strided, int32_t* out_rect, void* stream) {
+  return idwt_backward_any(dout, S, n, wave, dx, dyh, win, stream, strided, out_rect);
+}
+
 static int idwt_backward_any(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
-                             const int32_t* roi_host, void* stream) {
+                             const int32_t* roi_host, void* stream, int strided, int32_t* out_rect) {
   if (S == 0 || n == 0) return 0;
   if (S > 65535) return (int)hipErrorInvalidValue;
   Roi roi;
-  if (!make_roi(roi_host, S, 2 * n, roi)) return (int)hipErrorInvalidValue;
+  if (!make_roi(roi_host, S, 2 * n, roi, strided ? 4 : 64)) return (int)hipErrorInvalidValue;
+  roi.strided = (roi.rw && strided) ? 1 : 0;
+  if (out_rect != nullptr && roi_host == nullptr) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   switch (wave) {
-    case 0: return launch_bwd<0>(dout, S, n, dx, dyh, st, roi);
-    case 1: return launch_bwd<1>(dout, S, n, dx, dyh, st, roi);
-    case 2: return launch_bwd<2>(dout, S, n, dx, dyh, st, roi);
-    case 3: return launch_bwd<3>(dout, S, n, dx, dyh, st, roi);
-    case 4: return launch_bwd<4>(dout, S, n, dx, dyh, st, roi);
+    case 0: return launch_bwd<0>(dout, S, n, dx, dyh, st, roi, out_rect);
+    case 1: return launch_bwd<1>(dout, S, n, dx, dyh, st, roi, out_rect);
+    case 2: return launch_bwd<2>(dout, S, n, dx, dyh, st, roi, out_rect);
+    case 3: return launch_bwd<3>(dout, S, n, dx, dyh, st, roi, out_rect);
+    case 4: return launch_bwd<4>(dout, S, n, dx, dyh, st, roi, out_rect);
     default: return (int)hipErrorInvalidValue;
   }
 }
@@ -813,7 +865,7 @@ int tnl_idwt_level_backward_adam(const float* dout, uint32_t S, uint32_t n, int 
   const dim3 grid(cdiv(cdiv(n, TI), TPW), cdiv(n, TI), S);
   hipStream_t st = (hipStream_t)stream;
 #define TNL_BWD_ADAM(WW) \
-  hipLaunchKernelGGL((k_idwt_bwd_pipe<WW, true>), grid, dim3(NT), 0, st, dout, (int)n, dx, (float*)nullptr, fa, Roi{})
+  hipLaunchKernelGGL((k_idwt_bwd_pipe<WW, true>), grid, dim3(NT), 0, st, dout, (int)n, dx, (float*)nullptr, fa, Roi{}, Roi{})
   switch (wave) {
     case 0: TNL_BWD_ADAM(0); break;
     case 1: TNL_BWD_ADAM(1); break;

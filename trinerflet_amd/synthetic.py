@@ -68,7 +68,8 @@ def get_rays(poses, pix, H=800, W=800, camera_angle_x=0.6911):
 def training_rays(N, n_cams=100, seed=0, H=800, W=800):
     poses = hemisphere_poses(n_cams, seed=seed)
     rng = np.random.default_rng(seed + 1)
-    flat = rng.choice(n_cams * H * W, size=N, replace=False)
+    flat = np.unique(rng.integers(0, n_cams * H * W, size=N + N // 8 + 16))   # distinct pixels, O(N)
+    flat = rng.permutation(flat)[:N]
     pix = np.stack([flat // (H * W), flat % (H * W)], -1)
     return get_rays(poses, pix, H, W)
 

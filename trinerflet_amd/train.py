@@ -19,6 +19,7 @@ Multi-GPU: rays are sharded across ranks, planes and MLP weight
                     are reduce-scattered by slice, each rank runs adjoint + Adam + IDWT on 3C/G slices, and the
                     rebuilt planes are all-gathered -- same bytes on the wire, dense HBM work divided by G.
 """
+import ctypes as C_
 import math
 
 import torch
@@ -100,6 +101,10 @@ class TrainStep:
         self._roi = None          # 8 ints {ox[3], oy[3], rw, rh} or None (whole planes)
         self._roi_valid = False   # False: recompute from the bitfield before it is used
         self._tm_full = None      # persistent fp16 [3,R,R,C]; the ROI steps refresh its window in place
+        n0 = enc.planes_features.shape[-1]
+        # gradient-support chain (windowed adjoint + rectangle-aware Adam): level sizes must be powers of two
+        self._rect_ok = self.use_roi and n0 >= 32 and (n0 & (n0 - 1)) == 0 and self.R == n0 << self.J
+        self._rects = [None] * max(self.J, 1)
         dev = enc.planes_features.device
         self.dev = dev
         self.coef = _Flat(list(enc.planes_features_wavelet_coefs))
@@ -316,12 +321,54 @@ class TrainStep:
                 dyh = self.coef.grad_view(lvl).view(S, 3, n, n)[s0:s1]  # contiguous slice range of the flat buffer
                 if lvl == 0:
                     dx = self.ll.grad_view(0).view(S, n, n)[s0:s1]
-                lvl_roi = L.roi_array(list(roi) + [C, s0]) if (roi is not None and lvl == self.J - 1) else None
-                L.check(lib.tnl_idwt_level_backward_roi(L.ptr(g), L.u32(ns), L.u32(n), L.i32(self.enc.wave_id),
-                                                        L.ptr(dx), L.ptr(dyh), lvl_roi, L.stream()),
-                        "idwt_level_backward")
+                if roi is not None and self._rect_ok:
+                    # gradient-support chain: the window of this level's input -> the rectangle of coarse tiles it
+                    # reaches; nothing is stored outside it, the next level reads it as a strided window and the
+                    # Adam pass of this level takes g = 0 outside (self._rects[lvl])
+                    win = list(roi) if lvl == self.J - 1 else list(self._rects[lvl + 1])
+                    rect = (C_.c_int32 * 8)()
+                    L.check(lib.tnl_idwt_level_backward_win(
+                        L.ptr(g), L.u32(ns), L.u32(n), L.i32(self.enc.wave_id), L.ptr(dx), L.ptr(dyh),
+                        L.roi_array(win + [C, s0]), L.i32(0 if lvl == self.J - 1 else 1), rect, L.stream()),
+                        "idwt_level_backward_win")
+                    self._rects[lvl] = list(rect)
+                else:
+                    lvl_roi = L.roi_array(list(roi) + [C, s0]) if (roi is not None and lvl == self.J - 1) else None
+                    L.check(lib.tnl_idwt_level_backward_roi(L.ptr(g), L.u32(ns), L.u32(n), L.i32(self.enc.wave_id),
+                                                            L.ptr(dx), L.ptr(dyh), lvl_roi, L.stream()),
+                            "idwt_level_backward")
             g = dx
         return s0, s1
+
+    def _adam_levels(self, lr_t, l1, found_inf, inv_scale, s0, s1, rects):
+        """Adam(+L1) over this rank's slices [s0, s1) of every wavelet level and of LL.  rects: per level the
+        gradient-support rectangle from the windowed adjoint (None: gradients are dense)."""
+        lib = L.lib()
+        S, ns = 3 * self.C, s1 - s0
+
+        def rect_step(flat, off, bands, n, rect, l1c, abs_sum):
+            L.check(lib.tnl_adam_l1_step_rect(
+                L.ptr(flat.data[off:]), L.ptr(flat.grad[off:]), L.ptr(flat.m[off:]), L.ptr(flat.v[off:]), L.u32(ns),
+                L.u32(bands), L.u32(n), L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*rect), L.f32(lr_t),
+                L.ptr(self.opt_steps), L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0), L.ptr(inv_scale),
+                L.f32(l1c), L.ptr(found_inf), L.ptr(abs_sum), L.stream()), "adam_l1_step_rect")
+
+        if rects is None and ns == S:
+            self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum)
+            self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
+            return
+        for lvl in range(self.J):
+            n = self.coef.params[lvl].shape[-1]
+            base = self.coef.offsets[lvl] + s0 * 3 * n * n
+            if rects is not None:
+                rect_step(self.coef, base, 3, n, rects[lvl], l1, self.abs_sum)
+            else:
+                self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum, base, base + ns * 3 * n * n)
+        n0 = self.ll.params[0].shape[-1]
+        if rects is not None:
+            rect_step(self.ll, s0 * n0 * n0, 1, n0, rects[0], 0.0, None)
+        else:
+            self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale, None, s0 * n0 * n0, s1 * n0 * n0)
 
     # ------------------------------------------------------------------------------------------
     def step(self, rays_o, rays_d, gt_rgb, noises=None, n_global_rays=None, bg_color=None, next_rays=None):
@@ -476,11 +523,8 @@ class TrainStep:
             else:
                 s0, s1 = self._adjoint(None, g_cm, roi=roi)
                 self._mark("idwt_adjoint")
-                if self.dist_mode == "sharded":
-                    self._adam_sharded(lr_t, l1, found_inf, inv_scale, s0, s1)
-                else:
-                    self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum)
-                    self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
+                rects = self._rects if (roi is not None and self._rect_ok) else None
+                self._adam_levels(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
                 self._mark("adam_coef")
         else:
             grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
