@@ -303,6 +303,11 @@ TNL_API int tnl_ray_batch(const float *poses, const float *intrinsics_host, uint
  *       reads the gradient only inside the rectangle and uses 0 outside (24 instead of 28 bytes per coefficient).
  * Together: bit-identical to the whole-plane adjoint + Adam, without storing or re-reading the zeros.
  * ------------------------------------------------------------------------------------------- */
+/* Forward counterpart for the levels below the finest: only the window `win` (10 ints, multiples of 64, fine
+ * coordinates of this level) of the full-size fp32 output (S, 2n, 2n) is computed; the rest keeps its contents.
+ * The caller chooses each level's window as the next level's window halved and grown by the filter halo. */
+TNL_API int tnl_idwt_level_forward_win(const float *x, const float *yh, uint32_t S, uint32_t n, int wave, float *out,
+                                       const int32_t *win, void *stream);
 TNL_API int tnl_idwt_level_backward_win(const float *dout, uint32_t S, uint32_t n, int wave, float *dx, float *dyh,
                                         const int32_t *win, int strided, int32_t *out_rect, void *stream);
 TNL_API int tnl_adam_l1_step_rect(float *p, float *grad, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n,

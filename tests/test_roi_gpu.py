@@ -230,6 +230,32 @@ def test_window_covers_every_marched_footprint(cuda):
         assert t0[:, ya[p]].min() >= roi[3 + p] and t1[:, ya[p]].max() < roi[3 + p] + roi[7]
 
 
+def test_windowed_rebuild_equals_full_rebuild_inside_the_window(cuda):
+    """Three wavelet levels: the window chain (every level only computes what the next one needs) reproduces the full
+    rebuild inside the occupancy window bit for bit and leaves the rest of the persistent array alone."""
+    from trinerflet_amd.train import TrainStep
+    m = _model(cuda, R=512, scale=8, bound=1.0)
+    with torch.no_grad():
+        for p in m.encoder.planes_features_wavelet_coefs:
+            p.normal_(0, 0.05)
+    m.density_bitfield.copy_(torch.from_numpy(synthetic.sphere_bitfield(128, 1, 1.0, 0.12, 0.0)).to(cuda))
+    ts = TrainStep(m, update_extra_interval=0)
+    full = ts.rebuild_planes().clone()                      # whole planes, sets the persistent array
+    ts._roi, ts._roi_valid = ts._compute_roi(), True
+    roi = ts._roi
+    assert roi is not None and roi[6] <= 128
+    wins = ts._forward_windows()
+    assert wins[2] == list(roi) and wins[1] is not None, (roi, wins)     # the level below the finest is windowed too
+    ts._tm_full.fill_(5.0)
+    tm = ts.rebuild_planes(roi=True)
+    for p in range(3):
+        win = (slice(roi[3 + p], roi[3 + p] + roi[7]), slice(roi[p], roi[p] + roi[6]))
+        assert torch.equal(tm[p][win], full[p][win])
+        mask = torch.ones(512, 512, dtype=torch.bool, device=cuda)
+        mask[win] = False
+        assert bool((tm[p][mask] == 5.0).all())
+
+
 def test_training_with_window_equals_whole_plane_training(cuda):
     """Six steps (one grid refresh inside) with and without the occupancy window: same parameters."""
     from trinerflet_amd.train import TrainStep
@@ -258,4 +284,9 @@ def test_training_with_window_equals_whole_plane_training(cuda):
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-4)
     for a, b in zip(res[0][1], res[1][1]):
         # Adam's first steps are sign-like: compare where the whole-plane run actually moved the parameter
-        assert torch.allclose(a, b, rtol=1e-3, atol=2e-3), float((a - b).abs().max())
+        # The tile reduction sums in the order the bin-fill atomics produced, so gradients differ in the last bits
+        # from run to run; Adam (eps = 1e-15) turns a gradient at noise level into a +-lr step.  Such coefficients
+        # are isolated (measured: 0-1 of 2.4 M): allow a 1e-5 fraction of them, bounded by lr * steps.
+        bad = ((a - b).abs() > 2e-3 + 1e-3 * b.abs())
+        assert int(bad.sum()) <= max(1, int(1e-5 * a.numel())) and float((a - b).abs().max()) < 6e-2, \
+            (int(bad.sum()), a.numel(), float((a - b).abs().max()), bad.nonzero()[:5].tolist())

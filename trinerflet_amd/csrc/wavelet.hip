@@ -291,8 +291,10 @@ k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n
   const int m2 = 2 * n;
   const int pl = roi.rw ? (s + roi.s0) / roi.spp : 0;
   const int fox = roi.rw ? roi.ox[pl] : 0, foy = roi.rw ? roi.oy[pl] : 0;   // fine-grid origin of the tile walk
-  const int orow = roi.rw ? roi.rw : m2;                                     // output row stride
-  const size_t oplane = roi.rw ? (size_t)roi.rh * roi.rw : (size_t)m2 * m2;  // output slice stride
+  const bool compact = roi.rw && !roi.strided;   // strided: the window of a full-size output array is written
+  const int orow = compact ? roi.rw : m2;                                     // output row stride
+  const size_t oplane = compact ? (size_t)roi.rh * roi.rw : (size_t)m2 * m2;  // output slice stride
+  const int sox = compact ? fox : 0, soy = compact ? foy : 0;                 // array origin in fine coordinates
   const int a_r = foy / 2 + blockIdx.y * TI;
   const int ntx = roi.rw ? roi.rw / (2 * TI) : (n + TI - 1) / TI;
   const int tx0 = blockIdx.x * TPW, tx1 = min(tx0 + TPW, ntx);
@@ -389,7 +391,7 @@ k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n
       }
       const int gr = 2 * a_r + r, gc = 2 * (a_c + m0);
       if (gr < m2 && gc < m2) {  // m2 % 8 == 0 and gc % 8 == 0: the 8 outputs are in range together
-        const size_t off = (size_t)s * oplane + (size_t)(gr - foy) * orow + (gc - fox);
+        const size_t off = (size_t)s * oplane + (size_t)(gr - soy) * orow + (gc - sox);
         if (HALF_OUT) {
           typedef _Float16 h8 __attribute__((ext_vector_type(8)));
           h8 hv;
@@ -756,9 +758,10 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
 extern "C" {
 
 static int idwt_forward_any(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, void* out,
-                            int half_out, void* stream, const int32_t* roi_host = nullptr) {
+                            int half_out, void* stream, const int32_t* roi_host = nullptr, int strided = 0) {
   Roi roi;
   if (!make_roi(roi_host, S, 2 * n, roi)) return (int)hipErrorInvalidValue;
+  roi.strided = (roi.rw && strided) ? 1 : 0;
   if (S == 0 || n == 0) return 0;
   if (S > 65535) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
@@ -787,6 +790,12 @@ int tnl_idwt_level_forward_half_roi(const float* x, const float* yh, uint32_t S,
                                     const int32_t* roi, void* stream) {
   if (n % 4 != 0) return (int)hipErrorInvalidValue;
   return idwt_forward_any(x, yh, S, n, wave, out_half, 1, stream, roi);
+}
+
+int tnl_idwt_level_forward_win(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, float* out,
+                               const int32_t* win, void* stream) {
+  if (n % 4 != 0) return (int)hipErrorInvalidValue;
+  return idwt_forward_any(x, yh, S, n, wave, out, 0, stream, win, 1);
 }
 
 static int planes_half_to_tm(const void* planes_cm_half, uint32_t C, uint32_t R, void* planes_tm_half,

@@ -203,6 +203,42 @@ class TrainStep:
         oy = [min(t0, R - rh) for t0, _ in yr]
         return ox + oy + [rw, rh]
 
+    def _forward_windows(self):
+        """Per level the window of its OUTPUT that the next level needs: the finest level's window is the occupancy
+        window; below it, the next window halved and grown by 8 texels (the kernel stages a 4-texel halo), aligned
+        outward to 64 with a common size over the planes.  None where the whole plane is needed anyway."""
+        wins = [None] * self.J
+        if self._roi is None:
+            return wins
+        wins[self.J - 1] = list(self._roi)
+        for lvl in range(self.J - 2, -1, -1):
+            nxt = wins[lvl + 1]
+            m = self.R >> (self.J - 1 - lvl)              # output size of this level
+            if nxt is None or m % 64 != 0:
+                break
+            lo_x = [max((nxt[p] // 2 - 8) // 64 * 64, 0) for p in range(3)]
+            lo_y = [max((nxt[3 + p] // 2 - 8) // 64 * 64, 0) for p in range(3)]
+            hi_x = [min(((nxt[p] + nxt[6]) // 2 + 8 + 63) // 64 * 64, m) for p in range(3)]
+            hi_y = [min(((nxt[3 + p] + nxt[7]) // 2 + 8 + 63) // 64 * 64, m) for p in range(3)]
+            rw = max(h - l for l, h in zip(lo_x, hi_x))
+            rh = max(h - l for l, h in zip(lo_y, hi_y))
+            if rw * rh > 0.8 * m * m:
+                break
+            wins[lvl] = [min(l, m - rw) for l in lo_x] + [min(l, m - rh) for l in lo_y] + [rw, rh]
+        return wins
+
+    def _idwt_level_win(self, x, yh, win, s0=0):
+        """One non-finest level restricted to the window of its output (fp32, full-size array, rest undefined)."""
+        x = x.detach().contiguous()
+        yh = yh.detach().contiguous()
+        P, Cc, n = x.shape[0], x.shape[1], x.shape[-1]
+        out = torch.empty(P, Cc, 2 * n, 2 * n, dtype=torch.float32, device=x.device)
+        L.check(L.lib().tnl_idwt_level_forward_win(L.ptr(x), L.ptr(yh), L.u32(P * Cc), L.u32(n),
+                                                   L.i32(self.enc.wave_id), L.ptr(out),
+                                                   L.roi_array(list(win) + [self.C, s0]), L.stream()),
+                "idwt_level_forward_win")
+        return out
+
     def rebuild_planes(self, roi=False):
         """encoder.reset_cahce(); encoder.get_planes() of utils.py:1138-1140, outside autograd.
         roi=True (step() between grid refreshes): only the occupancy window of the finest level is rebuilt and
@@ -211,8 +247,9 @@ class TrainStep:
         fast = (self.J > 0 and enc.plane_dtype == torch.float16 and self.C % 8 == 0 and self.R % 16 == 0)
         roi = roi and self._roi is not None and self._tm_full is not None
         with torch.no_grad():
+            wins = self._forward_windows() if roi else [None] * self.J
             if self.dist_mode == "sharded":
-                planes = self._rebuild_sharded(roi)
+                planes = self._rebuild_sharded(roi, wins)
             else:
                 x = enc.planes_features
                 for lvl in range(self.J):
@@ -220,6 +257,8 @@ class TrainStep:
                     if fast and lvl == self.J - 1:  # finest level written as fp16: the fp32 planes never exist
                         x = idwt_level_half_roi(x, yh, enc.wave_id, self._roi10()) if roi else \
                             idwt_level_half(x, yh, enc.wave_id)
+                    elif wins[lvl] is not None:
+                        x = self._idwt_level_win(x, yh, wins[lvl])
                     else:
                         x = _IDWTLevel.apply(x, yh, enc.wave_id)
                 planes = x
@@ -238,7 +277,7 @@ class TrainStep:
     def _slice_range(self):
         return D.slice_range(3 * self.C, self.world, self.rank)
 
-    def _rebuild_sharded(self, roi=False):
+    def _rebuild_sharded(self, roi=False, wins=None):
         """IDWT of this rank's (plane, channel) slices, then all-gather of the rebuilt slices -- in fp16 when the
         sampler's planes are fp16 (half the bytes on the wire); with roi only the occupancy window travels."""
         enc = self.enc
@@ -252,6 +291,8 @@ class TrainStep:
             if fast and lvl == self.J - 1:
                 x = idwt_level_half_roi(x, yh, enc.wave_id, self._roi10(s0)) if roi else \
                     idwt_level_half(x, yh, enc.wave_id)
+            elif wins is not None and wins[lvl] is not None:
+                x = self._idwt_level_win(x, yh, wins[lvl], s0)
             else:
                 x = _IDWTLevel.apply(x, yh, enc.wave_id)
         if roi:
