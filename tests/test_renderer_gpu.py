@@ -126,3 +126,29 @@ def test_non_cuda_ray_renderer_runs(cuda):
                        max_ray_batch=100, num_steps=64, upsample_steps=0, bg_color=1)
     assert out["image"].shape == (1, 256, 3) and torch.isfinite(out["image"]).all()
     assert float(out["image"].min()) >= 0 and float(out["image"].max()) <= 1.0 + 1e-4
+
+
+def test_device_driven_inference_loop_equals_host_driven(cuda):
+    """The alive-ray loop with its sizes on the device (tnl_infer_plan / *_dev) renders exactly what the
+    host-driven loop (one survivor-count read-back per iteration, renderer.py:345,364) renders; the host-driven loop
+    is the one tied to the oracle in tests/test_raymarching_gpu.py::test_inference_loop."""
+    from trinerflet_amd import synthetic
+    m = _model(cuda)
+    synthetic.init_field_parameters(m, seed=5)
+    with torch.no_grad():
+        m.sigma_net[1].weight[0] += 0.6           # some opacity, so that rays terminate at different iterations
+    m.density_bitfield.copy_(torch.from_numpy(synthetic.sphere_bitfield(128, m.cascade, float(m.bound), 0.8, 0.2)).to(cuda))
+    m.eval()
+    o, d = synthetic.training_rays(5000, n_cams=6, seed=4)
+    o, d = torch.from_numpy(o).to(cuda)[None], torch.from_numpy(d).to(cuda)[None]
+    outs = []
+    with torch.no_grad():
+        for dev_loop in (False, True):
+            for max_steps in (64, 1024):
+                outs.append(m.render(o, d, staged=True, bg_color=0.5, perturb=False, max_steps=max_steps,
+                                     device_loop=dev_loop))
+    for a, b in ((outs[0], outs[2]), (outs[1], outs[3])):
+        for k in ("image", "depth", "weights_sum"):
+            # rays that miss the box carry depth = 0 / 0 = nan in the reference as well (renderer.py:370)
+            assert torch.equal(torch.nan_to_num(a[k], nan=-1.0), torch.nan_to_num(b[k], nan=-1.0)), k
+    assert float(outs[1]["weights_sum"].max()) > 0.5 and not torch.equal(outs[0]["image"], outs[1]["image"])

@@ -531,6 +531,131 @@ __global__ void k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thre
   image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
 }
 
+// ---- inference loop driven from the device -----------------------------------------------------
+// The reference's loop (renderer.py:338-372) reads the survivor count back on the host every iteration to size
+// the next launches.  Here the loop state lives on the device: state = {n_alive, n_step, step, rows}; every
+// iteration's kernels are launched with the worst-case grid (N rays) and look the live sizes up themselves, so the
+// host only polls the state occasionally to stop.  Same arithmetic, same ray order, same n_step rule.
+struct InferState {
+  int n_alive, n_step, step, rows;
+};
+
+__global__ void k_infer_plan(InferState* __restrict__ st, uint32_t N, uint32_t max_steps) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int n_alive = st->n_alive;
+  if (st->step >= (int)max_steps) n_alive = 0;                       // `while step < max_steps`
+  int n_step = 1;
+  if (n_alive > 0) n_step = max(min((int)(N / (uint32_t)n_alive), 8), 1);   // renderer.py:349
+  st->n_alive = n_alive;
+  st->n_step = n_step;
+  st->rows = n_alive * n_step;
+}
+
+template <bool WIDE>
+__global__ void k_march_rays_dev(const InferState* __restrict__ st, const int* __restrict__ rays_alive,
+                                 const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                 const float* __restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                                 uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                                 const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs,
+                                 float* __restrict__ deltas, const float* __restrict__ noises) {
+  const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+  const uint32_t n_alive = (uint32_t)st->n_alive, n_step = (uint32_t)st->n_step;
+  if (n >= n_alive) return;
+  const int index = rays_alive[n];
+  float* xo = xyzs + (size_t)n * n_step * 3;
+  float* dro = dirs + (size_t)n * n_step * 3;
+  float* dlo = deltas + (size_t)n * n_step * 2;
+  // the reference zero-fills the sample buffers every iteration (raymarching.py:337-339): rows a ray does not
+  // reach must read deltas == 0 in composite_rays
+  for (uint32_t k = 0; k < n_step; k++) {
+    xo[3 * k] = 0.f; xo[3 * k + 1] = 0.f; xo[3 * k + 2] = 0.f;
+    dro[3 * k] = 0.f; dro[3 * k + 1] = 0.f; dro[3 * k + 2] = 0.f;
+    dlo[2 * k] = 0.f; dlo[2 * k + 1] = 0.f;
+  }
+  MarchCtx m;
+  march_init(m, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
+  float t = rays_t[index];
+  const float nz = noises != nullptr ? noises[n] : 0.f;
+  t = fmaf(clampf_(t * dt_gamma, m.dt_min, m.dt_max), nz, t);
+  march_run<true, WIDE>(m, t, fars[index], n_step, xo, dro, dlo);
+}
+
+__global__ void k_composite_rays_dev(const InferState* __restrict__ st, float T_thresh, int* __restrict__ rays_alive,
+                                     float* __restrict__ rays_t, const float* __restrict__ sigmas,
+                                     const float* __restrict__ rgbs, const float* __restrict__ deltas,
+                                     float* __restrict__ weights_sum, float* __restrict__ depth,
+                                     float* __restrict__ image) {
+  const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+  const uint32_t n_alive = (uint32_t)st->n_alive, n_step = (uint32_t)st->n_step;
+  if (n >= n_alive) return;
+  const int index = rays_alive[n];
+  sigmas += (size_t)n * n_step;
+  rgbs += (size_t)n * n_step * 3;
+  deltas += (size_t)n * n_step * 2;
+  float t = rays_t[index];
+  float weight_sum = weights_sum[index], d = depth[index];
+  float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+  uint32_t step = 0;
+  while (step < n_step) {
+    if (deltas[0] == 0) break;
+    const float alpha = 1.0f - __expf(-sigmas[0] * deltas[0]);
+    const float T = 1 - weight_sum;
+    const float weight = alpha * T;
+    weight_sum += weight;
+    t += deltas[1];
+    d += weight * t;
+    r += weight * rgbs[0]; g += weight * rgbs[1]; b += weight * rgbs[2];
+    if (T < T_thresh) break;
+    sigmas++; rgbs += 3; deltas += 2; step++;
+  }
+  if (step < n_step) rays_alive[n] = -1; else rays_t[index] = t;
+  weights_sum[index] = weight_sum; depth[index] = d;
+  image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
+__global__ void __launch_bounds__(256)
+k_compact_count_dev(const InferState* __restrict__ st, const int* __restrict__ rays_alive,
+                    int* __restrict__ block_counts) {
+  __shared__ int smem4[4];
+  const uint32_t n = (uint32_t)st->n_alive;
+  const uint32_t i = threadIdx.x + blockIdx.x * 256;
+  const int keep = (i < n && rays_alive[i] >= 0) ? 1 : 0;
+  int total;
+  block_excl_scan_256(keep, smem4, &total);
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(256)
+k_compact_write_dev(const InferState* __restrict__ st, const int* __restrict__ rays_alive,
+                    const int* __restrict__ block_counts, int* __restrict__ out, int* __restrict__ next_n) {
+  __shared__ int smem4[4];
+  __shared__ int s_base;
+  const uint32_t n = (uint32_t)st->n_alive;
+  int part = 0;
+  for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) part += block_counts[i];
+  int tot;
+  block_excl_scan_256(part, smem4, &tot);
+  if (threadIdx.x == 0) s_base = tot;
+  __syncthreads();
+  const int base = s_base;
+  __syncthreads();
+  const uint32_t i = threadIdx.x + blockIdx.x * 256;
+  const int v = i < n ? rays_alive[i] : -1;
+  const int keep = v >= 0 ? 1 : 0;
+  int total;
+  const int off = base + block_excl_scan_256(keep, smem4, &total);
+  if (keep) out[off] = v;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *next_n = base + total;   // all blocks beyond n contribute 0
+}
+// closes the iteration: step += n_step, n_alive = survivors (kept apart from the count so that the kernels of the
+// iteration all see one consistent state)
+__global__ void k_infer_advance(InferState* __restrict__ st, const int* __restrict__ next_n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (st->n_alive > 0) {
+    st->step += st->n_step;
+    st->n_alive = *next_n;
+  }
+}
+
 // order-preserving compaction: per-block survivor counts, then offsets + scatter
 __global__ void __launch_bounds__(256)
 k_compact_count(const int* __restrict__ rays_alive, uint32_t n, int* __restrict__ block_counts) {
@@ -748,6 +873,50 @@ int tnl_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
   if (n_alive == 0) return 0;
   hipLaunchKernelGGL(k_composite_rays, dim3(cdiv(n_alive, 128)), dim3(128), 0, (hipStream_t)stream, n_alive, n_step,
                      T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+  return launch_status();
+}
+
+int tnl_infer_plan(int32_t* state, uint32_t N, uint32_t max_steps, void* stream) {
+  hipLaunchKernelGGL(k_infer_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<InferState*>(state), N,
+                     max_steps);
+  return launch_status();
+}
+
+int tnl_march_rays_dev(const int32_t* state, uint32_t N, const int32_t* rays_alive, const float* rays_t,
+                       const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                       uint32_t C, uint32_t H, const uint8_t* grid, const float* fars, float* xyzs, float* dirs,
+                       float* deltas, const float* noises, void* stream) {
+  if (N == 0) return 0;
+  const InferState* st = reinterpret_cast<const InferState*>(state);
+  if (wide_bitfield(grid, C, H))
+    hipLaunchKernelGGL(k_march_rays_dev<true>, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, st, rays_alive,
+                       rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
+  else
+    hipLaunchKernelGGL(k_march_rays_dev<false>, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, st, rays_alive,
+                       rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
+  return launch_status();
+}
+
+int tnl_composite_rays_dev(const int32_t* state, uint32_t N, float T_thresh, int32_t* rays_alive, float* rays_t,
+                           const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
+                           float* depth, float* image, void* stream) {
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_composite_rays_dev, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream,
+                     reinterpret_cast<const InferState*>(state), T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
+                     weights_sum, depth, image);
+  return launch_status();
+}
+
+int tnl_compact_rays_dev(int32_t* state, uint32_t N, const int32_t* rays_alive, int32_t* rays_alive_out,
+                         int32_t* workspace, void* stream) {
+  if (N == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t nb = cdiv(N, 256);
+  InferState* s = reinterpret_cast<InferState*>(state);
+  int* next_n = workspace + nb;
+  hipLaunchKernelGGL(k_compact_count_dev, dim3(nb), dim3(256), 0, st, s, rays_alive, workspace);
+  hipLaunchKernelGGL(k_compact_write_dev, dim3(nb), dim3(256), 0, st, s, rays_alive, workspace, rays_alive_out, next_n);
+  hipLaunchKernelGGL(k_infer_advance, dim3(1), dim3(64), 0, st, s, next_n);
   return launch_status();
 }
 

@@ -115,6 +115,19 @@ class NeRFNetwork(NeRFRenderer):
         sigma, geo_feat = self._sigma_mlp(x)
         return sigma, self._color_mlp(d, geo_feat)
 
+    @torch.no_grad()
+    def field_rows(self, xyzs, dirs, m_actual):
+        """sigma, rgb of the first m_actual[0] rows (device int32) of fixed-capacity buffers: the inference loop's
+        field query when its sizes live on the device (NeRFRenderer.run_cuda).  Fused path only."""
+        enc = self.encoder
+        tm = enc.get_planes_texel_major()
+        packed = _field.pack_weights(self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight,
+                                     self.color_net[1].weight, self.color_net[2].weight, enc.number_of_features,
+                                     self.hidden_dim)
+        sigma, rgb, _ = _field.field_forward(tm, xyzs, dirs, packed, float(self.bound), enc.number_of_features,
+                                             enc.plane_resolution, self.hidden_dim, m_actual=m_actual)
+        return sigma, rgb
+
     def density(self, x):
         # network.py:149-166
         if self._fused_ok() and not torch.is_grad_enabled():

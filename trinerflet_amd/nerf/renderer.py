@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import _lib as L
 from .. import raymarching
 
 
@@ -138,6 +139,15 @@ class NeRFRenderer(nn.Module):
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             results['weights_sum'] = weights_sum
+        elif kwargs.get("device_loop", True) and getattr(self, "_fused_ok", lambda: False)() \
+                and not torch.is_grad_enabled():
+            weights_sum, depth, image = self._infer_device_loop(rays_o, rays_d, nears, fars, dt_gamma, perturb,
+                                                                max_steps, T_thresh)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            image = image.view(*prefix, 3)
+            depth = depth.view(*prefix)
+            weights_sum = weights_sum.view(*prefix)
         else:
             weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
             depth = torch.zeros(N, dtype=torch.float32, device=device)
@@ -172,6 +182,51 @@ class NeRFRenderer(nn.Module):
         results['image'] = image
         results['weights_sum'] = weights_sum
         return results
+
+    def _infer_device_loop(self, rays_o, rays_d, nears, fars, dt_gamma, perturb, max_steps, T_thresh, poll=4):
+        """The alive-ray loop of renderer.py:338-372 with its sizes on the device (include/trinerflet_hip.h,
+        tnl_infer_plan ...): iterations are enqueued back to back, the host reads the state only every `poll`
+        iterations to stop.  Same n_step rule, ray order and arithmetic as the host-driven loop below."""
+        lib = L.lib()
+        N, dev = rays_o.shape[0], rays_o.device
+        weights_sum = torch.zeros(N, dtype=torch.float32, device=dev)
+        depth = torch.zeros(N, dtype=torch.float32, device=dev)
+        image = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        if N == 0:
+            return weights_sum, depth, image
+        state = torch.tensor([N, 0, 0, 0], dtype=torch.int32, device=dev)
+        alive = [torch.arange(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev)]
+        rays_t = nears.clone()
+        xyzs = torch.empty(N + 128, 3, dtype=torch.float32, device=dev)
+        dirs = torch.empty(N + 128, 3, dtype=torch.float32, device=dev)
+        deltas = torch.empty(N + 128, 2, dtype=torch.float32, device=dev)
+        cws = torch.empty((N + 255) // 256 + 2, dtype=torch.int32, device=dev)
+        noises = torch.rand(N, dtype=torch.float32, device=dev) if perturb else None
+        rows = state[3:4]
+        it = 0
+        while it < max_steps:                      # every iteration advances `step` by at least 1
+            for _ in range(poll):
+                L.check(lib.tnl_infer_plan(L.ptr(state), L.u32(N), L.u32(max_steps), L.stream()), "infer_plan")
+                L.check(lib.tnl_march_rays_dev(
+                    L.ptr(state), L.u32(N), L.ptr(alive[0]), L.ptr(rays_t), L.ptr(rays_o), L.ptr(rays_d),
+                    L.f32(self.bound), L.f32(dt_gamma), L.u32(max_steps), L.u32(self.cascade), L.u32(self.grid_size),
+                    L.ptr(self.density_bitfield), L.ptr(fars), L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas),
+                    L.ptr(noises if it == 0 else None), L.stream()), "march_rays_dev")
+                sigmas, rgbs = self.field_rows(xyzs, dirs, rows)
+                if self.density_scale != 1:
+                    sigmas = self.density_scale * sigmas
+                L.check(lib.tnl_composite_rays_dev(
+                    L.ptr(state), L.u32(N), L.f32(T_thresh), L.ptr(alive[0]), L.ptr(rays_t), L.ptr(sigmas),
+                    L.ptr(rgbs), L.ptr(deltas), L.ptr(weights_sum), L.ptr(depth), L.ptr(image), L.stream()),
+                    "composite_rays_dev")
+                L.check(lib.tnl_compact_rays_dev(L.ptr(state), L.u32(N), L.ptr(alive[0]), L.ptr(alive[1]),
+                                                 L.ptr(cws), L.stream()), "compact_rays_dev")
+                alive.reverse()
+                it += 1
+            n_alive, _, step, _ = state.tolist()
+            if n_alive <= 0 or step >= max_steps:
+                break
+        return weights_sum, depth, image
 
     # ------------------------------------------------------------------------------------------
     # density grid upkeep
