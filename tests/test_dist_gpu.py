@@ -86,8 +86,11 @@ def _refresh_worker(rank, port, out):
         lo, hi = D.shard_rays(N, 2, rank)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev)
         ts = TrainStep(m, fp16=True, update_extra_interval=1, dist_mode="sharded")
+        ts.step(t(o), t(d), t(gt), noises=t(noise), n_global_rays=N)       # full refresh, cells split over the ranks
+        full = (m.density_grid.cpu().numpy(), m.density_bitfield.cpu().numpy(), m.mean_density)
+        m.iter_density = 16                                               # next refresh takes the partial branch
         ts.step(t(o), t(d), t(gt), noises=t(noise), n_global_rays=N)
-        out[rank] = (m.density_grid.cpu().numpy(), m.density_bitfield.cpu().numpy(), m.mean_density)
+        out[rank] = full + (m.density_grid.cpu().numpy(), m.density_bitfield.cpu().numpy(), m.mean_density)
     finally:
         dist.destroy_process_group()
 
@@ -97,9 +100,11 @@ def test_grid_refresh_is_replicated(cuda):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_refresh_worker, args=(port, out), nprocs=2, join=True)
-    g0, b0, m0 = out[0]
-    g1, b1, m1 = out[1]
+    g0, b0, m0, pg0, pb0, pm0 = out[0]
+    g1, b1, m1, pg1, pb1, pm1 = out[1]
     assert np.array_equal(g0, g1) and np.array_equal(b0, b1) and m0 == m1 and b0.any()
+    assert np.array_equal(pg0, pg1) and np.array_equal(pb0, pb1) and pm0 == pm1       # partial refresh too
+    assert not np.array_equal(pg0, g0)
 
 
 @pytest.mark.parametrize("mode", ["sharded", "allreduce"])

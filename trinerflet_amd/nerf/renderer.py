@@ -268,28 +268,34 @@ class NeRFRenderer(nn.Module):
         self.density_grid[count == 0] = -1
 
     @torch.no_grad()
-    def update_extra_state(self, decay=0.95, S=128):
-        # reference: renderer.py:448-542
+    def update_extra_state(self, decay=0.95, S=128, shard=None):
+        # reference: renderer.py:448-542.  shard=(rank, world, gather): multi-GPU refresh: every
+        # rank evaluates 1/world of the cells (full refresh: a contiguous block of the Morton-ordered cell list;
+        # partial refresh: 1/world of the uniform and of the occupied picks) and `gather` (rank-ordered all-gather
+        # along dim 0) completes the candidate grid identically on every rank.
         if not self.cuda_ray:
             return
         dev = self.density_bitfield.device
         H = self.grid_size
+        rank, world, gather = shard if shard is not None else (0, 1, None)
         tmp_grid = -torch.ones_like(self.density_grid)
         if self.iter_density < 16:  # full refresh: every cell of every cascade
             cells = self._cells()
+            c0, c1 = cells.shape[0] * rank // world, cells.shape[0] * (rank + 1) // world
             for cas in range(self.cascade):
                 bound = min(2 ** cas, self.bound)
                 half_grid_size = bound / H
-                xyzs = cells * (bound - half_grid_size)
+                xyzs = cells[c0:c1] * (bound - half_grid_size)
                 xyzs = xyzs + (torch.rand_like(xyzs) * 2 - 1) * half_grid_size
-                tmp_grid[cas] = self.density(xyzs)['sigma'].reshape(-1).detach().float() * self.density_scale
+                dens = self.density(xyzs)['sigma'].reshape(-1).detach().float() * self.density_scale
+                tmp_grid[cas] = dens if world == 1 else gather(dens)
         else:  # partial refresh: H^3/4 uniform cells + H^3/4 currently occupied cells per cascade
-            N = H ** 3 // 4
+            N = H ** 3 // 4 // world
             for cas in range(self.cascade):
                 coords = torch.randint(0, H, (N, 3), device=dev)
                 indices = raymarching.morton3D(coords).long()
                 occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
-                if occ_indices.shape[0] > 0:
+                if occ_indices.shape[0] > 0:     # identical on every rank (the grids are), so the sizes agree
                     pick = torch.randint(0, occ_indices.shape[0], [N], dtype=torch.long, device=dev)
                     occ_indices = occ_indices[pick]
                     occ_coords = raymarching.morton3D_invert(occ_indices)
@@ -300,7 +306,13 @@ class NeRFRenderer(nn.Module):
                 half_grid_size = bound / H
                 xyzs = xyzs * (bound - half_grid_size)
                 xyzs = xyzs + (torch.rand_like(xyzs) * 2 - 1) * half_grid_size
-                tmp_grid[cas, indices] = self.density(xyzs)['sigma'].reshape(-1).detach().float() * self.density_scale
+                dens = self.density(xyzs)['sigma'].reshape(-1).detach().float() * self.density_scale
+                if world == 1:
+                    tmp_grid[cas, indices] = dens
+                else:
+                    # a cell drawn twice keeps the larger value (index assignment would keep an arbitrary one,
+                    # possibly a different one on each rank; the grids must stay bit-identical across ranks)
+                    tmp_grid[cas].scatter_reduce_(0, gather(indices), gather(dens), reduce="amax", include_self=True)
         valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
         self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
         self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()

@@ -467,15 +467,12 @@ class TrainStep:
         tm = self.rebuild_planes(roi=self.use_roi and not refresh)
         self._mark("idwt_fwd")
         if refresh:
-            model.update_extra_state()
             if self.world > 1:
-                # the refresh draws its in-cell jitter from each rank's RNG: keep the replicas' occupancy identical
-                # by adopting rank 0's grid (16 MB + 0.5 MB every `update_extra_interval` steps)
-                dist.broadcast(model.density_grid, 0, group=self.pg)
-                dist.broadcast(model.density_bitfield, 0, group=self.pg)
-                md = torch.tensor([float(model.mean_density)], device=self.dev)
-                dist.broadcast(md, 0, group=self.pg)
-                model.mean_density = float(md.item())
+                # every rank evaluates 1/world of the candidate cells; the all-gather keeps the replicas' grids (hence
+                # bitfield, occupancy window and collective sizes) bit-identical
+                model.update_extra_state(shard=(self.rank, self.world, lambda t: D.all_gather_slices(t, self.pg)))
+            else:
+                model.update_extra_state()
             if self.post_refresh is not None:
                 self.post_refresh()
             if self.use_roi:
