@@ -12,6 +12,8 @@
  *     reference's own TriPlaneVolume.build_planes (tests/golden/idwt_*.npz, make_golden.py).
  *   - triplane sample (orc_triplane_*): PINNED against the reference's
  *     TriPlaneVolume.sample_from_planes run in-container (tests/golden/sample_*.npz).
+ *   - ray generation (orc_get_rays): PINNED against the reference's get_rays (nerf/utils.py:65-149) run
+ *     in-container (tests/golden/trainer_reference.npz, make_golden_trainer.py).
  *   - raymarching / shencoder kernels: the reference is CUDA-only and cannot execute in this
  *     image; these restatements are "parity unpinned" by execution, and are anchored on
  *     line-by-line restatement plus domain properties (see tests/test_oracle_props.py).
