@@ -201,7 +201,7 @@ TNL_API int tnl_field_backward(const float *grad_sigma, const float *grad_rgb, c
                                void *stream);
 
 /* Plane-gradient accumulation without global float atomics (csrc/scatter.hip).  When tnl_field_backward is
- * given dfeat_half (fp16 [M,3C]) it writes the feature gradient there instead of scattering it; this call
+ * given dfeat_half (fp16, plane-major [3][M][C]) it writes the feature gradient there instead of scattering it; this call
  * then counting-sorts the samples by 32x8-texel tile per plane and lets one workgroup per tile reduce its
  * samples on the matrix cores and store the tile.  EVERY tile of the gradient is written (no zero fill needed): texel-major
  * [3,R,R,C] if channel_major == 0, the reference's (3,C,R,R) otherwise (the adjoint IDWT reads that directly,
@@ -219,7 +219,8 @@ TNL_API int tnl_plane_grad_binned(const void *dfeat_half, const float *xyz, floa
  * _reduce consumes the sorted workspace together with dfeat.  Same workspace size and contents contract. */
 TNL_API int tnl_plane_grad_sort(const float *xyz, float bound, uint32_t M, const int32_t *m_actual, uint32_t R,
                                 void *workspace, void *stream);
-TNL_API int tnl_plane_grad_reduce(const void *dfeat_half, const float *xyz, float bound, uint32_t C, uint32_t R,
+TNL_API int tnl_plane_grad_reduce(const void *dfeat_half, const float *xyz, float bound, uint32_t M, uint32_t C,
+                                  uint32_t R,
                                   float grad_scale, float *grad_out, int channel_major, int32_t *nonfinite_flag,
                                   const int32_t *roi, const void *workspace, void *stream);
 

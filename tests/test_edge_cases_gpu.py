@@ -56,13 +56,13 @@ def test_empty_batches_through_the_c_abi(cuda):
     # zero samples: sort + reduce write an all-zero gradient
     C, R = 16, 64
     xyz = torch.empty(0, 3, device=cuda)
-    dfeat = torch.empty(0, 3 * C, dtype=torch.float16, device=cuda)
+    dfeat = torch.empty(3, 0, C, dtype=torch.float16, device=cuda)
     g = torch.full((3, C, R, R), 9.0, device=cuda)
     F_.plane_grad_binned(dfeat, xyz, 1.0, C, R, g, channel_major=True)
     assert float(g.abs().sum()) == 0
     # m_actual = 0 on a non-empty buffer: nothing is read or accumulated
     xyz = torch.rand(1000, 3, device=cuda) - 0.5
-    dfeat = torch.randn(1000, 3 * C, device=cuda).half()
+    dfeat = torch.randn(3, 1000, C, device=cuda).half()
     zero = torch.zeros(1, dtype=torch.int32, device=cuda)
     g.fill_(9.0)
     F_.plane_grad_binned(dfeat, xyz, 1.0, C, R, g, m_actual=zero, channel_major=True)

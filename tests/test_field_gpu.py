@@ -141,7 +141,7 @@ def test_binned_plane_gradient_equals_atomic(cuda, C, H, R, M):
                           m_actual=m_act)
     g_bin = torch.full((3, R, R, C), float("nan"), device=cuda)      # every tile must be overwritten
     w_bin = torch.zeros(nW, device=cuda)
-    dfeat = torch.empty(M, 3 * C, dtype=torch.float16, device=cuda)
+    dfeat = torch.empty(3, M, C, dtype=torch.float16, device=cuda)      # plane-major [3,M,C]
     gfield.field_backward(a.to(cuda), b.to(cuda), None, None, feats, xg, dg, packed, bound, C, R, H, g_bin, w_bin,
                           m_actual=m_act, dfeat=dfeat)
     gfield.plane_grad_binned(dfeat, xg, bound, C, R, g_bin, m_actual=m_act)

@@ -77,7 +77,7 @@ def test_plane_gradient_roi_matches_whole_plane(cuda):
     # positions inside a box whose footprint is covered by the window below
     xyz = np.stack([rng.uniform(-0.45, 0.2, M), rng.uniform(-0.3, 0.45, M), rng.uniform(0.05, 0.45, M)], 1)
     xyz = torch.from_numpy(xyz.astype(np.float32)).to(cuda)
-    dfeat = torch.from_numpy(rng.standard_normal((M, 3 * C)).astype(np.float16)).to(cuda)
+    dfeat = torch.from_numpy(rng.standard_normal((3, M, C)).astype(np.float16)).to(cuda)
     # texel = (u+1)/2*255: x in [70,153] -> [64,192), y in [89,185] -> [64,192), z in [133,185] -> [128,192)
     ox, oy, rw, rh = (64, 64, 64), (64, 64, 64), 128, 128   # plane0 (x,z), plane1 (x,y), plane2 (y,z)
     full = torch.empty(3, C, R, R, device=cuda)

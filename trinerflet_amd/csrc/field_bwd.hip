@@ -105,6 +105,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   using G = FieldGeom<C, H>;
   using B = BwdGeom<C, H, NW, ATOMIC>;
   constexpr int BW_THREADS = B::BW_THREADS, ST = B::ST, LS = B::LS;
+  const uint32_t Mcap = M;   // row capacity: the plane stride of the plane-major dfeat output
   if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   _Float16* Xs = reinterpret_cast<_Float16*>(smem);
@@ -295,7 +296,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     // feature gradient dF^T = W0^T dH1^T
     if (!ATOMIC) {
-      // binned mode: dF leaves as fp16 [M, 3C]; scatter.hip accumulates it per tile without global atomics
+      // binned mode: dF leaves as fp16, plane-major [3][M][C] (each plane's tile pass of scatter.hip then reads
+      // whole 128-B lines of ITS channels; a [M][3C] row would hand it one useful 64-B third per line)
       typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #pragma unroll
       for (int ib = 0; ib < G::IB0; ib++) {
@@ -309,7 +311,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
             half4 v;
             v[0] = (_Float16)df[4 * q]; v[1] = (_Float16)df[4 * q + 1];
             v[2] = (_Float16)df[4 * q + 2]; v[3] = (_Float16)df[4 * q + 3];
-            *reinterpret_cast<half4*>(dfeat + (size_t)i * G::F + f0) = v;
+            const int pl = f0 / C, fc = f0 - pl * C;   // 4 consecutive features never straddle planes (C % 4 == 0)
+            *reinterpret_cast<half4*>(dfeat + ((size_t)pl * Mcap + i) * C + fc) = v;
           }
         }
       }

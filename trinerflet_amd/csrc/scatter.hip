@@ -162,13 +162,12 @@ typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
 template <int C>
 __global__ void __launch_bounds__(NT)
-k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ xyz, float bound, int R, int TNX,
+k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float* __restrict__ xyz, float bound, int R, int TNX,
                   int TNY, const int* __restrict__ offsets, const uint32_t* __restrict__ entries, float grad_scale,
                   float* __restrict__ grad_out, int channel_major, int* __restrict__ nonfinite_flag, Roi roi) {
   constexpr int NTEX = TSX * TSY;
   constexpr int TILE_F = NTEX * C;
-  constexpr int F = 3 * C;
-  constexpr int NB = (C + 31) / 32;          // 32-channel column blocks
+    constexpr int NB = (C + 31) / 32;          // 32-channel column blocks
   constexpr int QS = NT + 8;                 // record stride (halfs) of the transposed stages: 16-B aligned rows
   constexpr int XS = TSX + 4;                // epilogue staging stride (floats)
   constexpr size_t STAGE_A = (size_t)(32 * NB + TSY) * QS * 2 + NT * 4 + NT * 4;
@@ -245,7 +244,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, const float* __restrict__ 
     if (pv) {
       const uint32_t i = entries[base + threadIdx.x];
       px = xyz[(size_t)i * 3]; py = xyz[(size_t)i * 3 + 1]; pz = xyz[(size_t)i * 3 + 2];
-      const h8v* src = reinterpret_cast<const h8v*>(dfeat + (size_t)i * F + p * C);
+      const h8v* src = reinterpret_cast<const h8v*>(dfeat + ((size_t)p * Mcap + i) * C);   // plane-major [3][M][C]
 #pragma unroll
       for (int k = 0; k < C / 8; k++) pg[k] = src[k];
     }
@@ -429,7 +428,7 @@ int tnl_plane_grad_sort(const float* xyz, float bound, uint32_t M, const int32_t
 }
 
 // Part 2: one workgroup per (plane, tile) reduces the tile's sorted samples on the matrix cores.
-int tnl_plane_grad_reduce(const void* dfeat_half, const float* xyz, float bound, uint32_t C, uint32_t R,
+int tnl_plane_grad_reduce(const void* dfeat_half, const float* xyz, float bound, uint32_t M, uint32_t C, uint32_t R,
                           float grad_scale, float* grad_out, int channel_major, int32_t* nonfinite_flag,
                           const int32_t* roi_host, const void* workspace, void* stream) {
   if (R % TSX != 0 || (C != 16 && C != 32 && C != 48)) return (int)hipErrorInvalidValue;
@@ -444,13 +443,13 @@ int tnl_plane_grad_reduce(const void* dfeat_half, const float* xyz, float bound,
   const _Float16* df = reinterpret_cast<const _Float16*>(dfeat_half);
   const int ntiles = roi.rw ? 3 * (roi.rw / TSX) * (roi.rh / TSY) : w.nb;
   if (C == 16)
-    hipLaunchKernelGGL(k_tile_accumulate<16>, dim3(ntiles), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY,
+    hipLaunchKernelGGL(k_tile_accumulate<16>, dim3(ntiles), dim3(NT), 0, st, df, M, xyz, bound, (int)R, TNX, TNY,
                        offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   else if (C == 32)
-    hipLaunchKernelGGL(k_tile_accumulate<32>, dim3(ntiles), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY,
+    hipLaunchKernelGGL(k_tile_accumulate<32>, dim3(ntiles), dim3(NT), 0, st, df, M, xyz, bound, (int)R, TNX, TNY,
                        offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   else
-    hipLaunchKernelGGL(k_tile_accumulate<48>, dim3(ntiles), dim3(NT), 0, st, df, xyz, bound, (int)R, TNX, TNY,
+    hipLaunchKernelGGL(k_tile_accumulate<48>, dim3(ntiles), dim3(NT), 0, st, df, M, xyz, bound, (int)R, TNX, TNY,
                        offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   return (int)hipGetLastError();
 }
@@ -462,7 +461,7 @@ int tnl_plane_grad_binned_roi(const void* dfeat_half, const float* xyz, float bo
   if (R % TSX != 0 || (C != 16 && C != 32 && C != 48)) return (int)hipErrorInvalidValue;
   const int e = tnl_plane_grad_sort(xyz, bound, M, m_actual, R, workspace, stream);
   if (e != 0) return e;
-  return tnl_plane_grad_reduce(dfeat_half, xyz, bound, C, R, grad_scale, grad_out, channel_major, nonfinite_flag,
+  return tnl_plane_grad_reduce(dfeat_half, xyz, bound, M, C, R, grad_scale, grad_out, channel_major, nonfinite_flag,
                                roi_host, workspace, stream);
 }
 

@@ -112,7 +112,7 @@ def plane_grad_sort(xyz, bound, R, m_actual=None):
 def plane_grad_reduce(ws, dfeat, xyz, bound, C, R, grad_out, grad_scale=1.0, channel_major=False, nonfinite_flag=None,
                       roi=None):
     """Second half: per-tile matrix-core reduction of dfeat over the sorted samples in `ws`."""
-    L.check(L.lib().tnl_plane_grad_reduce(L.ptr(dfeat), L.ptr(xyz), L.f32(bound), L.u32(C), L.u32(R),
+    L.check(L.lib().tnl_plane_grad_reduce(L.ptr(dfeat), L.ptr(xyz), L.f32(bound), L.u32(xyz.shape[0]), L.u32(C), L.u32(R),
                                           L.f32(grad_scale), L.ptr(grad_out), L.i32(int(channel_major)),
                                           L.ptr(nonfinite_flag), L.roi_array(roi), L.ptr(ws), L.stream()),
             "plane_grad_reduce")
@@ -121,7 +121,8 @@ def plane_grad_reduce(ws, dfeat, xyz, bound, C, R, grad_out, grad_scale=1.0, cha
 
 def plane_grad_binned(dfeat, xyz, bound, C, R, grad_out, m_actual=None, grad_scale=1.0, channel_major=False,
                       nonfinite_flag=None, roi=None):
-    """fp16 feature gradients [M,3C] -> plane gradient fp32 by tile-sorted matrix-core reduction
+    """fp16 feature gradients (plane-major [3,M,C], as field_backward(dfeat=...) writes them) -> plane gradient fp32
+    by tile-sorted matrix-core reduction
     (csrc/scatter.hip): [3,R,R,C], or (3,C,R,R) with channel_major=True; writes every tile of grad_out.
     roi (8 ints): only the window's tiles, grad_out compact (3C, rh, rw), channel_major required."""
     lib = L.lib()

@@ -533,7 +533,7 @@ class TrainStep:
                 g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=self.dev)
             else:
                 g_cm = torch.empty(3 * C, roi[7], roi[6], dtype=torch.float32, device=self.dev)
-            dfeat = torch.empty(M, 3 * C, dtype=torch.float16, device=self.dev)
+            dfeat = torch.empty(3, M, C, dtype=torch.float16, device=self.dev)   # plane-major, see field_bwd.hip
             F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
                               g_cm, self.mlp.grad, m_actual=counter, dfeat=dfeat)
             self._mark("field_bwd")
