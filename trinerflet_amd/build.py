@@ -17,6 +17,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include")]
+# extra flags for A/B experiments on the GPU box (e.g. TNL_HIPCC_FLAGS="-DTNL_FWD_NT=0"), empty in normal builds
+COMMON += os.environ.get("TNL_HIPCC_FLAGS", "").split()
 # the marching kernels must not contract a*b+c on their own: bit-exact sample counts (see raymarch.hip)
 PER_FILE = {"raymarch.hip": ["-ffp-contract=off"], "rays.hip": ["-ffp-contract=off"]}
 

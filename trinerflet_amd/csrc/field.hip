@@ -59,6 +59,7 @@ k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, cons
       for (int kk = 0; kk < C / 16; kk++) {
         const half8 f = gather_frag<C, HALFP>(planes, R, p, kk, h, t);
         const int ks = p * (C / 16) + kk;
+        // (a non-temporal store here was measured SLOWER: field_fwd 1.05 -> 1.14 ms)
         if (feats_save != nullptr && valid)
           *reinterpret_cast<half8*>(feats_save + (size_t)i * G::F + 16 * ks + 8 * h) = f;
 #pragma unroll
