@@ -312,6 +312,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
             v[0] = (_Float16)df[4 * q]; v[1] = (_Float16)df[4 * q + 1];
             v[2] = (_Float16)df[4 * q + 2]; v[3] = (_Float16)df[4 * q + 3];
             const int pl = f0 / C, fc = f0 - pl * C;   // 4 consecutive features never straddle planes (C % 4 == 0)
+            // (non-temporal feats loads + dF stores: 1.46 -> 1.86 ms, not used)
             *reinterpret_cast<half4*>(dfeat + ((size_t)pl * Mcap + i) * C + fc) = v;
           }
         }

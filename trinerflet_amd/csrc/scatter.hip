@@ -246,7 +246,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
       px = xyz[(size_t)i * 3]; py = xyz[(size_t)i * 3 + 1]; pz = xyz[(size_t)i * 3 + 2];
       const h8v* src = reinterpret_cast<const h8v*>(dfeat + ((size_t)p * Mcap + i) * C);   // plane-major [3][M][C]
 #pragma unroll
-      for (int k = 0; k < C / 8; k++) pg[k] = src[k];
+      for (int k = 0; k < C / 8; k++) pg[k] = src[k];   // (non-temporal loads here: 0.80 -> 0.85 ms, not used)
     }
   };
   prefetch(beg);
