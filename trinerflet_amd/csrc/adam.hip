@@ -14,6 +14,10 @@
 #include "../../include/trinerflet_hip.h"
 #include "adam_common.h"
 
+#ifndef TNL_ADAM_BLOCKS
+#define TNL_ADAM_BLOCKS 4096
+#endif
+
 namespace {
 
 // Gradient support of one wavelet level laid out [S][bands][n][n] (n a power of two): per plane a rectangle of the
@@ -129,7 +133,7 @@ static int adam_launch(float* p, float* grad, float* m, float* v, uint64_t n, fl
     return (int)hipErrorInvalidValue;
   AdamArgs a{step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef};
   uint64_t blocks = (n / 4 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > TNL_ADAM_BLOCKS) blocks = TNL_ADAM_BLOCKS;
   if (blocks == 0) blocks = 1;
   // Non-temporal loads/stores: every byte is touched exactly once per step and the arrays are ~40x the Infinity Cache;
   // measured 1.99 -> 1.85 ms per step at base (A/B in one session).  TNL_ADAM_TEMPORAL=1 restores default caching.

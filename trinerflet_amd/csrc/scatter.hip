@@ -170,16 +170,17 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
     constexpr int NB = (C + 31) / 32;          // 32-channel column blocks
   constexpr int QS = NT + 8;                 // record stride (halfs) of the transposed stages: 16-B aligned rows
   constexpr int XS = TSX + 4;                // epilogue staging stride (floats)
-  constexpr size_t STAGE_A = (size_t)(32 * NB + TSY) * QS * 2 + NT * 4 + NT * 4;
+  constexpr size_t STAGE_A = (size_t)(32 * NB + TSY + TSX) * QS * 2;
   constexpr size_t STAGE_E = (size_t)4 * 2 * 32 * NB * XS * 4;
   constexpr size_t LDS_BYTES = STAGE_A > STAGE_E ? STAGE_A : STAGE_E;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-  _Float16* gT = reinterpret_cast<_Float16*>(smem);                 // [32*NB][QS]
-  _Float16* rwT = gT + (size_t)32 * NB * QS;                        // [TSY][QS]
-  // column taps: x0 (int, may be -1: then x0+1 = 0 can still be inside) and the weight pair (1-wx | wx) as half2;
-  // a weight is stored as 0 when its column lies outside the tile, so only x0 is needed to place both
-  int* cx0 = reinterpret_cast<int*>(rwT + (size_t)TSY * QS);          // [NT]
-  h2v* cww = reinterpret_cast<h2v*>(cx0 + NT);                         // [NT]
+  _Float16* gT = reinterpret_cast<_Float16*>(smem);                 // [32*NB][QS]   dF transposed: [channel][record]
+  _Float16* rwT = gT + (size_t)32 * NB * QS;                        // [TSY][QS]     row weights    [tile row][record]
+  // column weights [tile column][record]: a record has at most two non-zero entries (columns x0, x0+1 if inside the
+  // tile), written once by the record's thread in phase A; every wave then reads its A-fragment factor with one
+  // 16-byte LDS load instead of rebuilding it from the taps (that rebuild was ~40 VALU instructions per k-step,
+  // repeated by all four waves, and made phase B VALU-bound)
+  _Float16* cwT = rwT + (size_t)TSY * QS;                           // [TSX][QS]
 
   // With a ROI only its tiles are launched (samples binned elsewhere are dropped: the caller guarantees there are
   // none) and the output is the compact channel-major window [3C][rh][rw].
@@ -234,6 +235,13 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
   if (C % 32 != 0) {
     for (int q = threadIdx.x; q < (32 * NB - C) * QS; q += NT) gT[(size_t)C * QS + q] = (_Float16)0.f;
   }
+  for (int q = threadIdx.x; q < TSX * QS / 8; q += NT) {
+    h8v z;
+#pragma unroll
+    for (int j = 0; j < 8; j++) z[j] = (_Float16)0.f;
+    reinterpret_cast<h8v*>(cwT)[q] = z;
+  }
+  int prev_c0 = -100;   // first of the (up to) two cwT rows this thread's previous record wrote
 
   // prefetch registers for one record
   float px = 0.f, py = 0.f, pz = 0.f;
@@ -255,9 +263,10 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
     // ---- A: one thread per record
     {
       const int q = threadIdx.x;
-      int tx0 = -100;
-      h2v tw;
-      tw[0] = (_Float16)0.f; tw[1] = (_Float16)0.f;
+      // clear what this thread's previous record left in cwT
+      if ((unsigned)prev_c0 < (unsigned)TSX) cwT[(size_t)prev_c0 * QS + q] = (_Float16)0.f;
+      if ((unsigned)(prev_c0 + 1) < (unsigned)TSX) cwT[(size_t)(prev_c0 + 1) * QS + q] = (_Float16)0.f;
+      prev_c0 = -100;
       int ly0 = -1, ly1 = -1;
       float wy0 = 0.f, wy1 = 0.f;
       if (pv) {
@@ -266,9 +275,9 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
         const float wx = t.w01 + t.w11, wy = t.w10 + t.w11;  // weights are (1-wx|wx) x (1-wy|wy)
         const int lx0 = t.x0 - x_lo, lx1 = t.x1 - x_lo;
         ly0 = t.y0 - y_lo; ly1 = (t.y1 != t.y0) ? t.y1 - y_lo : -1;
-        tx0 = lx0;
-        if ((unsigned)lx0 < (unsigned)TSX) tw[0] = (_Float16)(1.f - wx);
-        if ((unsigned)lx1 < (unsigned)TSX && t.x1 != t.x0) tw[1] = (_Float16)wx;
+        if ((unsigned)lx0 < (unsigned)TSX) cwT[(size_t)lx0 * QS + q] = (_Float16)(1.f - wx);
+        if ((unsigned)lx1 < (unsigned)TSX && t.x1 != t.x0) cwT[(size_t)lx1 * QS + q] = (_Float16)wx;
+        prev_c0 = lx0;   // lx1 is lx0 + 1 whenever it is written
         wy0 = (1.f - wy) * grad_scale; wy1 = wy * grad_scale;
 #pragma unroll
         for (int k = 0; k < C / 8; k++)
@@ -278,8 +287,6 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
 #pragma unroll
         for (int c = 0; c < C; c++) gT[(size_t)c * QS + q] = (_Float16)0.f;  // 0 * stale NaN would poison the MFMA
       }
-      cx0[q] = tx0;
-      cww[q] = tw;
 #pragma unroll
       for (int y = 0; y < TSY; y++) rwT[(size_t)y * QS + q] = (_Float16)((y == ly0 ? wy0 : 0.f) + (y == ly1 ? wy1 : 0.f));
     }
@@ -289,19 +296,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
     const int nks = (min(NT, end - base) + 15) / 16;
     for (int ks = 0; ks < nks; ks++) {
       const int q0 = 16 * ks + 8 * h;
-      // column weights of this lane's texel column r for its 8 records, kept in fp16: cw = d==0 ? w0 : d==1 ? w1 : 0
-      h8v cw;
-      {
-        const int4 xa = *reinterpret_cast<const int4*>(cx0 + q0), xb = *reinterpret_cast<const int4*>(cx0 + q0 + 4);
-        const h8v wa = *reinterpret_cast<const h8v*>(cww + q0), wb = *reinterpret_cast<const h8v*>(cww + q0 + 4);
-        const int xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const int d = r - xs[j];
-          const _Float16 w0 = j < 4 ? wa[2 * j] : wb[2 * (j - 4)], w1 = j < 4 ? wa[2 * j + 1] : wb[2 * (j - 4) + 1];
-          cw[j] = d == 0 ? w0 : (d == 1 ? w1 : (_Float16)0.f);
-        }
-      }
+      const h8v cw = *reinterpret_cast<const h8v*>(cwT + (size_t)r * QS + q0);   // column r, records q0..q0+7
       h8v bf[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; nb++) bf[nb] = *reinterpret_cast<const h8v*>(gT + (size_t)(32 * nb + r) * QS + q0);
