@@ -27,7 +27,7 @@ def load(root, counter):
                 a = rows.setdefault(key, [0, 0.0])
                 a[0] += 1
                 a[1] += float(r["Counter_Value"])
-                if "k_adam_l1<true>" in r["Kernel_Name"]:
+                if "k_adam_l1<true" in r["Kernel_Name"]:      # the rectangle-aware launches (levels + LL)
                     adam.append(float(r["Counter_Value"]))
     return rows, adam
 
