@@ -75,7 +75,7 @@ class NeRFNetwork(NeRFRenderer):
     # ------------------------------------------------------------------------------------------
     def _fused_ok(self):
         enc = self.encoder
-        return (not self.force_modular and hasattr(enc, 'get_planes_texel_major') and enc.dropout is None
+        return (not self.force_modular and hasattr(enc, 'get_planes_texel_major') and enc.is_plain() and enc.dropout is None
                 and self.num_layers == 2 and self.num_layers_color == 3 and self.geo_feat_dim == 15
                 and getattr(self.encoder_dir, 'degree', 0) == 4 and self.density_blob_scale <= 1e-5
                 and _field.supported(enc.number_of_features, self.hidden_dim, self.hidden_dim_color))

@@ -13,12 +13,18 @@ What differs underneath (MI355X-first):
   * sampling reads a texel-major [3,R,R,C] copy of the planes (fp16 by default = the "e=2" fast mode of
     SURVEY.md 8(d); `plane_dtype=torch.float32` is the train-parity mode) so a texel's channels are one
     contiguous segment; get_planes() still returns the reference-shaped (3,C,R,R) fp32 tensor.
-Options no README configuration uses (learn_rotation_axis, lbound_auto_scale, upscale_*,
-apply_activation_on_features, two_planes_per_axis, inner_multi_res_scale_current != 1) raise
-NotImplementedError: SURVEY.md 8(f) rank 4, out of this tier.
+Options no README configuration uses -- learn_rotation_axis, lbound_auto_scale,
+upscale_ratio_bound / upscale_levels (nested zoom planes), apply_activation_on_features,
+inner_multi_res_scale_current != 1, get_grid_features, get_params2 -- follow the reference line by line on top of
+the same kernels (the IDWT levels and, where the coordinates are not re-mapped per plane, the lookup); the two
+re-mapped lookups (per-plane coordinate scale, per-channel rotated axes) use torch's grid_sample on the GPU as the
+reference does.  They switch the fused field / TrainStep fast path off (`is_plain()` is False).  Pinned by
+tests/golden/triplane_options_reference.npz (the reference class run here).  Only wavelet_base_resolution > 0 raises
+NotImplementedError.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib as L
@@ -211,17 +217,9 @@ class TriPlaneVolume(torch.nn.Module):
                  ):
         super().__init__()
         # reference: triplane_encoder.py:27-94
-        unsupported = {
-            'two_planes_per_axis': two_planes_per_axis, 'apply_activation_on_features': apply_activation_on_features,
-            'learn_rotation_axis': learn_rotation_axis, 'lbound_auto_scale': lbound_auto_scale,
-            'upscale_ratio_bound': 0 < upscale_ratio_bound < 1,
-            'inner_multi_res_scale_current != 1': inner_multi_res_scale_current != 1,
-            'wavelet_base_resolution': wavelet_base_resolution > 0,
-        }
-        for name, on in unsupported.items():
-            if on:
-                raise NotImplementedError(f"TriPlaneVolume option `{name}` is outside the MI355X hot-path tier "
-                                          "(SURVEY.md 8(f) rank 4)")
+        if wavelet_base_resolution > 0:
+            # changes the level sizes in a filter-length dependent way (:190-196, :391-393); no configuration uses it
+            raise NotImplementedError("TriPlaneVolume option `wavelet_base_resolution` > 0 is not implemented")
         self.number_of_features = number_of_features
         self.plane_resolution = plane_resolution
         self.init_sigma = init_sigma
@@ -251,16 +249,55 @@ class TriPlaneVolume(torch.nn.Module):
 
         self.init_plane_features(planes_features)
 
-        self.learn_rotation_axis = False
+        # :72-94 (parameters are created in the reference's order: state-dict / optimiser layout)
+        self.learn_rotation_axis = learn_rotation_axis
         self.rotation_matrix = None
+        if self.learn_rotation_axis:
+            self.rotation_matrix = nn.Parameter(torch.randn(number_of_features, 3, 3))
+            self.register_buffer('eye_matrix', torch.eye(3).unsqueeze(0))
         self.dropout = None
         if (dropout > 0) and (dropout < 1):
             self.dropout = nn.Dropout(dropout)
-        self.lbound_auto_scale = False
+        self.lbound_auto_scale = lbound_auto_scale
         self.lbound_scale = None
+        if self.lbound_auto_scale:
+            self.lbound_scale = nn.Parameter(0.5 * torch.ones(3))
         self.upscale_ratio_bound = upscale_ratio_bound
         self.upscale_levels = upscale_levels
+        self.init_upscale()
+
+    def init_upscale(self):
+        # reference: triplane_encoder.py:98-129 -- nested zoom planes: level k refines the central
+        # upscale_ratio_bound^(k+1) part of the volume with one more wavelet level of its own
         self.upscale_enabled = False
+        if 0 < self.upscale_ratio_bound < 1:
+            assert self.upscale_levels > 0
+            self.upscale_enabled = True
+            plane_resolution = self.plane_resolution
+            wavelets, self.upscale_base_resolution_lst = [], []
+            self.upscale_base_corner_lst, self.upscale_bound_ratio_lst = [], []
+            for level in range(self.upscale_levels):
+                base = round(plane_resolution * self.upscale_ratio_bound)
+                assert plane_resolution % base == 0
+                corner = round(plane_resolution / 2 - base / 2)
+                plane_resolution = 2 * base
+                self.upscale_bound_ratio_lst.append(self.upscale_ratio_bound ** (level + 1))
+                self.upscale_base_resolution_lst.append(base)
+                self.upscale_base_corner_lst.append(corner)
+                wavelets.append(nn.Parameter(torch.zeros(3, self.number_of_features, 3, base, base)))
+            self.upscale_wavelet_lst = nn.ParameterList(wavelets)
+
+    def is_plain(self):
+        """True when the lookup is the plain three-plane bilinear one over a single set of planes: the case the fused
+        field kernels and TrainStep are built for."""
+        return not (self.learn_rotation_axis or self.lbound_auto_scale or self.upscale_enabled
+                    or self.apply_activation_on_features)
+
+    def get_params2(self, lr):
+        # reference: triplane_encoder.py:135-151 (10x learning rate for lbound_scale)
+        res_1 = [p for n, p in self.named_parameters() if 'lbound_scale' in n]
+        res_2 = [p for n, p in self.named_parameters() if 'lbound_scale' not in n]
+        return [{'params': res_1, 'lr': 10 * lr}, {'params': res_2, 'lr': lr}]
 
     def init_plane_features(self, planes_features):
         # reference: triplane_encoder.py:155-231.  The reference runs a real forward DWT of a ones tensor only
@@ -292,35 +329,51 @@ class TriPlaneVolume(torch.nn.Module):
         if planes_features is None:
             planes_features = self.init_sigma * torch.randn(3, C, base, base)
         self.planes_features = nn.Parameter(planes_features.clone().detach())
-        self.planes_features_wavelet_current_level = 0
+        # :220-227: the finest get_levels(inner_multi_res_scale_current) levels are not learnable (zero detail)
+        self.planes_features_wavelet_current_level = utils.get_levels(self.inner_multi_res_scale_current)
         self.planes_features_wavelet_all_level = levels
+        n_learn = levels - self.planes_features_wavelet_current_level
         self.planes_features_wavelet_coefs = nn.ParameterList(
-            [nn.Parameter(torch.zeros(s)) for s in self.planes_features_wavelet_yh_shapes])
+            [nn.Parameter(torch.zeros(s)) for s in self.planes_features_wavelet_yh_shapes[:n_learn]])
 
     def get_wavelet_features(self):
         return list(self.planes_features_wavelet_coefs) if self.inner_wavelet_scale > 1 else []
 
     def get_wavelet_features_upscaled(self):
-        return []
+        return self.upscale_wavelet_lst if self.upscale_enabled else []
 
     def get_lbound_scale(self):
-        return None
+        # reference: triplane_encoder.py:304-312
+        if self.lbound_scale is None:
+            return None
+        return torch.exp(self.lbound_scale.abs())
 
-    def build_planes(self, get_all_resolutions=False, max_res=-1, max_scale=-1):
+    def build_planes(self, get_all_resolutions=False, max_res=-1, max_scale=-1, planes_features=None, coefs=None,
+                     all_level=None, inner_wavelet_scale=None):
         # reference: triplane_encoder.py:364-405
         all_res = []
         current_scale = 1
-        x = self.planes_features
-        if self.inner_wavelet_scale > 1:
-            for level_idx in range(self.planes_features_wavelet_all_level):
+        x = self.planes_features if planes_features is None else planes_features
+        coefs = self.planes_features_wavelet_coefs if coefs is None else coefs
+        all_level = self.planes_features_wavelet_all_level if all_level is None else all_level
+        inner = self.inner_wavelet_scale if inner_wavelet_scale is None else inner_wavelet_scale
+        if inner > 1:
+            for level_idx in range(all_level):
                 if get_all_resolutions:
                     all_res.append(x)
                 if ((max_res > 0) and (min(x.shape[2:]) >= max_res)) or ((max_scale > 0) and (current_scale >= max_scale)):
                     break
-                x = _IDWTLevel.apply(x, self.planes_features_wavelet_coefs[level_idx], self.wave_id)
+                if level_idx < len(coefs):
+                    yh = coefs[level_idx]
+                else:   # a level that is not learnable (yet): zero detail coefficients (:387-389)
+                    n = x.shape[-1]
+                    yh = torch.zeros(x.shape[0], x.shape[1], 3, n, n, dtype=x.dtype, device=x.device)
+                x = _IDWTLevel.apply(x, yh, self.wave_id)
                 current_scale *= 2
             if get_all_resolutions:
                 all_res.append(x)
+        if self.apply_activation_on_features:
+            x = torch.tanh(x)
         return x, all_res
 
     def get_planes(self, max_res=-1, max_scale=-1, get_all_resolutions=False):
@@ -331,12 +384,27 @@ class TriPlaneVolume(torch.nn.Module):
         planes, all_res = self.build_planes(get_all_resolutions, max_res, max_scale)
         self.last_used_planes = planes
         self._planes_tm = None
+        if self.upscale_enabled:
+            # :417-436: level k = the central crop of level k-1, refined by one IDWT level with its own wavelets
+            up = planes
+            planes, all_res = [planes], [all_res]
+            for level in range(self.upscale_levels):
+                c0, w = self.upscale_base_corner_lst[level], self.upscale_base_resolution_lst[level]
+                up = up[:, :, c0:c0 + w, c0:c0 + w]
+                up, all_up = self.build_planes(get_all_resolutions, max_res, max_scale, planes_features=up,
+                                               coefs=[self.upscale_wavelet_lst[level]], all_level=1,
+                                               inner_wavelet_scale=2)
+                planes.append(up)
+                all_res.append(all_up)
+            self.last_used_planes = planes
         if get_all_resolutions:
             return all_res
         return planes
 
     def get_planes_texel_major(self):
         """[3,R,R,C] copy of get_planes() in `plane_dtype`, cached with it (what the samplers read)."""
+        if not self.is_plain():
+            raise RuntimeError("the texel-major fast path only exists for the plain three-plane lookup")
         planes = self.get_planes()
         if self._planes_tm is None:
             self._planes_tm = _ToTexelMajor.apply(planes, self.plane_dtype == torch.float16)
@@ -346,16 +414,88 @@ class TriPlaneVolume(torch.nn.Module):
         self.last_used_planes = None
         self._planes_tm = None
 
+    def _project(self, plane_axes, coords):
+        # project_into_planes (:293-300): [N,dim] -> [N,Np,dim-1]
+        return torch.matmul(plane_axes.transpose(-1, -2).unsqueeze(0), coords.unsqueeze(-1).unsqueeze(1)).squeeze(-1)
+
+    def sample_from_planes_aux(self, coordinates, plane_features, plane_axes, lbound=1):
+        # reference: triplane_encoder.py:314-332 -> [N, Np, C]
+        if not self.lbound_auto_scale:
+            tm = _ToTexelMajor.apply(plane_features, self.plane_dtype == torch.float16)
+            return _Sample.apply(tm, coordinates, float(lbound)).view(coordinates.shape[0], 3, -1)
+        # per-plane learnable zoom of the projected coordinates: torch's grid_sample, as in the reference
+        proj = self._project(plane_axes, coordinates / lbound).transpose(0, 1).unsqueeze(2)      # Np,N,1,2
+        proj = (proj * self.get_lbound_scale().view(-1, 1, 1, 1)).clamp(-1, 1)
+        vals = F.grid_sample(plane_features, proj.to(plane_features.dtype), mode='bilinear', padding_mode='border',
+                             align_corners=True)
+        return vals.permute(2, 0, 1, 3).squeeze(-1)
+
+    def sample_from_planes_aux_rotation(self, coordinates, plane_features, plane_axes, lbound=1):
+        # reference: triplane_encoder.py:335-362: every channel samples its own rotated copy of the three axes
+        Np, C, H, W = plane_features.shape
+        dim = plane_axes.shape[1]
+        rot = torch.matmul(self.rotation_matrix.transpose(1, 2), self.rotation_matrix) + 1e-6 * self.eye_matrix
+        rot, _ = torch.linalg.qr(rot)                                                    # C,dim,dim
+        axes = torch.matmul(rot.unsqueeze(1), plane_axes.unsqueeze(0)).transpose(0, 1)   # Np,C,dim,dim-1
+        axes = axes.reshape(-1, dim, dim - 1)
+        proj = self._project(axes, coordinates / lbound).transpose(0, 1).unsqueeze(2)    # Np*C,N,1,2
+        vals = F.grid_sample(plane_features.reshape(-1, 1, H, W), proj.to(plane_features.dtype), mode='bilinear',
+                             padding_mode='border', align_corners=True)
+        vals = vals.view(Np, C, vals.shape[2], vals.shape[3])
+        return vals.permute(2, 0, 1, 3).squeeze(-1)
+
     def sample_from_planes(self, coordinates, plane_features=None, lbound=None):
         # reference: triplane_encoder.py:443-484 -> [N, 3, C]
         if lbound is None:
             lbound = self.lbound
+        if self.is_plain():
+            if plane_features is None:
+                tm = self.get_planes_texel_major()
+            else:
+                tm = _ToTexelMajor.apply(plane_features, self.plane_dtype == torch.float16)
+            feats = _Sample.apply(tm, coordinates, float(lbound))
+            return feats.view(coordinates.shape[0], 3, -1)
         if plane_features is None:
-            tm = self.get_planes_texel_major()
-        else:
-            tm = _ToTexelMajor.apply(plane_features, self.plane_dtype == torch.float16)
-        feats = _Sample.apply(tm, coordinates, float(lbound))
-        return feats.view(coordinates.shape[0], 3, -1)
+            plane_features = self.get_planes()
+        N = coordinates.shape[0]
+        if self.learn_rotation_axis:
+            return self.sample_from_planes_aux_rotation(coordinates, plane_features, self.plane_axes, lbound)
+        if not self.upscale_enabled:
+            return self.sample_from_planes_aux(coordinates, plane_features, self.plane_axes, lbound)
+        # nested zoom planes (:454-483): a point uses the finest level whose box contains it
+        all_planes, base = plane_features, plane_features[0]
+        cmax = coordinates.abs().max(dim=-1).values
+        res = torch.zeros(N, base.shape[0], base.shape[1], device=base.device, dtype=base.dtype)
+        used = None
+        for level in range(self.upscale_levels):
+            lb = self.upscale_bound_ratio_lst[level] * lbound
+            if level < self.upscale_levels - 1:
+                flag = torch.logical_and(cmax <= lb, cmax > self.upscale_bound_ratio_lst[level + 1] * lbound)
+            else:
+                flag = cmax <= lb
+            res[flag] = self.sample_from_planes_aux(coordinates[flag], all_planes[level + 1], self.plane_axes, lb) \
+                .to(res.dtype)
+            used = flag if used is None else torch.logical_or(used, flag)
+        rest = ~used
+        res[rest] = self.sample_from_planes_aux(coordinates[rest], base, self.plane_axes, lbound).to(res.dtype)
+        return res
+
+    def get_grid_features(self, grid_res, plane_features=None, grid=None):
+        # reference: triplane_encoder.py:486-510
+        if grid is None:
+            ax = torch.arange(grid_res)
+            gx, gy, gz = torch.meshgrid(ax, ax, ax, indexing='xy')
+            grid = torch.stack([gx, gy, gz], dim=-1) / (grid_res - 1)
+        assert grid.max() <= 1 and grid.min() >= 0
+        grid = 2 * self.lbound * grid - self.lbound
+        grid = grid[..., [2, 0, 1]]
+        if plane_features is None:
+            plane_features = self.get_planes(2 * grid_res)
+        ref = plane_features[0] if isinstance(plane_features, (list, tuple)) else plane_features
+        grid = grid.to(device=ref.device, dtype=ref.dtype)
+        shape = grid.shape
+        feats = self.sample_from_planes(grid.view(-1, shape[-1]), plane_features=plane_features)
+        return self.lbound, feats.view(*shape[:-1], -1), grid
 
     def get_params(self, opt_cfg):
         return self.parameters()
