@@ -10,6 +10,7 @@ them is touched by the functions called below):
   decay_function(iter, opt)                      utils.py:55-62    -> lr/{iters,warmup,it,factor}
   PSNRMeter.update / measure                     utils.py:245-282  -> psnr/{pred,truth,value}
   shuffle_data / select_batch shapes             utils.py:228-243  -> batch/{...} (shape contract only)
+  sample_pdf(bins, weights, n, det=True)         renderer.py:18-55 -> pdf/{bins,weights,samples}
 and the torch objects whose state_dict layout a checkpoint carries (main_nerf.py:119-129, utils.py:1390-1412):
   torch.optim.Adam(model.get_params(lr)) / LambdaLR / GradScaler -> ckpt/{optimizer_keys, scheduler_keys, scaler_keys}
 """
@@ -83,6 +84,14 @@ def main():
     out.update({"batch/shuffled_rows": np.array(sh["rays_o"].shape), "batch/sel_shape": np.array(b1["rays_o"].shape),
                 "batch/last_shape": np.array(U.select_batch(sh, 2, 4, torch.device("cpu"))["rays_o"].shape),
                 "batch/is_perm": np.array(sorted(sh["rays_o"][:, 0].tolist()) == data["rays_o"].view(-1, 3)[:, 0].tolist())})
+    # ---- sample_pdf (hierarchical resampling of NeRFRenderer.run)
+    from nerf import renderer as RR
+    bins = torch.sort(torch.rand(7, 33, generator=torch.Generator().manual_seed(4)) * 3 + 0.5, dim=-1).values
+    weights = torch.rand(7, 32, generator=torch.Generator().manual_seed(5))
+    weights[2] = 0                                   # a ray that saw nothing
+    weights[3, :30] = 0                              # all the mass in the last bins
+    samples = RR.sample_pdf(bins, weights, 16, det=True)
+    out.update({"pdf/bins": bins.numpy(), "pdf/weights": weights.numpy(), "pdf/samples": samples.numpy()})
     # ---- checkpoint component layouts (torch objects the reference saves)
     p = [torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2, 2))]
     optim_ = torch.optim.Adam([{"params": [p[0]], "lr": 1e-2}, {"params": [p[1]], "lr": 1e-2}], betas=(0.9, 0.99),

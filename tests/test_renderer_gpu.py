@@ -126,6 +126,19 @@ def test_non_cuda_ray_renderer_runs(cuda):
                        max_ray_batch=100, num_steps=64, upsample_steps=0, bg_color=1)
     assert out["image"].shape == (1, 256, 3) and torch.isfinite(out["image"]).all()
     assert float(out["image"].min()) >= 0 and float(out["image"].max()) <= 1.0 + 1e-4
+    # with the importance resampling pass (renderer.py:176-213), eval = deterministic strata, train = random + grads
+    m.eval()
+    with torch.no_grad():
+        up = m.render(torch.from_numpy(o).to(cuda)[None], torch.from_numpy(d).to(cuda)[None], staged=True,
+                      max_ray_batch=100, num_steps=32, upsample_steps=32, bg_color=1)
+        up2 = m.render(torch.from_numpy(o).to(cuda)[None], torch.from_numpy(d).to(cuda)[None], staged=True,
+                       max_ray_batch=100, num_steps=32, upsample_steps=32, bg_color=1)
+    assert torch.isfinite(up["image"]).all() and torch.equal(up["image"], up2["image"])
+    m.train()
+    res = m.run(torch.from_numpy(o[:64]).to(cuda), torch.from_numpy(d[:64]).to(cuda), num_steps=16, upsample_steps=16,
+                bg_color=1, perturb=True)
+    res["image"].sum().backward()
+    assert m.sigma_net[0].weight.grad is not None and res["weights_sum"].shape == (64,)
 
 
 def test_device_driven_inference_loop_equals_host_driven(cuda):

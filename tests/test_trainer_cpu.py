@@ -60,3 +60,11 @@ def test_permutation_is_a_bijection_and_library_agrees():
     a = cref.permute_index(np.arange(4097), 4097, 1)
     b = cref.permute_index(np.arange(4097), 4097, 2)
     assert (a == b).mean() < 0.01 and abs(np.corrcoef(a, np.arange(4097))[0, 1]) < 0.1
+
+
+def test_sample_pdf_matches_reference(golden_dir):
+    """Importance resampling of NeRFRenderer.run (renderer.py:18-55), deterministic mode, incl. an empty ray."""
+    from trinerflet_amd.nerf.renderer import sample_pdf
+    g = _g(golden_dir)
+    got = sample_pdf(torch.from_numpy(g["pdf/bins"]), torch.from_numpy(g["pdf/weights"]), 16, det=True)
+    np.testing.assert_allclose(got.numpy(), g["pdf/samples"], rtol=1e-6, atol=1e-6)

@@ -18,6 +18,28 @@ from .. import _lib as L
 from .. import raymarching
 
 
+def sample_pdf(bins, weights, n_samples, det=False):
+    """Inverse-transform sampling of a piecewise-constant density (renderer.py:18-55): bins [B,T], weights [B,T-1] ->
+    [B,n_samples] positions; det=True takes the midpoints of n_samples equal probability strata."""
+    pdf = weights + 1e-5
+    pdf = pdf / pdf.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)             # [B,T]
+    if det:
+        u = torch.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples, device=weights.device)
+        u = u.expand(*cdf.shape[:-1], n_samples)
+    else:
+        u = torch.rand(*cdf.shape[:-1], n_samples, device=weights.device)
+    u = u.contiguous()
+    hi = torch.searchsorted(cdf, u, right=True)
+    lo = (hi - 1).clamp(min=0)
+    hi = hi.clamp(max=cdf.shape[-1] - 1)
+    c_lo, c_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+    b_lo, b_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+    span = c_hi - c_lo
+    span = torch.where(span < 1e-5, torch.ones_like(span), span)
+    return b_lo + (u - c_lo) / span * (b_hi - b_lo)
+
+
 class NeRFRenderer(nn.Module):
     def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1,
                  **kwargs):
@@ -65,12 +87,10 @@ class NeRFRenderer(nn.Module):
         self.local_step = 0
 
     # ------------------------------------------------------------------------------------------
-    # non-cuda_ray renderer (renderer.py:126-254): uniform steps, torch compositing.  Kept for API
-    # completeness; upsample_steps > 0 (sample_pdf) is not part of any README configuration.
+    # non-cuda_ray renderer (renderer.py:126-254): uniform steps (+ optional importance resampling), torch
+    # compositing.  The CPU-baseline semantics of SURVEY.md A14; no README configuration trains with it.
     # ------------------------------------------------------------------------------------------
     def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, **kwargs):
-        if upsample_steps > 0:
-            raise NotImplementedError("hierarchical resampling (upsample_steps > 0) is outside the hot-path tier")
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
@@ -88,6 +108,23 @@ class NeRFRenderer(nn.Module):
         dens = self.density(xyzs.reshape(-1, 3))
         sigma = dens['sigma'].view(N, num_steps)
         geo = dens['geo_feat'].view(N, num_steps, -1)
+        if upsample_steps > 0:
+            # renderer.py:176-213: resample along each ray where the coarse pass put its weight, then merge by depth
+            with torch.no_grad():
+                d0 = z_vals[..., 1:] - z_vals[..., :-1]
+                d0 = torch.cat([d0, sample_dist * torch.ones_like(d0[..., :1])], dim=-1)
+                a0 = 1 - torch.exp(-d0 * self.density_scale * sigma)
+                w0 = a0 * torch.cumprod(torch.cat([torch.ones_like(a0[..., :1]), 1 - a0 + 1e-15], dim=-1), dim=-1)[..., :-1]
+                z_mid = z_vals[..., :-1] + 0.5 * d0[..., :-1]
+                new_z = sample_pdf(z_mid, w0[:, 1:-1], upsample_steps, det=not self.training).detach()
+                new_xyzs = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * new_z.unsqueeze(-1)
+                new_xyzs = torch.min(torch.max(new_xyzs, aabb[:3]), aabb[3:])
+            new_dens = self.density(new_xyzs.reshape(-1, 3))
+            z_vals, order = torch.sort(torch.cat([z_vals, new_z], dim=1), dim=1)
+            xyzs = torch.gather(torch.cat([xyzs, new_xyzs], dim=1), 1, order.unsqueeze(-1).expand(-1, -1, 3))
+            sigma = torch.gather(torch.cat([sigma, new_dens['sigma'].view(N, upsample_steps)], dim=1), 1, order)
+            geo = torch.cat([geo, new_dens['geo_feat'].view(N, upsample_steps, -1)], dim=1)
+            geo = torch.gather(geo, 1, order.unsqueeze(-1).expand(-1, -1, geo.shape[-1]))
         deltas = z_vals[..., 1:] - z_vals[..., :-1]
         deltas = torch.cat([deltas, sample_dist * torch.ones_like(deltas[..., :1])], dim=-1)
         alphas = 1 - torch.exp(-deltas * self.density_scale * sigma)
