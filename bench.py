@@ -210,6 +210,42 @@ def main():
     n_launch += 1
     achieved = adam_bytes / (adam_ms * 1e-3) / 1e9 if adam_ms == adam_ms and adam_ms > 0 else float("nan")
 
+    # secondary rooflines (north star: HBM GB/s of the sampling / IDWT kernels, MFMA rate of the MLP), from the same
+    # HIP-event sections; bytes and flops are the algorithmic ones of SURVEY.md 8(d) for what each section moves
+    Cc, Rr, Hh = ts.C, ts.R, ts.H
+    Ms = samples_per_step
+    e_pl = 2 if model.encoder.plane_dtype == torch.float16 else 4
+    mac = 3 * Cc * Hh + 16 * Hh + 31 * Hh + Hh * Hh + 3 * Hh
+    wins = ts._forward_windows() if ts._roi is not None else [None] * ts.J
+
+    def win_area(lvl, m):           # texels of level lvl's output that are computed
+        w = wins[lvl]
+        return float(w[6] * w[7]) if w is not None else float(m * m)
+    fwd_bytes = adj_bytes = 0.0
+    for lvl in range(ts.J):
+        m = Rr >> (ts.J - 1 - lvl)
+        out_b = e_pl if lvl == ts.J - 1 else 4
+        fwd_bytes += S_own * win_area(lvl, m) * (4.0 + out_b)      # 4 input bands at a quarter of the area + output
+        rect = rects[lvl][6] * rects[lvl][7] if rects is not None else (m // 2) ** 2
+        adj_bytes += S_own * (win_area(lvl, m) * 4.0 + 4.0 * rect * 4.0)   # gradient window in, 4 bands out
+    fwd_bytes += (3 * Cc // (world if ts.dist_mode == "sharded" else 1)) * win_area(ts.J - 1, Rr) * 2 * e_pl  # layout
+
+    def rate(nbytes, key):
+        t = sec.get(key, float("nan"))
+        return round(nbytes / (t * 1e-3) / 1e9, 1) if t == t and t > 0 else None
+    kernels = {
+        "field_fwd": {"GB/s": rate(Ms * (12 * Cc * e_pl + 48 + 6 * Cc), "field_fwd"),
+                      "mfma_TFLOP/s": rate(2.0 * mac * Ms / 1e3, "field_fwd"),
+                      "note": "gather 12*C*e + 48 B/sample + 6*C B/sample of saved features; 2*MAC flops/sample"},
+        "field_bwd": {"GB/s": rate(Ms * (6 * Cc + 6 * Cc + 40), "field_bwd"),
+                      "mfma_TFLOP/s": rate(6.0 * mac * Ms / 1e3, "field_bwd"),
+                      "note": "features in, fp16 dF out; recompute + dX + dW = 6*MAC flops/sample; "
+                              "dense fp16 MFMA peak 2500 TFLOP/s"},
+        "plane_grad_reduce": {"GB/s": rate(Ms * 3 * (2 * Cc + 12 + 4.4) + 3 * Cc * win_area(ts.J - 1, Rr) * 4, "plane_grad_binned")},
+        "idwt_forward_all_levels_plus_layout": {"GB/s": rate(fwd_bytes, "idwt_fwd")},
+        "idwt_adjoint_all_levels": {"GB/s": rate(adj_bytes, "idwt_adjoint")},
+    }
+
     if rank == 0:
         C, R, scale, H, _, lam = WORKLOADS[args.workload]
         ms = elapsed / args.steps * 1e3
@@ -224,7 +260,8 @@ def main():
                        "rays_per_step_per_gpu": N, "samples_per_step_per_gpu": samples_per_step,
                        "sample_budget_M": mean_count, "parallelism": f"ray-dp{world}" + (f"+{args.dist_mode}" if world > 1 else ""),
                        "samples_per_sec": samples_per_step * world * args.steps / elapsed,
-                       "sections_ms": {k: round(v, 4) for k, v in sec.items()}},
+                       "sections_ms": {k: round(v, 4) for k, v in sec.items()},
+                       "kernels": kernels},
             "roofline": {"bound": "hbm", "kernel": "k_adam_l1 (fused Adam + wavelet-L1), the step's launches over all "
                                                    "wavelet levels + LL taken together",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
