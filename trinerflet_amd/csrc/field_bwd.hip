@@ -42,7 +42,11 @@ struct BwdGeom {
   static constexpr size_t YS_BYTES = (size_t)YROWS * LS * 2;
   static constexpr size_t STAGE_BYTES = ATOMIC ? (size_t)BW_WAVES * 32 * STAGE_LD * 4 : 0;
   static constexpr size_t W_BYTES = (size_t)G::NTOT * 1024;
-  static constexpr size_t BASE_BYTES = XS_BYTES + YS_BYTES + STAGE_BYTES;
+  // the sample's features, published once per super-tile for the layer-0 weight gradient (rows F..32*IB0-1 stay zero)
+  // (binned mode only: the atomic mode's fp32 staging area leaves no room at C = 48 and re-reads them instead)
+  static constexpr bool EARLY_F = !ATOMIC;
+  static constexpr size_t FS_BYTES = EARLY_F ? (size_t)32 * G::IB0 * LS * 2 : 0;
+  static constexpr size_t BASE_BYTES = XS_BYTES + YS_BYTES + STAGE_BYTES + FS_BYTES;
   static constexpr bool LDSW = BASE_BYTES + W_BYTES <= 160 * 1024;  // weights cached in LDS when they fit
   static constexpr size_t LDS_BYTES = BASE_BYTES + (LDSW ? W_BYTES : 0);
   static constexpr int NT0 = G::OB * G::IB0, NT1 = G::OB, NT2 = G::OB, NT3 = G::OB * G::OB, NT4 = G::OB;
@@ -111,6 +115,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   _Float16* Xs = reinterpret_cast<_Float16*>(smem);
   _Float16* Ys = reinterpret_cast<_Float16*>(smem + B::XS_BYTES);
   float* stage_all = reinterpret_cast<float*>(smem + B::XS_BYTES + B::YS_BYTES);
+  _Float16* Fs = reinterpret_cast<_Float16*>(smem + B::XS_BYTES + B::YS_BYTES + B::STAGE_BYTES);
   const half8* w = packed;
   if (B::LDSW) {
     half8* wl = reinterpret_cast<half8*>(smem + B::BASE_BYTES);
@@ -136,15 +141,50 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   for (int k = 0; k < B::A4; k++) dw4[k] = zero16();
 
   const uint32_t nst = M == 0 ? 0 : (M + ST - 1) / ST;
+  // One wave per SIMD: nothing else hides a global load, so the inputs of super-tile t+1 are requested at the top of
+  // super-tile t and sit in registers until the next trip (measured: see DESIGN.md).
+  struct Inputs {
+    float px, py, pz, dx, dy, dz, g_s, g_c0, g_c1, g_c2;
+    half8 fk[G::KS0];
+  };
+  auto load_inputs = [&](uint32_t st_, Inputs& in) {
+    const uint32_t i_ = st_ * ST + col;
+    const bool v_ = i_ < M;
+    const uint32_t il_ = v_ ? i_ : M - 1;
+    if (ATOMIC) { in.px = xyz[(size_t)il_ * 3]; in.py = xyz[(size_t)il_ * 3 + 1]; in.pz = xyz[(size_t)il_ * 3 + 2]; }
+    else { in.px = in.py = in.pz = 0.f; }
+    in.dx = dirs[(size_t)il_ * 3]; in.dy = dirs[(size_t)il_ * 3 + 1]; in.dz = dirs[(size_t)il_ * 3 + 2];
+    in.g_s = v_ ? gsig[i_] : 0.f;
+    in.g_c0 = v_ ? grgb[(size_t)i_ * 3] : 0.f; in.g_c1 = v_ ? grgb[(size_t)i_ * 3 + 1] : 0.f;
+    in.g_c2 = v_ ? grgb[(size_t)i_ * 3 + 2] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < G::KS0; ks++) {
+      in.fk[ks] = *reinterpret_cast<const half8*>(feats + (size_t)il_ * G::F + 16 * ks + 8 * h);
+      if (!v_) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) in.fk[ks][j] = (_Float16)0.f;
+      }
+    }
+  };
+  // rows F .. 32*IB0-1 of the feature stage are never written again
+  if (B::EARLY_F)
+    for (int q = threadIdx.x; q < (32 * G::IB0 - G::F) * LS; q += BW_THREADS) Fs[(size_t)G::F * LS + q] = (_Float16)0.f;
+  Inputs nxt;
+  if (blockIdx.x < nst) load_inputs(blockIdx.x, nxt);
   for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
     const uint32_t i = st * ST + col;
     const bool valid = i < M;
-    const uint32_t il = valid ? i : M - 1;
-    const float px = xyz[(size_t)il * 3], py = xyz[(size_t)il * 3 + 1], pz = xyz[(size_t)il * 3 + 2];
-    const float dx = dirs[(size_t)il * 3], dy = dirs[(size_t)il * 3 + 1], dz = dirs[(size_t)il * 3 + 2];
-    const float g_s = valid ? gsig[i] : 0.f;
-    const float g_c0 = valid ? grgb[(size_t)i * 3] : 0.f, g_c1 = valid ? grgb[(size_t)i * 3 + 1] : 0.f,
-                g_c2 = valid ? grgb[(size_t)i * 3 + 2] : 0.f;
+    const Inputs in = nxt;
+    if (st + gridDim.x < nst) load_inputs(st + gridDim.x, nxt);
+    const float px = in.px, py = in.py, pz = in.pz, dx = in.dx, dy = in.dy, dz = in.dz;
+    const float g_s = in.g_s, g_c0 = in.g_c0, g_c1 = in.g_c1, g_c2 = in.g_c2;
+    // publish the features for the layer-0 weight gradient now (they are in registers); read after the last barrier
+    if (B::EARLY_F) {
+#pragma unroll
+      for (int ks = 0; ks < G::KS0; ks++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) Fs[(16 * ks + 8 * h + j) * LS + col] = in.fk[ks][j];
+    }
 
     // ---- recompute the forward chain from the saved fp16 features
     f32x16 acc0[G::OB];
@@ -152,13 +192,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     for (int ob = 0; ob < G::OB; ob++) acc0[ob] = zero16();
 #pragma unroll
     for (int ks = 0; ks < G::KS0; ks++) {
-      half8 fk = *reinterpret_cast<const half8*>(feats + (size_t)il * G::F + 16 * ks + 8 * h);
-      if (!valid) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
-      }
-#pragma unroll
-      for (int ob = 0; ob < G::OB; ob++) acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], fk, acc0[ob]);
+      for (int ob = 0; ob < G::OB; ob++)
+        acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], in.fk[ks], acc0[ob]);
     }
     Chain<C, H> ch;
     chain_tail<C, H, false>(w, lane, h, acc0, dx, dy, dz, ch);
@@ -275,16 +311,18 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     __syncthreads();
 
-    // ---- layer 0: X = F (natural k order), rows F..32*IB0-1 zero.  The features are re-read here (L2-hot)
-    // rather than kept in 4*KS0 registers through the whole backward chain.
+    // ---- layer 0: X = F (natural k order) from the feature stage written at the top of the super-tile
+    if (!B::EARLY_F) {   // atomic mode: re-read (L2-hot) into Xs, rows F..32*IB0-1 zero
+      const uint32_t il = valid ? i : M - 1;
 #pragma unroll
-    for (int ks = 0; ks < 2 * G::IB0; ks++) {
-      half8 fk;
+      for (int ks = 0; ks < 2 * G::IB0; ks++) {
+        half8 fk;
 #pragma unroll
-      for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
-      if (ks < G::KS0 && valid) fk = *reinterpret_cast<const half8*>(feats + (size_t)il * G::F + 16 * ks + 8 * h);
+        for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
+        if (ks < G::KS0 && valid) fk = *reinterpret_cast<const half8*>(feats + (size_t)il * G::F + 16 * ks + 8 * h);
 #pragma unroll
-      for (int j = 0; j < 8; j++) Xs[(16 * ks + 8 * h + j) * LS + col] = fk[j];
+        for (int j = 0; j < 8; j++) Xs[(16 * ks + 8 * h + j) * LS + col] = fk[j];
+      }
     }
 #pragma unroll
     for (int ib = 0; ib < G::OB; ib++) put_acc<LS>(Ys, ib, d1[ib], h, col);
@@ -292,7 +330,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int k = 0; k < B::A0; k++) {
       const int t = wv + NW * k;
-      if (t < B::NT0) dw0[k] = dw_tile<ST, LS>(Ys, Xs, t / G::IB0, t % G::IB0, r, h, dw0[k]);
+      if (t < B::NT0) dw0[k] = dw_tile<ST, LS>(Ys, B::EARLY_F ? Fs : Xs, t / G::IB0, t % G::IB0, r, h, dw0[k]);
     }
     // feature gradient dF^T = W0^T dH1^T
     if (!ATOMIC) {
