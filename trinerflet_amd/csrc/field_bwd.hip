@@ -424,12 +424,19 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   }
 }
 
-__global__ void k_slab_reduce(const float* __restrict__ slabs, int nslab, int nw, float* __restrict__ gradW) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nw) return;
+// gradW[e] += sum over the workgroups' slabs.  64 elements per workgroup, the slab loop split over 4 threads per element
+// (fixed order: deterministic), so 13.5 k weights give 212 workgroups instead of 53 long serial loops (61 -> ~20 us).
+__global__ void __launch_bounds__(256)
+k_slab_reduce(const float* __restrict__ slabs, int nslab, int nw, float* __restrict__ gradW) {
+  __shared__ float part[4][64];
+  const int le = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + le;
   float s = 0.f;
-  for (int k = 0; k < nslab; k++) s += slabs[(size_t)k * nw + e];
-  gradW[e] += s;
+  if (e < nw)
+    for (int k = grp; k < nslab; k += 4) s += slabs[(size_t)k * nw + e];
+  part[grp][le] = s;
+  __syncthreads();
+  if (grp == 0 && e < nw) gradW[e] += (part[0][le] + part[1][le]) + (part[2][le] + part[3][le]);
 }
 
 inline uint32_t bwd_blocks(uint32_t M) {
@@ -455,7 +462,7 @@ int launch_bwd_impl(const float* gsig, const float* grgb, const void* feats, con
   hipLaunchKernelGGL((k_field_bwd<C, H, NW, ATOMIC>), dim3(blocks), dim3(B::BW_THREADS), B::LDS_BYTES, st, gsig, grgb,
                      reinterpret_cast<const _Float16*>(feats), xyz, dirs, bound, M, (int)R,
                      reinterpret_cast<const half8*>(packed), grad_tm, slabs, m_actual, reinterpret_cast<_Float16*>(dfeat));
-  hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 255) / 256), dim3(256), 0, st, slabs, (int)blocks, (int)G::NW, gradW);
+  hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 63) / 64), dim3(256), 0, st, slabs, (int)blocks, (int)G::NW, gradW);
   return (int)hipGetLastError();
 }
 
