@@ -274,6 +274,18 @@ TNL_API int tnl_adam_l1_step_dev(float *p, float *grad, float *m, float *v, uint
                                  float *abs_sum, int zero_grad, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Background mix + MSE + gradient in one pass (csrc/loss.hip): pred = image + (1 - weights_sum) * bg
+ * (reconstruction/nerf/renderer.py:317), loss = mean over rays and channels of (pred - gt)^2
+ * (nerf/utils.py:595,633), grad_pred = d(scale * loss)/d pred, grad_weights_sum = -sum_c grad_pred * bg.
+ * bg = bg_rays[n] ([N,3], --train_rand_bg) if non-NULL else bg_color; inv_norm = 1 / (3 * rays in the global batch);
+ * scale_dev (device float, may be NULL) = the GradScaler's loss scale; mse_accum (device float) += this launch's share
+ * of the loss (the caller zeroes it).
+ * ------------------------------------------------------------------------------------------- */
+TNL_API int tnl_mse_loss(const float *image, const float *weights_sum, const float *gt_rgb, float bg_color,
+                         const float *bg_rays, uint32_t N, float inv_norm, const float *scale_dev, float *pred,
+                         float *grad_pred, float *grad_weights_sum, float *mse_accum, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Ray batches from a device-resident pixel pool.  One launch replaces get_rays over whole
  * images (reconstruction/nerf/utils.py:65-149), shuffle_data (CPU randperm + gather of every tensor, :228-236),
  * select_batch (slice + H2D, :238-243) and the background blend of train_step / eval_step (:559-577, :690-695).

@@ -140,6 +140,38 @@ def test_composite_train_fwd_bwd(cuda, rays):
     np.testing.assert_allclose(s_t.grad.cpu().numpy(), gs, rtol=1e-3, atol=2e-5 * scale)
 
 
+def test_composite_backward_covers_every_row_before_the_budget(cuda, rays):
+    """With a sample budget that drops the last rays (raymarching.cu:422), every row of the gradient buffers below
+    min(M, counter) is written by the backward kernel itself -- kept rays write theirs, the first dropped ray zeroes
+    the tail it still owns -- so a caller that ignores the rows behind the count needs no zero fill."""
+    from trinerflet_amd import _lib as L
+    from trinerflet_amd import raymarching
+    o, d, aabb, nears, fars = rays
+    bf = scene.sphere_bitfield(HG, CAS, BOUND, 0.8, 0.6)
+    N = o.shape[0]
+    noises = np.zeros(N, np.float32)
+    _, _, _, _, cr = cref.march_rays_train(o, d, BOUND, bf, CAS, HG, nears, fars, noises, N * 1024)
+    M = int(cr[0]) * 2 // 3                      # a budget that cuts a ray in the middle of the buffer
+    xr, dr, lr, rr, cr = cref.march_rays_train(o, d, BOUND, bf, CAS, HG, nears, fars, noises, M)
+    kept = rr[(rr[:, 2] > 0) & (rr[:, 1] + rr[:, 2] <= M)]
+    end_kept = int((kept[:, 1] + kept[:, 2]).max())
+    assert end_kept < M < int(cr[0])             # the first dropped ray owns [end_kept, M)
+    rng = np.random.default_rng(3)
+    sig = _t(rng.random(M).astype(np.float32) * 3, cuda)
+    rgb = _t(rng.random((M, 3)).astype(np.float32), cuda)
+    ws, dep, img = raymarching.composite_rays_train(sig, rgb, _t(lr[:M], cuda), _t(rr, cuda))
+    gs = torch.full((M,), float("nan"), device=cuda)
+    gc = torch.full((M, 3), float("nan"), device=cuda)
+    g_ws = torch.randn(N, device=cuda)
+    g_img = torch.randn(N, 3, device=cuda)
+    L.check(L.lib().tnl_composite_rays_train_backward(
+        L.ptr(g_ws), L.ptr(g_img), L.ptr(sig), L.ptr(rgb), L.ptr(_t(lr[:M], cuda)), L.ptr(_t(rr, cuda)), L.ptr(ws),
+        L.ptr(img), L.u32(M), L.u32(N), L.f32(1e-4), L.ptr(gs), L.ptr(gc), L.stream()), "composite_bwd")
+    assert torch.isfinite(gs).all() and torch.isfinite(gc).all()
+    assert float(gs[end_kept:].abs().sum()) == 0 and float(gc[end_kept:].abs().sum()) == 0
+    assert float(gs[:end_kept].abs().sum()) > 0
+
+
 def test_inference_loop(cuda, rays):
     """run_cuda's eval branch (renderer.py:324-374) with the GPU kernels vs the oracle, same sigma/rgb field."""
     from trinerflet_amd import raymarching

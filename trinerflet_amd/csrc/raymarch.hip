@@ -428,7 +428,16 @@ k_composite_train_bwd(const float* __restrict__ grad_weights_sum, const float* _
   if (n >= N) return;
   const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1],
                  num_steps = (uint32_t)rays[n * 3 + 2];
-  if (num_steps == 0 || offset + num_steps > M) return;
+  if (num_steps == 0 || offset + num_steps > M) {
+    // a ray dropped by the sample budget (raymarching.cu:422) may still own the tail [offset, M) of the buffers: its
+    // rows get no gradient.  Writing the zeros here lets a caller skip the zero fill of grad_sigmas / grad_rgbs
+    // (raymarching.py:283-284) when everything behind the sample count is ignored anyway.
+    for (uint32_t s = offset + lane; s < min(offset + num_steps, M); s += WAVE) {
+      grad_sigmas[s] = 0.f;
+      grad_rgbs[(size_t)s * 3] = 0.f; grad_rgbs[(size_t)s * 3 + 1] = 0.f; grad_rgbs[(size_t)s * 3 + 2] = 0.f;
+    }
+    return;
+  }
   const float gws = grad_weights_sum[index];
   const float gr = grad_image[index * 3], gg = grad_image[index * 3 + 1], gb = grad_image[index * 3 + 2];
   const float ws_final = weights_sum[index];

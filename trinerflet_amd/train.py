@@ -498,21 +498,23 @@ class TrainStep:
         L.check(lib.tnl_composite_rays_train_forward(L.ptr(sigma), L.ptr(rgb), L.ptr(deltas), L.ptr(rays), L.u32(M),
                                                      L.u32(N), L.f32(self.T_thresh), L.ptr(ws), L.ptr(depth),
                                                      L.ptr(image), L.stream()), "composite_rays_train_forward")
-        # image = image + (1 - ws) * bg (renderer.py:317); MSE mean over rays and channels (utils.py:595)
+        # image + (1 - ws) * bg (renderer.py:317), MSE mean over rays and channels (utils.py:595) and d(scaled loss):
+        # one launch (csrc/loss.hip)
         bg = self.bg if bg_color is None else bg_color
-        pred = image + (1 - ws).unsqueeze(-1) * bg
-        diff = pred - gt_rgb
-        mse_local = (diff * diff).sum() / (3.0 * n_glob)
-        g_pred = diff * (2.0 / (3.0 * n_glob)) * self.scale          # d(scaled loss)/d pred
-        if torch.is_tensor(bg) or bg != 0:
-            g_ws = -(g_pred * bg).sum(-1)
-        else:
-            g_ws = torch.zeros(N, dtype=torch.float32, device=self.dev)
+        pred = torch.empty(N, 3, dtype=torch.float32, device=self.dev)
+        g_pred = torch.empty(N, 3, dtype=torch.float32, device=self.dev)
+        g_ws = torch.empty(N, dtype=torch.float32, device=self.dev)
+        mse_local = torch.zeros((), dtype=torch.float32, device=self.dev)
+        bg_rays = bg.to(torch.float32).contiguous() if torch.is_tensor(bg) else None
+        L.check(lib.tnl_mse_loss(L.ptr(image), L.ptr(ws), L.ptr(gt_rgb.contiguous()), L.f32(0.0 if bg_rays is not None else bg),
+                                 L.ptr(bg_rays), L.u32(N), L.f32(1.0 / (3.0 * n_glob)), L.ptr(self.scale), L.ptr(pred),
+                                 L.ptr(g_pred), L.ptr(g_ws), L.ptr(mse_local), L.stream()), "mse_loss")
+        # rows behind the sample count are never read (m_actual) and the composite backward zeroes the in-buffer tail
+        # of a ray the budget dropped: no zero fill of the two gradient buffers (raymarching.py:283-284)
         g_sigma = torch.empty(M, dtype=torch.float32, device=self.dev)
         g_rgb = torch.empty(M, 3, dtype=torch.float32, device=self.dev)
-        g_sigma.zero_(); g_rgb.zero_()  # rows of dropped rays / budget padding (raymarching.py:283-284)
         self._mark("composite_fwd_loss")
-        L.check(lib.tnl_composite_rays_train_backward(L.ptr(g_ws), L.ptr(g_pred.contiguous()), L.ptr(sigma), L.ptr(rgb),
+        L.check(lib.tnl_composite_rays_train_backward(L.ptr(g_ws), L.ptr(g_pred), L.ptr(sigma), L.ptr(rgb),
                                                       L.ptr(deltas), L.ptr(rays), L.ptr(ws), L.ptr(image), L.u32(M),
                                                       L.u32(N), L.f32(self.T_thresh), L.ptr(g_sigma), L.ptr(g_rgb),
                                                       L.stream()), "composite_rays_train_backward")
