@@ -35,7 +35,8 @@ struct BwdGeom {
   static constexpr int BW_THREADS = 64 * NW;
   static constexpr int ST = 32 * NW;      // samples per super-tile
   static constexpr int LS = ST + 8;       // LDS row stride in halfs (16-B aligned rows)
-  static constexpr int XROWS = (32 * G::IB0 > H) ? 32 * G::IB0 : H;
+  static constexpr bool EARLY_F = !ATOMIC;   // features staged once per super-tile in their own LDS region (binned mode)
+  static constexpr int XROWS = EARLY_F ? H : ((32 * G::IB0 > H) ? 32 * G::IB0 : H);
   static constexpr int YROWS = H;
   static constexpr int STAGE_LD = G::F + 1;                       // floats per staged sample row
   static constexpr size_t XS_BYTES = (size_t)XROWS * LS * 2;
@@ -44,9 +45,11 @@ struct BwdGeom {
   static constexpr size_t W_BYTES = (size_t)G::NTOT * 1024;
   // the sample's features, published once per super-tile for the layer-0 weight gradient (rows F..32*IB0-1 stay zero)
   // (binned mode only: the atomic mode's fp32 staging area leaves no room at C = 48 and re-reads them instead)
-  static constexpr bool EARLY_F = !ATOMIC;
   static constexpr size_t FS_BYTES = EARLY_F ? (size_t)32 * G::IB0 * LS * 2 : 0;
-  static constexpr size_t BASE_BYTES = XS_BYTES + YS_BYTES + STAGE_BYTES + FS_BYTES;
+  // Double-buffered X / Y stages (layers alternate between the two pairs): the barrier that protected a stage from
+  // the next layer's writes disappears, one barrier per layer remains.  Only where it fits next to the weights.
+  static constexpr bool DB = EARLY_F && 2 * (XS_BYTES + YS_BYTES) + FS_BYTES + W_BYTES <= 160 * 1024;
+  static constexpr size_t BASE_BYTES = (DB ? 2 : 1) * (XS_BYTES + YS_BYTES) + STAGE_BYTES + FS_BYTES;
   static constexpr bool LDSW = BASE_BYTES + W_BYTES <= 160 * 1024;  // weights cached in LDS when they fit
   static constexpr size_t LDS_BYTES = BASE_BYTES + (LDSW ? W_BYTES : 0);
   static constexpr int NT0 = G::OB * G::IB0, NT1 = G::OB, NT2 = G::OB, NT3 = G::OB * G::OB, NT4 = G::OB;
@@ -112,10 +115,13 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   const uint32_t Mcap = M;   // row capacity: the plane stride of the plane-major dfeat output
   if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  _Float16* Xs = reinterpret_cast<_Float16*>(smem);
-  _Float16* Ys = reinterpret_cast<_Float16*>(smem + B::XS_BYTES);
-  float* stage_all = reinterpret_cast<float*>(smem + B::XS_BYTES + B::YS_BYTES);
-  _Float16* Fs = reinterpret_cast<_Float16*>(smem + B::XS_BYTES + B::YS_BYTES + B::STAGE_BYTES);
+  constexpr size_t XY = B::XS_BYTES + B::YS_BYTES;
+  _Float16* const Xb[2] = {reinterpret_cast<_Float16*>(smem), reinterpret_cast<_Float16*>(smem + (B::DB ? XY : 0))};
+  _Float16* const Yb[2] = {reinterpret_cast<_Float16*>(smem + B::XS_BYTES),
+                           reinterpret_cast<_Float16*>(smem + (B::DB ? XY : 0) + B::XS_BYTES)};
+  float* stage_all = reinterpret_cast<float*>(smem + (B::DB ? 2 : 1) * XY);
+  _Float16* Fs = reinterpret_cast<_Float16*>(smem + (B::DB ? 2 : 1) * XY + B::STAGE_BYTES);
+  auto sync_stage = [&]() { if (!B::DB) __syncthreads(); };   // stage reuse barrier, not needed when double-buffered
   const half8* w = packed;
   if (B::LDSW) {
     half8* wl = reinterpret_cast<half8*>(smem + B::BASE_BYTES);
@@ -209,6 +215,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       dz4[2] = g_c2 * c2 * (1.f - c2);
     }
     const half8 dz4f = acc_to_frag<false>(dz4, 0);
+    _Float16 *Xs = Xb[0], *Ys = Yb[0];
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<LS>(Xs, ks, ch.h4[ks], h, col);
     put_acc<LS>(Ys, 0, dz4, h, col);
@@ -227,9 +234,10 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       d4f[2 * ib] = acc_to_frag<false>(d4[ib], 0);
       d4f[2 * ib + 1] = acc_to_frag<false>(d4[ib], 1);
     }
-    __syncthreads();
+    sync_stage();
 
     // ---- layer 3
+    Xs = Xb[1]; Ys = Yb[1];
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<LS>(Xs, ks, ch.h3[ks], h, col);
 #pragma unroll
@@ -251,9 +259,10 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       d3f[2 * ib] = acc_to_frag<false>(d3[ib], 0);
       d3f[2 * ib + 1] = acc_to_frag<false>(d3[ib], 1);
     }
-    __syncthreads();
+    sync_stage();
 
     // ---- layer 2: X = z = [SH(16) | geo(15) | 0]
+    Xs = Xb[0]; Ys = Yb[0];
     {
       const half8 shf = sh_frag(dx, dy, dz, h);
       half8 geo;
@@ -283,9 +292,10 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     const float dlogit = g_s * expf(fminf(fmaxf(logit, -15.f), 15.f));  // trunc_exp backward (activation.py:14-17)
     half8 dof = acc_to_frag<false>(dzz, 1);
     if (h == 1) dof[7] = (_Float16)dlogit;
-    __syncthreads();
+    sync_stage();
 
     // ---- layer 1: X = H1, dY = dO (16 rows) + 16 zero rows
+    Xs = Xb[1]; Ys = Yb[1];
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<LS>(Xs, ks, ch.h1[ks], h, col);
 #pragma unroll
@@ -309,9 +319,10 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       d1f[2 * ib] = acc_to_frag<false>(d1[ib], 0);
       d1f[2 * ib + 1] = acc_to_frag<false>(d1[ib], 1);
     }
-    __syncthreads();
+    sync_stage();
 
     // ---- layer 0: X = F (natural k order) from the feature stage written at the top of the super-tile
+    Xs = Xb[0]; Ys = Yb[0];
     if (!B::EARLY_F) {   // atomic mode: re-read (L2-hot) into Xs, rows F..32*IB0-1 zero
       const uint32_t il = valid ? i : M - 1;
 #pragma unroll
