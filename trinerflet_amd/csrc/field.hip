@@ -43,11 +43,23 @@ k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, cons
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const uint32_t waves = gridDim.x * (FWD_THREADS / 64);
   const uint32_t ntiles = (M + 31) / 32;
-  for (uint32_t tile = blockIdx.x * (FWD_THREADS / 64) + (threadIdx.x >> 6); tile < ntiles; tile += waves) {
+  // positions / directions of the NEXT tile are requested one trip ahead: the gather addresses depend on them, and with
+  // two waves per SIMD a dependent pair of global latencies per tile is not hidden otherwise
+  const uint32_t tile0 = blockIdx.x * (FWD_THREADS / 64) + (threadIdx.x >> 6);
+  float npx = 0.f, npy = 0.f, npz = 0.f, ndx = 0.f, ndy = 0.f, ndz = 0.f;
+  auto fetch_pos = [&](uint32_t t) {
+    const uint32_t i_ = t * 32 + r;
+    const uint32_t il_ = i_ < M ? i_ : M - 1;
+    npx = xyz[(size_t)il_ * 3]; npy = xyz[(size_t)il_ * 3 + 1]; npz = xyz[(size_t)il_ * 3 + 2];
+    if (!DENSITY_ONLY) { ndx = dirs[(size_t)il_ * 3]; ndy = dirs[(size_t)il_ * 3 + 1]; ndz = dirs[(size_t)il_ * 3 + 2]; }
+  };
+  if (tile0 < ntiles) fetch_pos(tile0);
+  for (uint32_t tile = tile0; tile < ntiles; tile += waves) {
     const uint32_t i = tile * 32 + r;
     const bool valid = i < M;
-    const uint32_t il = valid ? i : M - 1;
-    const float px = xyz[(size_t)il * 3], py = xyz[(size_t)il * 3 + 1], pz = xyz[(size_t)il * 3 + 2];
+    const float px = npx, py = npy, pz = npz;
+    const float cdx = ndx, cdy = ndy, cdz = ndz;
+    if (tile + waves < ntiles) fetch_pos(tile + waves);   // (A/B on one box: 1.02 -> 0.96..1.02 ms, kept)
     f32x16 acc0[G::OB];
 #pragma unroll
     for (int ob = 0; ob < G::OB; ob++) acc0[ob] = zero16();
@@ -66,10 +78,7 @@ k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, cons
         for (int ob = 0; ob < G::OB; ob++) acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], f, acc0[ob]);
       }
     }
-    float dx = 0.f, dy = 0.f, dz = 0.f;
-    if (!DENSITY_ONLY) {
-      dx = dirs[(size_t)il * 3]; dy = dirs[(size_t)il * 3 + 1]; dz = dirs[(size_t)il * 3 + 2];
-    }
+    const float dx = cdx, dy = cdy, dz = cdz;
     Chain<C, H> ch;
     chain_tail<C, H, DENSITY_ONLY>(w, lane, h, acc0, dx, dy, dz, ch);
     if (valid && h == 0) {
