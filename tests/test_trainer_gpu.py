@@ -169,3 +169,29 @@ def test_stage_handoff_keeps_coarse_levels_and_trains_on(cuda, tmp_path):
     assert p2_start > p1 - 1.5, (p1, p2_start)
     t2.train(train, valid)
     assert t2.evaluate_one_epoch(valid)["PSNR"] > p2_start - 0.5
+
+
+def test_per_ray_background_equals_constant_background(cuda):
+    """--train_rand_bg hands TrainStep a per-ray [N,3] background (utils.py:568-570): with a constant tensor it must
+    reproduce the scalar background_color path; with random colours the epoch loop runs and the loss stays finite."""
+    from trinerflet_amd.train import TrainStep
+    from trinerflet_amd.trainer import Trainer
+    import copy
+    train, _ = _pools(cuda, n_cams=4, hw=32)
+    batch = train.batch(0, 1024, bg_color=0.3)
+    base = _model(cuda)
+    base.density_bitfield.copy_(torch.from_numpy(synthetic.sphere_bitfield(128, base.cascade, 1.5, 0.8, 0.0)).to(cuda))
+    noise = torch.rand(1024, device=cuda)
+    outs = []
+    for per_ray in (False, True):
+        m = copy.deepcopy(base)
+        ts = TrainStep(m, background_color=0.3, update_extra_interval=0)
+        m.mean_count = 0
+        bg = torch.full((1024, 3), 0.3, device=cuda) if per_ray else None
+        loss = ts.step(batch["rays_o"], batch["rays_d"], batch["gt_rgb"], noises=noise, bg_color=bg)
+        outs.append((float(loss), ts.last["image"].clone(), m.sigma_net[0].weight.detach().clone()))
+    assert abs(outs[0][0] - outs[1][0]) < 1e-7 and torch.equal(outs[0][1], outs[1][1])
+    assert torch.allclose(outs[0][2], outs[1][2], atol=1e-6)
+    tr = Trainer("rb", _model(cuda), lr=1e-2, iters=50, num_rays=1024, train_rand_bg=True, fast_training=True)
+    tr.train(train, None, max_epochs=2)
+    assert np.isfinite(tr.stats["loss"]).all() and tr.global_step == 2 * train.steps_per_epoch(1024)
