@@ -58,8 +58,13 @@ def test_reference_api_surface():
     for m in ("forward", "get_planes", "reset_cahce", "get_wavelet_features", "get_wavelet_features_upscaled",
               "get_lbound_scale", "sample_from_planes", "get_params"):
         assert hasattr(vol, m)
+    for m in ("get_grid_features", "get_params2", "init_upscale", "sample_from_planes_aux",
+              "sample_from_planes_aux_rotation", "build_planes"):
+        assert hasattr(vol, m)
+    rot = TriPlaneVolume(number_of_features=16, plane_resolution=512, inner_multi_res_scale=8, learn_rotation_axis=True)
+    assert tuple(rot.rotation_matrix.shape) == (16, 3, 3) and not rot.is_plain() and vol.is_plain()
     with pytest.raises(NotImplementedError):
-        TriPlaneVolume(number_of_features=16, plane_resolution=512, inner_multi_res_scale=8, learn_rotation_axis=True)
+        TriPlaneVolume(number_of_features=16, plane_resolution=512, inner_multi_res_scale=8, wavelet_base_resolution=64)
     from trinerflet_amd.nerf.network import NeRFNetwork
     net = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, triplane_channels=16,
                       triplane_resolution=256, triplane_wavelet_levels=4, density_thresh=10)
