@@ -18,9 +18,10 @@ from . import _lib as L
 
 
 class RayPool:
-    def __init__(self, poses, intrinsics, H, W, images=None, device="cuda", store_u8=False):
+    def __init__(self, poses, intrinsics, H, W, images=None, device="cuda", store_u8=False, color_space="srgb"):
         """poses [B,4,4] cam2world (NGP frame, provider.py:23-31), intrinsics (fx, fy, cx, cy), images [B,H,W,3|4]
-        float in [0,1] (or uint8), or None for a pose-only pool (test-time rendering)."""
+        float in [0,1] (or uint8), or None for a pose-only pool (test-time rendering).  color_space="linear"
+        converts the colour channels once at load time (utils.py:50-52,561-562 do it per batch)."""
         self.device = torch.device(device)
         self.poses = torch.as_tensor(poses, dtype=torch.float32).to(self.device).contiguous()
         assert self.poses.dim() == 3 and self.poses.shape[1:] == (4, 4)
@@ -33,6 +34,11 @@ class RayPool:
         if images is not None:
             images = torch.as_tensor(images)
             assert images.shape[:3] == (self.B, self.H, self.W) and images.shape[3] in (3, 4)
+            if color_space == "linear":
+                images = images.to(torch.float32) / (255.0 if images.dtype == torch.uint8 else 1.0)
+                rgb = images[..., :3]
+                images = torch.cat([torch.where(rgb < 0.04045, rgb / 12.92, ((rgb + 0.055) / 1.055) ** 2.4),
+                                    images[..., 3:]], -1)
             if images.dtype == torch.uint8:
                 self.u8 = True
             elif store_u8:
