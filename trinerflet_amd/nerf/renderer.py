@@ -240,28 +240,37 @@ class NeRFRenderer(nn.Module):
         cws = torch.empty((N + 255) // 256 + 2, dtype=torch.int32, device=dev)
         noises = torch.rand(N, dtype=torch.float32, device=dev) if perturb else None
         rows = state[3:4]
+
+        def iteration(nz):
+            L.check(lib.tnl_infer_plan(L.ptr(state), L.u32(N), L.u32(max_steps), L.stream()), "infer_plan")
+            L.check(lib.tnl_march_rays_dev(
+                L.ptr(state), L.u32(N), L.ptr(alive[0]), L.ptr(rays_t), L.ptr(rays_o), L.ptr(rays_d),
+                L.f32(self.bound), L.f32(dt_gamma), L.u32(max_steps), L.u32(self.cascade), L.u32(self.grid_size),
+                L.ptr(self.density_bitfield), L.ptr(fars), L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas),
+                L.ptr(nz), L.stream()), "march_rays_dev")
+            sigmas, rgbs = self.field_rows(xyzs, dirs, rows)
+            if self.density_scale != 1:
+                sigmas = self.density_scale * sigmas
+            L.check(lib.tnl_composite_rays_dev(
+                L.ptr(state), L.u32(N), L.f32(T_thresh), L.ptr(alive[0]), L.ptr(rays_t), L.ptr(sigmas),
+                L.ptr(rgbs), L.ptr(deltas), L.ptr(weights_sum), L.ptr(depth), L.ptr(image), L.stream()),
+                "composite_rays_dev")
+            L.check(lib.tnl_compact_rays_dev(L.ptr(state), L.u32(N), L.ptr(alive[0]), L.ptr(alive[1]),
+                                             L.ptr(cws), L.stream()), "compact_rays_dev")
+            alive.reverse()
+
+        def finished():
+            n_alive, _, step, _ = state.tolist()
+            return n_alive <= 0 or step >= max_steps
+
+        # (replaying the iterations as a captured hipGraph was tried: 24.9 vs 23.6 ms per 800x800 image -- the loop is
+        #  bound by the device work of its early, full-width iterations, not by the host's launch rate)
         it = 0
         while it < max_steps:                      # every iteration advances `step` by at least 1
             for _ in range(poll):
-                L.check(lib.tnl_infer_plan(L.ptr(state), L.u32(N), L.u32(max_steps), L.stream()), "infer_plan")
-                L.check(lib.tnl_march_rays_dev(
-                    L.ptr(state), L.u32(N), L.ptr(alive[0]), L.ptr(rays_t), L.ptr(rays_o), L.ptr(rays_d),
-                    L.f32(self.bound), L.f32(dt_gamma), L.u32(max_steps), L.u32(self.cascade), L.u32(self.grid_size),
-                    L.ptr(self.density_bitfield), L.ptr(fars), L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas),
-                    L.ptr(noises if it == 0 else None), L.stream()), "march_rays_dev")
-                sigmas, rgbs = self.field_rows(xyzs, dirs, rows)
-                if self.density_scale != 1:
-                    sigmas = self.density_scale * sigmas
-                L.check(lib.tnl_composite_rays_dev(
-                    L.ptr(state), L.u32(N), L.f32(T_thresh), L.ptr(alive[0]), L.ptr(rays_t), L.ptr(sigmas),
-                    L.ptr(rgbs), L.ptr(deltas), L.ptr(weights_sum), L.ptr(depth), L.ptr(image), L.stream()),
-                    "composite_rays_dev")
-                L.check(lib.tnl_compact_rays_dev(L.ptr(state), L.u32(N), L.ptr(alive[0]), L.ptr(alive[1]),
-                                                 L.ptr(cws), L.stream()), "compact_rays_dev")
-                alive.reverse()
+                iteration(noises if it == 0 else None)
                 it += 1
-            n_alive, _, step, _ = state.tolist()
-            if n_alive <= 0 or step >= max_steps:
+            if finished():
                 break
         return weights_sum, depth, image
 
