@@ -309,16 +309,19 @@ TNL_API int tnl_ray_batch(const float *poses, const float *intrinsics_host, uint
  * the survivor count back every iteration).  state = device int32[4] {n_alive, n_step, step, rows}; the caller
  * initialises {N, 0, 0, 0}.  One iteration = plan -> march -> (field forward over `rows` = state[3], passed as its
  * m_actual) -> composite -> compact.  Every launch is sized for N rays and reads the live sizes from `state`:
- *   tnl_infer_plan          n_alive = 0 once step >= max_steps; n_step = max(min(N / n_alive, 8), 1); rows = n_alive*n_step
+ *   tnl_infer_plan          n_alive = 0 once step >= max_steps; n_step = max(min(N / n_alive, 8), min_step) (min_step = 1 is
+ *                           the reference's rule; up to 8 regroups the same sample sequences into fewer, wider
+ *                           iterations: identical colours for every ray that ends before the max_steps cap; buffers
+ *                           then need min_step * N + 128 rows); rows = n_alive*n_step
  *   tnl_march_rays_dev      tnl_march_rays for the first n_alive entries of rays_alive; zero-fills the n_alive*n_step
  *                           sample rows it owns first (raymarching.py:337-339); noises may be NULL (no perturbation)
  *   tnl_composite_rays_dev  tnl_composite_rays
  *   tnl_compact_rays_dev    ordered compaction of the survivors into rays_alive_out, then step += n_step and
  *                           n_alive = survivors; workspace: (N + 255) / 256 + 2 int32
- * Buffers: xyzs/dirs [N + 128, 3], deltas [N + 128, 2] (n_alive * n_step <= N always).  The host may poll state[0]
+ * Buffers: xyzs/dirs [min_step*N + 128, 3], deltas [min_step*N + 128, 2] (n_alive * n_step <= max(min_step, 1) * N).  The host may poll state[0]
  * whenever it likes; iterations enqueued after the rays ran out do nothing.
  * ------------------------------------------------------------------------------------------- */
-TNL_API int tnl_infer_plan(int32_t *state, uint32_t N, uint32_t max_steps, void *stream);
+TNL_API int tnl_infer_plan(int32_t *state, uint32_t N, uint32_t max_steps, uint32_t min_step, void *stream);
 TNL_API int tnl_march_rays_dev(const int32_t *state, uint32_t N, const int32_t *rays_alive, const float *rays_t,
                                const float *rays_o, const float *rays_d, float bound, float dt_gamma,
                                uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid, const float *fars,

@@ -19,11 +19,13 @@ o, d = synthetic.get_rays(poses, pix)
 o, d = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
 with torch.no_grad():
     for max_steps in (1024, 4096):
-        for dev_loop in (False, True):
+        for dev_loop, min_step in ((False, 1), (True, 1), (True, 8)):
             for rep in range(3):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                out = m.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, device_loop=dev_loop)
+                out = m.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, device_loop=dev_loop,
+                               infer_min_step=min_step)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
-            print(f"max_steps {max_steps} device_loop {dev_loop}: {dt * 1e3:.1f} ms / image  ({640000 / dt / 1e6:.1f} M rays/s)")
+            print(f"max_steps {max_steps} device_loop {dev_loop} min_step {min_step}: {dt * 1e3:.1f} ms / image  "
+                  f"({640000 / dt / 1e6:.1f} M rays/s)")

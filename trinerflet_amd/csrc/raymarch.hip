@@ -549,12 +549,16 @@ struct InferState {
   int n_alive, n_step, step, rows;
 };
 
-__global__ void k_infer_plan(InferState* __restrict__ st, uint32_t N, uint32_t max_steps) {
+__global__ void k_infer_plan(InferState* __restrict__ st, uint32_t N, uint32_t max_steps, int min_step) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int n_alive = st->n_alive;
   if (st->step >= (int)max_steps) n_alive = 0;                       // `while step < max_steps`
   int n_step = 1;
-  if (n_alive > 0) n_step = max(min((int)(N / (uint32_t)n_alive), 8), 1);   // renderer.py:349
+  // renderer.py:349 is min_step = 1.  A larger floor regroups the same per-ray sample sequence into fewer, wider
+  // iterations: every ray still composites its samples in order and stops at the same one, so a ray that ends before
+  // the max_steps cap gets the identical colour; only rays still alive at the cap can see up to 7 samples more or
+  // fewer than under the reference's schedule (whose own last iteration overshoots the cap by up to 7 as well).
+  if (n_alive > 0) n_step = max(min((int)(N / (uint32_t)n_alive), 8), max(min_step, 1));
   st->n_alive = n_alive;
   st->n_step = n_step;
   st->rows = n_alive * n_step;
@@ -885,9 +889,9 @@ int tnl_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
   return launch_status();
 }
 
-int tnl_infer_plan(int32_t* state, uint32_t N, uint32_t max_steps, void* stream) {
+int tnl_infer_plan(int32_t* state, uint32_t N, uint32_t max_steps, uint32_t min_step, void* stream) {
   hipLaunchKernelGGL(k_infer_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<InferState*>(state), N,
-                     max_steps);
+                     max_steps, (int)min_step);
   return launch_status();
 }
 

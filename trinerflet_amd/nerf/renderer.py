@@ -179,7 +179,8 @@ class NeRFRenderer(nn.Module):
         elif kwargs.get("device_loop", True) and getattr(self, "_fused_ok", lambda: False)() \
                 and not torch.is_grad_enabled():
             weights_sum, depth, image = self._infer_device_loop(rays_o, rays_d, nears, fars, dt_gamma, perturb,
-                                                                max_steps, T_thresh)
+                                                                max_steps, T_thresh,
+                                                                min_step=kwargs.get("infer_min_step", 1))
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
             depth = torch.clamp(depth - nears, min=0) / (fars - nears)
             image = image.view(*prefix, 3)
@@ -220,7 +221,8 @@ class NeRFRenderer(nn.Module):
         results['weights_sum'] = weights_sum
         return results
 
-    def _infer_device_loop(self, rays_o, rays_d, nears, fars, dt_gamma, perturb, max_steps, T_thresh, poll=4):
+    def _infer_device_loop(self, rays_o, rays_d, nears, fars, dt_gamma, perturb, max_steps, T_thresh, poll=4,
+                           min_step=1):
         """The alive-ray loop of renderer.py:338-372 with its sizes on the device (include/trinerflet_hip.h,
         tnl_infer_plan ...): iterations are enqueued back to back, the host reads the state only every `poll`
         iterations to stop.  Same n_step rule, ray order and arithmetic as the host-driven loop below."""
@@ -234,15 +236,22 @@ class NeRFRenderer(nn.Module):
         state = torch.tensor([N, 0, 0, 0], dtype=torch.int32, device=dev)
         alive = [torch.arange(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev)]
         rays_t = nears.clone()
-        xyzs = torch.empty(N + 128, 3, dtype=torch.float32, device=dev)
-        dirs = torch.empty(N + 128, 3, dtype=torch.float32, device=dev)
-        deltas = torch.empty(N + 128, 2, dtype=torch.float32, device=dev)
+        # min_step: the reference starts with one sample per ray and iteration (n_step = max(min(N / n_alive, 8), 1));
+        # render(..., infer_min_step=8) regroups the same per-ray sample sequences into an eighth of the iterations
+        # (the set-up of 640 000 rays is paid ~60 times instead of ~470).  Rays that end before the max_steps cap get
+        # identical colours; the default 1 keeps the reference's schedule exactly.
+        min_step = max(1, min(int(min_step), 8))
+        cap = min_step * N + 128
+        xyzs = torch.empty(cap, 3, dtype=torch.float32, device=dev)
+        dirs = torch.empty(cap, 3, dtype=torch.float32, device=dev)
+        deltas = torch.empty(cap, 2, dtype=torch.float32, device=dev)
         cws = torch.empty((N + 255) // 256 + 2, dtype=torch.int32, device=dev)
         noises = torch.rand(N, dtype=torch.float32, device=dev) if perturb else None
         rows = state[3:4]
 
         def iteration(nz):
-            L.check(lib.tnl_infer_plan(L.ptr(state), L.u32(N), L.u32(max_steps), L.stream()), "infer_plan")
+            L.check(lib.tnl_infer_plan(L.ptr(state), L.u32(N), L.u32(max_steps), L.u32(min_step), L.stream()),
+                    "infer_plan")
             L.check(lib.tnl_march_rays_dev(
                 L.ptr(state), L.u32(N), L.ptr(alive[0]), L.ptr(rays_t), L.ptr(rays_o), L.ptr(rays_d),
                 L.f32(self.bound), L.f32(dt_gamma), L.u32(max_steps), L.u32(self.cascade), L.u32(self.grid_size),

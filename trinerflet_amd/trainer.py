@@ -67,7 +67,7 @@ class Trainer:
                  wavelet_regularization=0.0, background_color=0.0, train_rand_bg=False, fp16=True,
                  update_extra_interval=16, max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, use_checkpoint="latest",
                  max_keep_ckpt=2, eval_interval=1, fast_training=False, seed=0, dist_mode=None, process_group=None,
-                 mute=True, train_step_kwargs=None):
+                 mute=True, train_step_kwargs=None, infer_min_step=1):
         self.name, self.model, self.workspace = name, model, workspace
         self.lr, self.iters, self.warmup_steps, self.num_rays = lr, iters, warmup_steps, num_rays
         self.background_color, self.train_rand_bg = background_color, train_rand_bg
@@ -75,6 +75,7 @@ class Trainer:
         self.max_steps, self.dt_gamma, self.T_thresh = max_steps, dt_gamma, T_thresh
         self.max_keep_ckpt, self.eval_interval, self.fast_training = max_keep_ckpt, eval_interval, fast_training
         self.seed, self.mute = seed, mute
+        self.infer_min_step = infer_min_step   # 8: wider inference iterations (NeRFRenderer._infer_device_loop)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -201,7 +202,7 @@ class Trainer:
         data = pool.image_rays(index, bg_color=self.background_color)
         out = model.render(data["rays_o"].unsqueeze(0), data["rays_d"].unsqueeze(0), staged=True,
                            bg_color=self.background_color, perturb=perturb, dt_gamma=self.dt_gamma,
-                           max_steps=max_steps or self.max_steps)
+                           max_steps=max_steps or self.max_steps, infer_min_step=self.infer_min_step)
         H, W = pool.H, pool.W
         pred = out["image"].reshape(H, W, 3)
         depth = out["depth"].reshape(H, W)
