@@ -541,8 +541,10 @@ class TrainStep:
             self._mark("field_bwd")
             # The following batch's march + tile sort (ALU/latency-bound, few waves) start here, underneath the
             # HBM-bound tail of the step (tile reduction, adjoint IDWT; in the multi-GPU modes the collectives).
-            # Measured at base: started before the MFMA field kernels it costs them the same 0.5 ms; started under
-            # Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms stay exposed.
+            # Measured at base: started before the MFMA field kernels it costs them the same 0.5 ms (a field wave owns
+            # its SIMD's whole register file -- 480 / 2 x 242 registers -- so the march cannot co-reside with them and
+            # is time-sliced in); started under Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms
+            # stay exposed.  At the small configuration (dense tail 0.5 ms) 1 ms of the march stays exposed either way.
             self._prefetch_next(next_rays, march_on_side)
             self.nonfinite.zero_()
             F_.plane_grad_reduce(sort_ws, dfeat, xyzs, float(model.bound), C, R, g_cm, channel_major=True,
@@ -573,8 +575,10 @@ class TrainStep:
             self._mark("field_bwd")
             # The following batch's march + tile sort (ALU/latency-bound, few waves) start here, underneath the
             # HBM-bound tail of the step (tile reduction, adjoint IDWT; in the multi-GPU modes the collectives).
-            # Measured at base: started before the MFMA field kernels it costs them the same 0.5 ms; started under
-            # Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms stay exposed.
+            # Measured at base: started before the MFMA field kernels it costs them the same 0.5 ms (a field wave owns
+            # its SIMD's whole register file -- 480 / 2 x 242 registers -- so the march cannot co-reside with them and
+            # is time-sliced in); started under Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms
+            # stay exposed.  At the small configuration (dense tail 0.5 ms) 1 ms of the march stays exposed either way.
             self._prefetch_next(next_rays, march_on_side)
             if self.world > 1:
                 dist.all_reduce(self.mlp.grad, group=self.pg)
