@@ -35,6 +35,7 @@ WORKLOADS = {
     # name: (channels, resolution, wavelet scale, hidden, rays, lambda)
     "base": (32, 2048, 32, 64, 60000, 0.4),
     "small": (16, 1024, 16, 64, 60000, 0.2),
+    "large": (48, 2048, 32, 128, 60000, 0.6),
     "tiny": (16, 256, 4, 64, 4096, 0.2),
 }
 

@@ -178,6 +178,17 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   Inputs nxt;
   if (blockIdx.x < nst) load_inputs(blockIdx.x, nxt);
   for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
+    if (!B::LDSW) {
+      // Hidden 128: the 180 weight fragments do not fit in LDS next to the stages and are read from global memory
+      // (L2).  Keep the compiler from hoisting these loop-invariant loads out of the super-tile loop: it tried to hold
+      // them all in registers and spilled ~1000 per lane to scratch (18.3 -> 10.5 ms at C = 48 / hidden 128).
+      // That configuration stays spill-bound: the doubled chain plus 12 weight-gradient tiles per wave exceed the
+      // 512 registers, and ~400 scratch accesses per super-tile are exposed at one wave per SIMD.  Measured without
+      // gain: weight-gradient tiles split over 2 / 4 workgroups that each recompute the chain (27 / 47 ms), H1 / H3 /
+      // H4 kept in LDS stages instead of registers (16 ms), the weights streamed through a 56-KB LDS window in four
+      // phases per super-tile (10.4 ms: the operand latency is not what binds).
+      asm volatile("" : "+s"(w));
+    }
     const uint32_t i = st * ST + col;
     const bool valid = i < M;
     const Inputs in = nxt;
