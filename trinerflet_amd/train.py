@@ -156,8 +156,10 @@ class TrainStep:
         return {k: tot[k] / cnt[k] for k in tot}
 
     def invalidate_roi(self):
-        """Call after changing model.density_bitfield by hand (update_extra_state inside step() is tracked)."""
+        """Call after changing model.density_bitfield by hand (update_extra_state inside step() is tracked): the
+        occupancy window is recomputed and a march already started for the following batch is dropped."""
         self._roi_valid = False
+        self._prefetched = None
 
     def _roi10(self, s0=0):
         return None if self._roi is None else list(self._roi) + [self.C, s0]
