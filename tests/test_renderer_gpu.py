@@ -171,3 +171,22 @@ def test_device_driven_inference_loop_equals_host_driven(cuda):
         wide = m.render(o, d, staged=True, bg_color=0.5, perturb=False, max_steps=4096, infer_min_step=8)
     for k in ("image", "depth", "weights_sum"):
         assert torch.equal(torch.nan_to_num(ref[k], nan=-1.0), torch.nan_to_num(wide[k], nan=-1.0)), k
+
+
+def test_planes_get_gradient_right_after_a_grid_refresh(cuda):
+    """update_extra_state queries the field under no_grad; the texel-major plane copy it caches must not be handed to
+    the differentiable lookup of the same step (the reference refreshes the grid between get_planes() and
+    train_step, utils.py:1138-1147)."""
+    from trinerflet_amd import synthetic
+    m = _model(cuda)
+    m.train()
+    m.encoder.reset_cahce()
+    m.encoder.get_planes()
+    m.update_extra_state()
+    o, d = synthetic.training_rays(256, n_cams=2, seed=3)
+    out = m.render(torch.from_numpy(o).to(cuda)[None], torch.from_numpy(d).to(cuda)[None], staged=False, bg_color=0,
+                   perturb=True, force_all_rays=True)
+    out["image"].sum().backward()
+    g = m.encoder.planes_features.grad
+    assert g is not None and float(g.abs().sum()) > 0
+    assert float(m.encoder.planes_features_wavelet_coefs[0].grad.abs().sum()) > 0

@@ -406,7 +406,10 @@ class TriPlaneVolume(torch.nn.Module):
         if not self.is_plain():
             raise RuntimeError("the texel-major fast path only exists for the plain three-plane lookup")
         planes = self.get_planes()
-        if self._planes_tm is None:
+        # A copy made under no_grad (the density-grid refresh queries the field inside @torch.no_grad) must not be
+        # served to a later differentiable lookup: the planes would silently get no gradient on that step.
+        want_grad = torch.is_grad_enabled() and planes.requires_grad
+        if self._planes_tm is None or (want_grad and not self._planes_tm.requires_grad):
             self._planes_tm = _ToTexelMajor.apply(planes, self.plane_dtype == torch.float16)
         return self._planes_tm
 
