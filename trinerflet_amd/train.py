@@ -268,10 +268,13 @@ class TrainStep:
                 enc.last_used_planes = None
                 enc._planes_tm = None
                 return half_roi_into_texel_major(planes, self._tm_full, self._roi10())
-            enc.last_used_planes = planes
             if planes.dtype == torch.float16:
+                # the (3,C,R,R) fp32 planes never exist on this path: only the sampler's copy is installed in the
+                # encoder's cache (get_planes() rebuilds on demand; get_planes_texel_major() serves this copy)
+                enc.last_used_planes = None
                 enc._planes_tm = half_to_texel_major(planes)
             else:
+                enc.last_used_planes = planes
                 enc._planes_tm = _ToTexelMajor.apply(planes, enc.plane_dtype == torch.float16)
             self._tm_full = enc._planes_tm if self.use_roi else None
         return enc._planes_tm

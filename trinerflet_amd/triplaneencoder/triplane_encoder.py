@@ -405,12 +405,11 @@ class TriPlaneVolume(torch.nn.Module):
         """[3,R,R,C] copy of get_planes() in `plane_dtype`, cached with it (what the samplers read)."""
         if not self.is_plain():
             raise RuntimeError("the texel-major fast path only exists for the plain three-plane lookup")
-        planes = self.get_planes()
-        # A copy made under no_grad (the density-grid refresh queries the field inside @torch.no_grad) must not be
-        # served to a later differentiable lookup: the planes would silently get no gradient on that step.
-        want_grad = torch.is_grad_enabled() and planes.requires_grad
+        # A copy made under no_grad (the density-grid refresh queries the field inside @torch.no_grad; TrainStep installs
+        # its own) must not be served to a later differentiable lookup: the planes would silently get no gradient.
+        want_grad = torch.is_grad_enabled() and self.planes_features.requires_grad
         if self._planes_tm is None or (want_grad and not self._planes_tm.requires_grad):
-            self._planes_tm = _ToTexelMajor.apply(planes, self.plane_dtype == torch.float16)
+            self._planes_tm = _ToTexelMajor.apply(self.get_planes(), self.plane_dtype == torch.float16)
         return self._planes_tm
 
     def reset_cahce(self):
