@@ -124,3 +124,63 @@ def test_two_ranks_equal_one(cuda, mode):
         # Adam's early steps are sign-like (eps = 1e-15): compare where the parameter moved consistently
         frac = np.mean(np.abs(a - b) > 2e-3)                     # 2 steps x lr 1e-2: a flipped sign moves 2e-2
         assert frac < 5e-3, (k, frac)
+
+
+# ---- the occupancy window / gradient-support chain under rank sharding (R = 256: window and rectangles are active)
+def _build_roi(dev):
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=1.0, cuda_ray=True, density_thresh=10, hidden_dim=H,
+                    hidden_dim_color=H, triplane_channels=C, triplane_resolution=256, triplane_wavelet_levels=4,
+                    wavelet_type="bior6.8").to(dev)
+    synthetic.init_field_parameters(m, seed=3)
+    m.density_bitfield.copy_(torch.from_numpy(synthetic.sphere_bitfield(128, 1, 1.0, 0.4, 0.0)).to(dev))
+    m.mean_count = 0
+    return m
+
+
+def _run_roi(mode, rank, world):
+    from trinerflet_amd.train import TrainStep
+    from trinerflet_amd import distributed as D
+    dev = torch.device("cuda:0")
+    n = 2048
+    o, d = synthetic.training_rays(n, n_cams=4, seed=7)
+    gt = synthetic.target_colors(d)
+    noise = np.random.default_rng(0).random(n).astype(np.float32)
+    lo, hi = D.shard_rays(n, world, rank)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev)
+    m = _build_roi(dev)
+    bf = m.density_bitfield.clone()
+    ts = TrainStep(m, lr=1e-2, wavelet_regularization=LAM, iters=1000, fp16=True, update_extra_interval=4, dist_mode=mode)
+    ts.post_refresh = lambda: m.density_bitfield.copy_(bf)          # keep the analytic occupancy
+    losses = []
+    for it in range(6):
+        losses.append(float(ts.step(t(o), t(d), t(gt), noises=t(noise), n_global_rays=n)))
+        if it % 4 != 0:
+            assert ts._roi is not None and ts._roi[6] < 256 and ts._rect_ok and ts._rects[0] is not None
+    ts.sync_sharded_parameters()
+    return losses, {k: v.detach().cpu().numpy() for k, v in m.named_parameters()}
+
+
+def _roi_worker(rank, port, mode, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        torch.cuda.set_device(0)
+        out[rank] = _run_roi(mode, rank, 2)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+def test_two_ranks_with_occupancy_window(cuda, mode):
+    ref_losses, ref_params = _run_roi(None, 0, 1)
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_roi_worker, args=(port, mode, out), nprocs=2, join=True)
+    (l0, p0), (l1, p1) = out[0], out[1]
+    assert np.allclose(l0, l1, rtol=1e-6) and np.allclose(l0, ref_losses, rtol=3e-3), (l0, l1, ref_losses)
+    for k in ref_params:
+        assert np.array_equal(p0[k], p1[k]), k                       # replicas stay identical
+        frac = np.mean(np.abs(p0[k] - ref_params[k]) > 2e-3)         # sign-like Adam steps: see test_two_ranks_equal_one
+        assert frac < 2e-2, (k, frac)
