@@ -184,3 +184,46 @@ def test_two_ranks_with_occupancy_window(cuda, mode):
         assert np.array_equal(p0[k], p1[k]), k                       # replicas stay identical
         frac = np.mean(np.abs(p0[k] - ref_params[k]) > 2e-3)         # sign-like Adam steps: see test_two_ranks_equal_one
         assert frac < 2e-2, (k, frac)
+
+
+# ---- the Trainer loop on two ranks: rays of every batch split over the ranks, evaluation striped over the images
+def _trainer_worker(rank, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        torch.cuda.set_device(0)
+        out[rank] = _run_trainer(2)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_trainer(world):
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    from trinerflet_amd.raypool import RayPool
+    from trinerflet_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    poses, intr, images = synthetic.sphere_dataset(8, 48, 48, seed=1)
+    train = RayPool(poses[2:], intr, 48, 48, images[2:], device=dev)
+    valid = RayPool(poses[:2], intr, 48, 48, images[:2], device=dev)
+    torch.manual_seed(0)
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, density_thresh=10, hidden_dim=64,
+                    hidden_dim_color=64, triplane_channels=16, triplane_resolution=128, triplane_wavelet_levels=2,
+                    wavelet_type="bior6.8").to(dev)
+    tr = Trainer("d", m, lr=1e-2, iters=200, num_rays=2048, wavelet_regularization=0.05, fast_training=True,
+                 dist_mode="sharded" if world > 1 else None)
+    tr.train(train, None, max_epochs=6)
+    ev = tr.evaluate_one_epoch(valid)
+    return tr.stats["loss"], ev["PSNR"], float(m.sigma_net[0].weight.detach().abs().sum())
+
+
+def test_trainer_on_two_ranks(cuda):
+    ref_loss, ref_psnr, _ = _run_trainer(1)
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_trainer_worker, args=(port, out), nprocs=2, join=True)
+    (l0, p0, w0), (l1, p1, w1) = out[0], out[1]
+    assert l0 == l1 and p0 == p1 and w0 == w1                        # the replicas agree exactly
+    assert l0[-1] < 0.5 * l0[0]
+    np.testing.assert_allclose(l0, ref_loss, rtol=0.15)              # same training, rays merely split over two ranks
+    assert abs(p0 - ref_psnr) < 1.0, (p0, ref_psnr)
