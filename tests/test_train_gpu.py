@@ -164,3 +164,34 @@ def test_scaler_skips_on_overflow(cuda):
     assert float(ts.scale) == 2.0 ** 39
     for n, p in m.named_parameters():
         assert torch.equal(p.detach(), before[n]), n
+
+
+def test_train_parity_mode_fp32_planes_and_unscaled_loss(cuda):
+    """`plane_dtype=torch.float32` ("train-parity mode": fp32 texels, no occupancy window) and `fp16=False` (no
+    GradScaler): the same step as the default fast mode up to the fp16 rounding of the texels."""
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    from trinerflet_amd.train import TrainStep
+    o, d = synthetic.training_rays(N, n_cams=4, seed=7)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    gt = t(synthetic.target_colors(d))
+    noise = t(np.random.default_rng(0).random(N).astype(np.float32))
+    bf = t(synthetic.sphere_bitfield(128, 2, BOUND, 0.8, 0.55))
+    losses = {}
+    for tag, kw, fp16 in (("fast", {}, True), ("fp32planes", dict(plane_dtype=torch.float32), True),
+                          ("noscaler", {}, False)):
+        torch.manual_seed(0)
+        m = NeRFNetwork(encoding="triplane_wavelet", bound=BOUND, cuda_ray=True, density_thresh=10, hidden_dim=H,
+                        hidden_dim_color=H, triplane_channels=C, triplane_resolution=R, triplane_wavelet_levels=SCALE,
+                        wavelet_type="bior6.8", **kw).to(cuda)
+        synthetic.init_field_parameters(m, seed=3)
+        m.density_bitfield.copy_(bf)
+        ts = TrainStep(m, lr=1e-2, wavelet_regularization=LAM, fp16=fp16, update_extra_interval=0)
+        m.mean_count = 0
+        ls = [float(ts.step(t(o), t(d), gt, noises=noise)) for _ in range(3)]
+        assert np.isfinite(ls).all() and ls[-1] < ls[0]
+        assert float(ts.last["found_inf"]) == 0.0
+        if not fp16:
+            assert float(ts.scale) == 1.0
+        losses[tag] = ls
+    np.testing.assert_allclose(losses["fp32planes"], losses["fast"], rtol=2e-3)
+    np.testing.assert_allclose(losses["noscaler"], losses["fast"], rtol=2e-3)
