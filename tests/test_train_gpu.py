@@ -195,3 +195,37 @@ def test_train_parity_mode_fp32_planes_and_unscaled_loss(cuda):
         losses[tag] = ls
     np.testing.assert_allclose(losses["fp32planes"], losses["fast"], rtol=2e-3)
     np.testing.assert_allclose(losses["noscaler"], losses["fast"], rtol=2e-3)
+
+
+@pytest.mark.parametrize("force_modular", [False, True])
+def test_reference_loop_under_autocast(cuda, force_modular):
+    """The reference wraps train_step in torch.cuda.amp.autocast(fp16) (utils.py:1162): the drop-in modules must run
+    there, fused and modular (nn.Linear in fp16, everything else fp32 as the reference's custom_fwd casts dictate)."""
+    m = _model(cuda)
+    m.force_modular = force_modular
+    m.train()
+    m.density_bitfield.copy_(torch.from_numpy(synthetic.sphere_bitfield(128, 2, BOUND, 0.8, 0.55)).to(cuda))
+    m.mean_count = 0
+    o, d = synthetic.training_rays(N, n_cams=4, seed=7)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    gt = t(synthetic.target_colors(d))
+    opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    scaler = torch.amp.GradScaler("cuda")
+    losses = []
+    for it in range(4):
+        m.encoder.reset_cahce(); m.encoder.get_planes()
+        if it == 0:
+            with torch.autocast("cuda", dtype=torch.float16):
+                m.update_extra_state()
+            m.density_bitfield.copy_(torch.from_numpy(synthetic.sphere_bitfield(128, 2, BOUND, 0.8, 0.55)).to(cuda))
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = m.render(t(o)[None], t(d)[None], staged=False, bg_color=0, perturb=True, force_all_rays=True)
+            loss = ((out["image"][0] - gt) ** 2).mean()
+            m.encoder.reset_cahce()
+            scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(float(loss))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
