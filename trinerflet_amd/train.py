@@ -476,6 +476,10 @@ class TrainStep:
                 # every rank evaluates 1/world of the candidate cells; the all-gather keeps the replicas' grids (hence
                 # bitfield, occupancy window and collective sizes) bit-identical
                 model.update_extra_state(shard=(self.rank, self.world, lambda t: D.all_gather_slices(t, self.pg)))
+                # one sample budget for all ranks: the mean of the ranks' mean counts
+                mc = torch.tensor([float(model.mean_count)], dtype=torch.float64, device=self.dev)
+                dist.all_reduce(mc, group=self.pg)
+                model.mean_count = int(mc.item() / self.world)
             else:
                 model.update_extra_state()
             if self.post_refresh is not None:
