@@ -110,3 +110,12 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b|oracle/_build|trinerflet_oracle", text, re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_ray_pool_has_no_cpu_path():
+    import numpy as np
+    from trinerflet_amd.raypool import RayPool
+    pool = RayPool(np.tile(np.eye(4, dtype=np.float32), (1, 1, 1)), (4.0, 4.0, 2.0, 2.0), 4, 4,
+                   np.zeros((1, 4, 4, 3), np.float32), device="cpu")
+    with pytest.raises(RuntimeError):
+        pool.batch(0, 8)

@@ -66,6 +66,7 @@ class RayPool:
 
     # -- batches --------------------------------------------------------------------------------------------
     def _launch(self, pix, first, perm, n, bg_color, bg_rand, want_gt, want_pix):
+        L.require_cuda(self.poses, self.images, pix, bg_rand)   # no CPU path: the batch is made by csrc/rays.hip
         lib = L.lib()
         rays_o = torch.empty(n, 3, dtype=torch.float32, device=self.device)
         rays_d = torch.empty(n, 3, dtype=torch.float32, device=self.device)
