@@ -172,12 +172,11 @@ def main():
     for i in range(args.warmup):
         one_step(model, ts, bitfield, batches[i % nb], mean_count, batches[(i + 1) % nb])
 
-    ts.section_events = [] if True else None
+    ts.section_events = []   # HIP events around every stage of the timed steps (TrainStep._mark)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    samples = 0
     for i in range(args.steps):
         one_step(model, ts, bitfield, batches[(args.warmup + i) % nb], mean_count, batches[(args.warmup + i + 1) % nb])
     torch.cuda.synchronize()
