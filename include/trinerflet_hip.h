@@ -179,11 +179,13 @@ TNL_API uint32_t tnl_field_packed_bytes(uint32_t C, uint32_t Hd, uint32_t Hc);
 TNL_API int tnl_field_pack(const float *W0, const float *W1, const float *W2, const float *W3,
                            const float *W4, uint32_t C, uint32_t Hd, uint32_t Hc, void *packed,
                            void *stream);
-/* sigma:[M] rgb:[M,3] fp32.  feats_save (fp16 [M,3C], may be NULL) keeps the interpolated
- * features for the backward pass.  dirs == NULL or rgb == NULL: density only (NeRFNetwork.density,
+/* sigma:[M] rgb:[M,3] fp32.  feats_save (tnl_field_feats_save_bytes(M, C, Hd) bytes, may be NULL) keeps
+ * the interpolated features (fp16 [M,3C]) for the backward pass, followed for hidden 128 by the 16
+ * sigma-net outputs per sample (fp16 [M,16]) that the colour half of the split backward starts from.  dirs == NULL or rgb == NULL: density only (NeRFNetwork.density,
  * network.py:149-166); with dirs == NULL and rgb != NULL, rgb receives the 15 geo features ([M,15]).
  * m_actual (device int32, may be NULL): rows >= min(M, *m_actual) are skipped -- march_rays_train's
  * counter[0], so the zero rows that pad the sample buffer to its budget M cost nothing. */
+TNL_API uint32_t tnl_field_feats_save_bytes(uint32_t M, uint32_t C, uint32_t Hd);
 TNL_API int tnl_field_forward(const void *planes_tm, int half_in, const float *xyz, const float *dirs,
                               float bound, uint32_t M, uint32_t C, uint32_t R, uint32_t Hd,
                               uint32_t Hc, const void *packed, float *sigma, float *rgb,
@@ -191,7 +193,9 @@ TNL_API int tnl_field_forward(const void *planes_tm, int half_in, const float *x
 /* grad_sigma:[M], grad_rgb:[M,3] -> grad_tm:[3,R,R,C] fp32 (atomic, caller zero-fills) and
  * gradW:[Hd*3C + 16*Hd + Hc*31 + Hc*Hc + 3*Hc] fp32 in nn.Linear layout, concatenated W0..W4
  * (accumulated, caller zero-fills); workspace bytes from tnl_field_backward_workspace.  sigma / rgb may be
- * NULL (the chain is recomputed from feats_save). */
+ * NULL (the chain is recomputed from feats_save), except that hidden 128 with dfeat_half != NULL needs
+ * sigma (its two-launch backward reads exp(logit) instead of recomputing the sigma net twice).  M must
+ * be the M of the forward call that filled feats_save. */
 TNL_API uint32_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint32_t Hc);
 TNL_API int tnl_field_backward(const float *grad_sigma, const float *grad_rgb, const float *sigma,
                                const float *rgb, const void *feats_save, const float *xyz,

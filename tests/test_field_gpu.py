@@ -119,7 +119,7 @@ def test_network_fused_equals_modular(cuda):
     assert float(rel.median()) < 1e-3 and float(rel.max()) < 2e-2
 
 
-@pytest.mark.parametrize("C,H,R,M", [(32, 64, 96, 6000), (16, 64, 64, 2500)])
+@pytest.mark.parametrize("C,H,R,M", [(32, 64, 96, 6000), (16, 64, 64, 2500), (48, 128, 64, 5003)])
 def test_binned_plane_gradient_equals_atomic(cuda, C, H, R, M):
     """TrainStep's atomic-free path (dF as fp16 -> tile-sorted LDS accumulation) against the atomic scatter
     and the oracle; includes border / out-of-range samples (clamped footprints) and a device-side row count."""
@@ -142,7 +142,12 @@ def test_binned_plane_gradient_equals_atomic(cuda, C, H, R, M):
     g_bin = torch.full((3, R, R, C), float("nan"), device=cuda)      # every tile must be overwritten
     w_bin = torch.zeros(nW, device=cuda)
     dfeat = torch.empty(3, M, C, dtype=torch.float16, device=cuda)      # plane-major [3,M,C]
-    gfield.field_backward(a.to(cuda), b.to(cuda), None, None, feats, xg, dg, packed, bound, C, R, H, g_bin, w_bin,
+    if H > 64:   # the two-launch backward of the hidden-128 network reads sigma and says so when it is missing
+        with pytest.raises(RuntimeError):
+            gfield.field_backward(a.to(cuda), b.to(cuda), None, None, feats, xg, dg, packed, bound, C, R, H, g_bin,
+                                  w_bin, m_actual=m_act, dfeat=dfeat)
+        w_bin.zero_()
+    gfield.field_backward(a.to(cuda), b.to(cuda), s, None, feats, xg, dg, packed, bound, C, R, H, g_bin, w_bin,
                           m_actual=m_act, dfeat=dfeat)
     gfield.plane_grad_binned(dfeat, xg, bound, C, R, g_bin, m_actual=m_act)
     assert torch.isfinite(g_bin).all()

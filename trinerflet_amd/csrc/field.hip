@@ -30,7 +30,8 @@ template <int C, int H, bool HALFP, bool DENSITY_ONLY>
 __global__ void __launch_bounds__(FWD_THREADS)
 k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, const float* __restrict__ dirs,
             float bound, uint32_t M, int R, const half8* __restrict__ packed, float* __restrict__ sigma,
-            float* __restrict__ rgb, _Float16* __restrict__ feats_save, const int32_t* __restrict__ m_actual) {
+            float* __restrict__ rgb, _Float16* __restrict__ feats_save, _Float16* __restrict__ geo_save,
+            const int32_t* __restrict__ m_actual) {
   using G = FieldGeom<C, H>;
   if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
   if (M == 0) return;
@@ -80,7 +81,14 @@ k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, cons
     }
     const float dx = cdx, dy = cdy, dz = cdz;
     Chain<C, H> ch;
-    chain_tail<C, H, DENSITY_ONLY>(w, lane, h, acc0, dx, dy, dz, ch);
+    chain_tail<C, H, DENSITY_ONLY>(w, w, lane, h, acc0, dx, dy, dz, ch);
+    if (!DENSITY_ONLY && geo_save != nullptr && valid) {
+      // hidden 128: the colour half of the split backward starts from the 16 sigma-net outputs instead of recomputing them
+      half8 g;
+#pragma unroll
+      for (int j = 0; j < 8; j++) g[j] = (_Float16)ch.o8[j];
+      *reinterpret_cast<half8*>(geo_save + (size_t)i * 16 + 8 * h) = g;
+    }
     if (valid && h == 0) {
       sigma[i] = expf(ch.o8[0]);  // trunc_exp forward (activation.py:9-10)
       if (!DENSITY_ONLY) {
@@ -129,9 +137,10 @@ int launch_fwd(const void* planes, int half_in, const float* xyz, const float* d
   if (blocks > 2048) blocks = 2048;
   const half8* pk = reinterpret_cast<const half8*>(packed);
   _Float16* fs = reinterpret_cast<_Float16*>(feats_save);
+  _Float16* gs = (H > 64 && fs != nullptr) ? fs + (size_t)M * G::F : nullptr;   // see tnl_field_feats_save_bytes
 #define TNL_LAUNCH(HP, DO)                                                                                        \
   hipLaunchKernelGGL((k_field_fwd<C, H, HP, DO>), dim3(blocks), dim3(FWD_THREADS), (DO ? G::F2 : G::NF) * 1024, st, \
-                     planes, xyz, dirs, bound, M, (int)R, pk, sigma, rgb, fs, m_actual)
+                     planes, xyz, dirs, bound, M, (int)R, pk, sigma, rgb, fs, gs, m_actual)
   if (density_only) {
     if (half_in) TNL_LAUNCH(true, true); else TNL_LAUNCH(false, true);
   } else {
@@ -152,6 +161,10 @@ uint32_t tnl_field_packed_bytes(uint32_t C, uint32_t Hd, uint32_t Hc) {
   if (C == 32 && Hd == 64) return FieldGeom<32, 64>::NTOT * 1024;
   if (C == 48 && Hd == 128) return FieldGeom<48, 128>::NTOT * 1024;
   return 0;
+}
+
+uint32_t tnl_field_feats_save_bytes(uint32_t M, uint32_t C, uint32_t Hd) {
+  return M * (3 * C + (Hd > 64 ? 16 : 0)) * 2;
 }
 
 int tnl_field_pack(const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, uint32_t C,

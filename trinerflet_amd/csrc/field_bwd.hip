@@ -28,24 +28,31 @@ namespace {
 // NW waves per workgroup, 32 samples per wave.  Measured: the kernel needs ~480 registers per lane (dW accumulators
 // + the recomputed chain), i.e. one wave per SIMD, and is VALU-issue-bound there; an 8-wave variant capped at 256
 // registers (two waves per SIMD) spills 90 VGPRs to scratch and runs 1.9x SLOWER (2.72 vs 1.46 ms), so NW = 4.
-template <int C, int H, int NW, bool ATOMIC>
+template <int C, int H, int NW, bool ATOMIC, int PART = 0>
 struct BwdGeom {
   using G = FieldGeom<C, H>;
   static constexpr int BW_WAVES = NW;
   static constexpr int BW_THREADS = 64 * NW;
   static constexpr int ST = 32 * NW;      // samples per super-tile
   static constexpr int LS = ST + 8;       // LDS row stride in halfs (16-B aligned rows)
-  static constexpr bool EARLY_F = !ATOMIC;   // features staged once per super-tile in their own LDS region (binned mode)
+  // features staged once per super-tile in their own LDS region (binned mode).  PART 2 (sigma half of the split launch)
+  // instead keeps them in registers and stages them into the X region for layer 0, which leaves room for its 80
+  // weight fragments in LDS.
+  static constexpr bool EARLY_F = !ATOMIC && PART != 2;
   static constexpr int XROWS = EARLY_F ? H : ((32 * G::IB0 > H) ? 32 * G::IB0 : H);
   static constexpr int YROWS = H;
   static constexpr int STAGE_LD = G::F + 1;                       // floats per staged sample row
   static constexpr size_t XS_BYTES = (size_t)XROWS * LS * 2;
   static constexpr size_t YS_BYTES = (size_t)YROWS * LS * 2;
   static constexpr size_t STAGE_BYTES = ATOMIC ? (size_t)BW_WAVES * 32 * STAGE_LD * 4 : 0;
-  static constexpr size_t W_BYTES = (size_t)G::NTOT * 1024;
+  // fragments a launch touches: everything, or for PART 2 the forward layer-0 range [F0, F1) and the transposed
+  // layer-1 / layer-0 range [T1, NTOT)
+  // PART 1 keeps [F3, T1) = layers 3, 4 forward and 4, 3, 2 transposed in LDS and reads layers 0..2 forward from L2.
+  static constexpr int NFRAG = PART == 2 ? (G::F1 - G::F0) + (G::NTOT - G::T1) : (PART == 1 ? G::T1 - G::F3 : G::NTOT);
+  static constexpr size_t W_BYTES = (size_t)NFRAG * 1024;
   // the sample's features, published once per super-tile for the layer-0 weight gradient (rows F..32*IB0-1 stay zero)
   // (binned mode only: the atomic mode's fp32 staging area leaves no room at C = 48 and re-reads them instead)
-  static constexpr size_t FS_BYTES = EARLY_F ? (size_t)32 * G::IB0 * LS * 2 : 0;
+  static constexpr size_t FS_BYTES = EARLY_F && PART != 1 ? (size_t)32 * G::IB0 * LS * 2 : 0;
   // Double-buffered X / Y stages (layers alternate between the two pairs): the barrier that protected a stage from
   // the next layer's writes disappears, one barrier per layer remains.  Only where it fits next to the weights.
   static constexpr bool DB = EARLY_F && 2 * (XS_BYTES + YS_BYTES) + FS_BYTES + W_BYTES <= 160 * 1024;
@@ -103,14 +110,24 @@ __device__ __forceinline__ void slab_tile(float* slab, int off, int out_dim, int
   }
 }
 
-template <int C, int H, int NW, bool ATOMIC>
+// PART splits the layers over two launches for the hidden-128 network, whose single-launch form needs ~650 registers
+// per lane (12 weight-gradient tiles per wave + the doubled chain) and spills:
+//   PART 1 = colour net: recompute layers 2..4 from the 16 sigma-net outputs the forward saved behind the features
+//            (tnl_field_feats_save_bytes) and from sigma, backward through layers 4, 3, 2, weight gradients of W2..W4,
+//            and hand the gradient of the 16 sigma-net outputs (dO, 32 B per sample) to
+//   PART 2 = sigma net: recompute layer 0 only, backward through layers 1, 0, weight gradients of W0, W1, dF.
+// Each part holds 6 weight-gradient tiles per wave and half the chain; PART 0 = everything in one launch (hidden 64).
+template <int C, int H, int NW, bool ATOMIC, int PART>
 __global__ void __launch_bounds__(64 * NW)
-k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, const _Float16* __restrict__ feats,
+k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, const float* __restrict__ sigma,
+            const _Float16* __restrict__ feats,
             const float* __restrict__ xyz, const float* __restrict__ dirs, float bound, uint32_t M, int R,
             const half8* __restrict__ packed, float* __restrict__ grad_tm, float* __restrict__ slabs,
-            const int32_t* __restrict__ m_actual, _Float16* __restrict__ dfeat) {
+            const int32_t* __restrict__ m_actual, _Float16* __restrict__ dfeat, _Float16* __restrict__ dO) {
   using G = FieldGeom<C, H>;
-  using B = BwdGeom<C, H, NW, ATOMIC>;
+  using B = BwdGeom<C, H, NW, ATOMIC, PART>;
+  static_assert(PART == 0 || !ATOMIC, "the split launch exists for the binned mode only");
+  constexpr bool DO_COL = PART != 2, DO_SIG = PART != 1;
   constexpr int BW_THREADS = B::BW_THREADS, ST = B::ST, LS = B::LS;
   const uint32_t Mcap = M;   // row capacity: the plane stride of the plane-major dfeat output
   if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
@@ -122,11 +139,23 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   float* stage_all = reinterpret_cast<float*>(smem + (B::DB ? 2 : 1) * XY);
   _Float16* Fs = reinterpret_cast<_Float16*>(smem + (B::DB ? 2 : 1) * XY + B::STAGE_BYTES);
   auto sync_stage = [&]() { if (!B::DB) __syncthreads(); };   // stage reuse barrier, not needed when double-buffered
-  const half8* w = packed;
+  const half8* w = packed;    // forward fragments (and, outside PART 2, all of them)
+  const half8* wH = packed;   // layers 3, 4 forward and 4, 3, 2 transposed
+  const half8* wT = packed;   // transposed fragments of layers 1 and 0
   if (B::LDSW) {
     half8* wl = reinterpret_cast<half8*>(smem + B::BASE_BYTES);
-    for (int i = threadIdx.x; i < G::NTOT * 64; i += BW_THREADS) wl[i] = packed[i];
-    w = wl;
+    if (PART == 1) {
+      for (int i = threadIdx.x; i < (G::T1 - G::F3) * 64; i += BW_THREADS) wl[i] = packed[G::F3 * 64 + i];
+      wH = wl - G::F3 * 64;
+    } else if (PART == 2) {
+      for (int i = threadIdx.x; i < G::F1 * 64; i += BW_THREADS) wl[i] = packed[i];
+      for (int i = threadIdx.x; i < (G::NTOT - G::T1) * 64; i += BW_THREADS) wl[G::F1 * 64 + i] = packed[G::T1 * 64 + i];
+      wT = wl + (G::F1 - G::T1) * 64;
+    } else {
+      for (int i = threadIdx.x; i < G::NTOT * 64; i += BW_THREADS) wl[i] = packed[i];
+      wT = wH = wl;
+    }
+    if (PART != 1) w = wl;
   }
   __syncthreads();
 
@@ -152,17 +181,35 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   struct Inputs {
     float px, py, pz, dx, dy, dz, g_s, g_c0, g_c1, g_c2;
     half8 fk[G::KS0];
+    half8 dof;   // PART 2: gradient of the sigma net's 16 outputs, written by PART 1
+    half8 geo;   // PART 1: the sigma net's 16 outputs (fp16 fragment) and sigma, saved by the forward
+    float sg;
   };
+  const _Float16* geo_save = feats + (size_t)Mcap * G::F;
   auto load_inputs = [&](uint32_t st_, Inputs& in) {
     const uint32_t i_ = st_ * ST + col;
     const bool v_ = i_ < M;
     const uint32_t il_ = v_ ? i_ : M - 1;
     if (ATOMIC) { in.px = xyz[(size_t)il_ * 3]; in.py = xyz[(size_t)il_ * 3 + 1]; in.pz = xyz[(size_t)il_ * 3 + 2]; }
     else { in.px = in.py = in.pz = 0.f; }
-    in.dx = dirs[(size_t)il_ * 3]; in.dy = dirs[(size_t)il_ * 3 + 1]; in.dz = dirs[(size_t)il_ * 3 + 2];
-    in.g_s = v_ ? gsig[i_] : 0.f;
-    in.g_c0 = v_ ? grgb[(size_t)i_ * 3] : 0.f; in.g_c1 = v_ ? grgb[(size_t)i_ * 3 + 1] : 0.f;
-    in.g_c2 = v_ ? grgb[(size_t)i_ * 3 + 2] : 0.f;
+    if (DO_COL) {
+      in.dx = dirs[(size_t)il_ * 3]; in.dy = dirs[(size_t)il_ * 3 + 1]; in.dz = dirs[(size_t)il_ * 3 + 2];
+      in.g_s = v_ ? gsig[i_] : 0.f;
+      in.g_c0 = v_ ? grgb[(size_t)i_ * 3] : 0.f; in.g_c1 = v_ ? grgb[(size_t)i_ * 3 + 1] : 0.f;
+      in.g_c2 = v_ ? grgb[(size_t)i_ * 3 + 2] : 0.f;
+    } else {
+      in.dx = in.dy = in.dz = in.g_s = in.g_c0 = in.g_c1 = in.g_c2 = 0.f;
+      in.dof = *reinterpret_cast<const half8*>(dO + (size_t)il_ * 16 + 8 * h);
+      if (!v_) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) in.dof[j] = (_Float16)0.f;
+      }
+    }
+    if (PART == 1) {
+      in.geo = *reinterpret_cast<const half8*>(geo_save + (size_t)il_ * 16 + 8 * h);
+      in.sg = sigma[il_];
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < G::KS0; ks++) {
       in.fk[ks] = *reinterpret_cast<const half8*>(feats + (size_t)il_ * G::F + 16 * ks + 8 * h);
@@ -173,21 +220,23 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
   };
   // rows F .. 32*IB0-1 of the feature stage are never written again
-  if (B::EARLY_F)
+  if (B::EARLY_F && DO_SIG)
     for (int q = threadIdx.x; q < (32 * G::IB0 - G::F) * LS; q += BW_THREADS) Fs[(size_t)G::F * LS + q] = (_Float16)0.f;
   Inputs nxt;
   if (blockIdx.x < nst) load_inputs(blockIdx.x, nxt);
   for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
-    if (!B::LDSW) {
-      // Hidden 128: the 180 weight fragments do not fit in LDS next to the stages and are read from global memory
-      // (L2).  Keep the compiler from hoisting these loop-invariant loads out of the super-tile loop: it tried to hold
-      // them all in registers and spilled ~1000 per lane to scratch (18.3 -> 10.5 ms at C = 48 / hidden 128).
-      // That configuration stays spill-bound: the doubled chain plus 12 weight-gradient tiles per wave exceed the
-      // 512 registers, and ~400 scratch accesses per super-tile are exposed at one wave per SIMD.  Measured without
-      // gain: weight-gradient tiles split over 2 / 4 workgroups that each recompute the chain (27 / 47 ms), H1 / H3 /
-      // H4 kept in LDS stages instead of registers (16 ms), the weights streamed through a 56-KB LDS window in four
-      // phases per super-tile (10.4 ms: the operand latency is not what binds).
+    if (!B::LDSW || PART == 1) {
+      // Weight fragments read from global memory (L2) inside the loop: the 8 layer-2 fragments of PART 1, and all 180
+      // of the one-launch hidden-128 kernel (atomic mode only, the drop-in autograd path).  Keep the compiler from
+      // hoisting these loop-invariant loads out of the super-tile loop: it tried to hold them all in registers and
+      // spilled ~1000 per lane to scratch (18.3 -> 10.5 ms at C = 48 / hidden 128).  The one-launch form stays
+      // spill-bound (12 weight-gradient tiles per wave + the doubled chain exceed the 512 registers); what fixed the
+      // training path is the split into PART 1 / PART 2 above (10.5 -> 1.47 + 1.25 ms).  Measured without gain on the
+      // one-launch form: weight-gradient tiles split over 2 / 4 workgroups that each recompute the whole chain
+      // (27 / 47 ms), H1 / H3 / H4 kept in LDS stages instead of registers (16 ms), the weights streamed through a
+      // 56-KB LDS window in four phases per super-tile (10.4 ms).
       asm volatile("" : "+s"(w));
+      if (!B::LDSW) wT = wH = w;
     }
     const uint32_t i = st * ST + col;
     const bool valid = i < M;
@@ -196,7 +245,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     const float px = in.px, py = in.py, pz = in.pz, dx = in.dx, dy = in.dy, dz = in.dz;
     const float g_s = in.g_s, g_c0 = in.g_c0, g_c1 = in.g_c1, g_c2 = in.g_c2;
     // publish the features for the layer-0 weight gradient now (they are in registers); read after the last barrier
-    if (B::EARLY_F) {
+    if (B::EARLY_F && DO_SIG) {
 #pragma unroll
       for (int ks = 0; ks < G::KS0; ks++)
 #pragma unroll
@@ -205,17 +254,29 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 
     // ---- recompute the forward chain from the saved fp16 features
     f32x16 acc0[G::OB];
+    if (PART != 1) {
 #pragma unroll
-    for (int ob = 0; ob < G::OB; ob++) acc0[ob] = zero16();
+      for (int ob = 0; ob < G::OB; ob++) acc0[ob] = zero16();
 #pragma unroll
-    for (int ks = 0; ks < G::KS0; ks++) {
+      for (int ks = 0; ks < G::KS0; ks++) {
 #pragma unroll
-      for (int ob = 0; ob < G::OB; ob++)
-        acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], in.fk[ks], acc0[ob]);
+        for (int ob = 0; ob < G::OB; ob++)
+          acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], in.fk[ks], acc0[ob]);
+      }
     }
     Chain<C, H> ch;
-    chain_tail<C, H, false>(w, lane, h, acc0, dx, dy, dz, ch);
-
+    if (PART == 1) {
+      chain_colour<C, H>(w, wH, lane, h, in.geo, dx, dy, dz, ch);
+    } else if (DO_COL) {
+      chain_tail<C, H, false>(w, wH, lane, h, acc0, dx, dy, dz, ch);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < G::KH; ks++)
+        ch.h1[ks] = (ks & 1) ? acc_to_frag<true>(acc0[ks >> 1], 1) : acc_to_frag<true>(acc0[ks >> 1], 0);
+    }
+    _Float16 *Xs, *Ys;
+    half8 dof;
+    if (DO_COL) {
     // ---- layer 4: dZ4 = drgb * rgb * (1 - rgb) on rows 0..2 (lanes h == 0)
     f32x16 dz4 = zero16();
     if (h == 0) {
@@ -226,7 +287,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       dz4[2] = g_c2 * c2 * (1.f - c2);
     }
     const half8 dz4f = acc_to_frag<false>(dz4, 0);
-    _Float16 *Xs = Xb[0], *Ys = Yb[0];
+    Xs = Xb[0]; Ys = Yb[0];
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<LS>(Xs, ks, ch.h4[ks], h, col);
     put_acc<LS>(Ys, 0, dz4, h, col);
@@ -240,7 +301,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     half8 d4f[G::KH];
 #pragma unroll
     for (int ib = 0; ib < G::OB; ib++) {
-      d4[ib] = MFMA32(w[(G::T4 + ib) * 64 + lane], dz4f, zero16());
+      d4[ib] = MFMA32(wH[(G::T4 + ib) * 64 + lane], dz4f, zero16());
       relu_mask(d4[ib], ch.h4[2 * ib], ch.h4[2 * ib + 1]);
       d4f[2 * ib] = acc_to_frag<false>(d4[ib], 0);
       d4f[2 * ib + 1] = acc_to_frag<false>(d4[ib], 1);
@@ -265,7 +326,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     for (int ib = 0; ib < G::OB; ib++) {
       d3[ib] = zero16();
 #pragma unroll
-      for (int ks = 0; ks < G::KH; ks++) d3[ib] = MFMA32(w[(G::T3 + ib * G::KH + ks) * 64 + lane], d4f[ks], d3[ib]);
+      for (int ks = 0; ks < G::KH; ks++) d3[ib] = MFMA32(wH[(G::T3 + ib * G::KH + ks) * 64 + lane], d4f[ks], d3[ib]);
       relu_mask(d3[ib], ch.h3[2 * ib], ch.h3[2 * ib + 1]);
       d3f[2 * ib] = acc_to_frag<false>(d3[ib], 0);
       d3f[2 * ib + 1] = acc_to_frag<false>(d3[ib], 1);
@@ -276,9 +337,11 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     Xs = Xb[0]; Ys = Yb[0];
     {
       const half8 shf = sh_frag(dx, dy, dz, h);
-      half8 geo;
+      half8 geo = in.geo;
+      if (PART != 1) {
 #pragma unroll
-      for (int j = 0; j < 8; j++) geo[j] = (_Float16)ch.o8[j];
+        for (int j = 0; j < 8; j++) geo[j] = (_Float16)ch.o8[j];
+      }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         Xs[(8 * h + j) * LS + col] = shf[j];
@@ -297,13 +360,24 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     f32x16 dzz = zero16();
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) dzz = MFMA32(w[(G::T2 + ks) * 64 + lane], d3f[ks], dzz);
+    for (int ks = 0; ks < G::KH; ks++) dzz = MFMA32(wH[(G::T2 + ks) * 64 + lane], d3f[ks], dzz);
     // dO fragment: slots rho = 0..14 <- d geo (rows 16..30 of dz = regs 8..15); slot rho = 15 <- d logit
-    const float logit = __shfl(ch.o8[0], r);  // row 0 lives in lanes h == 0
-    const float dlogit = g_s * expf(fminf(fmaxf(logit, -15.f), 15.f));  // trunc_exp backward (activation.py:14-17)
-    half8 dof = acc_to_frag<false>(dzz, 1);
+    // trunc_exp backward (activation.py:14-17): g * exp(clamp(logit, -15, 15)); PART 1 has sigma = exp(logit) instead
+    float dlogit;
+    if (PART == 1) {
+      dlogit = g_s * fminf(fmaxf(in.sg, 3.0590232e-7f), 3269017.25f);
+    } else {
+      const float logit = __shfl(ch.o8[0], r);  // row 0 lives in lanes h == 0
+      dlogit = g_s * expf(fminf(fmaxf(logit, -15.f), 15.f));
+    }
+    dof = acc_to_frag<false>(dzz, 1);
     if (h == 1) dof[7] = (_Float16)dlogit;
+    if (PART == 1 && valid) *reinterpret_cast<half8*>(dO + (size_t)i * 16 + 8 * h) = dof;
     sync_stage();
+    } else {
+      dof = in.dof;
+    }
+    if (DO_SIG) {
 
     // ---- layer 1: X = H1, dY = dO (16 rows) + 16 zero rows
     Xs = Xb[1]; Ys = Yb[1];
@@ -325,7 +399,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     half8 d1f[G::KH];
 #pragma unroll
     for (int ib = 0; ib < G::OB; ib++) {
-      d1[ib] = MFMA32(w[(G::T1 + ib) * 64 + lane], dof, zero16());
+      d1[ib] = MFMA32(wT[(G::T1 + ib) * 64 + lane], dof, zero16());
       relu_mask(d1[ib], ch.h1[2 * ib], ch.h1[2 * ib + 1]);
       d1f[2 * ib] = acc_to_frag<false>(d1[ib], 0);
       d1f[2 * ib + 1] = acc_to_frag<false>(d1[ib], 1);
@@ -334,14 +408,15 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 
     // ---- layer 0: X = F (natural k order) from the feature stage written at the top of the super-tile
     Xs = Xb[0]; Ys = Yb[0];
-    if (!B::EARLY_F) {   // atomic mode: re-read (L2-hot) into Xs, rows F..32*IB0-1 zero
+    if (!B::EARLY_F) {   // into Xs, rows F..32*IB0-1 zero: re-read (L2-hot) in atomic mode, from registers in PART 2
       const uint32_t il = valid ? i : M - 1;
 #pragma unroll
       for (int ks = 0; ks < 2 * G::IB0; ks++) {
         half8 fk;
 #pragma unroll
         for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
-        if (ks < G::KS0 && valid) fk = *reinterpret_cast<const half8*>(feats + (size_t)il * G::F + 16 * ks + 8 * h);
+        if (PART == 2) { if (ks < G::KS0) fk = in.fk[ks < G::KS0 ? ks : 0]; }
+        else if (ks < G::KS0 && valid) fk = *reinterpret_cast<const half8*>(feats + (size_t)il * G::F + 16 * ks + 8 * h);
 #pragma unroll
         for (int j = 0; j < 8; j++) Xs[(16 * ks + 8 * h + j) * LS + col] = fk[j];
       }
@@ -363,7 +438,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       for (int ib = 0; ib < G::IB0; ib++) {
         f32x16 df = zero16();
 #pragma unroll
-        for (int ks = 0; ks < G::KH; ks++) df = MFMA32(w[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
+        for (int ks = 0; ks < G::KH; ks++) df = MFMA32(wT[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int f0 = 32 * ib + 8 * q + 4 * h;  // registers 4q..4q+3 hold features f0..f0+3
@@ -414,6 +489,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       }
     }
     }
+    }  // DO_SIG
     __syncthreads();  // Xs/Ys are rewritten by the next super-tile
   }
 
@@ -422,27 +498,27 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
   for (int k = 0; k < B::A0; k++) {
     const int t = wv + NW * k;
-    if (t < B::NT0) slab_tile(slab, G::OFF0, H, G::F, t / G::IB0, t % G::IB0, dw0[k], r, h);
+    if (DO_SIG && t < B::NT0) slab_tile(slab, G::OFF0, H, G::F, t / G::IB0, t % G::IB0, dw0[k], r, h);
   }
 #pragma unroll
   for (int k = 0; k < B::A1; k++) {
     const int t = wv + NW * k;
-    if (t < B::NT1) slab_tile(slab, G::OFF1, 16, H, 0, t, dw1[k], r, h);
+    if (DO_SIG && t < B::NT1) slab_tile(slab, G::OFF1, 16, H, 0, t, dw1[k], r, h);
   }
 #pragma unroll
   for (int k = 0; k < B::A2; k++) {
     const int t = wv + NW * k;
-    if (t < B::NT2) slab_tile(slab, G::OFF2, H, 31, t, 0, dw2[k], r, h);
+    if (DO_COL && t < B::NT2) slab_tile(slab, G::OFF2, H, 31, t, 0, dw2[k], r, h);
   }
 #pragma unroll
   for (int k = 0; k < B::A3; k++) {
     const int t = wv + NW * k;
-    if (t < B::NT3) slab_tile(slab, G::OFF3, H, H, t / G::OB, t % G::OB, dw3[k], r, h);
+    if (DO_COL && t < B::NT3) slab_tile(slab, G::OFF3, H, H, t / G::OB, t % G::OB, dw3[k], r, h);
   }
 #pragma unroll
   for (int k = 0; k < B::A4; k++) {
     const int t = wv + NW * k;
-    if (t < B::NT4) slab_tile(slab, G::OFF4, 3, H, 0, t, dw4[k], r, h);
+    if (DO_COL && t < B::NT4) slab_tile(slab, G::OFF4, 3, H, 0, t, dw4[k], r, h);
   }
 }
 
@@ -466,36 +542,62 @@ inline uint32_t bwd_blocks(uint32_t M) {
   return nst < 256 ? nst : 256;
 }
 
-template <int C, int H, int NW, bool ATOMIC>
-int launch_bwd_impl(const float* gsig, const float* grgb, const void* feats, const float* xyz, const float* dirs,
-                    float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW,
-                    void* workspace, const int32_t* m_actual, void* dfeat, hipStream_t st) {
-  using G = FieldGeom<C, H>;
-  using B = BwdGeom<C, H, NW, ATOMIC>;
-  const uint32_t blocks = bwd_blocks(M);
+// hidden 128 runs as two launches (see PART above); the dO hand-over buffer follows the slabs in the workspace
+template <int C, int H, bool ATOMIC>
+constexpr bool split_launch() { return H > 64 && !ATOMIC; }
+
+template <int C, int H, int NW, bool ATOMIC, int PART>
+int launch_bwd_part(const float* gsig, const float* grgb, const float* sigma, const void* feats, const float* xyz, const float* dirs,
+                    float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* slabs,
+                    const int32_t* m_actual, void* dfeat, _Float16* dO, uint32_t blocks, hipStream_t st) {
+  using B = BwdGeom<C, H, NW, ATOMIC, PART>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd<C, H, NW, ATOMIC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd<C, H, NW, ATOMIC, PART>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)B::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  hipLaunchKernelGGL((k_field_bwd<C, H, NW, ATOMIC, PART>), dim3(blocks), dim3(B::BW_THREADS), B::LDS_BYTES, st, gsig,
+                     grgb, sigma, reinterpret_cast<const _Float16*>(feats), xyz, dirs, bound, M, (int)R,
+                     reinterpret_cast<const half8*>(packed), grad_tm, slabs, m_actual,
+                     reinterpret_cast<_Float16*>(dfeat), dO);
+  return 0;
+}
+
+template <int C, int H, int NW, bool ATOMIC>
+int launch_bwd_impl(const float* gsig, const float* grgb, const float* sigma, const void* feats, const float* xyz, const float* dirs,
+                    float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW,
+                    void* workspace, const int32_t* m_actual, void* dfeat, hipStream_t st) {
+  using G = FieldGeom<C, H>;
+    const uint32_t blocks = bwd_blocks(M);
   float* slabs = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL((k_field_bwd<C, H, NW, ATOMIC>), dim3(blocks), dim3(B::BW_THREADS), B::LDS_BYTES, st, gsig, grgb,
-                     reinterpret_cast<const _Float16*>(feats), xyz, dirs, bound, M, (int)R,
-                     reinterpret_cast<const half8*>(packed), grad_tm, slabs, m_actual, reinterpret_cast<_Float16*>(dfeat));
+  int e;
+  if constexpr (split_launch<C, H, ATOMIC>()) {
+    _Float16* dO = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(workspace) + (size_t)blocks * G::NW * 4);
+    if (sigma == nullptr) return (int)hipErrorInvalidValue;   // the colour half takes exp(logit) from the forward
+    e = launch_bwd_part<C, H, NW, ATOMIC, 1>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, slabs, m_actual,
+                                             dfeat, dO, blocks, st);
+    if (e != 0) return e;
+    e = launch_bwd_part<C, H, NW, ATOMIC, 2>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, slabs, m_actual,
+                                             dfeat, dO, blocks, st);
+  } else {
+    e = launch_bwd_part<C, H, NW, ATOMIC, 0>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, slabs, m_actual,
+                                             dfeat, nullptr, blocks, st);
+  }
+  if (e != 0) return e;
   hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 63) / 64), dim3(256), 0, st, slabs, (int)blocks, (int)G::NW, gradW);
   return (int)hipGetLastError();
 }
 
 template <int C, int H, int NWB>
-int launch_bwd(const float* gsig, const float* grgb, const void* feats, const float* xyz, const float* dirs,
+int launch_bwd(const float* gsig, const float* grgb, const float* sigma, const void* feats, const float* xyz, const float* dirs,
                float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW, void* workspace,
                const int32_t* m_actual, void* dfeat, hipStream_t st) {
   if (dfeat != nullptr)
-    return launch_bwd_impl<C, H, NWB, false>(gsig, grgb, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
+    return launch_bwd_impl<C, H, NWB, false>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
                                              m_actual, dfeat, st);
-  return launch_bwd_impl<C, H, 4, true>(gsig, grgb, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
+  return launch_bwd_impl<C, H, 4, true>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
                                         m_actual, dfeat, st);
 }
 
@@ -508,7 +610,7 @@ uint32_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint3
   const uint32_t blocks = bwd_blocks(M);
   if (C == 16 && Hd == 64) return blocks * FieldGeom<16, 64>::NW * 4;
   if (C == 32 && Hd == 64) return blocks * FieldGeom<32, 64>::NW * 4;
-  if (C == 48 && Hd == 128) return blocks * FieldGeom<48, 128>::NW * 4;
+  if (C == 48 && Hd == 128) return blocks * FieldGeom<48, 128>::NW * 4 + M * 32;   // + the dO hand-over (split launch)
   return 0;
 }
 
@@ -516,16 +618,17 @@ int tnl_field_backward(const float* grad_sigma, const float* grad_rgb, const flo
                        const void* feats_save, const float* xyz, const float* dirs, float bound, uint32_t M,
                        uint32_t C, uint32_t R, uint32_t Hd, uint32_t Hc, const void* packed, float* grad_tm,
                        float* gradW, void* workspace, const int32_t* m_actual, void* dfeat_half, void* stream) {
-  (void)sigma; (void)rgb;  // the chain is recomputed bit-identically from feats_save
+  (void)rgb;  // the chain is recomputed bit-identically from feats_save (hidden 128, binned: layers 2..4 from the saved
+              // sigma-net outputs, and sigma is required)
   if (M == 0) return 0;
   if (Hd != Hc) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   if (C == 16 && Hd == 64)
-    return launch_bwd<16, 64, 4>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
+    return launch_bwd<16, 64, 4>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   if (C == 32 && Hd == 64)
-    return launch_bwd<32, 64, 4>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
+    return launch_bwd<32, 64, 4>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   if (C == 48 && Hd == 128)
-    return launch_bwd<48, 128, 4>(grad_sigma, grad_rgb, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
+    return launch_bwd<48, 128, 4>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   return (int)hipErrorInvalidValue;
 }
 

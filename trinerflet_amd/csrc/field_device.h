@@ -106,10 +106,15 @@ struct Chain {
 template <int C, int H>
 __device__ __forceinline__ const half8& wfrag(const half8* w, int f, int lane) { return w[f * 64 + lane]; }
 
-// layers 1..4 given acc0 = W0 * F^T ; DENSITY_ONLY stops after layer 1
+template <int C, int H>
+__device__ __forceinline__ void chain_colour(const half8* w, const half8* wH, int lane, int h, const half8 geo,
+                                             float dx, float dy, float dz, Chain<C, H>& ch);
+
+// layers 1..4 given acc0 = W0 * F^T ; DENSITY_ONLY stops after layer 1.  `w` serves the fragments of layers 1 and 2,
+// `wH` those of layers 3 and 4 (the same table unless a kernel keeps only part of it in LDS).
 template <int C, int H, bool DENSITY_ONLY>
-__device__ __forceinline__ void chain_tail(const half8* w, int lane, int h, f32x16 (&acc0)[H / 32], float dx,
-                                           float dy, float dz, Chain<C, H>& ch) {
+__device__ __forceinline__ void chain_tail(const half8* w, const half8* wH, int lane, int h, f32x16 (&acc0)[H / 32],
+                                           float dx, float dy, float dz, Chain<C, H>& ch) {
   using G = FieldGeom<C, H>;
 #pragma unroll
   for (int ks = 0; ks < G::KH; ks++) {
@@ -121,8 +126,15 @@ __device__ __forceinline__ void chain_tail(const half8* w, int lane, int h, f32x
 #pragma unroll
   for (int g = 0; g < 8; g++) ch.o8[g] = o[g];
   if (DENSITY_ONLY) return;
+  chain_colour<C, H>(w, wH, lane, h, acc_to_frag<false>(o, 0), dx, dy, dz, ch);
+}
+
+// layers 2..4 from the 16 sigma-net outputs as a fragment (slot 0 = the logit, multiplied by zero weights)
+template <int C, int H>
+__device__ __forceinline__ void chain_colour(const half8* w, const half8* wH, int lane, int h, const half8 geo,
+                                             float dx, float dy, float dz, Chain<C, H>& ch) {
+  using G = FieldGeom<C, H>;
   const half8 shf = sh_frag(dx, dy, dz, h);
-  const half8 geo = acc_to_frag<false>(o, 0);
   f32x16 acc2[G::OB];
 #pragma unroll
   for (int ob = 0; ob < G::OB; ob++) {
@@ -137,14 +149,14 @@ __device__ __forceinline__ void chain_tail(const half8* w, int lane, int h, f32x
   for (int ob = 0; ob < G::OB; ob++) {
     acc3[ob] = zero16();
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) acc3[ob] = MFMA32(w[(G::F3 + ob * G::KH + ks) * 64 + lane], ch.h3[ks], acc3[ob]);
+    for (int ks = 0; ks < G::KH; ks++) acc3[ob] = MFMA32(wH[(G::F3 + ob * G::KH + ks) * 64 + lane], ch.h3[ks], acc3[ob]);
   }
 #pragma unroll
   for (int ks = 0; ks < G::KH; ks++)
     ch.h4[ks] = (ks & 1) ? acc_to_frag<true>(acc3[ks >> 1], 1) : acc_to_frag<true>(acc3[ks >> 1], 0);
   f32x16 out = zero16();
 #pragma unroll
-  for (int ks = 0; ks < G::KH; ks++) out = MFMA32(w[(G::F4 + ks) * 64 + lane], ch.h4[ks], out);
+  for (int ks = 0; ks < G::KH; ks++) out = MFMA32(wH[(G::F4 + ks) * 64 + lane], ch.h4[ks], out);
   ch.rgbl[0] = out[0]; ch.rgbl[1] = out[1]; ch.rgbl[2] = out[2];
 }
 

@@ -498,6 +498,7 @@ class TrainStep:
         # rows past counter[0] are the zero padding of the sample budget: skipped on the device
         sigma, rgb, feats = F_.field_forward(tm, xyzs, dirs, packed, float(model.bound), C, R, H, save_feats=True,
                                              m_actual=counter)
+        sigma_field = sigma   # exp(logit) as the field produced it: the hidden-128 backward reads it
         if model.density_scale != 1:
             sigma = sigma * model.density_scale
         self._mark("field_fwd")
@@ -545,7 +546,7 @@ class TrainStep:
             else:
                 g_cm = torch.empty(3 * C, roi[7], roi[6], dtype=torch.float32, device=self.dev)
             dfeat = torch.empty(3, M, C, dtype=torch.float16, device=self.dev)   # plane-major, see field_bwd.hip
-            F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
+            F_.field_backward(g_sigma, g_rgb, sigma_field, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
                               g_cm, self.mlp.grad, m_actual=counter, dfeat=dfeat)
             self._mark("field_bwd")
             # The following batch's march + tile sort (ALU/latency-bound, few waves) start here, underneath the
@@ -579,7 +580,7 @@ class TrainStep:
                 self._mark("adam_coef")
         else:
             grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
-            F_.field_backward(g_sigma, g_rgb, None, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
+            F_.field_backward(g_sigma, g_rgb, sigma_field, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
                               grad_tm, self.mlp.grad, m_actual=counter)
             self._mark("field_bwd")
             # The following batch's march + tile sort (ALU/latency-bound, few waves) start here, underneath the
