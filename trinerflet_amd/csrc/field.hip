@@ -26,6 +26,8 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // forward kernel
 // ---------------------------------------------------------------------------------------------
+// (capping the registers at 256 for two waves per SIMD, `__launch_bounds__(FWD_THREADS, 2)`, compiles without scratch
+// at hidden 64 but runs slower at base: 1.03 vs 0.95 ms, A/B on one box -- the gathers are not latency-starved)
 template <int C, int H, bool HALFP, bool DENSITY_ONLY>
 __global__ void __launch_bounds__(FWD_THREADS)
 k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, const float* __restrict__ dirs,
