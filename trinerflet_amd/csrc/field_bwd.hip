@@ -64,7 +64,11 @@ struct BwdGeom {
                        A3 = (NT3 + NW - 1) / NW, A4 = (NT4 + NW - 1) / NW;
 };
 
-// one 32x32 weight-gradient tile: D[out][in] += sum over the staged samples of the super-tile
+// one 32x32 weight-gradient tile: D[out][in] += sum over the staged samples of the super-tile.
+// (The compiler emits read, read, wait, MFMA per k-step.  Requesting all 2 * ST/16 operand fragments before the first
+// MFMA was measured: 1.22 vs 1.23 ms at base, slower for the colour half of hidden 128 (1.57 vs 1.47 ms) -- the LDS
+// latency of these reads is not what binds.  Halving the number of 2-byte stage writes, as an experiment with wrong
+// results, gave 1.22 -> 1.11 ms: the ~290 ds_write_b16 per lane and super-tile are worth ~20 % of the kernel.)
 template <int ST, int LS>
 __device__ __forceinline__ f32x16 dw_tile(const _Float16* Ys, const _Float16* Xs, int ob, int ib, int r, int h,
                                           f32x16 acc) {
@@ -159,7 +163,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile ownership tests become scalar branches
   const int col = 32 * wv + r;
   float* stage = stage_all + (size_t)(ATOMIC ? wv : 0) * 32 * B::STAGE_LD;
 
