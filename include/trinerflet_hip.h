@@ -290,6 +290,26 @@ TNL_API int tnl_mse_loss(const float *image, const float *weights_sum, const flo
                          float *grad_pred, float *grad_weights_sum, float *mse_accum, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Scalar bookkeeping of one optimisation step (csrc/stepstate.hip), replacing torch.cuda.amp.GradScaler's
+ * unscale_/step/update bookkeeping and the wavelet-L1 value (reconstruction/nerf/utils.py:1158-1166, :641-655)
+ * -- two dozen tiny dependent launches -- by three.  All pointers are device memory.
+ *   prologue: small_grad[0..n) = 0 (the MLP gradient), *inv_scale = 1 / *scale, *abs_sum = 0, *nonfinite = 0,
+ *             *mse = 0.
+ *   probe:    *probe = sum |g0| + sum |g1| (g1 may be NULL with n1 = 0), +inf if *nonfinite != 0 (NULL: ignored);
+ *             *found_inf = 1.0 when *probe is not finite else 0.0 (GradScaler.unscale_'s found_inf).  With several
+ *             ranks the caller all-reduces *probe and recomputes found_inf.
+ *   epilogue: *opt_steps += 1 - *found_inf; if update_scale, GradScaler.update() with the given growth / backoff
+ *             factors and interval (_amp_update_scale_ semantics); *reg = *abs_sum * l1_coef (abs_sum may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+TNL_API int tnl_step_prologue(const float *scale, float *inv_scale, float *abs_sum, int32_t *nonfinite, float *mse,
+                              float *small_grad, uint32_t n, void *stream);
+TNL_API int tnl_scaler_probe(const float *g0, uint32_t n0, const float *g1, uint32_t n1, const int32_t *nonfinite,
+                             float *probe, float *found_inf, void *stream);
+TNL_API int tnl_step_epilogue(const float *found_inf, float *opt_steps, float *scale, int32_t *growth_tracker,
+                              float growth, float backoff, int32_t growth_interval, int32_t update_scale,
+                              const float *abs_sum, float l1_coef, float *reg, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Ray batches from a device-resident pixel pool.  One launch replaces get_rays over whole
  * images (reconstruction/nerf/utils.py:65-149), shuffle_data (CPU randperm + gather of every tensor, :228-236),
  * select_batch (slice + H2D, :238-243) and the background blend of train_step / eval_step (:559-577, :690-695).

@@ -229,3 +229,59 @@ def test_reference_loop_under_autocast(cuda, force_modular):
         losses.append(float(loss))
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.gpu
+def test_step_state_kernels_match_gradscaler(cuda):
+    """csrc/stepstate.hip against the torch expressions it replaces: zeroing + 1/scale, the found_inf probe of
+    GradScaler.unscale_, and GradScaler.update() (`torch._amp_update_scale_`) over a sequence with skipped steps."""
+    import trinerflet_amd._lib as L
+    lib = L.lib()
+    scale = torch.tensor([1024.0], device=cuda)
+    inv, abs_sum, mse = (torch.full((1,), 7.0, device=cuda) for _ in range(3))
+    flag = torch.ones(1, dtype=torch.int32, device=cuda)
+    g = torch.randn(13571, device=cuda)
+    L.check(lib.tnl_step_prologue(L.ptr(scale), L.ptr(inv), L.ptr(abs_sum), L.ptr(flag), L.ptr(mse), L.ptr(g),
+                                  L.u32(g.numel()), L.stream()), "prologue")
+    assert float(inv) == 1.0 / 1024.0 and float(abs_sum) == 0 and float(mse) == 0 and int(flag) == 0
+    assert not g.any()
+
+    probe, found = torch.empty(1, device=cuda), torch.empty(1, device=cuda)
+
+    def run_probe(g0, g1, fl):
+        L.check(lib.tnl_scaler_probe(L.ptr(g0), L.u32(g0.numel()), L.ptr(g1), L.u32(0 if g1 is None else g1.numel()),
+                                     L.ptr(fl), L.ptr(probe), L.ptr(found), L.stream()), "probe")
+        return float(probe), float(found)
+    a, b = torch.randn(13571, device=cuda), torch.randn(777, device=cuda)
+    p, f = run_probe(a, b, flag)
+    ref = float(a.double().abs().sum() + b.double().abs().sum())
+    assert f == 0.0 and abs(p - ref) < 1e-4 * ref
+    p, f = run_probe(a, None, None)
+    assert f == 0.0 and abs(p - float(a.double().abs().sum())) < 1e-4 * ref
+    flag.fill_(1)
+    assert run_probe(a, b, flag)[1] == 1.0
+    flag.zero_()
+    b[5] = float("nan")
+    assert run_probe(a, b, flag)[1] == 1.0
+    b[5] = float("-inf")
+    assert run_probe(a, b, flag)[1] == 1.0
+
+    # GradScaler.update(): growth after `interval` clean steps, backoff and tracker reset on a skipped one
+    interval = 3
+    s_k, t_k = torch.tensor([65536.0], device=cuda), torch.zeros(1, dtype=torch.int32, device=cuda)
+    s_t, t_t = s_k.clone(), t_k.clone()
+    steps_k = torch.zeros(1, device=cuda)
+    reg = torch.empty(1, device=cuda)
+    abs_sum.fill_(3.5)
+    seq = [0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0]
+    for fi in seq:
+        fi_t = torch.tensor([float(fi)], device=cuda)
+        L.check(lib.tnl_step_epilogue(L.ptr(fi_t), L.ptr(steps_k), L.ptr(s_k), L.ptr(t_k), L.f32(2.0), L.f32(0.5),
+                                      L.i32(interval), L.i32(1), L.ptr(abs_sum), L.f32(0.25), L.ptr(reg), L.stream()),
+                "epilogue")
+        torch._amp_update_scale_(s_t, t_t, fi_t, 2.0, 0.5, interval)
+        assert torch.equal(s_k, s_t) and torch.equal(t_k, t_t)
+    assert float(steps_k) == seq.count(0) and float(reg) == 3.5 * 0.25
+    L.check(lib.tnl_step_epilogue(L.ptr(fi_t), L.ptr(steps_k), L.ptr(s_k), L.ptr(t_k), L.f32(2.0), L.f32(0.5),
+                                  L.i32(interval), L.i32(0), L.ptr(None), L.f32(0.25), L.ptr(reg), L.stream()), "epilogue")
+    assert torch.equal(s_k, s_t) and float(reg) == 0.0     # update_scale = 0 (fp32 training): scale untouched

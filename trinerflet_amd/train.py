@@ -121,6 +121,7 @@ class TrainStep:
         self.opt_steps = torch.zeros(1, dtype=torch.float32, device=dev)   # optimiser steps taken (skips excluded)
         self.abs_sum = torch.zeros(1, dtype=torch.float32, device=dev)
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.inv_scale = torch.ones(1, dtype=torch.float32, device=dev)   # 1 / loss scale, written by csrc/stepstate.hip
         self.last = {}
         self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
         self._side = None
@@ -442,10 +443,16 @@ class TrainStep:
             out = raymarching.march_rays_train(
                 o, d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars,
                 counter, model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, nz)
+            # the field forward needs the march only; the tile sort of the plane gradient (needed much later, by the
+            # tile reduction) rides behind it on the same stream and gets its own event
+            ev_march = torch.cuda.Event()
+            ev_march.record()
             # the tile sort of the plane gradient needs only the positions: it rides with the march (side stream)
             sort_ws = F_.plane_grad_sort(out[0], float(model.bound), R, counter) if (self.binned and R % 32 == 0) \
                 else torch.empty(0, device=self.dev)
-            return (counter, *out, sort_ws)
+            ev_sort = torch.cuda.Event()
+            ev_sort.record()
+            return (counter, *out, sort_ws), (ev_march, ev_sort)
 
         def march_on_side(*a):
             main = torch.cuda.current_stream()
@@ -454,7 +461,7 @@ class TrainStep:
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 out = march(*a)
-            for t_ in out:
+            for t_ in out[0]:
                 t_.record_stream(main)
             return out
 
@@ -488,10 +495,11 @@ class TrainStep:
                 self._roi, self._roi_valid = self._compute_roi(), True
             self._mark("grid_refresh")
         packed = F_.pack_weights(*self.Ws, C, H)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-        else:
+        if side is None:
             marched = march()
+        marched, (ev_march, ev_sort) = marched
+        if side is not None:
+            torch.cuda.current_stream().wait_event(ev_march)
         counter, xyzs, dirs, deltas, rays, sort_ws = marched
         M = xyzs.shape[0]
         self._mark("march")
@@ -514,7 +522,11 @@ class TrainStep:
         pred = torch.empty(N, 3, dtype=torch.float32, device=self.dev)
         g_pred = torch.empty(N, 3, dtype=torch.float32, device=self.dev)
         g_ws = torch.empty(N, dtype=torch.float32, device=self.dev)
-        mse_local = torch.zeros((), dtype=torch.float32, device=self.dev)
+        # one launch: MSE / L1 / non-finite accumulators and the MLP gradient zeroed, 1 / loss scale (csrc/stepstate.hip)
+        mse_local = torch.empty((), dtype=torch.float32, device=self.dev)
+        L.check(lib.tnl_step_prologue(L.ptr(self.scale), L.ptr(self.inv_scale), L.ptr(self.abs_sum),
+                                      L.ptr(self.nonfinite), L.ptr(mse_local), L.ptr(self.mlp.grad),
+                                      L.u32(self.mlp.grad.numel()), L.stream()), "step_prologue")
         bg_rays = bg.to(torch.float32).contiguous() if torch.is_tensor(bg) else None
         L.check(lib.tnl_mse_loss(L.ptr(image), L.ptr(ws), L.ptr(gt_rgb.contiguous()), L.f32(0.0 if bg_rays is not None else bg),
                                  L.ptr(bg_rays), L.u32(N), L.f32(1.0 / (3.0 * n_glob)), L.ptr(self.scale), L.ptr(pred),
@@ -531,12 +543,10 @@ class TrainStep:
         if model.density_scale != 1:
             g_sigma = g_sigma * model.density_scale
         self._mark("composite_bwd")
-        self.mlp.grad.zero_()
         g_cm = None
         lr_t = self.lr * lr_factor(self.global_step, self.iters, self.warmup)
         l1 = self.lam / (self.J * self.coef_numel) if (self.J > 0 and self.lam > 0) else 0.0
-        inv_scale = 1.0 / self.scale
-        self.abs_sum.zero_()
+        inv_scale = self.inv_scale
         if self.binned and R % 32 == 0:
             # no global float atomics: dF -> fp16 -> tile-sorted matrix-core accumulation (csrc/scatter.hip), written
             # straight in the (3,C,R,R) layout the adjoint IDWT reads
@@ -556,7 +566,8 @@ class TrainStep:
             # is time-sliced in); started under Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms
             # stay exposed.  At the small configuration (dense tail 0.5 ms) 1 ms of the march stays exposed either way.
             self._prefetch_next(next_rays, march_on_side)
-            self.nonfinite.zero_()
+            if side is not None:
+                torch.cuda.current_stream().wait_event(ev_sort)
             F_.plane_grad_reduce(sort_ws, dfeat, xyzs, float(model.bound), C, R, g_cm, channel_major=True,
                                  nonfinite_flag=self.nonfinite, roi=self._roi10() if roi is not None else None)
             self._mark("plane_grad_binned")
@@ -564,10 +575,7 @@ class TrainStep:
                 dist.all_reduce(self.mlp.grad, group=self.pg)
             # GradScaler probe BEFORE the dense backward, so that the optimiser can be fused into it: the plane
             # gradient reports non-finite values through the tile kernel's flag, the MLP gradient is 13.5k floats
-            probe = self.mlp.grad.abs().sum() + torch.where(self.nonfinite[0] != 0, float("inf"), 0.0)
-            if self.world > 1:
-                dist.all_reduce(probe, group=self.pg)
-            found_inf = (~torch.isfinite(probe)).to(torch.float32).reshape(1)
+            found_inf = self._scaler_probe(self.mlp.grad, None, self.nonfinite)
             self._mark("scaler_probe")
             if self.fuse_adam:
                 s0, s1 = self._adjoint(None, g_cm, fuse=(lr_t, l1, found_inf, inv_scale))
@@ -596,10 +604,7 @@ class TrainStep:
             self._mark("idwt_adjoint")
             # GradScaler: skip the step when any gradient is non-finite.  A non-finite plane gradient always
             # reaches the coarse LL gradient through the low-pass adjoint, so checking LL + MLP grads suffices.
-            probe = self.ll.grad.abs().sum() + self.mlp.grad.abs().sum()
-            if self.world > 1:
-                dist.all_reduce(probe, group=self.pg)
-            found_inf = (~torch.isfinite(probe)).to(torch.float32).reshape(1)
+            found_inf = self._scaler_probe(self.mlp.grad, self.ll.grad, None)
             self._mark("scaler_probe")
             if self.dist_mode == "sharded":
                 self._adam_sharded(lr_t, l1, found_inf, inv_scale, s0, s1)
@@ -608,12 +613,13 @@ class TrainStep:
                 self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
             self._mark("adam_coef")
         self._adam(self.mlp, lr_t, 0.0, found_inf, inv_scale)
-        self.opt_steps += 1.0 - found_inf
-        if self.fp16:
-            torch._amp_update_scale_(self.scale, self.growth_tracker, found_inf, 2.0, 0.5, self.growth_interval)
+        # optimiser-step count, GradScaler.update(), L1 value: one launch
+        reg = torch.empty((), dtype=torch.float32, device=self.dev)
+        L.check(lib.tnl_step_epilogue(L.ptr(found_inf), L.ptr(self.opt_steps), L.ptr(self.scale),
+                                      L.ptr(self.growth_tracker), L.f32(2.0), L.f32(0.5), L.i32(self.growth_interval),
+                                      L.i32(int(self.fp16)), L.ptr(self.abs_sum if l1 > 0 else None), L.f32(l1),
+                                      L.ptr(reg), L.stream()), "step_epilogue")
         self.global_step += 1
-
-        reg = self.abs_sum[0] * l1 if l1 > 0 else torch.zeros((), device=self.dev)
         if self.world > 1:
             mse = mse_local.clone()
             dist.all_reduce(mse, group=self.pg)
@@ -635,6 +641,17 @@ class TrainStep:
         no, nd = next_rays[0], next_rays[1]
         nn = next_rays[2] if len(next_rays) > 2 else None
         self._prefetched = ((no.data_ptr(), nd.data_ptr(), no.shape[0]), march_on_side(no, nd, nn))
+
+    def _scaler_probe(self, g0, g1, flag):
+        """GradScaler.unscale_'s found_inf over g0 (+ g1) and an optional device flag; [1] float tensor."""
+        probe = torch.empty(1, dtype=torch.float32, device=self.dev)
+        found = torch.empty(1, dtype=torch.float32, device=self.dev)
+        L.check(L.lib().tnl_scaler_probe(L.ptr(g0), L.u32(g0.numel()), L.ptr(g1), L.u32(0 if g1 is None else g1.numel()),
+                                         L.ptr(flag), L.ptr(probe), L.ptr(found), L.stream()), "scaler_probe")
+        if self.world > 1:
+            dist.all_reduce(probe, group=self.pg)
+            return (~torch.isfinite(probe)).to(torch.float32)
+        return found
 
     def _adam_sharded(self, lr_t, l1, found_inf, inv_scale, s0, s1):
         """Each rank updates only its (plane, channel) slices; afterwards parameters are all-gathered so the

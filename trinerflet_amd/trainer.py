@@ -22,6 +22,7 @@ stage loop of reconstruction/main_nerf.py:168-205, restricted to what the README
 Not here (out of scope): tensorboard, EMA, LPIPS/SSIM, video/mesh export, the GUI, error maps,
 patch sampling, CLIP loss.
 """
+import gc
 import glob
 import math
 import os
@@ -132,6 +133,10 @@ class Trainer:
             self.ts.invalidate_roi()
         if not self.fast_training and valid_pool is not None:
             self.evaluate_one_epoch(valid_pool)
+        # the module tree and the ray pool live for the whole run: out of the collector's way, so that a generation-2
+        # pass (10-20 ms) does not stall the launch queue of a 7-ms step
+        gc.collect()
+        gc.freeze()
         t_train = 0.0
         for epoch in range(self.epoch + 1, max_epochs + 1):
             t0 = time.time()
