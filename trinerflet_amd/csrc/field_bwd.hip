@@ -7,11 +7,14 @@
 //      forward MFMA chain in registers (32 MFMAs per 32 samples: cheaper than storing activations);
 //   2. data path, still in chain layout: dY_l^T -> W_l^T * dY_l^T with the transposed weight fragments,
 //      ReLU masks taken from the recomputed fragments;
-//   3. weight gradients: per layer the waves publish X_l and dY_l as fp16 [feature][sample] rows in LDS;
-//      after a barrier every wave owns a few 32x32 tiles of dW_l = dY_l^T X_l (K = 128 samples, both MFMA
-//      operands read with ds_read_b128), accumulated in registers over all super-tiles of the
-//      workgroup and written ONCE as an fp32 slab; a second tiny kernel sums the slabs (no atomics on
-//      the 13.5k shared weights);
+//   3. weight gradients: per layer the waves publish X_l and dY_l as fp16 stage images in LDS, [32-feature block]
+//      [sample][32 features] with XOR-swizzled 8-byte chunks: a lane stores four consecutive features of its sample
+//      with one ds_write_b64 (the chain fragments already are fp16), and after a barrier every wave owns a few 32x32
+//      tiles of dW_l = dY_l^T X_l (K = 128 samples) whose operands -- 8 samples of one feature per lane -- come out of
+//      that image through the transposing ds_read_b64_tr_b16 of gfx950, conflict-free both ways.  (The first version
+//      kept [feature][sample] rows and wrote them with ~290 ds_write_b16 per lane and super-tile: 1.23 -> 1.11 ms at
+//      base.)  The tiles are accumulated in registers over all super-tiles of the workgroup and written ONCE as an
+//      fp32 slab; a second tiny kernel sums the slabs (no atomics on the 13.5k shared weights);
 //   4. feature gradient dF (fp32) is staged through LDS so that the plane-gradient atomics are issued
 //      with lanes = channels: one wave-instruction adds 256 contiguous bytes (two adjacent texels at
 //      C = 32), the shape the memory-side fp32 atomic unit runs at full rate for
@@ -34,25 +37,28 @@ struct BwdGeom {
   static constexpr int BW_WAVES = NW;
   static constexpr int BW_THREADS = 64 * NW;
   static constexpr int ST = 32 * NW;      // samples per super-tile
-  static constexpr int LS = ST + 8;       // LDS row stride in halfs (16-B aligned rows)
+  // A stage image holds fp16 [32-feature block][sample][32 features]: 64-byte rows whose eight 8-byte chunks are
+  // XOR-swizzled with the row (img_off), so that a lane stores four consecutive features of its sample with one
+  // ds_write_b64 and the weight-gradient MFMA reads both operands (8 samples of one feature per lane) with the
+  // transposing ds_read_b64_tr_b16, all conflict-free.
+  static constexpr int BLK = ST * 64;     // bytes per 32-feature block
   // features staged once per super-tile in their own LDS region (binned mode).  PART 2 (sigma half of the split launch)
   // instead keeps them in registers and stages them into the X region for layer 0, which leaves room for its 80
   // weight fragments in LDS.
   static constexpr bool EARLY_F = !ATOMIC && PART != 2;
-  static constexpr int XROWS = EARLY_F ? H : ((32 * G::IB0 > H) ? 32 * G::IB0 : H);
-  static constexpr int YROWS = H;
+  static constexpr int XBLKS = EARLY_F ? G::OB : (G::IB0 > G::OB ? G::IB0 : G::OB);
   static constexpr int STAGE_LD = G::F + 1;                       // floats per staged sample row
-  static constexpr size_t XS_BYTES = (size_t)XROWS * LS * 2;
-  static constexpr size_t YS_BYTES = (size_t)YROWS * LS * 2;
+  static constexpr size_t XS_BYTES = (size_t)XBLKS * BLK;
+  static constexpr size_t YS_BYTES = (size_t)G::OB * BLK;
   static constexpr size_t STAGE_BYTES = ATOMIC ? (size_t)BW_WAVES * 32 * STAGE_LD * 4 : 0;
   // fragments a launch touches: everything, or for PART 2 the forward layer-0 range [F0, F1) and the transposed
   // layer-1 / layer-0 range [T1, NTOT)
   // PART 1 keeps [F3, T1) = layers 3, 4 forward and 4, 3, 2 transposed in LDS and reads layers 0..2 forward from L2.
   static constexpr int NFRAG = PART == 2 ? (G::F1 - G::F0) + (G::NTOT - G::T1) : (PART == 1 ? G::T1 - G::F3 : G::NTOT);
   static constexpr size_t W_BYTES = (size_t)NFRAG * 1024;
-  // the sample's features, published once per super-tile for the layer-0 weight gradient (rows F..32*IB0-1 stay zero)
+  // the sample's features, published once per super-tile for the layer-0 weight gradient
   // (binned mode only: the atomic mode's fp32 staging area leaves no room at C = 48 and re-reads them instead)
-  static constexpr size_t FS_BYTES = EARLY_F && PART != 1 ? (size_t)32 * G::IB0 * LS * 2 : 0;
+  static constexpr size_t FS_BYTES = EARLY_F && PART != 1 ? (size_t)G::IB0 * BLK : 0;
   // Double-buffered X / Y stages (layers alternate between the two pairs): the barrier that protected a stage from
   // the next layer's writes disappears, one barrier per layer remains.  Only where it fits next to the weights.
   static constexpr bool DB = EARLY_F && 2 * (XS_BYTES + YS_BYTES) + FS_BYTES + W_BYTES <= 160 * 1024;
@@ -64,34 +70,59 @@ struct BwdGeom {
                        A3 = (NT3 + NW - 1) / NW, A4 = (NT4 + NW - 1) / NW;
 };
 
-// one 32x32 weight-gradient tile: D[out][in] += sum over the staged samples of the super-tile.
-// (The compiler emits read, read, wait, MFMA per k-step.  Requesting all 2 * ST/16 operand fragments before the first
-// MFMA was measured: 1.22 vs 1.23 ms at base, slower for the colour half of hidden 128 (1.57 vs 1.47 ms) -- the LDS
-// latency of these reads is not what binds.  Halving the number of 2-byte stage writes, as an experiment with wrong
-// results, gave 1.22 -> 1.11 ms: the ~290 ds_write_b16 per lane and super-tile are worth ~20 % of the kernel.)
-template <int ST, int LS>
-__device__ __forceinline__ f32x16 dw_tile(const _Float16* Ys, const _Float16* Xs, int ob, int ib, int r, int h,
-                                          f32x16 acc) {
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_t;
+
+// byte offset of 8-byte chunk `chunk` (four consecutive features) of sample row `row` inside a 32-feature block
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+__device__ __forceinline__ void st4(char* blk, int row, int chunk, half4v v) {
+  *reinterpret_cast<half4v*>(blk + img_off(row, chunk)) = v;
+}
+// ds_read_b64_tr_b16: per 16-lane group a block of 4 rows x 16 columns of halfs, delivered column-major (lane i of the
+// group gets column i of the 4 rows).  Needs EXEC all ones: only called from wave-uniform control flow.
+__device__ __forceinline__ half4v tr4(const char* p) {
+  const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+      (__attribute__((address_space(3))) fp16x4_t*)(const_cast<char*>(p)));
+  return __builtin_bit_cast(half4v, v);
+}
+
+// one 32x32 weight-gradient tile: D[out][in] += sum over the staged samples of the super-tile; yb / xb = the blocks
+// holding the 32 output / input features, t0 / t1 = this lane's transposed-read offsets (rows 8h + q and 8h + 4 + q).
+template <int ST>
+__device__ __forceinline__ f32x16 dw_tile(const char* yb, const char* xb, int t0, int t1, f32x16 acc) {
 #pragma unroll
   for (int ks = 0; ks < ST / 16; ks++) {
-    const half8 a = *reinterpret_cast<const half8*>(Ys + (32 * ob + r) * LS + 16 * ks + 8 * h);
-    const half8 b = *reinterpret_cast<const half8*>(Xs + (32 * ib + r) * LS + 16 * ks + 8 * h);
+    const half8 a = __builtin_shufflevector(tr4(yb + t0 + 1024 * ks), tr4(yb + t1 + 1024 * ks), 0, 1, 2, 3, 4, 5, 6, 7);
+    const half8 b = __builtin_shufflevector(tr4(xb + t0 + 1024 * ks), tr4(xb + t1 + 1024 * ks), 0, 1, 2, 3, 4, 5, 6, 7);
     acc = MFMA32(a, b, acc);
   }
   return acc;
 }
 
-// publish an accumulator-layout tile (16 rows per lane) as fp16 rows [32*blk + acc_row][col]
-template <int LS>
-__device__ __forceinline__ void put_acc(_Float16* S, int blk, const f32x16& a, int h, int col) {
+// publish an accumulator-layout tile (registers 4q..4q+3 = features 8q + 4h .. + 3 of the lane's sample) into a block
+template <int NQ = 4>
+__device__ __forceinline__ void put_acc(char* blk, const f32x16& a, int h, int col) {
 #pragma unroll
-  for (int g = 0; g < 16; g++) S[(32 * blk + acc_row(g, h)) * LS + col] = (_Float16)a[g];
+  for (int q = 0; q < NQ; q++) {
+    half4v v;
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = (_Float16)a[4 * q + e];
+    st4(blk, col, 2 * q + h, v);
+  }
 }
-// publish a chain fragment of k-step ks: slot (h,j) -> row kslot_feature(ks,h,j)
-template <int LS>
-__device__ __forceinline__ void put_frag(_Float16* S, int ks, const half8& f, int h, int col) {
-#pragma unroll
-  for (int j = 0; j < 8; j++) S[kslot_feature(ks, h, j) * LS + col] = f[j];
+// publish a chain fragment of k-step ks: slots j = 0..3 carry features 16ks + 4h .. + 3, slots 4..7 the same + 8
+template <int BLK>
+__device__ __forceinline__ void put_frag(char* img, int ks, const half8& f, int h, int col) {
+  char* blk = img + (ks >> 1) * BLK;
+  st4(blk, col, 4 * (ks & 1) + h, __builtin_shufflevector(f, f, 0, 1, 2, 3));
+  st4(blk, col, 4 * (ks & 1) + 2 + h, __builtin_shufflevector(f, f, 4, 5, 6, 7));
+}
+// publish a natural-order fragment: slot j = feature 16ks + 8h + j
+template <int BLK>
+__device__ __forceinline__ void put_nat(char* img, int ks, const half8& f, int h, int col) {
+  char* blk = img + (ks >> 1) * BLK;
+  st4(blk, col, 4 * (ks & 1) + 2 * h, __builtin_shufflevector(f, f, 0, 1, 2, 3));
+  st4(blk, col, 4 * (ks & 1) + 2 * h + 1, __builtin_shufflevector(f, f, 4, 5, 6, 7));
 }
 
 // ReLU backward: keep dY where the recomputed activation fragment is positive; returns the two k-step fragments
@@ -103,14 +134,22 @@ __device__ __forceinline__ void relu_mask(f32x16& d, const half8& x0, const half
   }
 }
 
-// write one dW tile of a layer into the workgroup's slab (nn.Linear layout [out][in])
+// write one dW tile of a layer into the workgroup's slab (nn.Linear layout [out][in]).  Two stages keep the chain's
+// slot order instead of the layer's own index order, and the tile is mapped back here:
+//   MODE 1 (layer 1): tile row rho -> W1 row (rho == 15 ? 0 : rho + 1), rows >= 16 do not exist
+//   MODE 2 (layer 2): tile column c < 16 -> SH input c; c == 16 is the logit's slot (no input); c > 16 -> input c - 1
+template <int MODE = 0>
 __device__ __forceinline__ void slab_tile(float* slab, int off, int out_dim, int in_dim, int ob, int ib,
                                           const f32x16& a, int r, int h) {
-  const int in = 32 * ib + r;
+  int in = 32 * ib + r;
+  bool in_ok = in < in_dim;
+  if (MODE == 2) { in_ok = r != 16; in = r < 16 ? r : r - 1; }
 #pragma unroll
   for (int g = 0; g < 16; g++) {
-    const int out = 32 * ob + acc_row(g, h);
-    if (out < out_dim && in < in_dim) slab[off + out * in_dim + in] = a[g];
+    int out = 32 * ob + acc_row(g, h);
+    bool out_ok = out < out_dim;
+    if (MODE == 1) { out_ok = out < 16; out = out == 15 ? 0 : out + 1; }
+    if (out_ok && in_ok) slab[off + out * in_dim + in] = a[g];
   }
 }
 
@@ -132,16 +171,15 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   using B = BwdGeom<C, H, NW, ATOMIC, PART>;
   static_assert(PART == 0 || !ATOMIC, "the split launch exists for the binned mode only");
   constexpr bool DO_COL = PART != 2, DO_SIG = PART != 1;
-  constexpr int BW_THREADS = B::BW_THREADS, ST = B::ST, LS = B::LS;
+  constexpr int BW_THREADS = B::BW_THREADS, ST = B::ST, BLK = B::BLK;
   const uint32_t Mcap = M;   // row capacity: the plane stride of the plane-major dfeat output
   if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr size_t XY = B::XS_BYTES + B::YS_BYTES;
-  _Float16* const Xb[2] = {reinterpret_cast<_Float16*>(smem), reinterpret_cast<_Float16*>(smem + (B::DB ? XY : 0))};
-  _Float16* const Yb[2] = {reinterpret_cast<_Float16*>(smem + B::XS_BYTES),
-                           reinterpret_cast<_Float16*>(smem + (B::DB ? XY : 0) + B::XS_BYTES)};
+  char* const Xb[2] = {smem, smem + (B::DB ? XY : 0)};
+  char* const Yb[2] = {smem + B::XS_BYTES, smem + (B::DB ? XY : 0) + B::XS_BYTES};
   float* stage_all = reinterpret_cast<float*>(smem + (B::DB ? 2 : 1) * XY);
-  _Float16* Fs = reinterpret_cast<_Float16*>(smem + (B::DB ? 2 : 1) * XY + B::STAGE_BYTES);
+  char* Fs = smem + (B::DB ? 2 : 1) * XY + B::STAGE_BYTES;
   auto sync_stage = [&]() { if (!B::DB) __syncthreads(); };   // stage reuse barrier, not needed when double-buffered
   const half8* w = packed;    // forward fragments (and, outside PART 2, all of them)
   const half8* wH = packed;   // layers 3, 4 forward and 4, 3, 2 transposed
@@ -166,6 +204,10 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile ownership tests become scalar branches
   const int col = 32 * wv + r;
+  // transposed-read offsets of the weight-gradient operands: lane 4q + p of a 16-lane group addresses sample row q of
+  // the block, chunk p of the group's 16 features
+  const int tq = (lane & 15) >> 2, tc = 4 * ((lane >> 4) & 1) + (lane & 3);
+  const int t0 = img_off(8 * h + tq, tc), t1 = img_off(8 * h + 4 + tq, tc);
   float* stage = stage_all + (size_t)(ATOMIC ? wv : 0) * 32 * B::STAGE_LD;
 
   f32x16 dw0[B::A0], dw1[B::A1], dw2[B::A2], dw3[B::A3], dw4[B::A4];
@@ -224,11 +266,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       }
     }
   };
-  // rows F .. 32*IB0-1 of the feature stage are never written again
-  if (B::EARLY_F && DO_SIG)
-    for (int q = threadIdx.x; q < (32 * G::IB0 - G::F) * LS; q += BW_THREADS) Fs[(size_t)G::F * LS + q] = (_Float16)0.f;
+  constexpr bool PREFETCH = PART != 1;   // the colour half of hidden 128 is register-bound: its 44 B of inputs are read in place
   Inputs nxt;
-  if (blockIdx.x < nst) load_inputs(blockIdx.x, nxt);
+  if (PREFETCH && blockIdx.x < nst) load_inputs(blockIdx.x, nxt);
   for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
     if (!B::LDSW || PART == 1) {
       // Weight fragments read from global memory (L2) inside the loop: the 8 layer-2 fragments of PART 1, and all 180
@@ -245,16 +285,15 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     const uint32_t i = st * ST + col;
     const bool valid = i < M;
+    if (!PREFETCH) load_inputs(st, nxt);
     const Inputs in = nxt;
-    if (st + gridDim.x < nst) load_inputs(st + gridDim.x, nxt);
+    if (PREFETCH && st + gridDim.x < nst) load_inputs(st + gridDim.x, nxt);
     const float px = in.px, py = in.py, pz = in.pz, dx = in.dx, dy = in.dy, dz = in.dz;
     const float g_s = in.g_s, g_c0 = in.g_c0, g_c1 = in.g_c1, g_c2 = in.g_c2;
     // publish the features for the layer-0 weight gradient now (they are in registers); read after the last barrier
     if (B::EARLY_F && DO_SIG) {
 #pragma unroll
-      for (int ks = 0; ks < G::KS0; ks++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) Fs[(16 * ks + 8 * h + j) * LS + col] = in.fk[ks][j];
+      for (int ks = 0; ks < G::KS0; ks++) put_nat<BLK>(Fs, ks, in.fk[ks], h, col);
     }
 
     // ---- recompute the forward chain from the saved fp16 features
@@ -271,7 +310,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     Chain<C, H> ch;
     if (PART == 1) {
-      chain_colour<C, H>(w, wH, lane, h, in.geo, dx, dy, dz, ch);
+      chain_colour<C, H, true>(w, wH, lane, h, in.geo, dx, dy, dz, ch);
     } else if (DO_COL) {
       chain_tail<C, H, false>(w, wH, lane, h, acc0, dx, dy, dz, ch);
     } else {
@@ -279,7 +318,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       for (int ks = 0; ks < G::KH; ks++)
         ch.h1[ks] = (ks & 1) ? acc_to_frag<true>(acc0[ks >> 1], 1) : acc_to_frag<true>(acc0[ks >> 1], 0);
     }
-    _Float16 *Xs, *Ys;
+    char *Xs, *Ys;
     half8 dof;
     if (DO_COL) {
     // ---- layer 4: dZ4 = drgb * rgb * (1 - rgb) on rows 0..2 (lanes h == 0)
@@ -294,74 +333,72 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     const half8 dz4f = acc_to_frag<false>(dz4, 0);
     Xs = Xb[0]; Ys = Yb[0];
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag<LS>(Xs, ks, ch.h4[ks], h, col);
-    put_acc<LS>(Ys, 0, dz4, h, col);
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h4[ks], h, col);
+    put_acc<1>(Ys, dz4, h, col);   // rows 0..7 (rgb logits' gradient in rows 0..2); the rest of the block is never used
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A4; k++) {
       const int t = wv + NW * k;
-      if (t < B::NT4) dw4[k] = dw_tile<ST, LS>(Ys, Xs, 0, t, r, h, dw4[k]);
+      if (t < B::NT4) dw4[k] = dw_tile<ST>(Ys, Xs + t * BLK, t0, t1, dw4[k]);
     }
-    f32x16 d4[G::OB];
+    // (a gradient tile leaves the registers as soon as it is masked and converted: its two fp16 fragments feed the next
+    // layer's MFMAs AND are what the stage receives -- put_frag of fragments 2ib, 2ib+1 writes exactly put_acc's chunks)
     half8 d4f[G::KH];
 #pragma unroll
     for (int ib = 0; ib < G::OB; ib++) {
-      d4[ib] = MFMA32(wH[(G::T4 + ib) * 64 + lane], dz4f, zero16());
-      relu_mask(d4[ib], ch.h4[2 * ib], ch.h4[2 * ib + 1]);
-      d4f[2 * ib] = acc_to_frag<false>(d4[ib], 0);
-      d4f[2 * ib + 1] = acc_to_frag<false>(d4[ib], 1);
+      f32x16 t = MFMA32(wH[(G::T4 + ib) * 64 + lane], dz4f, zero16());
+      relu_mask(t, ch.h4[2 * ib], ch.h4[2 * ib + 1]);
+      d4f[2 * ib] = acc_to_frag<false>(t, 0);
+      d4f[2 * ib + 1] = acc_to_frag<false>(t, 1);
     }
     sync_stage();
 
     // ---- layer 3
     Xs = Xb[1]; Ys = Yb[1];
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag<LS>(Xs, ks, ch.h3[ks], h, col);
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h3[ks], h, col);
 #pragma unroll
-    for (int ib = 0; ib < G::OB; ib++) put_acc<LS>(Ys, ib, d4[ib], h, col);
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d4f[ks], h, col);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A3; k++) {
       const int t = wv + NW * k;
-      if (t < B::NT3) dw3[k] = dw_tile<ST, LS>(Ys, Xs, t / G::OB, t % G::OB, r, h, dw3[k]);
+      if (t < B::NT3) dw3[k] = dw_tile<ST>(Ys + (t / G::OB) * BLK, Xs + (t % G::OB) * BLK, t0, t1, dw3[k]);
     }
-    f32x16 d3[G::OB];
     half8 d3f[G::KH];
 #pragma unroll
     for (int ib = 0; ib < G::OB; ib++) {
-      d3[ib] = zero16();
+      f32x16 t = zero16();
 #pragma unroll
-      for (int ks = 0; ks < G::KH; ks++) d3[ib] = MFMA32(wH[(G::T3 + ib * G::KH + ks) * 64 + lane], d4f[ks], d3[ib]);
-      relu_mask(d3[ib], ch.h3[2 * ib], ch.h3[2 * ib + 1]);
-      d3f[2 * ib] = acc_to_frag<false>(d3[ib], 0);
-      d3f[2 * ib + 1] = acc_to_frag<false>(d3[ib], 1);
+      for (int ks = 0; ks < G::KH; ks++) t = MFMA32(wH[(G::T3 + ib * G::KH + ks) * 64 + lane], d4f[ks], t);
+      relu_mask(t, ch.h3[2 * ib], ch.h3[2 * ib + 1]);
+      d3f[2 * ib] = acc_to_frag<false>(t, 0);
+      d3f[2 * ib + 1] = acc_to_frag<false>(t, 1);
+      // hidden 128: one tile's eight weight fragments at a time (the scheduler otherwise requests all 32 up front and
+      // the kernel spills)
+      if (H > 64) __builtin_amdgcn_sched_barrier(0);
     }
     sync_stage();
 
-    // ---- layer 2: X = z = [SH(16) | geo(15) | 0]
+    // ---- layer 2: X = z, staged as [SH(16) | the 16 chain slots of the sigma net's outputs] (slot 0 = the logit, which
+    // is no input of the colour net: slab_tile<2> drops that column and shifts the geo features back by one)
     Xs = Xb[0]; Ys = Yb[0];
     {
-      const half8 shf = sh_frag(dx, dy, dz, h);
       half8 geo = in.geo;
       if (PART != 1) {
 #pragma unroll
         for (int j = 0; j < 8; j++) geo[j] = (_Float16)ch.o8[j];
       }
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        Xs[(8 * h + j) * LS + col] = shf[j];
-        const int rho = kslot_feature(0, h, j);
-        if (rho == 0) Xs[31 * LS + col] = (_Float16)0.f;  // pad row (slot of the sigma logit)
-        else Xs[(15 + rho) * LS + col] = geo[j];
-      }
+      put_nat<BLK>(Xs, 0, sh_frag(dx, dy, dz, h), h, col);
+      put_frag<BLK>(Xs, 1, geo, h, col);
     }
 #pragma unroll
-    for (int ib = 0; ib < G::OB; ib++) put_acc<LS>(Ys, ib, d3[ib], h, col);
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d3f[ks], h, col);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A2; k++) {
       const int t = wv + NW * k;
-      if (t < B::NT2) dw2[k] = dw_tile<ST, LS>(Ys, Xs, t, 0, r, h, dw2[k]);
+      if (t < B::NT2) dw2[k] = dw_tile<ST>(Ys + t * BLK, Xs, t0, t1, dw2[k]);
     }
     f32x16 dzz = zero16();
 #pragma unroll
@@ -384,55 +421,50 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     if (DO_SIG) {
 
-    // ---- layer 1: X = H1, dY = dO (16 rows) + 16 zero rows
+    // ---- layer 1: X = H1, dY = dO in chain-slot order (slot 15 = the logit's gradient; slab_tile<1> maps the rows back)
     Xs = Xb[1]; Ys = Yb[1];
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag<LS>(Xs, ks, ch.h1[ks], h, col);
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int rho = kslot_feature(0, h, j);
-      Ys[(rho == 15 ? 0 : rho + 1) * LS + col] = dof[j];
-      Ys[(16 + rho) * LS + col] = (_Float16)0.f;
-    }
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h1[ks], h, col);
+    put_frag<BLK>(Ys, 0, dof, h, col);   // features 0..15 of the block; 16..31 are never used
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A1; k++) {
       const int t = wv + NW * k;
-      if (t < B::NT1) dw1[k] = dw_tile<ST, LS>(Ys, Xs, 0, t, r, h, dw1[k]);
+      if (t < B::NT1) dw1[k] = dw_tile<ST>(Ys, Xs + t * BLK, t0, t1, dw1[k]);
     }
-    f32x16 d1[G::OB];
     half8 d1f[G::KH];
 #pragma unroll
     for (int ib = 0; ib < G::OB; ib++) {
-      d1[ib] = MFMA32(wT[(G::T1 + ib) * 64 + lane], dof, zero16());
-      relu_mask(d1[ib], ch.h1[2 * ib], ch.h1[2 * ib + 1]);
-      d1f[2 * ib] = acc_to_frag<false>(d1[ib], 0);
-      d1f[2 * ib + 1] = acc_to_frag<false>(d1[ib], 1);
+      f32x16 t = MFMA32(wT[(G::T1 + ib) * 64 + lane], dof, zero16());
+      relu_mask(t, ch.h1[2 * ib], ch.h1[2 * ib + 1]);
+      d1f[2 * ib] = acc_to_frag<false>(t, 0);
+      d1f[2 * ib + 1] = acc_to_frag<false>(t, 1);
     }
     sync_stage();
 
     // ---- layer 0: X = F (natural k order) from the feature stage written at the top of the super-tile
     Xs = Xb[0]; Ys = Yb[0];
-    if (!B::EARLY_F) {   // into Xs, rows F..32*IB0-1 zero: re-read (L2-hot) in atomic mode, from registers in PART 2
+    if (!B::EARLY_F) {   // into Xs: re-read (L2-hot) in atomic mode, from registers in PART 2
       const uint32_t il = valid ? i : M - 1;
 #pragma unroll
-      for (int ks = 0; ks < 2 * G::IB0; ks++) {
-        half8 fk;
+      for (int ks = 0; ks < G::KS0; ks++) {
+        half8 fk = in.fk[ks];
+        if (PART != 2) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
-        if (PART == 2) { if (ks < G::KS0) fk = in.fk[ks < G::KS0 ? ks : 0]; }
-        else if (ks < G::KS0 && valid) fk = *reinterpret_cast<const half8*>(feats + (size_t)il * G::F + 16 * ks + 8 * h);
-#pragma unroll
-        for (int j = 0; j < 8; j++) Xs[(16 * ks + 8 * h + j) * LS + col] = fk[j];
+          for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
+          if (valid) fk = *reinterpret_cast<const half8*>(feats + (size_t)il * G::F + 16 * ks + 8 * h);
+        }
+        put_nat<BLK>(Xs, ks, fk, h, col);
       }
     }
 #pragma unroll
-    for (int ib = 0; ib < G::OB; ib++) put_acc<LS>(Ys, ib, d1[ib], h, col);
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d1f[ks], h, col);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A0; k++) {
       const int t = wv + NW * k;
-      if (t < B::NT0) dw0[k] = dw_tile<ST, LS>(Ys, B::EARLY_F ? Fs : Xs, t / G::IB0, t % G::IB0, r, h, dw0[k]);
+      if (t < B::NT0)
+        dw0[k] = dw_tile<ST>(Ys + (t / G::IB0) * BLK, (B::EARLY_F ? Fs : Xs) + (t % G::IB0) * BLK, t0, t1, dw0[k]);
     }
     // feature gradient dF^T = W0^T dH1^T
     if (!ATOMIC) {
@@ -508,12 +540,12 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
   for (int k = 0; k < B::A1; k++) {
     const int t = wv + NW * k;
-    if (DO_SIG && t < B::NT1) slab_tile(slab, G::OFF1, 16, H, 0, t, dw1[k], r, h);
+    if (DO_SIG && t < B::NT1) slab_tile<1>(slab, G::OFF1, 16, H, 0, t, dw1[k], r, h);
   }
 #pragma unroll
   for (int k = 0; k < B::A2; k++) {
     const int t = wv + NW * k;
-    if (DO_COL && t < B::NT2) slab_tile(slab, G::OFF2, H, 31, t, 0, dw2[k], r, h);
+    if (DO_COL && t < B::NT2) slab_tile<2>(slab, G::OFF2, H, 31, t, 0, dw2[k], r, h);
   }
 #pragma unroll
   for (int k = 0; k < B::A3; k++) {

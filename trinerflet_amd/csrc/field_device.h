@@ -106,7 +106,7 @@ struct Chain {
 template <int C, int H>
 __device__ __forceinline__ const half8& wfrag(const half8* w, int f, int lane) { return w[f * 64 + lane]; }
 
-template <int C, int H>
+template <int C, int H, bool FENCE = false>
 __device__ __forceinline__ void chain_colour(const half8* w, const half8* wH, int lane, int h, const half8 geo,
                                              float dx, float dy, float dz, Chain<C, H>& ch);
 
@@ -130,7 +130,7 @@ __device__ __forceinline__ void chain_tail(const half8* w, const half8* wH, int 
 }
 
 // layers 2..4 from the 16 sigma-net outputs as a fragment (slot 0 = the logit, multiplied by zero weights)
-template <int C, int H>
+template <int C, int H, bool FENCE>
 __device__ __forceinline__ void chain_colour(const half8* w, const half8* wH, int lane, int h, const half8 geo,
                                              float dx, float dy, float dz, Chain<C, H>& ch) {
   using G = FieldGeom<C, H>;
@@ -150,6 +150,7 @@ __device__ __forceinline__ void chain_colour(const half8* w, const half8* wH, in
     acc3[ob] = zero16();
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) acc3[ob] = MFMA32(wH[(G::F3 + ob * G::KH + ks) * 64 + lane], ch.h3[ks], acc3[ob]);
+    if (FENCE) __builtin_amdgcn_sched_barrier(0);   // one tile's fragments at a time (register pressure of the split backward)
   }
 #pragma unroll
   for (int ks = 0; ks < G::KH; ks++)
