@@ -50,6 +50,13 @@ TNL_API int tnl_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coo
 TNL_API int tnl_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield,
                          void *stream);
 
+/* Bounding box, in cell coordinates, of the occupied cells of each cascade of a Morton-ordered bitfield
+ * (the layout tnl_packbits writes): bounds[c] = {min x, y, z, max x, y, z} int32, preset by the caller to
+ * {H, H, H, -1, -1, -1}.  TrainStep derives the occupancy window of the planes from it after every density-grid
+ * refresh (renderer.py:448-542 changes the bitfield there); no reference counterpart. */
+TNL_API int tnl_occupancy_bounds(const uint8_t *bitfield, uint32_t bytes_per_cascade, uint32_t cascades,
+                                 int32_t *bounds, void *stream);
+
 /* Number of int32 scratch words tnl_march_rays_train needs for N rays. */
 TNL_API uint32_t tnl_march_rays_train_workspace(uint32_t N);
 

@@ -290,3 +290,24 @@ def test_training_with_window_equals_whole_plane_training(cuda):
         bad = ((a - b).abs() > 2e-3 + 1e-3 * b.abs())
         assert int(bad.sum()) <= max(1, int(1e-5 * a.numel())) and float((a - b).abs().max()) < 6e-2, \
             (int(bad.sum()), a.numel(), float((a - b).abs().max()), bad.nonzero()[:5].tolist())
+
+
+@pytest.mark.gpu
+def test_occupancy_bounds_kernel(cuda):
+    """tnl_occupancy_bounds against the plain definition (decode every set bit of the Morton-ordered bitfield)."""
+    import trinerflet_amd._lib as L
+    from trinerflet_amd import raymarching
+    Hg, casc = 32, 3
+    g = torch.Generator().manual_seed(5)
+    grid = torch.zeros(casc, Hg ** 3)
+    idx = torch.randint(0, Hg ** 3, (40,), generator=g)
+    grid[0, idx] = 1.0
+    grid[2, 12345] = 1.0                                   # cascade 1 stays empty
+    bits = raymarching.packbits(grid.to(cuda), 0.5)
+    bounds = torch.tensor([[Hg + 1] * 3 + [-1] * 3] * casc, dtype=torch.int32, device=cuda)
+    L.check(L.lib().tnl_occupancy_bounds(L.ptr(bits), L.u32(Hg ** 3 // 8), L.u32(casc), L.ptr(bounds), L.stream()), "ob")
+    coords = raymarching.morton3D_invert(torch.arange(Hg ** 3, dtype=torch.int32, device=cuda)).cpu()
+    for c in range(casc):
+        cells = coords[grid[c] > 0]
+        want = ([Hg + 1] * 3 + [-1] * 3) if len(cells) == 0 else cells.amin(0).tolist() + cells.amax(0).tolist()
+        assert bounds[c].tolist() == want

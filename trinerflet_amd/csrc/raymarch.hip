@@ -253,6 +253,39 @@ __global__ void k_morton3D_invert(const int* __restrict__ indices, uint32_t N, i
   coords[n * 3 + 2] = (int)morton3D_invert_((uint32_t)(ind >> 2));
 }
 
+// Bounding box (cell coordinates) of the occupied cells of each cascade of a Morton-ordered bitfield:
+// bounds[c] = {min x, min y, min z, max x, max y, max z}; the caller presets {H, H, H, -1, -1, -1}.
+__global__ void __launch_bounds__(256)
+k_occupancy_bounds(const uint8_t* __restrict__ bitfield, uint32_t bytes_per_cascade, uint32_t cascades,
+                   int* __restrict__ bounds) {
+  __shared__ int sb[6];
+  const uint32_t c = blockIdx.y;
+  if (threadIdx.x < 6) sb[threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : -1;
+  __syncthreads();
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+  for (uint32_t n = blockIdx.x * 256 + threadIdx.x; n < bytes_per_cascade; n += gridDim.x * 256) {
+    uint32_t b = bitfield[(size_t)c * bytes_per_cascade + n];
+    while (b) {
+      const uint32_t j = __builtin_ctz(b);
+      b &= b - 1;
+      const uint32_t cell = 8 * n + j;   // bit j of byte n = cell 8n + j (raymarching.cu:268-289)
+      const int x = (int)morton3D_invert_(cell), y = (int)morton3D_invert_(cell >> 1), z = (int)morton3D_invert_(cell >> 2);
+      lo[0] = min(lo[0], x); lo[1] = min(lo[1], y); lo[2] = min(lo[2], z);
+      hi[0] = max(hi[0], x); hi[1] = max(hi[1], y); hi[2] = max(hi[2], z);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    if (hi[a] >= 0) { atomicMin(&sb[a], lo[a]); atomicMax(&sb[3 + a], hi[a]); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && sb[3 + threadIdx.x] >= 0) {
+    atomicMin(&bounds[c * 6 + threadIdx.x], sb[threadIdx.x]);
+    atomicMax(&bounds[c * 6 + 3 + threadIdx.x], sb[3 + threadIdx.x]);
+  }
+}
+
+
 // One thread packs 4 output bytes from 32 floats read as 8 x float4 (coalesced 128 B per lane).
 __global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thresh,
                            uint8_t* __restrict__ bitfield) {
@@ -856,6 +889,14 @@ int tnl_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, voi
   if (N == 0) return 0;
   hipLaunchKernelGGL(k_morton3D_invert, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, indices, N, coords);
   return launch_status();
+}
+
+int tnl_occupancy_bounds(const uint8_t* bitfield, uint32_t bytes_per_cascade, uint32_t cascades, int32_t* bounds,
+                         void* stream) {
+  if (bytes_per_cascade == 0 || cascades == 0) return 0;
+  hipLaunchKernelGGL(k_occupancy_bounds, dim3(min(cdiv(bytes_per_cascade, 256u), 256u), cascades), dim3(256), 0,
+                     (hipStream_t)stream, bitfield, bytes_per_cascade, cascades, bounds);
+  return (int)hipGetLastError();
 }
 
 int tnl_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream) {

@@ -170,21 +170,18 @@ class TrainStep:
         footprint of every position inside an occupied cell of any cascade.  One small host read-back."""
         model, R = self.model, self.R
         Hg, casc = model.grid_size, model.cascade
-        if not hasattr(self, "_cell_coords"):
-            idx = torch.arange(Hg ** 3, dtype=torch.int32, device=self.dev)
-            self._cell_coords = raymarching.morton3D_invert(idx).t().contiguous()         # [3, H^3] int32
         bits = model.density_bitfield.view(casc, -1)                                       # [casc, H^3/8] uint8
-        shifts = torch.arange(8, dtype=torch.uint8, device=self.dev)
-        occ = ((bits.unsqueeze(-1) >> shifts) & 1).bool().view(casc, 1, -1)               # bit j of byte n = cell 8n+j
-        cc = self._cell_coords.unsqueeze(0)
-        cmin = torch.where(occ, cc, Hg + 1).amin(-1).to(torch.float32)                     # [casc, 3] (row reductions)
-        cmax = torch.where(occ, cc, -1).amax(-1).to(torch.float32)
-        sk = torch.tensor([[min(2.0 ** k, float(model.bound))] for k in range(casc)], device=self.dev)
-        has = cmax[:, :1] >= 0
-        inf = float("inf")
-        lo = torch.where(has, (cmin / Hg * 2 - 1) * sk, inf).amin(0)
-        hi = torch.where(has, ((cmax + 1) / Hg * 2 - 1) * sk, -inf).amax(0)
-        vals = torch.cat([lo, hi]).tolist()
+        bounds = torch.tensor([[Hg + 1] * 3 + [-1] * 3] * casc, dtype=torch.int32, device=self.dev)
+        L.check(L.lib().tnl_occupancy_bounds(L.ptr(bits), L.u32(bits.shape[1]), L.u32(casc), L.ptr(bounds), L.stream()),
+                "occupancy_bounds")
+        vals = [float("inf")] * 3 + [float("-inf")] * 3            # world-space box over the cascades
+        for k, bk in enumerate(bounds.tolist()):                    # the one read-back
+            if bk[3] < 0:
+                continue                                            # no occupied cell in this cascade
+            sk = min(2.0 ** k, float(model.bound))
+            for a in range(3):
+                vals[a] = min(vals[a], (bk[a] / Hg * 2 - 1) * sk)
+                vals[3 + a] = max(vals[3 + a], ((bk[3 + a] + 1) / Hg * 2 - 1) * sk)
         if not all(math.isfinite(v) for v in vals):
             vals = [0.0] * 6                                                                # empty grid: no samples
         b = float(model.bound)
