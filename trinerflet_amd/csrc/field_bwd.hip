@@ -336,10 +336,13 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h4[ks], h, col);
     put_acc<1>(Ys, dz4, h, col);   // rows 0..7 (rgb logits' gradient in rows 0..2); the rest of the block is never used
     __syncthreads();
+    // (Every wave accumulates A_l tiles per layer without a branch: behind `if (tile < NT_l)` the accumulators of that
+    // block live in VGPRs and are copied into AGPRs and back around the MFMAs, 32 moves per tile and super-tile.  The
+    // duplicates cost idle waves a few MFMAs and are dropped when the slabs are written.)
 #pragma unroll
     for (int k = 0; k < B::A4; k++) {
-      const int t = wv + NW * k;
-      if (t < B::NT4) dw4[k] = dw_tile<ST>(Ys, Xs + t * BLK, t0, t1, dw4[k]);
+      const int t = (wv + NW * k) % B::NT4;   // a wave without a tile of its own repeats another's
+      dw4[k] = dw_tile<ST>(Ys, Xs + t * BLK, t0, t1, dw4[k]);
     }
     // (a gradient tile leaves the registers as soon as it is masked and converted: its two fp16 fragments feed the next
     // layer's MFMAs AND are what the stage receives -- put_frag of fragments 2ib, 2ib+1 writes exactly put_acc's chunks)
@@ -362,8 +365,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A3; k++) {
-      const int t = wv + NW * k;
-      if (t < B::NT3) dw3[k] = dw_tile<ST>(Ys + (t / G::OB) * BLK, Xs + (t % G::OB) * BLK, t0, t1, dw3[k]);
+      const int t = (wv + NW * k) % B::NT3;   // a wave without a tile of its own repeats another's
+      dw3[k] = dw_tile<ST>(Ys + (t / G::OB) * BLK, Xs + (t % G::OB) * BLK, t0, t1, dw3[k]);
     }
     half8 d3f[G::KH];
 #pragma unroll
@@ -397,8 +400,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A2; k++) {
-      const int t = wv + NW * k;
-      if (t < B::NT2) dw2[k] = dw_tile<ST>(Ys + t * BLK, Xs, t0, t1, dw2[k]);
+      const int t = (wv + NW * k) % B::NT2;   // a wave without a tile of its own repeats another's
+      dw2[k] = dw_tile<ST>(Ys + t * BLK, Xs, t0, t1, dw2[k]);
     }
     f32x16 dzz = zero16();
 #pragma unroll
@@ -429,8 +432,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A1; k++) {
-      const int t = wv + NW * k;
-      if (t < B::NT1) dw1[k] = dw_tile<ST>(Ys, Xs + t * BLK, t0, t1, dw1[k]);
+      const int t = (wv + NW * k) % B::NT1;   // a wave without a tile of its own repeats another's
+      dw1[k] = dw_tile<ST>(Ys, Xs + t * BLK, t0, t1, dw1[k]);
     }
     half8 d1f[G::KH];
 #pragma unroll
@@ -462,9 +465,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < B::A0; k++) {
-      const int t = wv + NW * k;
-      if (t < B::NT0)
-        dw0[k] = dw_tile<ST>(Ys + (t / G::IB0) * BLK, (B::EARLY_F ? Fs : Xs) + (t % G::IB0) * BLK, t0, t1, dw0[k]);
+      const int t = (wv + NW * k) % B::NT0;   // a wave without a tile of its own repeats another's
+      dw0[k] = dw_tile<ST>(Ys + (t / G::IB0) * BLK, (B::EARLY_F ? Fs : Xs) + (t % G::IB0) * BLK, t0, t1, dw0[k]);
     }
     // feature gradient dF^T = W0^T dH1^T
     if (!ATOMIC) {
