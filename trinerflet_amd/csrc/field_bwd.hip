@@ -125,15 +125,6 @@ __device__ __forceinline__ void put_nat(char* img, int ks, const half8& f, int h
   st4(blk, col, 4 * (ks & 1) + 2 * h + 1, __builtin_shufflevector(f, f, 4, 5, 6, 7));
 }
 
-// ReLU backward: keep dY where the recomputed activation fragment is positive; returns the two k-step fragments
-__device__ __forceinline__ void relu_mask(f32x16& d, const half8& x0, const half8& x1) {
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    if (!((float)x0[j] > 0.f)) d[j] = 0.f;
-    if (!((float)x1[j] > 0.f)) d[8 + j] = 0.f;
-  }
-}
-
 // write one dW tile of a layer into the workgroup's slab (nn.Linear layout [out][in]).  Two stages keep the chain's
 // slot order instead of the layer's own index order, and the tile is mapped back here:
 //   MODE 1 (layer 1): tile row rho -> W1 row (rho == 15 ? 0 : rho + 1), rows >= 16 do not exist
@@ -350,9 +341,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ib = 0; ib < G::OB; ib++) {
       f32x16 t = MFMA32(wH[(G::T4 + ib) * 64 + lane], dz4f, zero16());
-      relu_mask(t, ch.h4[2 * ib], ch.h4[2 * ib + 1]);
-      d4f[2 * ib] = acc_to_frag<false>(t, 0);
-      d4f[2 * ib + 1] = acc_to_frag<false>(t, 1);
+      d4f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h4[2 * ib]);
+      d4f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h4[2 * ib + 1]);
     }
     sync_stage();
 
@@ -374,9 +364,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       f32x16 t = zero16();
 #pragma unroll
       for (int ks = 0; ks < G::KH; ks++) t = MFMA32(wH[(G::T3 + ib * G::KH + ks) * 64 + lane], d4f[ks], t);
-      relu_mask(t, ch.h3[2 * ib], ch.h3[2 * ib + 1]);
-      d3f[2 * ib] = acc_to_frag<false>(t, 0);
-      d3f[2 * ib + 1] = acc_to_frag<false>(t, 1);
+      d3f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h3[2 * ib]);
+      d3f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h3[2 * ib + 1]);
       // hidden 128: one tile's eight weight fragments at a time (the scheduler otherwise requests all 32 up front and
       // the kernel spills)
       if (H > 64) __builtin_amdgcn_sched_barrier(0);
@@ -439,9 +428,8 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ib = 0; ib < G::OB; ib++) {
       f32x16 t = MFMA32(wT[(G::T1 + ib) * 64 + lane], dof, zero16());
-      relu_mask(t, ch.h1[2 * ib], ch.h1[2 * ib + 1]);
-      d1f[2 * ib] = acc_to_frag<false>(t, 0);
-      d1f[2 * ib + 1] = acc_to_frag<false>(t, 1);
+      d1f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h1[2 * ib]);
+      d1f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h1[2 * ib + 1]);
     }
     sync_stage();
 
