@@ -90,6 +90,8 @@ __device__ __forceinline__ half4v tr4(const char* p) {
 // holding the 32 output / input features, t0 / t1 = this lane's transposed-read offsets (rows 8h + q and 8h + 4 + q).
 template <int ST>
 __device__ __forceinline__ f32x16 dw_tile(const char* yb, const char* xb, int t0, int t1, f32x16 acc) {
+  // (written k-step by k-step, the compiler requests all 4 * ST/16 operand reads up front and then issues the MFMAs;
+  // grouping the reads by hand in fours or eights makes it fall back to read, wait, MFMA per k-step)
 #pragma unroll
   for (int ks = 0; ks < ST / 16; ks++) {
     const half8 a = __builtin_shufflevector(tr4(yb + t0 + 1024 * ks), tr4(yb + t1 + 1024 * ks), 0, 1, 2, 3, 4, 5, 6, 7);
@@ -485,7 +487,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     for (int ib = 0; ib < G::IB0; ib++) {
       f32x16 df = zero16();
 #pragma unroll
-      for (int ks = 0; ks < G::KH; ks++) df = MFMA32(w[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
+      for (int ks = 0; ks < G::KH; ks++) df = MFMA32(wT[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
 #pragma unroll
       for (int g = 0; g < 16; g++) {
         const int f = 32 * ib + acc_row(g, h);
