@@ -28,9 +28,10 @@
 
 namespace {
 
-// NW waves per workgroup, 32 samples per wave.  Measured: the kernel needs ~480 registers per lane (dW accumulators
-// + the recomputed chain), i.e. one wave per SIMD, and is VALU-issue-bound there; an 8-wave variant capped at 256
-// registers (two waves per SIMD) spills 90 VGPRs to scratch and runs 1.9x SLOWER (2.72 vs 1.46 ms), so NW = 4.
+// NW waves per workgroup, 32 samples per wave.  The kernel needs ~320 registers per lane (dW accumulators + the
+// recomputed chain), i.e. one wave per SIMD; its waves wait 42 % of the time (SQ_WAIT_ANY) and issue 36 %.  An 8-wave
+// variant capped at 256 registers (two waves per SIMD) still spills ~120 dwords per lane to scratch -- the first one,
+// when the kernel needed 480 registers, ran 1.9x SLOWER (2.72 vs 1.46 ms) -- so NW = 4.
 template <int C, int H, int NW, bool ATOMIC, int PART = 0>
 struct BwdGeom {
   using G = FieldGeom<C, H>;
@@ -45,7 +46,7 @@ struct BwdGeom {
   // features staged once per super-tile in their own LDS region (binned mode).  PART 2 (sigma half of the split launch)
   // instead keeps them in registers and stages them into the X region for layer 0, which leaves room for its 80
   // weight fragments in LDS.
-  static constexpr bool EARLY_F = !ATOMIC && PART != 2;
+  static constexpr bool EARLY_F = !ATOMIC && PART != 2 && NW <= 4;
   static constexpr int XBLKS = EARLY_F ? G::OB : (G::IB0 > G::OB ? G::IB0 : G::OB);
   static constexpr int STAGE_LD = G::F + 1;                       // floats per staged sample row
   static constexpr size_t XS_BYTES = (size_t)XBLKS * BLK;
@@ -566,8 +567,8 @@ k_slab_reduce(const float* __restrict__ slabs, int nslab, int nw, float* __restr
   if (grp == 0 && e < nw) gradW[e] += (part[0][le] + part[1][le]) + (part[2][le] + part[3][le]);
 }
 
-inline uint32_t bwd_blocks(uint32_t M) {
-  uint32_t nst = (M + 127) / 128;
+inline uint32_t bwd_blocks(uint32_t M, uint32_t st = 128) {
+  uint32_t nst = (M + st - 1) / st;
   return nst < 256 ? nst : 256;
 }
 
@@ -599,7 +600,7 @@ int launch_bwd_impl(const float* gsig, const float* grgb, const float* sigma, co
                     float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW,
                     void* workspace, const int32_t* m_actual, void* dfeat, hipStream_t st) {
   using G = FieldGeom<C, H>;
-    const uint32_t blocks = bwd_blocks(M);
+    const uint32_t blocks = bwd_blocks(M, 32 * NW);
   float* slabs = reinterpret_cast<float*>(workspace);
   int e;
   if constexpr (split_launch<C, H, ATOMIC>()) {
