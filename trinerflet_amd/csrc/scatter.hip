@@ -152,13 +152,26 @@ k_scan_fix(int nb, int nblk, const int* __restrict__ block_tot, int* __restrict_
 //   per tile row y (one 32-texel block):  D_y[x, c] += A_y[x, q] * G[q, c],   A_y[x, q] = fp16(cw_q[x] * rw_q[y])
 // with v_mfma_f32_32x32x16_f16, fp32 accumulators in registers for the whole tile lifetime (wave w owns rows
 // 2w, 2w+1).  Records are consumed 256 at a time: phase A (one thread per record; the next chunk's id, xyz and
-// fp16 dF slice are prefetched into registers during phase B) computes the tap once and stages dF transposed
-// (gT[c][q]: a B fragment is one 16-byte LDS read), the row weights (rwT[y][q]) and the column taps; phase B is
+// fp16 dF slice are prefetched into registers during phase B) computes the tap once and stages dF
+// (the image gI, read back through ds_read_b64_tr_b16), the row weights (rwT[y][q]) and the column taps; phase B is
 // 16 k-steps x 2 rows of MFMA per wave.  Two barriers per chunk, no atomics, deterministic summation order.
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef float f16acc __attribute__((ext_vector_type(16)));
 
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_t;
+
+// The dF stage is an image [32-channel block][record][32 channels] with 64-byte rows whose eight 8-byte chunks are
+// XOR-swizzled with the row (the layout of field_bwd.hip's stages): a record's thread stores its channels with
+// ds_write_b64, and the MFMA B operand -- 8 records of one channel per lane -- is read with the transposing
+// ds_read_b64_tr_b16, conflict-free both ways.  ([channel][record] rows took one ds_write_b16 per channel and record.)
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+__device__ __forceinline__ h4v tr4(const char* p) {
+  const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+      (__attribute__((address_space(3))) fp16x4_t*)(const_cast<char*>(p)));
+  return __builtin_bit_cast(h4v, v);
+}
 
 template <int C>
 __global__ void __launch_bounds__(NT)
@@ -170,12 +183,13 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
     constexpr int NB = (C + 31) / 32;          // 32-channel column blocks
   constexpr int QS = NT + 8;                 // record stride (halfs) of the transposed stages: 16-B aligned rows
   constexpr int XS = TSX + 4;                // epilogue staging stride (floats)
-  constexpr size_t STAGE_A = (size_t)(32 * NB + TSY + TSX) * QS * 2;
+  constexpr int GBLK = NT * 64;              // bytes of one 32-channel block of the dF image
+  constexpr size_t STAGE_A = (size_t)NB * GBLK + (size_t)(TSY + TSX) * QS * 2;
   constexpr size_t STAGE_E = (size_t)4 * 2 * 32 * NB * XS * 4;
   constexpr size_t LDS_BYTES = STAGE_A > STAGE_E ? STAGE_A : STAGE_E;
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-  _Float16* gT = reinterpret_cast<_Float16*>(smem);                 // [32*NB][QS]   dF transposed: [channel][record]
-  _Float16* rwT = gT + (size_t)32 * NB * QS;                        // [TSY][QS]     row weights    [tile row][record]
+  char* gI = smem;                                                  // [NB][NT][32]  dF image (see img_off)
+  _Float16* rwT = reinterpret_cast<_Float16*>(smem + (size_t)NB * GBLK);   // [TSY][QS]  row weights [tile row][record]
   // column weights [tile column][record]: a record has at most two non-zero entries (columns x0, x0+1 if inside the
   // tile), written once by the record's thread in phase A; every wave then reads its A-fragment factor with one
   // 16-byte LDS load instead of rebuilding it from the taps (that rebuild was ~40 VALU instructions per k-step,
@@ -231,10 +245,15 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
     for (int nb = 0; nb < NB; nb++)
 #pragma unroll
       for (int g = 0; g < 16; g++) acc[b][nb][g] = 0.f;
-  // rows of gT beyond C (C = 16 or 48: the padded half of a column block) stay zero for the whole kernel
+  // channels beyond C (C = 16 or 48: the padded half of the last block) stay zero for the whole kernel
   if (C % 32 != 0) {
-    for (int q = threadIdx.x; q < (32 * NB - C) * QS; q += NT) gT[(size_t)C * QS + q] = (_Float16)0.f;
+    for (int q = threadIdx.x; q < GBLK / 16; q += NT)
+      reinterpret_cast<float4*>(gI + (size_t)(NB - 1) * GBLK)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // transposed-read offsets: lane 4q + p of a 16-lane group addresses record row q of a 4-row block, chunk p of the
+  // group's 16 channels
+  const int tq = (lane & 15) >> 2, tc = 4 * ((lane >> 4) & 1) + (lane & 3);
+  const int t0 = img_off(8 * h + tq, tc), t1 = img_off(8 * h + 4 + tq, tc);
   for (int q = threadIdx.x; q < TSX * QS / 8; q += NT) {
     h8v z;
 #pragma unroll
@@ -247,17 +266,27 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
   float px = 0.f, py = 0.f, pz = 0.f;
   h8v pg[C / 8];
   bool pv = false;
-  auto prefetch = [&](int base) {
-    pv = base + (int)threadIdx.x < end;
+  // two levels ahead: the record id of chunk t+2 is requested while the data of chunk t+1 (addressed by the id
+  // fetched one trip earlier) is in flight -- id -> xyz / dF is a dependent pair of global latencies
+  uint32_t nid = 0;
+  bool nv = false;
+  auto fetch_id = [&](int base) {
+    nv = base + (int)threadIdx.x < end;
+    if (nv) nid = entries[base + threadIdx.x];
+  };
+  auto prefetch = [&]() {   // data of the chunk whose ids are in (nid, nv)
+    pv = nv;
     if (pv) {
-      const uint32_t i = entries[base + threadIdx.x];
+      const uint32_t i = nid;
       px = xyz[(size_t)i * 3]; py = xyz[(size_t)i * 3 + 1]; pz = xyz[(size_t)i * 3 + 2];
       const h8v* src = reinterpret_cast<const h8v*>(dfeat + ((size_t)p * Mcap + i) * C);   // plane-major [3][M][C]
 #pragma unroll
       for (int k = 0; k < C / 8; k++) pg[k] = src[k];   // (non-temporal loads here: 0.80 -> 0.85 ms, not used)
     }
   };
-  prefetch(beg);
+  fetch_id(beg);
+  prefetch();
+  fetch_id(beg + NT);
   for (int base = beg; base < end; base += NT) {
     __syncthreads();  // previous chunk's fragments fully read
     // ---- A: one thread per record
@@ -280,17 +309,23 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
         prev_c0 = lx0;   // lx1 is lx0 + 1 whenever it is written
         wy0 = (1.f - wy) * grad_scale; wy1 = wy * grad_scale;
 #pragma unroll
-        for (int k = 0; k < C / 8; k++)
-#pragma unroll
-          for (int j = 0; j < 8; j++) gT[(size_t)(8 * k + j) * QS + q] = pg[k][j];
+        for (int k = 0; k < C / 8; k++) {
+          char* blk = gI + (size_t)((8 * k) / 32) * GBLK;
+          const int c0 = ((8 * k) % 32) / 4;
+          *reinterpret_cast<h4v*>(blk + img_off(q, c0)) = __builtin_shufflevector(pg[k], pg[k], 0, 1, 2, 3);
+          *reinterpret_cast<h4v*>(blk + img_off(q, c0 + 1)) = __builtin_shufflevector(pg[k], pg[k], 4, 5, 6, 7);
+        }
       } else {
+        const h4v z = {0, 0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < C; c++) gT[(size_t)c * QS + q] = (_Float16)0.f;  // 0 * stale NaN would poison the MFMA
+        for (int k = 0; k < C / 4; k++)   // 0 * stale NaN would poison the MFMA
+          *reinterpret_cast<h4v*>(gI + (size_t)((4 * k) / 32) * GBLK + img_off(q, ((4 * k) % 32) / 4)) = z;
       }
 #pragma unroll
       for (int y = 0; y < TSY; y++) rwT[(size_t)y * QS + q] = (_Float16)((y == ly0 ? wy0 : 0.f) + (y == ly1 ? wy1 : 0.f));
     }
-    if (base + NT < end) prefetch(base + NT); else pv = false;
+    prefetch();               // chunk base + NT (pv false past the end)
+    fetch_id(base + 2 * NT);
     __syncthreads();
     // ---- B: matrix-core accumulation, wave wv owns tile rows 2wv and 2wv+1
     const int nks = (min(NT, end - base) + 15) / 16;
@@ -299,7 +334,9 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
       const h8v cw = *reinterpret_cast<const h8v*>(cwT + (size_t)r * QS + q0);   // column r, records q0..q0+7
       h8v bf[NB];
 #pragma unroll
-      for (int nb = 0; nb < NB; nb++) bf[nb] = *reinterpret_cast<const h8v*>(gT + (size_t)(32 * nb + r) * QS + q0);
+      for (int nb = 0; nb < NB; nb++)
+        bf[nb] = __builtin_shufflevector(tr4(gI + (size_t)nb * GBLK + t0 + 1024 * ks),
+                                         tr4(gI + (size_t)nb * GBLK + t1 + 1024 * ks), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
       for (int b = 0; b < 2; b++) {
         const h8v rw = *reinterpret_cast<const h8v*>(rwT + (size_t)(2 * wv + b) * QS + q0);
@@ -337,7 +374,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
       }
     }
   } else {
-    __syncthreads();  // the staging area aliases gT / rwT / ctap
+    __syncthreads();  // the staging area aliases gI / rwT / cwT
     float* stg = reinterpret_cast<float*>(smem) + (size_t)wv * 2 * 32 * NB * XS;
 #pragma unroll
     for (int b = 0; b < 2; b++)
