@@ -26,3 +26,23 @@ def test_bench_prints_one_contract_line(cuda):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+
+
+def test_bench_two_ranks_on_one_device(cuda):
+    """The N > 1 code path of bench.py itself (ray shards, slice-sharded dense work, collectives, max-over-ranks
+    timing, rank-0 line), launched exactly as the driver does but with both ranks on cuda:0 over gloo -- the only way
+    to execute it on a one-GPU box.  RCCL replaces gloo on a real node; the call sequence is the same."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny",
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--backend", "gloo", "--same-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "dp2" in d["config"]["parallelism"]
