@@ -26,9 +26,11 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // forward kernel
 // ---------------------------------------------------------------------------------------------
-// (capping the registers at 256 for two waves per SIMD, `__launch_bounds__(FWD_THREADS, 2)`, compiles without scratch
-// at hidden 64 but runs slower at base: 1.03 vs 0.95 ms, A/B on one box -- the gathers are not latency-starved)
-template <int C, int H, bool HALFP, bool DENSITY_ONLY>
+// (Occupancy is not the lever: capping the registers at 256 for two waves per SIMD, `__launch_bounds__(FWD_THREADS, 2)`,
+// ran slower at base (1.03 vs 0.95 ms), and an 8-wave workgroup for hidden 128 -- two waves per SIMD sharing the 92 KB
+// of weights -- measured 1.61 vs 1.62 ms.  With all of a tile's loads in flight the kernel sits at the ~4 TB/s that
+// 64-byte texel gathers reach here: 3.6 GB in 0.81 ms at base, 5.4 GB in 1.5 ms at C = 48.)
+template <int C, int H, bool HALFP, bool DENSITY_ONLY, bool SAVE>
 __global__ void __launch_bounds__(FWD_THREADS)
 k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, const float* __restrict__ dirs,
             float bound, uint32_t M, int R, const half8* __restrict__ packed, float* __restrict__ sigma,
@@ -40,15 +42,16 @@ k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, cons
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half8* w = reinterpret_cast<half8*>(smem);
   constexpr int NFR = DENSITY_ONLY ? G::F2 : G::NF;
-  for (int i = threadIdx.x; i < NFR * 64; i += FWD_THREADS) w[i] = packed[i];
+  constexpr int FT = FWD_THREADS;
+  for (int i = threadIdx.x; i < NFR * 64; i += FT) w[i] = packed[i];
   __syncthreads();
 
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const uint32_t waves = gridDim.x * (FWD_THREADS / 64);
+  const uint32_t waves = gridDim.x * (FT / 64);
   const uint32_t ntiles = (M + 31) / 32;
   // positions / directions of the NEXT tile are requested one trip ahead: the gather addresses depend on them, and with
   // two waves per SIMD a dependent pair of global latencies per tile is not hidden otherwise
-  const uint32_t tile0 = blockIdx.x * (FWD_THREADS / 64) + (threadIdx.x >> 6);
+  const uint32_t tile0 = blockIdx.x * (FT / 64) + (threadIdx.x >> 6);
   float npx = 0.f, npy = 0.f, npz = 0.f, ndx = 0.f, ndy = 0.f, ndz = 0.f;
   auto fetch_pos = [&](uint32_t t) {
     const uint32_t i_ = t * 32 + r;
@@ -63,23 +66,36 @@ k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, cons
     const float px = npx, py = npy, pz = npz;
     const float cdx = ndx, cdy = ndy, cdz = ndz;
     if (tile + waves < ntiles) fetch_pos(tile + waves);   // (A/B on one box: 1.02 -> 0.96..1.02 ms, kept)
+    // All 12 * C / 16 texel loads of the tile are requested before anything consumes them: the feature store used to
+    // sit behind `if (feats_save && valid)` inside the gather loop, and that branch kept the scheduler from moving
+    // the next group of four loads above it -- six dependent round trips to memory per tile with one wave per SIMD.
+    // SAVE is a template parameter and rows past M store into row M - 1 what row M - 1 stores itself (their clamped
+    // position is that sample's), so the store needs no predicate.
+    // (hidden 128 is register-bound: there the planes are taken one at a time, 12 loads in flight instead of 36)
+    constexpr int PG = H > 64 ? 1 : 3;   // planes per group
+    const uint32_t il = valid ? i : M - 1;
     f32x16 acc0[G::OB];
 #pragma unroll
     for (int ob = 0; ob < G::OB; ob++) acc0[ob] = zero16();
 #pragma unroll
-    for (int p = 0; p < 3; p++) {
-      TexelTap t;
-      triplane_tap(px, py, pz, bound, R, p, t);
+    for (int p0 = 0; p0 < 3; p0 += PG) {
+      half8 fk[PG * (C / 16)];
 #pragma unroll
-      for (int kk = 0; kk < C / 16; kk++) {
-        const half8 f = gather_frag<C, HALFP>(planes, R, p, kk, h, t);
-        const int ks = p * (C / 16) + kk;
-        // (a non-temporal store here was measured SLOWER: field_fwd 1.05 -> 1.14 ms)
-        if (feats_save != nullptr && valid)
-          *reinterpret_cast<half8*>(feats_save + (size_t)i * G::F + 16 * ks + 8 * h) = f;
+      for (int p = p0; p < p0 + PG; p++) {
+        TexelTap t;
+        triplane_tap(px, py, pz, bound, R, p, t);
 #pragma unroll
-        for (int ob = 0; ob < G::OB; ob++) acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], f, acc0[ob]);
+        for (int kk = 0; kk < C / 16; kk++) fk[(p - p0) * (C / 16) + kk] = gather_frag<C, HALFP>(planes, R, p, kk, h, t);
       }
+#pragma unroll
+      for (int q = 0; q < PG * (C / 16); q++) {
+        const int ks = p0 * (C / 16) + q;
+        // (a non-temporal store here was measured SLOWER: field_fwd 1.05 -> 1.14 ms)
+        if (SAVE) *reinterpret_cast<half8*>(feats_save + (size_t)il * G::F + 16 * ks + 8 * h) = fk[q];
+#pragma unroll
+        for (int ob = 0; ob < G::OB; ob++) acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], fk[q], acc0[ob]);
+      }
+      if (PG < 3) __builtin_amdgcn_sched_barrier(0);
     }
     const float dx = cdx, dy = cdy, dz = cdz;
     Chain<C, H> ch;
@@ -135,19 +151,22 @@ int launch_fwd(const void* planes, int half_in, const float* xyz, const float* d
                const int32_t* m_actual, hipStream_t st) {
   using G = FieldGeom<C, H>;
   const uint32_t ntiles = (M + 31) / 32;
-  uint32_t blocks = (ntiles + 3) / 4;
+  constexpr uint32_t WPB = FWD_THREADS / 64;   // tiles (waves) per workgroup
+  uint32_t blocks = (ntiles + WPB - 1) / WPB;
   if (blocks > 2048) blocks = 2048;
   const half8* pk = reinterpret_cast<const half8*>(packed);
   _Float16* fs = reinterpret_cast<_Float16*>(feats_save);
   _Float16* gs = (H > 64 && fs != nullptr) ? fs + (size_t)M * G::F : nullptr;   // see tnl_field_feats_save_bytes
-#define TNL_LAUNCH(HP, DO)                                                                                        \
-  hipLaunchKernelGGL((k_field_fwd<C, H, HP, DO>), dim3(blocks), dim3(FWD_THREADS), (DO ? G::F2 : G::NF) * 1024, st, \
+#define TNL_LAUNCH(HP, DO, SV)                                                                                        \
+  hipLaunchKernelGGL((k_field_fwd<C, H, HP, DO, SV>), dim3(blocks), dim3(FWD_THREADS), (DO ? G::F2 : G::NF) * 1024, st, \
                      planes, xyz, dirs, bound, M, (int)R, pk, sigma, rgb, fs, gs, m_actual)
+#define TNL_LAUNCH_SV(HP, DO) do { if (fs != nullptr) TNL_LAUNCH(HP, DO, true); else TNL_LAUNCH(HP, DO, false); } while (0)
   if (density_only) {
-    if (half_in) TNL_LAUNCH(true, true); else TNL_LAUNCH(false, true);
+    if (half_in) TNL_LAUNCH_SV(true, true); else TNL_LAUNCH_SV(false, true);
   } else {
-    if (half_in) TNL_LAUNCH(true, false); else TNL_LAUNCH(false, false);
+    if (half_in) TNL_LAUNCH_SV(true, false); else TNL_LAUNCH_SV(false, false);
   }
+#undef TNL_LAUNCH_SV
 #undef TNL_LAUNCH
   return (int)hipGetLastError();
 }
