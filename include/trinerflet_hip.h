@@ -387,6 +387,10 @@ TNL_API int tnl_adam_l1_step_rect(float *p, float *grad, float *m, float *v, uin
                                   const float *opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
                                   const float *inv_scale_dev, float l1_coef, const float *found_inf,
                                   float *abs_sum, void *stream);
+/* Dynamic LDS (bytes, <= 64 KB) reserved by every workgroup of the FOLLOWING tnl_adam_l1_* launches of this process:
+ * limits the pass to 160 KB / bytes workgroups per CU so that kernels of another stream (the next batch's march and
+ * tile sort) find wave slots underneath it.  0 (default) = no limit.  Host-side state, not thread-safe. */
+TNL_API int tnl_adam_set_lds_reservation(uint32_t bytes);
 
 #ifdef __cplusplus
 }

@@ -124,6 +124,7 @@ class TrainStep:
         self.inv_scale = torch.ones(1, dtype=torch.float32, device=dev)   # 1 / loss scale, written by csrc/stepstate.hip
         self.last = {}
         self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
+        self.prefetch_at = "auto"   # "bwd" | "adam" | "auto": where step(next_rays=...) starts the next batch's march
         self._side = None
         self._prefetched = None     # (key, marched tensors) of a march started for the following call
         self.post_refresh = None    # optional callable run right after every density-grid refresh
@@ -562,7 +563,9 @@ class TrainStep:
             # its SIMD's whole register file -- 480 / 2 x 242 registers -- so the march cannot co-reside with them and
             # is time-sliced in); started under Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms
             # stay exposed.  At the small configuration (dense tail 0.5 ms) 1 ms of the march stays exposed either way.
-            self._prefetch_next(next_rays, march_on_side)
+            under_adam = self._prefetch_under_adam(next_rays)
+            if not under_adam:
+                self._prefetch_next(next_rays, march_on_side)
             if side is not None:
                 torch.cuda.current_stream().wait_event(ev_sort)
             F_.plane_grad_reduce(sort_ws, dfeat, xyzs, float(model.bound), C, R, g_cm, channel_major=True,
@@ -581,7 +584,15 @@ class TrainStep:
                 s0, s1 = self._adjoint(None, g_cm, roi=roi)
                 self._mark("idwt_adjoint")
                 rects = self._rects if (roi is not None and self._rect_ok) else None
+                # large coefficient sets: the next batch's march + tile sort start together with the Adam pass, whose
+                # workgroups are limited to 4 per CU (an unused 40-KB LDS reservation) so that the side stream finds
+                # wave slots; the tile reduction and the adjoint above then ran undisturbed
+                lib.tnl_adam_set_lds_reservation(L.u32(40960 if under_adam else 0))
+                if under_adam:
+                    self._prefetch_next(next_rays, march_on_side)
                 self._adam_levels(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
+                if under_adam:
+                    lib.tnl_adam_set_lds_reservation(L.u32(0))
                 self._mark("adam_coef")
         else:
             grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
@@ -629,6 +640,14 @@ class TrainStep:
         self.last = {'mse': mse, 'wavelet_reg': reg, 'M': M, 'found_inf': found_inf, 'image': pred, 'ws': ws,
                      'depth': depth, 'counter': counter, 'lr': lr_t}
         return loss
+
+    def _prefetch_under_adam(self, next_rays):
+        """Where the next batch's march + tile sort go: underneath the Adam pass when that pass is long enough to
+        cover them (>= 2e8 coefficients: ~1 ms of HBM time), else right after the field backward (see step())."""
+        mode = self.prefetch_at
+        if mode == "auto":
+            mode = "adam" if self.coef_numel >= 200_000_000 else "bwd"
+        return mode == "adam" and next_rays is not None and not self.fuse_adam
 
     def _prefetch_next(self, next_rays, march_on_side):
         model = self.model
