@@ -646,7 +646,8 @@ class TrainStep:
         cover them (>= 2e8 coefficients: ~1 ms of HBM time), else right after the field backward (see step())."""
         mode = self.prefetch_at
         if mode == "auto":
-            mode = "adam" if self.coef_numel >= 200_000_000 else "bwd"
+            own = self.coef_numel // (self.world if self.dist_mode == "sharded" else 1)   # this rank's share of the pass
+            mode = "adam" if own >= 200_000_000 else "bwd"
         return mode == "adam" and next_rays is not None and not self.fuse_adam
 
     def _prefetch_next(self, next_rays, march_on_side):
