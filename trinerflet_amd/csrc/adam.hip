@@ -14,6 +14,9 @@
 #include "../../include/trinerflet_hip.h"
 #include "adam_common.h"
 
+#ifndef TNL_ADAM_UNROLL
+#define TNL_ADAM_UNROLL 2
+#endif
 #ifndef TNL_ADAM_BLOCKS
 #define TNL_ADAM_BLOCKS 4096
 #endif
@@ -71,10 +74,11 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
   // (A/B in one process at 402 M parameters: 2.255 ms chunked vs 2.45 ms grid-stride)
   const uint64_t chunk = (n4 + gridDim.x - 1) / gridDim.x;
   const uint64_t c0 = (uint64_t)blockIdx.x * chunk, c1 = min(c0 + chunk, n4);
-  for (uint64_t i = c0 + threadIdx.x; i < c1; i += blockDim.x) {
-    float4 pp = NTMP ? ld_nt(p4 + i) : p4[i];
+  struct Quad { float4 pp, gg, mm, vv; };
+  auto load = [&](uint64_t i, Quad& q) {
+    q.pp = NTMP ? ld_nt(p4 + i) : p4[i];
+    q.gg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!skip) {
-      float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
       bool inside = true;
       if (RECT) {
         const uint64_t e = i * 4;
@@ -85,18 +89,41 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
         const int pl = sl >= 2 * rc.spp ? 2 : (sl >= rc.spp ? 1 : 0);
         inside = c >= rc.rx[pl] && c < rc.rx[pl] + rc.rw && r >= rc.ry[pl] && r < rc.ry[pl] + rc.rh;
       }
-      if (inside) gg = NTMP ? ld_nt(g4 + i) : g4[i];
-      float4 mm = NTMP ? ld_nt(m4 + i) : m4[i], vv = NTMP ? ld_nt(v4 + i) : v4[i];
-      adam1(pp.x, gg.x, mm.x, vv.x, a, acc);
-      adam1(pp.y, gg.y, mm.y, vv.y, a, acc);
-      adam1(pp.z, gg.z, mm.z, vv.z, a, acc);
-      adam1(pp.w, gg.w, mm.w, vv.w, a, acc);
-      if (NTMP) { st_nt(p4 + i, pp); st_nt(m4 + i, mm); st_nt(v4 + i, vv); }
-      else { p4[i] = pp; m4[i] = mm; v4[i] = vv; }
+      if (inside) q.gg = NTMP ? ld_nt(g4 + i) : g4[i];
+      q.mm = NTMP ? ld_nt(m4 + i) : m4[i];
+      q.vv = NTMP ? ld_nt(v4 + i) : v4[i];
+    }
+  };
+  auto finish = [&](uint64_t i, Quad& q) {
+    if (!skip) {
+      adam1(q.pp.x, q.gg.x, q.mm.x, q.vv.x, a, acc);
+      adam1(q.pp.y, q.gg.y, q.mm.y, q.vv.y, a, acc);
+      adam1(q.pp.z, q.gg.z, q.mm.z, q.vv.z, a, acc);
+      adam1(q.pp.w, q.gg.w, q.mm.w, q.vv.w, a, acc);
+      if (NTMP) { st_nt(p4 + i, q.pp); st_nt(m4 + i, q.mm); st_nt(v4 + i, q.vv); }
+      else { p4[i] = q.pp; m4[i] = q.mm; v4[i] = q.vv; }
     } else {
-      acc += fabsf(pp.x) + fabsf(pp.y) + fabsf(pp.z) + fabsf(pp.w);
+      acc += fabsf(q.pp.x) + fabsf(q.pp.y) + fabsf(q.pp.z) + fabsf(q.pp.w);
     }
     if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  // TNL_ADAM_UNROLL float4 per thread and trip, all loads first: bytes in flight per wave (the pass runs at reduced
+  // residency when the side stream works underneath it)
+  uint64_t i = c0 + threadIdx.x;
+  constexpr int U = TNL_ADAM_UNROLL;
+  if (U > 1) {
+    for (; i + (uint64_t)(U - 1) * blockDim.x < c1; i += (uint64_t)U * blockDim.x) {
+      Quad q[U];
+#pragma unroll
+      for (int k = 0; k < U; k++) load(i + (uint64_t)k * blockDim.x, q[k]);
+#pragma unroll
+      for (int k = 0; k < U; k++) finish(i + (uint64_t)k * blockDim.x, q[k]);
+    }
+  }
+  for (; i < c1; i += blockDim.x) {
+    Quad q;
+    load(i, q);
+    finish(i, q);
   }
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   // ragged tail
