@@ -106,9 +106,12 @@ packbits = _packbits.apply
 class _march_rays_train(Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
-                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, noises=None):
+                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, noises=None,
+                zero_fill=True):
         # reference: raymarching.py:161-233.  Extra trailing `noises` ([N] in [0,1)) lets a caller supply
         # the perturbation explicitly (used by tests/bench for seeded parity); None = reference behaviour.
+        # zero_fill=False skips the reference's zero fill of the padded sample buffers (:205-207) for a caller whose
+        # consumers never read rows past counter[0] (TrainStep: every kernel takes the count): 32 B x M less to write.
         rays_o = _f32c(rays_o).view(-1, 3)
         rays_d = _f32c(rays_d).view(-1, 3)
         nears, fars = _f32c(nears), _f32c(fars)
@@ -122,9 +125,10 @@ class _march_rays_train(Function):
             if align > 0:
                 mean_count += align - mean_count % align
             M = mean_count
-        xyzs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
-        dirs = torch.zeros(M, 3, dtype=torch.float32, device=dev)
-        deltas = torch.zeros(M, 2, dtype=torch.float32, device=dev)
+        alloc = torch.zeros if zero_fill else torch.empty
+        xyzs = alloc(M, 3, dtype=torch.float32, device=dev)
+        dirs = alloc(M, 3, dtype=torch.float32, device=dev)
+        deltas = alloc(M, 2, dtype=torch.float32, device=dev)
         rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)

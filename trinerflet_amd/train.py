@@ -440,7 +440,8 @@ class TrainStep:
             model.local_step += 1
             out = raymarching.march_rays_train(
                 o, d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars,
-                counter, model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, nz)
+                counter, model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, nz,
+                model.mean_count <= 0)   # zero fill only when the buffers are sized by the worst case (first steps)
             # the field forward needs the march only; the tile sort of the plane gradient (needed much later, by the
             # tile reduction) rides behind it on the same stream and gets its own event
             ev_march = torch.cuda.Event()
