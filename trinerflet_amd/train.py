@@ -123,6 +123,8 @@ class TrainStep:
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
         self.inv_scale = torch.ones(1, dtype=torch.float32, device=dev)   # 1 / loss scale, written by csrc/stepstate.hip
         self.last = {}
+        self.section_names = None   # see _mark
+        self._mark_seq = 0
         self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
         self.prefetch_at = "auto"   # "bwd" | "adam" | "auto": where step(next_rays=...) starts the next batch's march
         self._side = None
@@ -139,10 +141,13 @@ class TrainStep:
 
     # ------------------------------------------------------------------------------------------
     def _mark(self, name):
-        if self.section_events is not None:
+        """Section boundary.  With section_events set, a HIP event is recorded here (each costs the stream 6-8 us);
+        section_names limits the recording to those boundaries (None = all)."""
+        self._mark_seq += 1
+        if self.section_events is not None and (self.section_names is None or name in self.section_names):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()  # torch's current stream = the stream every kernel of the step is launched on
-            self.section_events.append((name, ev))
+            self.section_events.append((name, ev, self._mark_seq))
 
     def section_times(self):
         """Mean milliseconds per stage over the recorded steps (requires a prior torch.cuda.synchronize())."""
@@ -150,11 +155,12 @@ class TrainStep:
             return {}
         tot, cnt = {}, {}
         prev = None
-        for name, ev in self.section_events:
-            if name != "begin" and prev is not None:
-                tot[name] = tot.get(name, 0.0) + prev.elapsed_time(ev)
+        for name, ev, seq in self.section_events:
+            # a section is timed only when the boundary before it was recorded too (consecutive _mark calls)
+            if name != "begin" and prev is not None and prev[1] == seq - 1:
+                tot[name] = tot.get(name, 0.0) + prev[0].elapsed_time(ev)
                 cnt[name] = cnt.get(name, 0) + 1
-            prev = ev
+            prev = (ev, seq)
         return {k: tot[k] / cnt[k] for k in tot}
 
     def invalidate_roi(self):
