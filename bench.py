@@ -106,9 +106,9 @@ def cpu_baseline(workload):
 
 def pmc_traffic(workload, world):
     """HBM bytes of the step's k_adam_l1 launches from the committed rocprofv3 PMC passes
-    (profiles/r01m_pmc_adam.json, made by tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate --pmc runs,
+    (profiles/r01n_pmc_adam.json, made by tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate --pmc runs,
     gfx950 correction applied); null when no profile exists for this configuration."""
-    path = os.path.join(ROOT, "profiles", "r01m_pmc_adam.json")
+    path = os.path.join(ROOT, "profiles", "r01n_pmc_adam.json")
     if workload != "base" or world != 1 or not os.path.exists(path):
         return None
     return json.load(open(path))["hbm_bytes_per_launch"]
@@ -213,6 +213,19 @@ def main():
     torch.cuda.synchronize()
     sec = ts.section_times()
     sec["adam_coef"] = adam_ms
+    # The step starts the next batch's march + tile sort together with the Adam launches (TrainStep.prefetch_at): the
+    # figure above is the kernel sharing the GPU with them.  For the kernel by itself: the same steps with the side
+    # work started after the field backward instead (nothing runs beside Adam then).
+    adam_alone_ms = float("nan")
+    if ts._prefetch_under_adam(((),)):
+        ts.section_events, ts.section_names = [], {"idwt_adjoint", "scaler_probe", "adam_coef"}
+        ts.prefetch_at = "bwd"
+        for i in range(min(args.steps, 16)):
+            j = args.warmup + args.steps + 16 + i
+            one_step(model, ts, bitfield, batches[j % nb], mean_count, batches[(j + 1) % nb])
+        torch.cuda.synchronize()
+        adam_alone_ms = ts.section_times().get("adam_coef", float("nan"))
+        ts.prefetch_at = "auto"
     samples_per_step = float(np.mean(counts))
     P_coef = ts.coef_numel if ts.dist_mode != "sharded" else ts.coef_numel // world
     # algorithmic bytes of the step's Adam launches (one per wavelet level + LL): 16 B read (p, g, m, v) + 12 B
@@ -290,6 +303,12 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload, world), "algorithmic_bytes_per_launch": adam_bytes,
                          "avg_launch_ms": adam_ms, "launches_per_step": n_launch,
+                         "alone": None if adam_alone_ms != adam_alone_ms else {
+                             "avg_launch_ms": adam_alone_ms, "achieved": adam_bytes / (adam_alone_ms * 1e-3) / 1e9,
+                             "frac": adam_bytes / (adam_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "the same launches with nothing beside them: in the timed steps the next batch's "
+                                     "march + tile sort run underneath the Adam pass by design (the step is 0.2 ms "
+                                     "shorter for it), here they start after the field backward instead"},
                          "note": "achieved = algorithmic bytes of the step's k_adam_l1 launches / their summed duration "
                                  "(HIP events on the launch stream); 8000 GB/s is the spec peak, a float4 copy "
                                  "reaches 6290 GB/s on MI355X (MI355X_MICROARCH.md)"},
