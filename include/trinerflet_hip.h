@@ -57,11 +57,16 @@ TNL_API int tnl_packbits(const float *grid, uint32_t N, float density_thresh, ui
 TNL_API int tnl_occupancy_bounds(const uint8_t *bitfield, uint32_t bytes_per_cascade, uint32_t cascades,
                                  int32_t *bounds, void *stream);
 
-/* Number of int32 scratch words tnl_march_rays_train needs for N rays. */
+/* Number of int32 scratch words tnl_march_rays_train needs for N rays: the minimum (the samples are then written
+ * by a second march of every ray), and the size with which the count pass can record each sample's t
+ * (+ N * max_steps floats; 0 if that exceeds 32 bits) so that the samples are written from the record instead --
+ * bit-identical output, the ray is marched once. */
 TNL_API uint32_t tnl_march_rays_train_workspace(uint32_t N);
+TNL_API uint32_t tnl_march_rays_train_workspace_rec(uint32_t N, uint32_t max_steps);
 
 /* raymarching.h:13 march_rays_train ; kernel raymarching.cu:312-480.
- * Same arguments as the reference plus a scratch buffer.  Packing is DETERMINISTIC: rays[n] =
+ * Same arguments as the reference plus a scratch buffer of workspace_words int32 (see the two size functions
+ * above).  Packing is DETERMINISTIC: rays[n] =
  * (n, exclusive prefix of num_steps, num_steps), i.e. the ray-id arrival order of the
  * reference's atomics (which are nondeterministic there).  counter[0] += total steps,
  * counter[1] += N.  xyzs/dirs/deltas rows that no ray owns are left untouched (the caller
@@ -71,7 +76,7 @@ TNL_API int tnl_march_rays_train(const float *rays_o, const float *rays_d, const
                                  uint32_t C, uint32_t H, uint32_t M, const float *nears,
                                  const float *fars, float *xyzs, float *dirs, float *deltas,
                                  int32_t *rays, int32_t *counter, const float *noises,
-                                 int32_t *workspace, void *stream);
+                                 int32_t *workspace, uint32_t workspace_words, void *stream);
 
 /* raymarching.h:14 composite_rays_train_forward ; kernel raymarching.cu:501-577.
  * One 64-lane wavefront per ray; transmittance by a wavefront product scan. */

@@ -242,3 +242,41 @@ def test_sh(cuda):
     np.testing.assert_allclose(dt.grad.cpu().numpy(), num, rtol=2e-2, atol=2e-2)
     with pytest.raises(NotImplementedError):
         SHEncoder(3, 5)(_t(d, cuda))
+
+
+@pytest.mark.gpu
+def test_march_train_record_path_equals_two_march_path(cuda):
+    """tnl_march_rays_train writes the samples either by a second march of every ray (minimal workspace) or from the t
+    values its count pass recorded (workspace_rec): same bits, including a sample budget that drops rays."""
+    import trinerflet_amd._lib as L
+    from trinerflet_amd import raymarching, synthetic
+    lib = L.lib()
+    N, max_steps, Cc, Hg, bound = 3000, 256, 2, 64, 1.5
+    rng = np.random.default_rng(3)
+    poses = synthetic.hemisphere_poses(4, seed=1)
+    pix = np.stack([rng.integers(0, 4, N), rng.integers(0, 800 * 800, N)], -1)
+    o, d = (torch.from_numpy(a).to(cuda) for a in synthetic.get_rays(poses, pix))
+    bits = torch.from_numpy(synthetic.sphere_bitfield(Hg, Cc, bound, 0.8, 0.0)).to(cuda)
+    aabb = torch.tensor([-bound] * 3 + [bound] * 3, device=cuda)
+    nears, fars = raymarching.near_far_from_aabb(o, d, aabb, 0.2)
+    noise = torch.from_numpy(rng.random(N).astype(np.float32)).to(cuda)
+    outs = []
+    for dt_gamma in (0.0, 1.0 / 128):
+        for M in (N * 40, 20000):                       # roomy budget / one that drops rays
+            res = []
+            for rec in (False, True):
+                nws = lib.tnl_march_rays_train_workspace_rec(L.u32(N), L.u32(max_steps)) if rec else \
+                    lib.tnl_march_rays_train_workspace(L.u32(N))
+                ws = torch.empty(nws, dtype=torch.int32, device=cuda)
+                xyzs, dirs = torch.zeros(M, 3, device=cuda), torch.zeros(M, 3, device=cuda)
+                deltas = torch.zeros(M, 2, device=cuda)
+                rays = torch.empty(N, 3, dtype=torch.int32, device=cuda)
+                counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+                L.check(lib.tnl_march_rays_train(L.ptr(o), L.ptr(d), L.ptr(bits), L.f32(bound), L.f32(dt_gamma),
+                                                 L.u32(max_steps), L.u32(N), L.u32(Cc), L.u32(Hg), L.u32(M), L.ptr(nears),
+                                                 L.ptr(fars), L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas), L.ptr(rays),
+                                                 L.ptr(counter), L.ptr(noise), L.ptr(ws), L.u32(nws), L.stream()), "march")
+                res.append((xyzs, dirs, deltas, rays, counter))
+            for a, b in zip(*res):
+                assert torch.equal(a, b)
+            assert int(res[0][4][0]) > 0

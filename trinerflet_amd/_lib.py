@@ -28,7 +28,7 @@ def lib():
                 f"{LIB_PATH} not found: run `python -m trinerflet_amd.build` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback for the hot path.")
         _lib = C.CDLL(LIB_PATH)
-        for name in ("tnl_march_rays_train_workspace", "tnl_field_packed_bytes", "tnl_field_backward_workspace",
+        for name in ("tnl_march_rays_train_workspace", "tnl_march_rays_train_workspace_rec", "tnl_field_packed_bytes", "tnl_field_backward_workspace",
                      "tnl_field_feats_save_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_uint32

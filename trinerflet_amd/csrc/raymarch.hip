@@ -98,9 +98,9 @@ __device__ __forceinline__ void march_init(MarchCtx& m, const float* o, const fl
 // skipping) mostly hit the cached word.  The loop is a chain of dependent global loads otherwise (one wave per SIMD:
 // nothing hides their latency); with the cache only every ~10th test loads.  Needs the bitfield 8-byte aligned
 // (WIDE); the byte-wise path is kept for arbitrary pointers.  Results are identical.
-template <bool WRITE, bool WIDE, bool SPEC = true>
+template <bool WRITE, bool WIDE, bool SPEC = true, bool REC = false>
 __device__ __forceinline__ uint32_t march_run(const MarchCtx& m, float& t, float far, uint32_t limit,
-                                              float* xyzs, float* dirs, float* deltas) {
+                                              float* xyzs, float* dirs, float* deltas, float* trec = nullptr) {
   float last_t = t;
   uint32_t step = 0;
   uint32_t cached_blk = 0xffffffffu;
@@ -148,6 +148,7 @@ __device__ __forceinline__ uint32_t march_run(const MarchCtx& m, float& t, float
     return q;
   };
   auto take = [&](const Probe& q, float t_next) {   // an occupied step: emit the sample, advance
+    if (REC) *trec++ = t;   // the sample's t: everything k_march_train_emit writes follows from it
     if (WRITE) {
       xyzs[0] = q.x; xyzs[1] = q.y; xyzs[2] = q.z;
       dirs[0] = m.dx; dirs[1] = m.dy; dirs[2] = m.dz;
@@ -354,13 +355,13 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* smem4, int* total
   return base + incl - v;
 }
 
-template <bool WIDE>
+template <bool WIDE, bool REC>
 __global__ void __launch_bounds__(MARCH_BLOCK)
 k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                     const uint8_t* __restrict__ grid, float bound, float dt_gamma, uint32_t max_steps,
                     uint32_t N, uint32_t C, uint32_t H, const float* __restrict__ nears,
                     const float* __restrict__ fars, const float* __restrict__ noises,
-                    int* __restrict__ num_steps_out, int* __restrict__ block_sums) {
+                    int* __restrict__ num_steps_out, int* __restrict__ block_sums, float* __restrict__ tbuf) {
   __shared__ int smem4[4];
   const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
   int ns = 0;
@@ -369,7 +370,8 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
     march_init(m, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
     float t = nears[n];
     t = fmaf(clampf_(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
-    ns = (int)march_run<false, WIDE>(m, t, fars[n], max_steps, nullptr, nullptr, nullptr);
+    ns = (int)march_run<false, WIDE, true, REC>(m, t, fars[n], max_steps, nullptr, nullptr, nullptr,
+                                                REC ? tbuf + (size_t)n * max_steps : nullptr);
     num_steps_out[n] = ns;
   }
   int total;
@@ -377,7 +379,9 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-template <bool WIDE>
+// MARCH = true: second march of the ray, writing its samples (the two-pass form).  MARCH = false: only the ray records
+// {id, offset, count}; the samples follow from the t values the count pass recorded (k_march_train_emit).
+template <bool WIDE, bool MARCH>
 __global__ void __launch_bounds__(MARCH_BLOCK)
 k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                     const uint8_t* __restrict__ grid, float bound, float dt_gamma, uint32_t max_steps,
@@ -405,6 +409,7 @@ k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ 
   if (n >= N) return;
   int* r = rays + ((size_t)ray_base + n) * 3;
   r[0] = (int)n; r[1] = (int)off; r[2] = ns;
+  if (!MARCH) return;
   if (ns == 0) return;
   if (off + (uint32_t)ns > M) return;
   MarchCtx m;
@@ -413,6 +418,44 @@ k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ 
   t = fmaf(clampf_(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
   march_run<true, WIDE>(m, t, fars[n], (uint32_t)ns, xyzs + (size_t)off * 3, dirs + (size_t)off * 3,
                   deltas + (size_t)off * 2);
+}
+
+// Samples from recorded t values: one wavefront per ray, lanes = consecutive samples (coalesced reads of the record and
+// writes of the 32 B per sample).  Position, dt and the t-difference are the expressions of march_run's probe() / take()
+// on the same operands, so the output is bit-identical to the marching writer's -- without marching a second time.
+__global__ void __launch_bounds__(MARCH_BLOCK)
+k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound, float dt_gamma,
+                   uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                   const float* __restrict__ nears, const float* __restrict__ noises,
+                   const int* __restrict__ counter, const float* __restrict__ tbuf, const int* __restrict__ rays,
+                   float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
+  const uint32_t n = blockIdx.x * (MARCH_BLOCK / WAVE) + (threadIdx.x / WAVE);
+  const int lane = threadIdx.x % WAVE;
+  if (n >= N) return;
+  const int* r = rays + ((size_t)counter[1] + n) * 3;
+  const uint32_t off = (uint32_t)r[1];
+  const int ns = r[2];
+  if (ns == 0 || off + (uint32_t)ns > M) return;
+  MarchCtx m;
+  march_init(m, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, nullptr);
+  float t_start = nears[n];
+  t_start = fmaf(clampf_(t_start * dt_gamma, m.dt_min, m.dt_max), noises[n], t_start);
+  const float* tr = tbuf + (size_t)n * max_steps;
+  auto step_dt = [&](float t) { return m.fast ? m.dt0 : clampf_(t * m.dt_gamma, m.dt_min, m.dt_max); };
+  for (int k = lane; k < ns; k += WAVE) {
+    const float t = tr[k];
+    const float dt = step_dt(t);
+    float last_t = t_start;
+    if (k > 0) { const float tp = tr[k - 1]; last_t = tp + step_dt(tp); }
+    const float t_next = t + dt;
+    const size_t o = (size_t)off + k;
+    xyzs[o * 3 + 0] = clampf_(fmaf(t, m.dx, m.ox), -m.bound, m.bound);
+    xyzs[o * 3 + 1] = clampf_(fmaf(t, m.dy, m.oy), -m.bound, m.bound);
+    xyzs[o * 3 + 2] = clampf_(fmaf(t, m.dz, m.oz), -m.bound, m.bound);
+    dirs[o * 3 + 0] = m.dx; dirs[o * 3 + 1] = m.dy; dirs[o * 3 + 2] = m.dz;
+    deltas[o * 2 + 0] = dt;
+    deltas[o * 2 + 1] = t_next - last_t;
+  }
 }
 
 __global__ void k_march_train_finalize(const int* __restrict__ block_sums, uint32_t nblocks, uint32_t N,
@@ -916,27 +959,48 @@ int tnl_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
 }
 
 uint32_t tnl_march_rays_train_workspace(uint32_t N) { return N + cdiv(N, MARCH_BLOCK) + 1; }
+// with room for the count pass's record of every sample's t (N * max_steps floats): the samples are then written
+// from the record instead of by a second march; 0 if that does not fit 32 bits
+uint32_t tnl_march_rays_train_workspace_rec(uint32_t N, uint32_t max_steps) {
+  const uint64_t w = (uint64_t)tnl_march_rays_train_workspace(N) + (uint64_t)N * max_steps + 4;
+  return w > 0xffffffffull ? 0u : (uint32_t)w;
+}
 
 int tnl_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                          const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                          int32_t* rays, int32_t* counter, const float* noises, int32_t* workspace,
-                         void* stream) {
+                         uint32_t workspace_words, void* stream) {
   if (N == 0) return 0;
   const uint32_t nb = cdiv(N, MARCH_BLOCK);
   int* num_steps = workspace;
   int* block_sums = workspace + N;
   hipStream_t st = (hipStream_t)stream;
-  if (wide_bitfield(grid, C, H)) {
-    hipLaunchKernelGGL(k_march_train_count<true>, dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
-                       dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums);
-    hipLaunchKernelGGL(k_march_train_write<true>, dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
+  const uint32_t need_rec = tnl_march_rays_train_workspace_rec(N, max_steps);
+  if (need_rec != 0 && workspace_words >= need_rec) {
+    // one march: the count pass records each sample's t, the samples are written from the record
+    float* tbuf = reinterpret_cast<float*>(workspace + ((tnl_march_rays_train_workspace(N) + 3) & ~3u));
+    if (wide_bitfield(grid, C, H))
+      hipLaunchKernelGGL((k_march_train_count<true, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid,
+                         bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf);
+    else
+      hipLaunchKernelGGL((k_march_train_count<false, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid,
+                         bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf);
+    hipLaunchKernelGGL((k_march_train_write<true, false>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
+                       dt_gamma, max_steps, N, C, H, M, nears, fars, noises, num_steps, block_sums, counter, xyzs,
+                       dirs, deltas, rays);
+    hipLaunchKernelGGL(k_march_train_emit, dim3(cdiv(N, MARCH_BLOCK / WAVE)), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d,
+                       bound, dt_gamma, max_steps, N, C, H, M, nears, noises, counter, tbuf, rays, xyzs, dirs, deltas);
+  } else if (wide_bitfield(grid, C, H)) {
+    hipLaunchKernelGGL((k_march_train_count<true, false>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
+                       dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, nullptr);
+    hipLaunchKernelGGL((k_march_train_write<true, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
                        dt_gamma, max_steps, N, C, H, M, nears, fars, noises, num_steps, block_sums, counter, xyzs,
                        dirs, deltas, rays);
   } else {
-    hipLaunchKernelGGL(k_march_train_count<false>, dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
-                       dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums);
-    hipLaunchKernelGGL(k_march_train_write<false>, dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
+    hipLaunchKernelGGL((k_march_train_count<false, false>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
+                       dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, nullptr);
+    hipLaunchKernelGGL((k_march_train_write<false, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
                        dt_gamma, max_steps, N, C, H, M, nears, fars, noises, num_steps, block_sums, counter, xyzs,
                        dirs, deltas, rays);
   }

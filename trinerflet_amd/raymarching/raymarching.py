@@ -139,11 +139,16 @@ class _march_rays_train(Function):
         else:
             noises = torch.zeros(N, dtype=torch.float32, device=dev)
         lib = L.lib()
-        ws = torch.empty(lib.tnl_march_rays_train_workspace(L.u32(N)), dtype=torch.int32, device=dev)
+        # scratch incl. the per-sample t record (N * max_steps floats, never filled beyond the samples that exist): the
+        # rays are marched once; falls back to the two-march form if that size does not fit 32 bits
+        nws = lib.tnl_march_rays_train_workspace_rec(L.u32(N), L.u32(max_steps)) or \
+            lib.tnl_march_rays_train_workspace(L.u32(N))
+        ws = torch.empty(nws, dtype=torch.int32, device=dev)
         L.check(lib.tnl_march_rays_train(L.ptr(rays_o), L.ptr(rays_d), L.ptr(density_bitfield), L.f32(bound),
                                          L.f32(dt_gamma), L.u32(max_steps), L.u32(N), L.u32(C), L.u32(H), L.u32(M),
                                          L.ptr(nears), L.ptr(fars), L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas),
-                                         L.ptr(rays), L.ptr(step_counter), L.ptr(noises), L.ptr(ws), L.stream()),
+                                         L.ptr(rays), L.ptr(step_counter), L.ptr(noises), L.ptr(ws), L.u32(nws),
+                                         L.stream()),
                 "march_rays_train")
         if force_all_rays or mean_count <= 0:
             m = step_counter[0].item()  # D2H copy, as in the reference (:224)
