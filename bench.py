@@ -53,6 +53,7 @@ def build(workload, device, dist_mode):
     synthetic.init_field_parameters(model, seed=0)
     ts = TrainStep(model, lr=1e-2, wavelet_regularization=lam, iters=40000, warmup_steps=0, fp16=True,
                    background_color=0.0, dist_mode=dist_mode)
+    ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", ts.prefetch_at)   # "auto" | "bwd" | "adam" (experiments)
     bitfield = torch.from_numpy(synthetic.sphere_bitfield(128, model.cascade, 1.5, 0.8, 0.0)).to(device)
     model.density_bitfield.copy_(bitfield)
     return model, ts, bitfield, N
@@ -213,9 +214,9 @@ def main():
     torch.cuda.synchronize()
     sec = ts.section_times()
     sec["adam_coef"] = adam_ms
-    # The step starts the next batch's march + tile sort together with the Adam launches (TrainStep.prefetch_at): the
-    # figure above is the kernel sharing the GPU with them.  For the kernel by itself: the same steps with the side
-    # work started after the field backward instead (nothing runs beside Adam then).
+    # If the step starts the next batch's march + tile sort together with the Adam launches (TrainStep.prefetch_at =
+    # "adam"), the figure above is the kernel sharing the GPU with them; then also the kernel by itself: the same steps
+    # with the side work started after the field backward instead (nothing runs beside Adam).
     adam_alone_ms = float("nan")
     if ts._prefetch_under_adam(((),)):
         ts.section_events, ts.section_names = [], {"idwt_adjoint", "scaler_probe", "adam_coef"}
@@ -225,7 +226,7 @@ def main():
             one_step(model, ts, bitfield, batches[j % nb], mean_count, batches[(j + 1) % nb])
         torch.cuda.synchronize()
         adam_alone_ms = ts.section_times().get("adam_coef", float("nan"))
-        ts.prefetch_at = "auto"
+        ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", "auto")
     samples_per_step = float(np.mean(counts))
     P_coef = ts.coef_numel if ts.dist_mode != "sharded" else ts.coef_numel // world
     # algorithmic bytes of the step's Adam launches (one per wavelet level + LL): 16 B read (p, g, m, v) + 12 B

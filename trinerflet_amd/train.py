@@ -649,12 +649,14 @@ class TrainStep:
         return loss
 
     def _prefetch_under_adam(self, next_rays):
-        """Where the next batch's march + tile sort go: underneath the Adam pass when that pass is long enough to
-        cover them (>= 2e8 coefficients: ~1 ms of HBM time), else right after the field backward (see step())."""
+        """Where the next batch's march + tile sort go: right after the field backward (default), or together with the
+        Adam pass (prefetch_at = "adam"; see step())."""
         mode = self.prefetch_at
         if mode == "auto":
-            own = self.coef_numel // (self.world if self.dist_mode == "sharded" else 1)   # this rank's share of the pass
-            mode = "adam" if own >= 200_000_000 else "bwd"
+            # With the rays marched once (1 ms of side work instead of 1.6) the two placements tie at base and large
+            # (6.06-6.39 vs 6.06-6.17 ms, 10.0-10.3 vs 10.2 ms) and "bwd" wins at small: "auto" is "bwd".  "adam" remains
+            # selectable: it needs an Adam pass of >= ~1.5 ms to cover the side work.
+            mode = "bwd"
         return mode == "adam" and next_rays is not None and not self.fuse_adam
 
     def _prefetch_next(self, next_rays, march_on_side):
