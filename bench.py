@@ -107,9 +107,9 @@ def cpu_baseline(workload):
 
 def pmc_traffic(workload, world):
     """HBM bytes of the step's k_adam_l1 launches from the committed rocprofv3 PMC passes
-    (profiles/r01n_pmc_adam.json, made by tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate --pmc runs,
+    (profiles/r01o_pmc_adam.json, made by tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate --pmc runs,
     gfx950 correction applied); null when no profile exists for this configuration."""
-    path = os.path.join(ROOT, "profiles", "r01n_pmc_adam.json")
+    path = os.path.join(ROOT, "profiles", "r01o_pmc_adam.json")
     if workload != "base" or world != 1 or not os.path.exists(path):
         return None
     return json.load(open(path))["hbm_bytes_per_launch"]
