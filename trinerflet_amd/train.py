@@ -126,7 +126,7 @@ class TrainStep:
         self.section_names = None   # see _mark
         self._mark_seq = 0
         self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
-        self.prefetch_at = "auto"   # "bwd" | "adam" | "auto": where step(next_rays=...) starts the next batch's march
+        self.prefetch_at = "auto"   # "start" | "fwd" | "bwd" | "adam" | "auto": where step(next_rays=...) starts the next batch's march
         self._side = None
         self._prefetched = None     # (key, marched tensors) of a march started for the following call
         self.post_refresh = None    # optional callable run right after every density-grid refresh
@@ -481,6 +481,12 @@ class TrainStep:
             marched, side = march_on_side(), self._side
         if self.use_roi and not refresh and not self._roi_valid:
             self._roi, self._roi_valid = self._compute_roi(), True
+        # where the next batch's side work starts (see _prefetch_mode): "start" = here, "fwd" = before the field forward,
+        # "bwd" = after the field backward, "adam" = together with the Adam pass
+        pf = self._prefetch_mode()
+        early = pf in ("start", "fwd") and not refresh
+        if early and pf == "start":
+            self._prefetch_next(next_rays, march_on_side)
         tm = self.rebuild_planes(roi=self.use_roi and not refresh)
         self._mark("idwt_fwd")
         if refresh:
@@ -508,6 +514,8 @@ class TrainStep:
         counter, xyzs, dirs, deltas, rays, sort_ws = marched
         M = xyzs.shape[0]
         self._mark("march")
+        if early and pf == "fwd":
+            self._prefetch_next(next_rays, march_on_side)
         # rows past counter[0] are the zero padding of the sample budget: skipped on the device
         sigma, rgb, feats = F_.field_forward(tm, xyzs, dirs, packed, float(model.bound), C, R, H, save_feats=True,
                                              m_actual=counter)
@@ -571,7 +579,7 @@ class TrainStep:
             # is time-sliced in); started under Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms
             # stay exposed.  At the small configuration (dense tail 0.5 ms) 1 ms of the march stays exposed either way.
             under_adam = self._prefetch_under_adam(next_rays)
-            if not under_adam:
+            if not under_adam and not early:
                 self._prefetch_next(next_rays, march_on_side)
             if side is not None:
                 torch.cuda.current_stream().wait_event(ev_sort)
@@ -651,13 +659,18 @@ class TrainStep:
     def _prefetch_under_adam(self, next_rays):
         """Where the next batch's march + tile sort go: right after the field backward (default), or together with the
         Adam pass (prefetch_at = "adam"; see step())."""
+        return self._prefetch_mode() == "adam" and next_rays is not None and not self.fuse_adam
+
+    def _prefetch_mode(self):
+        """prefetch_at resolved.  Measured with the rays marched once (~1 ms of side work), ms per step for
+        bwd | start | fwd | adam: base 6.04 | 6.00-6.08 | 5.97-5.99 | 6.06-6.17, large 9.91-9.96 | 9.85-10.19 | 10.21 | 10.18,
+        small 3.04 | 2.94 | 3.03 | 3.25 -- all within the Adam pass's own per-process spread except small, whose dense
+        tail (0.5 ms) cannot cover the side work: "auto" starts it at the top of the step there, after the field
+        backward otherwise."""
         mode = self.prefetch_at
         if mode == "auto":
-            # With the rays marched once (1 ms of side work instead of 1.6) the two placements tie at base and large
-            # (6.06-6.39 vs 6.06-6.17 ms, 10.0-10.3 vs 10.2 ms) and "bwd" wins at small: "auto" is "bwd".  "adam" remains
-            # selectable: it needs an Adam pass of >= ~1.5 ms to cover the side work.
-            mode = "bwd"
-        return mode == "adam" and next_rays is not None and not self.fuse_adam
+            mode = "start" if self.coef_numel < 100_000_000 else "bwd"
+        return mode
 
     def _prefetch_next(self, next_rays, march_on_side):
         model = self.model
