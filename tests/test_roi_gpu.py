@@ -311,3 +311,38 @@ def test_occupancy_bounds_kernel(cuda):
         cells = coords[grid[c] > 0]
         want = ([Hg + 1] * 3 + [-1] * 3) if len(cells) == 0 else cells.amin(0).tolist() + cells.amax(0).tolist()
         assert bounds[c].tolist() == want
+
+
+def test_side_work_start_positions_agree(cuda):
+    """TrainStep.prefetch_at only moves where the next batch's march + tile sort are launched (top of the step, before
+    the field forward, after the field backward, together with the Adam pass): the training run must not change."""
+    from trinerflet_amd.train import TrainStep
+    N, bound = 2048, 1.0
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    batches = []
+    for seed in (7, 8):
+        o, d = synthetic.training_rays(N, n_cams=4, seed=seed)
+        batches.append((t(o), t(d), t(synthetic.target_colors(d)),
+                        t(np.random.default_rng(seed).random(N).astype(np.float32))))
+    base = _model(cuda, bound=bound)
+    bf = t(synthetic.sphere_bitfield(128, 1, bound, 0.4, 0.0))
+    base.density_bitfield.copy_(bf)
+    res = {}
+    for pf in ("bwd", "start", "fwd", "adam"):
+        m = copy.deepcopy(base)
+        ts = TrainStep(m, update_extra_interval=4)
+        ts.prefetch_at = pf
+        ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf)
+        m.mean_count = 0
+        losses = []
+        for it in range(7):
+            o, d, gt, nz = batches[it % 2]
+            no, nd, _, nnz = batches[(it + 1) % 2]
+            losses.append(float(ts.step(o, d, gt, noises=nz, next_rays=(no, nd, nnz))))
+        torch.cuda.synchronize()
+        res[pf] = (losses, [p.detach().clone() for p in m.parameters()])
+    for pf in ("start", "fwd", "adam"):
+        np.testing.assert_allclose(res["bwd"][0], res[pf][0], rtol=2e-4, err_msg=pf)
+        for a, b in zip(res["bwd"][1], res[pf][1]):
+            bad = ((a - b).abs() > 2e-3 + 1e-3 * b.abs())   # see test_training_with_window_equals_whole_plane_training
+            assert int(bad.sum()) <= max(1, int(1e-5 * a.numel())) and float((a - b).abs().max()) < 6e-2, pf
