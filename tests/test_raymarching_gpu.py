@@ -268,8 +268,9 @@ def test_march_train_record_path_equals_two_march_path(cuda):
                 nws = lib.tnl_march_rays_train_workspace_rec(L.u32(N), L.u32(max_steps)) if rec else \
                     lib.tnl_march_rays_train_workspace(L.u32(N))
                 ws = torch.empty(nws, dtype=torch.int32, device=cuda)
-                xyzs, dirs = torch.zeros(M, 3, device=cuda), torch.zeros(M, 3, device=cuda)
-                deltas = torch.zeros(M, 2, device=cuda)
+                # sentinel-filled: the kernels must not rely on the caller's zero fill for rows a dropped ray leaves
+                xyzs, dirs = torch.full((M, 3), 7.0, device=cuda), torch.full((M, 3), 7.0, device=cuda)
+                deltas = torch.full((M, 2), 7.0, device=cuda)
                 rays = torch.empty(N, 3, dtype=torch.int32, device=cuda)
                 counter = torch.zeros(2, dtype=torch.int32, device=cuda)
                 L.check(lib.tnl_march_rays_train(L.ptr(o), L.ptr(d), L.ptr(bits), L.f32(bound), L.f32(dt_gamma),
@@ -279,4 +280,13 @@ def test_march_train_record_path_equals_two_march_path(cuda):
                 res.append((xyzs, dirs, deltas, rays, counter))
             for a, b in zip(*res):
                 assert torch.equal(a, b)
-            assert int(res[0][4][0]) > 0
+            total = int(res[0][4][0])
+            assert total > 0
+            if total > M:   # rays were dropped: the kept rays' rows are followed by a zeroed tail, nothing is left over
+                rays = res[0][3].cpu().numpy()
+                kept = rays[rays[:, 1] + rays[:, 2] <= M]
+                end = int((kept[:, 1] + kept[:, 2]).max())
+                assert 0 < end < M and not res[0][0][end:].any() and not res[0][2][end:].any()
+                assert not (res[0][0][:end] == 7.0).all(1).any()
+            else:
+                assert bool((res[0][0][total:] == 7.0).all())

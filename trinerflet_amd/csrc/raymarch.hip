@@ -411,7 +411,14 @@ k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ 
   r[0] = (int)n; r[1] = (int)off; r[2] = ns;
   if (!MARCH) return;
   if (ns == 0) return;
-  if (off + (uint32_t)ns > M) return;
+  if (off + (uint32_t)ns > M) {   // dropped by the budget: zero the in-buffer tail (see k_march_train_emit)
+    for (uint32_t q = off; q < M; q++) {
+      xyzs[(size_t)q * 3 + 0] = 0.f; xyzs[(size_t)q * 3 + 1] = 0.f; xyzs[(size_t)q * 3 + 2] = 0.f;
+      dirs[(size_t)q * 3 + 0] = 0.f; dirs[(size_t)q * 3 + 1] = 0.f; dirs[(size_t)q * 3 + 2] = 0.f;
+      deltas[(size_t)q * 2 + 0] = 0.f; deltas[(size_t)q * 2 + 1] = 0.f;
+    }
+    return;
+  }
   MarchCtx m;
   march_init(m, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
   float t = nears[n];
@@ -435,7 +442,17 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
   const int* r = rays + ((size_t)counter[1] + n) * 3;
   const uint32_t off = (uint32_t)r[1];
   const int ns = r[2];
-  if (ns == 0 || off + (uint32_t)ns > M) return;
+  if (ns == 0) return;
+  if (off + (uint32_t)ns > M) {
+    // a ray the sample budget drops: the rows it would have started in stay in the buffer (off < M for at most one
+    // such ray) and are consumed as samples of no ray -- zero them, whatever the caller's buffers held
+    for (uint32_t q = off + lane; q < M; q += WAVE) {
+      xyzs[(size_t)q * 3 + 0] = 0.f; xyzs[(size_t)q * 3 + 1] = 0.f; xyzs[(size_t)q * 3 + 2] = 0.f;
+      dirs[(size_t)q * 3 + 0] = 0.f; dirs[(size_t)q * 3 + 1] = 0.f; dirs[(size_t)q * 3 + 2] = 0.f;
+      deltas[(size_t)q * 2 + 0] = 0.f; deltas[(size_t)q * 2 + 1] = 0.f;
+    }
+    return;
+  }
   MarchCtx m;
   march_init(m, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, nullptr);
   float t_start = nears[n];
