@@ -77,6 +77,16 @@ TNL_API int tnl_march_rays_train(const float *rays_o, const float *rays_d, const
                                  const float *fars, float *xyzs, float *dirs, float *deltas,
                                  int32_t *rays, int32_t *counter, const float *noises,
                                  int32_t *workspace, uint32_t workspace_words, void *stream);
+/* tnl_march_rays_train that also performs the first pass of the plane-gradient tile sort (the per-bin counts of
+ * tnl_plane_grad_sort for plane resolution R, into sort_workspace = a tnl_plane_grad_binned_workspace(M, R) buffer)
+ * while it writes the samples -- the writing wave's lanes are consecutive samples of one ray, the sort's best case.
+ * Needs the workspace_rec scratch size.  Follow with tnl_plane_grad_sort_counted on the same stream. */
+TNL_API int tnl_march_rays_train_binned(const float *rays_o, const float *rays_d, const uint8_t *grid,
+                                 float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                                 uint32_t C, uint32_t H, uint32_t M, const float *nears,
+                                 const float *fars, float *xyzs, float *dirs, float *deltas,
+                                 int32_t *rays, int32_t *counter, const float *noises,
+                                 int32_t *workspace, uint32_t workspace_words, uint32_t R, void *sort_workspace, void *stream);
 
 /* raymarching.h:14 composite_rays_train_forward ; kernel raymarching.cu:501-577.
  * One 64-lane wavefront per ray; transmittance by a wavefront product scan. */
@@ -235,6 +245,9 @@ TNL_API int tnl_plane_grad_binned(const void *dfeat_half, const float *xyz, floa
  * _reduce consumes the sorted workspace together with dfeat.  Same workspace size and contents contract. */
 TNL_API int tnl_plane_grad_sort(const float *xyz, float bound, uint32_t M, const int32_t *m_actual, uint32_t R,
                                 void *workspace, void *stream);
+/* _sort with the first pass (per-bin counts) already done by tnl_march_rays_train_binned: scan + fill only. */
+TNL_API int tnl_plane_grad_sort_counted(const float *xyz, float bound, uint32_t M, const int32_t *m_actual,
+                                        uint32_t R, void *workspace, void *stream);
 TNL_API int tnl_plane_grad_reduce(const void *dfeat_half, const float *xyz, float bound, uint32_t M, uint32_t C,
                                   uint32_t R,
                                   float grad_scale, float *grad_out, int channel_major, int32_t *nonfinite_flag,

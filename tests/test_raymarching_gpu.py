@@ -290,3 +290,43 @@ def test_march_train_record_path_equals_two_march_path(cuda):
                 assert not (res[0][0][:end] == 7.0).all(1).any()
             else:
                 assert bool((res[0][0][total:] == 7.0).all())
+
+
+@pytest.mark.gpu
+def test_march_fused_tile_count_equals_sort(cuda):
+    """march_rays_train(sort=(R, ws)) + plane_grad_sort_counted against plane_grad_sort on the samples it wrote: same
+    bin offsets, and per bin the same set of sample ids (the order inside a bin is the atomics' in both); with a budget
+    that drops rays as well (the zeroed tail rows are samples of the sort too)."""
+    from trinerflet_amd import raymarching, synthetic
+    from trinerflet_amd.nerf import field as gfield
+    N, max_steps, Cc, Hg, bound, R = 3000, 256, 2, 64, 1.5, 256
+    rng = np.random.default_rng(5)
+    poses = synthetic.hemisphere_poses(4, seed=2)
+    pix = np.stack([rng.integers(0, 4, N), rng.integers(0, 800 * 800, N)], -1)
+    o, d = (torch.from_numpy(a).to(cuda) for a in synthetic.get_rays(poses, pix))
+    bits = torch.from_numpy(synthetic.sphere_bitfield(Hg, Cc, bound, 0.8, 0.0)).to(cuda)
+    aabb = torch.tensor([-bound] * 3 + [bound] * 3, device=cuda)
+    nears, fars = raymarching.near_far_from_aabb(o, d, aabb, 0.2)
+    noise = torch.from_numpy(rng.random(N).astype(np.float32)).to(cuda)
+    nb = 3 * (R // 32) * (R // 8)
+    ent0 = 3 * (nb + 1) + 1 + (nb + 1023) // 1024 + 8
+
+    def parse(ws):
+        w = ws.view(torch.int32).cpu().numpy()
+        offsets = w[nb + 1:2 * nb + 2]
+        return offsets, w[ent0:ent0 + offsets[-1]]
+    for budget in (40 * N, 20000 - 20000 % 128):
+        counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+        mc = budget + (128 - budget % 128)
+        ws = gfield.plane_grad_sort_workspace(mc, R, cuda)
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, bound, bits, Cc, Hg, nears, fars, counter, budget,
+                                                                True, 128, False, 0, max_steps, noise, False, (R, ws))
+        assert xyzs.shape[0] == mc
+        gfield.plane_grad_sort_counted(ws, xyzs, bound, R, counter)
+        ref = gfield.plane_grad_sort(xyzs, bound, R, counter)
+        torch.cuda.synchronize()
+        (off_a, ent_a), (off_b, ent_b) = parse(ws), parse(ref)
+        assert np.array_equal(off_a, off_b) and off_a[-1] >= min(int(counter[0]), mc) * 3
+        for b in np.flatnonzero(np.diff(off_a))[::7]:
+            assert np.array_equal(np.sort(ent_a[off_a[b]:off_a[b + 1]]), np.sort(ent_b[off_b[b]:off_b[b + 1]]))
+        assert np.array_equal(np.sort(ent_a), np.sort(ent_b))

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "../../include/trinerflet_hip.h"
+#include "bin_common.h"
 
 namespace {
 
@@ -435,7 +436,11 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                    const float* __restrict__ nears, const float* __restrict__ noises,
                    const int* __restrict__ counter, const float* __restrict__ tbuf, const int* __restrict__ rays,
-                   float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
+                   float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int binR,
+                   int* __restrict__ bin_counts) {
+  // bin_counts != NULL: the first pass of the plane-gradient tile sort (scatter.hip k_bin<false>) rides along -- here
+  // the lanes of a wave ARE consecutive samples of one ray, the case its run aggregation is made for
+  const int TNX = binR / TSX, TNY = binR / TSY;
   const uint32_t n = blockIdx.x * (MARCH_BLOCK / WAVE) + (threadIdx.x / WAVE);
   const int lane = threadIdx.x % WAVE;
   if (n >= N) return;
@@ -446,10 +451,15 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
   if (off + (uint32_t)ns > M) {
     // a ray the sample budget drops: the rows it would have started in stay in the buffer (off < M for at most one
     // such ray) and are consumed as samples of no ray -- zero them, whatever the caller's buffers held
-    for (uint32_t q = off + lane; q < M; q += WAVE) {
-      xyzs[(size_t)q * 3 + 0] = 0.f; xyzs[(size_t)q * 3 + 1] = 0.f; xyzs[(size_t)q * 3 + 2] = 0.f;
-      dirs[(size_t)q * 3 + 0] = 0.f; dirs[(size_t)q * 3 + 1] = 0.f; dirs[(size_t)q * 3 + 2] = 0.f;
-      deltas[(size_t)q * 2 + 0] = 0.f; deltas[(size_t)q * 2 + 1] = 0.f;
+    for (uint32_t q0 = off; q0 < M; q0 += WAVE) {   // uniform trip count: bin_sample shuffles across the wave
+      const uint32_t q = q0 + lane;
+      const bool live = q < M;
+      if (live) {
+        xyzs[(size_t)q * 3 + 0] = 0.f; xyzs[(size_t)q * 3 + 1] = 0.f; xyzs[(size_t)q * 3 + 2] = 0.f;
+        dirs[(size_t)q * 3 + 0] = 0.f; dirs[(size_t)q * 3 + 1] = 0.f; dirs[(size_t)q * 3 + 2] = 0.f;
+        deltas[(size_t)q * 2 + 0] = 0.f; deltas[(size_t)q * 2 + 1] = 0.f;
+      }
+      if (bin_counts != nullptr) bin_sample<false>(0.f, 0.f, 0.f, live, q, bound, binR, TNX, TNY, bin_counts, nullptr, lane);
     }
     return;
   }
@@ -459,19 +469,26 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
   t_start = fmaf(clampf_(t_start * dt_gamma, m.dt_min, m.dt_max), noises[n], t_start);
   const float* tr = tbuf + (size_t)n * max_steps;
   auto step_dt = [&](float t) { return m.fast ? m.dt0 : clampf_(t * m.dt_gamma, m.dt_min, m.dt_max); };
-  for (int k = lane; k < ns; k += WAVE) {
-    const float t = tr[k];
+  for (int k0 = 0; k0 < ns; k0 += WAVE) {   // uniform trip count (bin_sample shuffles across the wave)
+    const int k = k0 + lane;
+    const bool live = k < ns;
+    const int kl = live ? k : ns - 1;
+    const float t = tr[kl];
     const float dt = step_dt(t);
     float last_t = t_start;
-    if (k > 0) { const float tp = tr[k - 1]; last_t = tp + step_dt(tp); }
+    if (kl > 0) { const float tp = tr[kl - 1]; last_t = tp + step_dt(tp); }
     const float t_next = t + dt;
-    const size_t o = (size_t)off + k;
-    xyzs[o * 3 + 0] = clampf_(fmaf(t, m.dx, m.ox), -m.bound, m.bound);
-    xyzs[o * 3 + 1] = clampf_(fmaf(t, m.dy, m.oy), -m.bound, m.bound);
-    xyzs[o * 3 + 2] = clampf_(fmaf(t, m.dz, m.oz), -m.bound, m.bound);
-    dirs[o * 3 + 0] = m.dx; dirs[o * 3 + 1] = m.dy; dirs[o * 3 + 2] = m.dz;
-    deltas[o * 2 + 0] = dt;
-    deltas[o * 2 + 1] = t_next - last_t;
+    const size_t o = (size_t)off + kl;
+    const float px = clampf_(fmaf(t, m.dx, m.ox), -m.bound, m.bound);
+    const float py = clampf_(fmaf(t, m.dy, m.oy), -m.bound, m.bound);
+    const float pz = clampf_(fmaf(t, m.dz, m.oz), -m.bound, m.bound);
+    if (live) {
+      xyzs[o * 3 + 0] = px; xyzs[o * 3 + 1] = py; xyzs[o * 3 + 2] = pz;
+      dirs[o * 3 + 0] = m.dx; dirs[o * 3 + 1] = m.dy; dirs[o * 3 + 2] = m.dz;
+      deltas[o * 2 + 0] = dt;
+      deltas[o * 2 + 1] = t_next - last_t;
+    }
+    if (bin_counts != nullptr) bin_sample<false>(px, py, pz, live, (uint32_t)o, bound, binR, TNX, TNY, bin_counts, nullptr, lane);
   }
 }
 
@@ -983,11 +1000,17 @@ uint32_t tnl_march_rays_train_workspace_rec(uint32_t N, uint32_t max_steps) {
   return w > 0xffffffffull ? 0u : (uint32_t)w;
 }
 
-int tnl_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
-                         float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                         const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
-                         int32_t* rays, int32_t* counter, const float* noises, int32_t* workspace,
-                         uint32_t workspace_words, void* stream) {
+static int march_rays_train_impl(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                 float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                 const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                 int32_t* rays, int32_t* counter, const float* noises, int32_t* workspace,
+                                 uint32_t workspace_words, uint32_t binR, void* sort_workspace, void* stream) {
+  if (sort_workspace != nullptr) {   // the tile sort's bin counts (first nb + 1 ints of its workspace) start from zero
+    if (binR == 0 || binR % TSX != 0) return (int)hipErrorInvalidValue;
+    const size_t nbins = 3ull * (binR / TSX) * (binR / TSY);
+    hipError_t e = hipMemsetAsync(sort_workspace, 0, (nbins + 1) * sizeof(int), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
   if (N == 0) return 0;
   const uint32_t nb = cdiv(N, MARCH_BLOCK);
   int* num_steps = workspace;
@@ -1007,7 +1030,10 @@ int tnl_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
                        dt_gamma, max_steps, N, C, H, M, nears, fars, noises, num_steps, block_sums, counter, xyzs,
                        dirs, deltas, rays);
     hipLaunchKernelGGL(k_march_train_emit, dim3(cdiv(N, MARCH_BLOCK / WAVE)), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d,
-                       bound, dt_gamma, max_steps, N, C, H, M, nears, noises, counter, tbuf, rays, xyzs, dirs, deltas);
+                       bound, dt_gamma, max_steps, N, C, H, M, nears, noises, counter, tbuf, rays, xyzs, dirs, deltas,
+                       (int)binR, reinterpret_cast<int*>(sort_workspace));
+  } else if (sort_workspace != nullptr) {
+    return (int)hipErrorInvalidValue;   // the fused count needs the record path (workspace_rec words of scratch)
   } else if (wide_bitfield(grid, C, H)) {
     hipLaunchKernelGGL((k_march_train_count<true, false>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
                        dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, nullptr);
@@ -1023,6 +1049,25 @@ int tnl_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
   }
   hipLaunchKernelGGL(k_march_train_finalize, dim3(1), dim3(MARCH_BLOCK), 0, st, block_sums, nb, N, counter);
   return launch_status();
+}
+
+int tnl_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                         float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                         const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                         int32_t* rays, int32_t* counter, const float* noises, int32_t* workspace,
+                         uint32_t workspace_words, void* stream) {
+  return march_rays_train_impl(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
+                               deltas, rays, counter, noises, workspace, workspace_words, 0, nullptr, stream);
+}
+
+int tnl_march_rays_train_binned(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                int32_t* rays, int32_t* counter, const float* noises, int32_t* workspace,
+                                uint32_t workspace_words, uint32_t R, void* sort_workspace, void* stream) {
+  if (sort_workspace == nullptr) return (int)hipErrorInvalidValue;
+  return march_rays_train_impl(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
+                               deltas, rays, counter, noises, workspace, workspace_words, R, sort_workspace, stream);
 }
 
 int tnl_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,

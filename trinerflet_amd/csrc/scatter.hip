@@ -19,80 +19,28 @@
 
 #include "../../include/trinerflet_hip.h"
 #include "roi_common.h"
+#include "bin_common.h"
 #include "triplane_common.h"
 
 namespace {
 
-constexpr int TSX = 32;  // tile width in texels (128-B rows in the channel-major output)
-constexpr int TSY = 8;   // tile height
 constexpr int NT = 256;
-
-struct Foot {  // tiles touched by a bilinear footprint on one plane
-  int tx0, ty0, tx1, ty1;
-};
-
-__device__ __forceinline__ Foot footprint(const TexelTap& t) {
-  Foot f;
-  f.tx0 = t.x0 / TSX; f.ty0 = t.y0 / TSY;
-  f.tx1 = t.x1 / TSX; f.ty1 = t.y1 / TSY;
-  return f;
-}
 
 __device__ __forceinline__ uint32_t eff_m(uint32_t M, const int32_t* m_actual) {
   return m_actual ? min(M, (uint32_t)max(*m_actual, 0)) : M;
 }
 
-// pass 1 / pass 3: FILL=false counts entries per bin, FILL=true writes sample ids at cursor positions.
-// Consecutive samples of a ray usually fall into the same tile, so the lanes of a wave form runs with equal
-// bins: only the head lane of a run issues the (integer, L2) atomic for the whole run and the members derive
-// their slot from it -- ~5x fewer atomics for the primary tile; the rare straddle tiles use one atomic each.
+// pass 1 / pass 3: FILL=false counts entries per bin, FILL=true writes sample ids at cursor positions (bin_common.h)
 template <bool FILL>
 __global__ void __launch_bounds__(NT)
 k_bin(const float* __restrict__ xyz, float bound, uint32_t M, const int32_t* __restrict__ m_actual, int R, int TNX,
       int TNY, int* __restrict__ counts_or_cursor, uint32_t* __restrict__ entries) {
   const uint32_t Me = eff_m(M, m_actual);
   const uint32_t i = blockIdx.x * NT + threadIdx.x;
-  const int lane = threadIdx.x & 63;
   const bool live = i < Me;
   const uint32_t il = live ? i : 0;
-  const float x = xyz[(size_t)il * 3], y = xyz[(size_t)il * 3 + 1], z = xyz[(size_t)il * 3 + 2];
-#pragma unroll
-  for (int p = 0; p < 3; p++) {
-    TexelTap t;
-    triplane_tap(x, y, z, bound, R, p, t);
-    const Foot f = footprint(t);
-    const int base = p * TNX * TNY;
-    // primary tile, run-aggregated
-    const int bin0 = live ? base + f.ty0 * TNX + f.tx0 : -1 - lane;
-    const int prev = __shfl_up(bin0, 1);
-    const bool head = (lane == 0) || (bin0 != prev);
-    const unsigned long long hmask = __ballot(head);
-    const unsigned long long below = hmask & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-    const int hp = 63 - __clzll((long long)below);                       // head of my run
-    const unsigned long long above = (hp == 63) ? 0ull : (hmask >> (hp + 1)) << (hp + 1);
-    const int nh = above ? (__ffsll((long long)above) - 1) : 64;         // head of the next run
-    int slot = 0;
-    if (head && live) {
-      if (FILL) slot = atomicAdd(counts_or_cursor + bin0, nh - hp);
-      else atomicAdd(counts_or_cursor + bin0, nh - hp);
-    }
-    if (FILL) {
-      slot = __shfl(slot, hp) + (lane - hp);
-      if (live) entries[slot] = i;
-    }
-    // straddle tiles (footprint crosses a tile edge): one atomic each
-    if (live) {
-#pragma unroll
-      for (int k = 1; k < 4; k++) {
-        const int tx = (k & 1) ? f.tx1 : f.tx0, ty = (k & 2) ? f.ty1 : f.ty0;
-        const bool dup = ((k & 1) && f.tx1 == f.tx0) || ((k & 2) && f.ty1 == f.ty0);
-        if (dup) continue;
-        const int bin = base + ty * TNX + tx;
-        if (FILL) entries[atomicAdd(counts_or_cursor + bin, 1)] = i;
-        else atomicAdd(counts_or_cursor + bin, 1);
-      }
-    }
-  }
+  bin_sample<FILL>(xyz[(size_t)il * 3], xyz[(size_t)il * 3 + 1], xyz[(size_t)il * 3 + 2], live, i, bound, R, TNX, TNY,
+                   counts_or_cursor, entries, threadIdx.x & 63);
 }
 
 // exclusive scan of the bin counts; also leaves a copy as the fill cursors.  Two tiny launches: (1) each
@@ -440,17 +388,19 @@ static SortWs sort_ws(void* workspace, uint32_t R) {
 
 // Part 1 (needs only the sample positions): counting sort of the samples by (plane, tile).  TrainStep runs it on
 // the march's side stream, so it is off the critical path of the step.
-int tnl_plane_grad_sort(const float* xyz, float bound, uint32_t M, const int32_t* m_actual, uint32_t R,
-                        void* workspace, void* stream) {
+static int plane_grad_sort_impl(const float* xyz, float bound, uint32_t M, const int32_t* m_actual, uint32_t R,
+                                void* workspace, bool counted, void* stream) {
   if (R % TSX != 0) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int TNX = R / TSX, TNY = R / TSY;
   const SortWs w = sort_ws(workspace, R);
-  hipError_t e = hipMemsetAsync(w.counts, 0, (size_t)(w.nb + 1) * sizeof(int), st);
-  if (e != hipSuccess) return (int)e;
-  if (M > 0) {
-    hipLaunchKernelGGL(k_bin<false>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
-                       w.counts, w.entries);
+  if (!counted) {
+    hipError_t e = hipMemsetAsync(w.counts, 0, (size_t)(w.nb + 1) * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    if (M > 0) {
+      hipLaunchKernelGGL(k_bin<false>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
+                         w.counts, w.entries);
+    }
   }
   hipLaunchKernelGGL(k_scan_local, dim3(w.nblk), dim3(1024), 0, st, w.counts, w.nb, w.offsets, w.block_tot);
   hipLaunchKernelGGL(k_scan_fix, dim3(w.nblk), dim3(1024), 0, st, w.nb, w.nblk, w.block_tot, w.offsets, w.cursor);
@@ -459,6 +409,18 @@ int tnl_plane_grad_sort(const float* xyz, float bound, uint32_t M, const int32_t
                        w.cursor, w.entries);
   }
   return (int)hipGetLastError();
+}
+
+int tnl_plane_grad_sort(const float* xyz, float bound, uint32_t M, const int32_t* m_actual, uint32_t R,
+                        void* workspace, void* stream) {
+  return plane_grad_sort_impl(xyz, bound, M, m_actual, R, workspace, false, stream);
+}
+
+// The same with the per-bin counts already in the workspace (tnl_march_rays_train_binned counted them while it wrote
+// the samples): scan + fill only.
+int tnl_plane_grad_sort_counted(const float* xyz, float bound, uint32_t M, const int32_t* m_actual, uint32_t R,
+                                void* workspace, void* stream) {
+  return plane_grad_sort_impl(xyz, bound, M, m_actual, R, workspace, true, stream);
 }
 
 // Part 2: one workgroup per (plane, tile) reduces the tile's sorted samples on the matrix cores.

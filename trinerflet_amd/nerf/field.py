@@ -114,6 +114,21 @@ def plane_grad_sort(xyz, bound, R, m_actual=None):
     return ws
 
 
+def plane_grad_sort_workspace(M, R, device):
+    """Workspace of plane_grad_sort / plane_grad_reduce for M samples (uninitialised)."""
+    nbytes = L.lib().tnl_plane_grad_binned_workspace(L.u32(M), L.u32(R))
+    if nbytes == 0:
+        raise NotImplementedError("binned plane gradient needs plane_resolution % 32 == 0")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def plane_grad_sort_counted(ws, xyz, bound, R, m_actual=None):
+    """plane_grad_sort whose counting pass was done by march_rays_train(..., sort=(R, ws)): scan + fill."""
+    L.check(L.lib().tnl_plane_grad_sort_counted(L.ptr(xyz), L.f32(bound), L.u32(xyz.shape[0]), L.ptr(m_actual), L.u32(R),
+                                                L.ptr(ws), L.stream()), "plane_grad_sort_counted")
+    return ws
+
+
 def plane_grad_reduce(ws, dfeat, xyz, bound, C, R, grad_out, grad_scale=1.0, channel_major=False, nonfinite_flag=None,
                       roi=None):
     """Second half: per-tile matrix-core reduction of dfeat over the sorted samples in `ws`."""

@@ -107,9 +107,11 @@ class _march_rays_train(Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
                 perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, noises=None,
-                zero_fill=True):
+                zero_fill=True, sort=None):
         # reference: raymarching.py:161-233.  Extra trailing `noises` ([N] in [0,1)) lets a caller supply
         # the perturbation explicitly (used by tests/bench for seeded parity); None = reference behaviour.
+        # sort=(R, workspace): the writing kernel also counts the samples per plane tile for the plane-gradient sort
+        # (nerf/field.py plane_grad_sort_counted finishes it).
         # zero_fill=False skips the reference's zero fill of the padded sample buffers (:205-207) for a caller whose
         # consumers never read rows past counter[0] (TrainStep: every kernel takes the count): 32 B x M less to write.
         rays_o = _f32c(rays_o).view(-1, 3)
@@ -144,12 +146,14 @@ class _march_rays_train(Function):
         nws = lib.tnl_march_rays_train_workspace_rec(L.u32(N), L.u32(max_steps)) or \
             lib.tnl_march_rays_train_workspace(L.u32(N))
         ws = torch.empty(nws, dtype=torch.int32, device=dev)
-        L.check(lib.tnl_march_rays_train(L.ptr(rays_o), L.ptr(rays_d), L.ptr(density_bitfield), L.f32(bound),
-                                         L.f32(dt_gamma), L.u32(max_steps), L.u32(N), L.u32(C), L.u32(H), L.u32(M),
-                                         L.ptr(nears), L.ptr(fars), L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas),
-                                         L.ptr(rays), L.ptr(step_counter), L.ptr(noises), L.ptr(ws), L.u32(nws),
-                                         L.stream()),
-                "march_rays_train")
+        args = (L.ptr(rays_o), L.ptr(rays_d), L.ptr(density_bitfield), L.f32(bound), L.f32(dt_gamma), L.u32(max_steps),
+                L.u32(N), L.u32(C), L.u32(H), L.u32(M), L.ptr(nears), L.ptr(fars), L.ptr(xyzs), L.ptr(dirs),
+                L.ptr(deltas), L.ptr(rays), L.ptr(step_counter), L.ptr(noises), L.ptr(ws), L.u32(nws))
+        if sort is None:
+            L.check(lib.tnl_march_rays_train(*args, L.stream()), "march_rays_train")
+        else:
+            L.check(lib.tnl_march_rays_train_binned(*args, L.u32(sort[0]), L.ptr(sort[1]), L.stream()),
+                    "march_rays_train_binned")
         if force_all_rays or mean_count <= 0:
             m = step_counter[0].item()  # D2H copy, as in the reference (:224)
             if align > 0:

@@ -444,17 +444,28 @@ class TrainStep:
             counter = model.step_counter[model.local_step % 16]
             counter.zero_()
             model.local_step += 1
+            # with a fixed sample budget the march also counts the samples per plane tile (first pass of the tile sort)
+            fused_sort = self.binned and R % 32 == 0 and model.mean_count > 0
+            sort_ws = None
+            if fused_sort:
+                mc = model.mean_count + (128 - model.mean_count % 128)    # the wrapper's budget rule (align = 128)
+                sort_ws = F_.plane_grad_sort_workspace(mc, R, self.dev)
             out = raymarching.march_rays_train(
                 o, d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars,
                 counter, model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, nz,
-                model.mean_count <= 0)   # zero fill only when the buffers are sized by the worst case (first steps)
+                model.mean_count <= 0,   # zero fill only when the buffers are sized by the worst case (first steps)
+                (R, sort_ws) if fused_sort else None)
             # the field forward needs the march only; the tile sort of the plane gradient (needed much later, by the
             # tile reduction) rides behind it on the same stream and gets its own event
             ev_march = torch.cuda.Event()
             ev_march.record()
             # the tile sort of the plane gradient needs only the positions: it rides with the march (side stream)
-            sort_ws = F_.plane_grad_sort(out[0], float(model.bound), R, counter) if (self.binned and R % 32 == 0) \
-                else torch.empty(0, device=self.dev)
+            if fused_sort:
+                assert out[0].shape[0] == mc
+                F_.plane_grad_sort_counted(sort_ws, out[0], float(model.bound), R, counter)
+            else:
+                sort_ws = F_.plane_grad_sort(out[0], float(model.bound), R, counter) if (self.binned and R % 32 == 0) \
+                    else torch.empty(0, device=self.dev)
             ev_sort = torch.cuda.Event()
             ev_sort.record()
             return (counter, *out, sort_ws), (ev_march, ev_sort)
