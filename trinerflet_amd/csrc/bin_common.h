@@ -53,16 +53,31 @@ __device__ __forceinline__ void bin_sample(float x, float y, float z, bool live,
       slot = __shfl(slot, hp) + (lane - hp);
       if (live) entries[slot] = i;
     }
-    // straddle tiles (footprint crosses a tile edge): one atomic each
-    if (live) {
+    // straddle tiles (footprint crosses a tile edge; ~15 % of the samples have one): the lanes that go to the same bin
+    // are found by ballot and share one atomic (1-4 distinct bins per wave and direction, where every straddling lane
+    // used to issue its own)
 #pragma unroll
-      for (int k = 1; k < 4; k++) {
-        const int tx = (k & 1) ? f.tx1 : f.tx0, ty = (k & 2) ? f.ty1 : f.ty0;
-        const bool dup = ((k & 1) && f.tx1 == f.tx0) || ((k & 2) && f.ty1 == f.ty0);
-        if (dup) continue;
-        const int bin = base + ty * TNX + tx;
-        if (FILL) entries[atomicAdd(counts_or_cursor + bin, 1)] = i;
-        else atomicAdd(counts_or_cursor + bin, 1);
+    for (int k = 1; k < 4; k++) {
+      const int tx = (k & 1) ? f.tx1 : f.tx0, ty = (k & 2) ? f.ty1 : f.ty0;
+      const bool dup = ((k & 1) && f.tx1 == f.tx0) || ((k & 2) && f.ty1 == f.ty0);
+      const bool act = live && !dup;
+      const int bin = base + ty * TNX + tx;
+      unsigned long long todo = __ballot(act);
+      while (todo) {   // wave-uniform
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lbin = __shfl(bin, leader);
+        const bool mine = act && bin == lbin;
+        const unsigned long long grp = __ballot(mine);
+        int slot = 0;
+        if (lane == leader) {
+          if (FILL) slot = atomicAdd(counts_or_cursor + lbin, __popcll(grp));
+          else atomicAdd(counts_or_cursor + lbin, __popcll(grp));
+        }
+        if (FILL) {
+          slot = __shfl(slot, leader);
+          if (mine) entries[slot + __popcll(grp & ((1ull << lane) - 1ull))] = i;
+        }
+        todo &= ~grp;
       }
     }
   }
