@@ -381,6 +381,7 @@ k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n
     __syncthreads();
 
     const int a_c = fox / 2 + tx * TI;
+    // (unrolling these two trips like the adjoint's row pass changes nothing here: 269 us either way)
     for (int u = threadIdx.x; u < 2 * TI * (TI / RM); u += NT) {
       const int run = u % (TI / RM), r = u / (TI / RM);
       const int m0 = run * RM;
@@ -536,7 +537,14 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
     __syncthreads();
     if (tx + 1 < tx1 && hits(tx + 1)) prefetch(tx + 1);
 
-    for (int u = threadIdx.x; u < FT * (TI / RM); u += NT) {
+    // Row pass: FT * TI / RM = 640 runs over 256 threads, as KT1 = 3 unrolled trips with the run index clamped (the
+    // surplus threads of the last trip recompute its last run and store the same values again) instead of a
+    // `for (u = tid; u < 640; u += NT)` loop, so that the scheduler may overlap one trip's LDS window reads with the
+    // previous trip's FMAs: 679 -> 671 us in an interleaved A/B (1 %: this kernel is not bound by that latency either).
+    constexpr int RUNS1 = FT * (TI / RM), KT1 = (RUNS1 + NT - 1) / NT;
+#pragma unroll
+    for (int kt = 0; kt < KT1; kt++) {
+      const int u = min((int)threadIdx.x + kt * NT, RUNS1 - 1);
       const int r = u % FT, j0 = (u / FT) * RM;
       float w[WIN];
 #pragma unroll
@@ -557,7 +565,10 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
     __syncthreads();
 
     const int a_c = tx * TI;
-    for (int u = threadIdx.x; u < TI * (TI / RM); u += NT) {
+    constexpr int RUNS2 = TI * (TI / RM), KT2 = (RUNS2 + NT - 1) / NT;   // 256 runs: one trip
+#pragma unroll
+    for (int kt = 0; kt < KT2; kt++) {
+      const int u = min((int)threadIdx.x + kt * NT, RUNS2 - 1);
       const int c = u % TI, j0 = (u / TI) * RM;
       float wl[WIN], wh[WIN];
 #pragma unroll
