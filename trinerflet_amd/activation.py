@@ -1,19 +1,31 @@
-"""trunc_exp -- mirror of reconstruction/activation.py:5-17 (forward exp in fp32, backward clamps to +-15)."""
+"""trunc_exp(x): exp(x) computed in fp32 whose gradient is taken at x clamped to [-15, 15]
+(semantics of reconstruction/activation.py:5-17; the fused field kernels implement the same rule, field_bwd.hip).
+
+exp is monotone, so exp(clamp(x, -15, 15)) == clamp(exp(x), e^-15, e^15): the backward needs only the forward's
+OUTPUT, which is what is kept for it (no second exponential, no copy of the input).
+"""
+import math
+
 import torch
-from torch.autograd import Function
+
+_LO, _HI = math.exp(-15.0), math.exp(15.0)
 
 
-class _trunc_exp(Function):
+class TruncExp(torch.autograd.Function):
+    """y = exp(float32(x));  dL/dx = dL/dy * clamp(y, e^-15, e^15)."""
+
     @staticmethod
     def forward(ctx, x):
-        x = x.to(torch.float32)
-        ctx.save_for_backward(x)
-        return torch.exp(x)
+        y = torch.exp(x.float())
+        ctx.save_for_backward(y)
+        ctx.in_dtype = x.dtype
+        return y
 
     @staticmethod
-    def backward(ctx, g):
-        x = ctx.saved_tensors[0]
-        return g * torch.exp(x.clamp(-15, 15))
+    def backward(ctx, grad_y):
+        (y,) = ctx.saved_tensors
+        return (grad_y * y.clamp(_LO, _HI)).to(ctx.in_dtype)
 
 
-trunc_exp = _trunc_exp.apply
+def trunc_exp(x):
+    return TruncExp.apply(x)
