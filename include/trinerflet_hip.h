@@ -207,7 +207,7 @@ TNL_API int tnl_field_pack(const float *W0, const float *W1, const float *W2, co
  * network.py:149-166); with dirs == NULL and rgb != NULL, rgb receives the 15 geo features ([M,15]).
  * m_actual (device int32, may be NULL): rows >= min(M, *m_actual) are skipped -- march_rays_train's
  * counter[0], so the zero rows that pad the sample buffer to its budget M cost nothing. */
-TNL_API uint32_t tnl_field_feats_save_bytes(uint32_t M, uint32_t C, uint32_t Hd);
+TNL_API uint64_t tnl_field_feats_save_bytes(uint32_t M, uint32_t C, uint32_t Hd);
 TNL_API int tnl_field_forward(const void *planes_tm, int half_in, const float *xyz, const float *dirs,
                               float bound, uint32_t M, uint32_t C, uint32_t R, uint32_t Hd,
                               uint32_t Hc, const void *packed, float *sigma, float *rgb,
@@ -218,7 +218,7 @@ TNL_API int tnl_field_forward(const void *planes_tm, int half_in, const float *x
  * NULL (the chain is recomputed from feats_save), except that hidden 128 with dfeat_half != NULL needs
  * sigma (its two-launch backward reads exp(logit) instead of recomputing the sigma net twice).  M must
  * be the M of the forward call that filled feats_save. */
-TNL_API uint32_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint32_t Hc);
+TNL_API uint64_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint32_t Hc);
 TNL_API int tnl_field_backward(const float *grad_sigma, const float *grad_rgb, const float *sigma,
                                const float *rgb, const void *feats_save, const float *xyz,
                                const float *dirs, float bound, uint32_t M, uint32_t C, uint32_t R,

@@ -23,6 +23,15 @@ def test_library_exports_every_declared_symbol():
     h.tnl_field_packed_bytes.restype = ctypes.c_uint32
     assert h.tnl_field_packed_bytes(32, 64, 64) == 60 * 1024       # 32 forward + 28 transposed fragments
     assert h.tnl_field_packed_bytes(32, 64, 128) == 0              # unsupported shape -> 0, not a crash
+    # sizes that pass 4 GB: an untrained occupancy grid lets 60 000 rays take 26 M samples (5 GB of saved features)
+    h.tnl_field_feats_save_bytes.restype = ctypes.c_uint64
+    assert h.tnl_field_feats_save_bytes(ctypes.c_uint32(26295552), 32, 64) == 26295552 * 96 * 2 > 2 ** 32
+    assert h.tnl_field_feats_save_bytes(ctypes.c_uint32(1000), 48, 128) == 1000 * (144 + 16) * 2
+    h.tnl_field_backward_workspace.restype = ctypes.c_uint64
+    assert h.tnl_field_backward_workspace(ctypes.c_uint32(150_000_000), 48, 128, 128) > 2 ** 32
+    h.tnl_march_rays_train_workspace_rec.restype = ctypes.c_uint32
+    assert h.tnl_march_rays_train_workspace_rec(ctypes.c_uint32(60000), 1024) > 60000 * 1024
+    assert h.tnl_march_rays_train_workspace_rec(ctypes.c_uint32(1 << 20), 4096) == 0   # does not fit: two-march form
 
 
 def test_reference_api_surface():

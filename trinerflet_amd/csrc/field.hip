@@ -184,8 +184,8 @@ uint32_t tnl_field_packed_bytes(uint32_t C, uint32_t Hd, uint32_t Hc) {
   return 0;
 }
 
-uint32_t tnl_field_feats_save_bytes(uint32_t M, uint32_t C, uint32_t Hd) {
-  return M * (3 * C + (Hd > 64 ? 16 : 0)) * 2;
+uint64_t tnl_field_feats_save_bytes(uint32_t M, uint32_t C, uint32_t Hd) {
+  return (uint64_t)M * (3 * C + (Hd > 64 ? 16 : 0)) * 2;   // 5 GB at the 26 M samples of an untrained grid: 64-bit
 }
 
 int tnl_field_pack(const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, uint32_t C,

@@ -635,12 +635,12 @@ int launch_bwd(const float* gsig, const float* grgb, const float* sigma, const v
 
 extern "C" {
 
-uint32_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint32_t Hc) {
+uint64_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint32_t Hc) {
   if (Hd != Hc || M == 0) return 0;
   const uint32_t blocks = bwd_blocks(M);
-  if (C == 16 && Hd == 64) return blocks * FieldGeom<16, 64>::NW * 4;
-  if (C == 32 && Hd == 64) return blocks * FieldGeom<32, 64>::NW * 4;
-  if (C == 48 && Hd == 128) return blocks * FieldGeom<48, 128>::NW * 4 + M * 32;   // + the dO hand-over (split launch)
+  if (C == 16 && Hd == 64) return (uint64_t)blocks * FieldGeom<16, 64>::NW * 4;
+  if (C == 32 && Hd == 64) return (uint64_t)blocks * FieldGeom<32, 64>::NW * 4;
+  if (C == 48 && Hd == 128) return (uint64_t)blocks * FieldGeom<48, 128>::NW * 4 + (uint64_t)M * 32;   // + the dO hand-over (split launch)
   return 0;
 }
 
