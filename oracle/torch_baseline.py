@@ -26,8 +26,10 @@ def _params(C, R, scale, H, seed=0):
     return ll, coefs, W
 
 
-def render_run(planes, W, rays_o, rays_d, nears, fars, bound, num_steps=512, bg=0.0):
-    """NeRFRenderer.run restated (renderer.py:126-254, upsample_steps=0, perturb off)."""
+def render_run(planes, W, rays_o, rays_d, nears, fars, bound, num_steps=512, bg=0.0, full=False):
+    """NeRFRenderer.run restated (renderer.py:126-254, upsample_steps=0, perturb off).  Pinned against the reference's
+    own run() by tests/golden/network_reference.npz (tests/test_reference_pins.py).  full=True also returns the
+    depth (renderer.py:227-228) and weights_sum."""
     N = rays_o.shape[0]
     nears, fars = nears.unsqueeze(-1), fars.unsqueeze(-1)
     z = torch.linspace(0.0, 1.0, num_steps).unsqueeze(0).expand(N, num_steps)
@@ -54,6 +56,9 @@ def render_run(planes, W, rays_o, rays_d, nears, fars, bound, num_steps=512, bg=
     rgbs = rgbs.view(N, num_steps, 3)
     ws = weights.sum(-1)
     image = (weights.unsqueeze(-1) * rgbs).sum(-2) + (1 - ws).unsqueeze(-1) * bg
+    if full:
+        depth = (weights * ((z - nears) / (fars - nears)).clamp(0, 1)).sum(-1)
+        return {"image": image, "depth": depth, "weights_sum": ws}
     return image
 
 

@@ -227,3 +227,78 @@ def test_trainer_on_two_ranks(cuda):
     assert l0[-1] < 0.5 * l0[0]
     np.testing.assert_allclose(l0, ref_loss, rtol=0.15)              # same training, rays merely split over two ranks
     assert abs(p0 - ref_psnr) < 1.0, (p0, ref_psnr)
+
+
+# ---- "sharded" mode with a workspace: full checkpoint (all collectives before the ranks diverge, moments gathered),
+# resume on both ranks, evaluation from synchronised parameters -- against an uninterrupted two-rank run
+def _sharded_ckpt_run(rank, workspace, resume_at):
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    from trinerflet_amd.raypool import RayPool
+    from trinerflet_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    poses, intr, images = synthetic.sphere_dataset(8, 48, 48, seed=1)
+    train = RayPool(poses[2:], intr, 48, 48, images[2:], device=dev)
+    valid = RayPool(poses[:2], intr, 48, 48, images[:2], device=dev)
+
+    def model():
+        torch.manual_seed(0)
+        return NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, density_thresh=10, hidden_dim=64,
+                           hidden_dim_color=64, triplane_channels=16, triplane_resolution=128,
+                           triplane_wavelet_levels=2, wavelet_type="bior6.8").to(dev)
+    kw = dict(lr=1e-2, iters=200, num_rays=2048, wavelet_regularization=0.05, fast_training=True,
+              dist_mode="sharded", workspace=workspace)
+    m = model()
+    tr = Trainer("s", m, use_checkpoint="scratch", **kw)
+    extra = {}
+    if resume_at is None:
+        tr.train(train, None, max_epochs=4)                   # train() ends with save_checkpoint(full=True): no hang
+    else:
+        tr.train(train, None, max_epochs=resume_at)
+        dist.barrier()
+        if rank == 0:
+            ck = torch.load(os.path.join(workspace, "checkpoints", f"s_ep{resume_at:04d}.pth"), map_location="cpu",
+                            weights_only=False)
+            st = ck["optimizer"]["state"]
+            # moments of EVERY (plane, channel) slice, not only of rank 0's half
+            extra["v_nonzero_slices"] = [bool((st[k]["exp_avg_sq"].reshape(48, -1).abs().sum(1) > 0).all())
+                                         for k in (0, 1, 2)]
+        m = model()
+        tr = Trainer("s", m, use_checkpoint="latest", **kw)
+        assert tr.epoch == resume_at and tr.global_step > 0
+        tr.train(train, None, max_epochs=4, mark_untrained=False)
+    ev = tr.evaluate_one_epoch(valid)
+    tr.ts.sync_sharded_parameters(moments=True)
+    state = {k: v.detach().cpu().numpy() for k, v in m.named_parameters()}
+    state["m"] = tr.ts.coef.m.cpu().numpy()
+    return tr.stats["loss"], ev["PSNR"], state, extra
+
+
+def _sharded_ckpt_worker(rank, port, workspace, resume_at, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        torch.cuda.set_device(0)
+        out[rank] = _sharded_ckpt_run(rank, workspace, resume_at)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_full_checkpoint_resume(cuda, tmp_path):
+    res = {}
+    for tag, resume_at in (("straight", None), ("resumed", 2)):
+        ws = str(tmp_path / tag)
+        os.makedirs(ws)
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_sharded_ckpt_worker, args=(_free_port(), ws, resume_at, out), nprocs=2, join=True)
+        (l0, p0, s0, e0), (l1, p1, s1, _) = out[0], out[1]
+        assert l0 == l1 and p0 == p1
+        for k in s0:
+            assert np.array_equal(s0[k], s1[k]), k              # replicas identical after the gathers
+        res[tag] = (l0, p0, s0, e0)
+    assert res["resumed"][3]["v_nonzero_slices"] == [True, True, True]
+    # resuming from the full checkpoint reproduces the uninterrupted run (parameters and moments bit for bit)
+    assert res["resumed"][0][-2:] == res["straight"][0][-2:]
+    for k in res["straight"][2]:
+        assert np.array_equal(res["straight"][2][k], res["resumed"][2][k]), k
+    assert res["straight"][1] == res["resumed"][1]

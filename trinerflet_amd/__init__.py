@@ -4,21 +4,51 @@ Sub-packages mirror the reference's module names:
   raymarching, shencoder, triplaneencoder.triplane_encoder, encoding, activation,
   nerf.network, nerf.renderer
 `install_dropin()` registers them under the reference's top-level names so that
-reconstruction/main_nerf.py imports them unchanged.
+reconstruction/main_nerf.py imports them unchanged; `install_backends()` only puts the native-name
+modules `_raymarching` / `_shencoder` on sys.path (the names aux_libs/*/ bind with `import _x as _backend`).
 """
 import importlib
+import os
 import sys
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
-_DROPIN = ("raymarching", "shencoder", "triplaneencoder", "encoding", "activation", "nerf")
+_TOP = ("raymarching", "shencoder", "triplaneencoder", "encoding", "activation")
+_BACKENDS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "backends")
+
+
+def install_backends():
+    """Make `import _raymarching` / `import _shencoder` (aux_libs/raymarching/raymarching.py:9-12,
+    aux_libs/shencoder/sphere_harmonics.py:9-12) resolve to the ctypes-backed modules of trinerflet_amd/backends."""
+    if _BACKENDS not in sys.path:
+        sys.path.insert(0, _BACKENDS)
 
 
 def install_dropin():
-    """Alias trinerflet_amd.<name> as top-level <name> (what main_nerf.py:15-16 expects on sys.path)."""
-    for name in _DROPIN:
+    """Register the MI355X build under the reference's top-level names (main_nerf.py:15-16 puts aux_libs/ on sys.path
+    and reconstruction/ is the script directory):
+
+      raymarching, shencoder, triplaneencoder[.triplane_encoder], encoding, activation  -> trinerflet_amd.<name>
+      nerf.network, nerf.renderer                                                       -> trinerflet_amd.nerf.<name>
+
+    The reference's `nerf` package itself is NOT replaced: `nerf.provider`, `nerf.utils` (its Trainer), ... keep
+    coming from reconstruction/nerf/ -- only the two hot-path modules inside it are overridden.  When no `nerf` package
+    is importable (stand-alone use), trinerflet_amd.nerf takes the name."""
+    install_backends()
+    for name in _TOP:
         sys.modules[name] = importlib.import_module(f"trinerflet_amd.{name}")
     sys.modules["triplaneencoder.triplane_encoder"] = importlib.import_module(
         "trinerflet_amd.triplaneencoder.triplane_encoder")
-    sys.modules["nerf.network"] = importlib.import_module("trinerflet_amd.nerf.network")
-    sys.modules["nerf.renderer"] = importlib.import_module("trinerflet_amd.nerf.renderer")
+    ours = importlib.import_module("trinerflet_amd.nerf")
+    pkg = sys.modules.get("nerf")
+    if pkg is None:
+        try:
+            pkg = importlib.import_module("nerf")      # the reference's (a namespace package: no __init__.py)
+        except ImportError:
+            pkg = None
+    if pkg is None or not hasattr(pkg, "__path__"):
+        pkg = sys.modules["nerf"] = ours
+    for sub in ("network", "renderer"):
+        mod = importlib.import_module(f"trinerflet_amd.nerf.{sub}")
+        sys.modules[f"nerf.{sub}"] = mod
+        setattr(pkg, sub, mod)

@@ -127,6 +127,10 @@ class _march_rays_train(Function):
             if align > 0:
                 mean_count += align - mean_count % align
             M = mean_count
+        if M >= 2 ** 32 or N >= 2 ** 31:
+            # the C ABI takes the sample budget as uint32 (raymarching.h:13 does too); do not truncate silently
+            raise ValueError(f"march_rays_train: sample budget M = {M} (N = {N}, max_steps = {max_steps}) does not fit "
+                             "the 32-bit sample index of the kernels; march fewer rays per call")
         alloc = torch.zeros if zero_fill else torch.empty
         xyzs = alloc(M, 3, dtype=torch.float32, device=dev)
         dirs = alloc(M, 3, dtype=torch.float32, device=dev)

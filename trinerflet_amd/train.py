@@ -129,6 +129,7 @@ class TrainStep:
         self.prefetch_at = "auto"   # "start" | "fwd" | "bwd" | "adam" | "auto": where step(next_rays=...) starts the next batch's march
         self._side = None
         self._prefetched = None     # (key, marched tensors) of a march started for the following call
+        self._stale_params = self._stale_moments = False
         self.post_refresh = None    # optional callable run right after every density-grid refresh
         self.section_events = None  # set to [] to record HIP events (on the launch stream) around every stage
         # distributed
@@ -138,6 +139,12 @@ class TrainStep:
         self.dist_mode = dist_mode if self.world > 1 else None
         if self.dist_mode == "sharded":
             assert (3 * self.C) % self.world == 0, "3*channels must be divisible by the world size"
+        if self.world > 1:
+            # the density-grid refresh splits the 128^3 cells (and the H^3/4 picks of a partial refresh) evenly over
+            # the ranks before an all-gather of equal shards (renderer.update_extra_state)
+            g3 = model.grid_size ** 3
+            assert g3 % self.world == 0 and (g3 // 4) % self.world == 0, \
+                f"grid_size^3 / 4 = {g3 // 4} candidate cells cannot be split evenly over {self.world} ranks"
 
     # ------------------------------------------------------------------------------------------
     def _mark(self, name):
@@ -167,7 +174,7 @@ class TrainStep:
         """Call after changing model.density_bitfield by hand (update_extra_state inside step() is tracked): the
         occupancy window is recomputed and a march already started for the following batch is dropped."""
         self._roi_valid = False
-        self._prefetched = None
+        self._drop_prefetch()
 
     def _roi10(self, s0=0):
         return None if self._roi is None else list(self._roi) + [self.C, s0]
@@ -485,11 +492,14 @@ class TrainStep:
         # the occupancy bitfield, not on the planes: it runs on a side stream underneath the HBM-bound plane
         # rebuild.  On grid-refresh steps the bitfield changes first, so there the march stays in order.
         side = None
-        pre, self._prefetched = self._prefetched, None
-        if pre is not None and not refresh and pre[0] == (rays_o.data_ptr(), rays_d.data_ptr(), N):
+        pre = self._prefetched
+        if pre is not None and not refresh and self._prefetch_matches(pre[0], rays_o, rays_d, noises):
+            self._prefetched = None
             marched, side = pre[1], self._side          # started during the previous call
-        elif self.overlap_march and not refresh and model.mean_count > 0:
-            marched, side = march_on_side(), self._side
+        else:
+            self._drop_prefetch()                       # other rays than announced (or a refresh): marched for nothing
+            if self.overlap_march and not refresh and model.mean_count > 0:
+                marched, side = march_on_side(), self._side
         if self.use_roi and not refresh and not self._roi_valid:
             self._roi, self._roi_valid = self._compute_roi(), True
         # where the next batch's side work starts (see _prefetch_mode): "start" = here, "fwd" = before the field forward,
@@ -614,11 +624,13 @@ class TrainStep:
                 # workgroups are limited to 4 per CU (an unused 40-KB LDS reservation) so that the side stream finds
                 # wave slots; the tile reduction and the adjoint above then ran undisturbed
                 lib.tnl_adam_set_lds_reservation(L.u32(40960 if under_adam else 0))
-                if under_adam:
-                    self._prefetch_next(next_rays, march_on_side)
-                self._adam_levels(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
-                if under_adam:
-                    lib.tnl_adam_set_lds_reservation(L.u32(0))
+                try:
+                    if under_adam:
+                        self._prefetch_next(next_rays, march_on_side)
+                    self._adam_levels(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
+                finally:
+                    if under_adam:
+                        lib.tnl_adam_set_lds_reservation(L.u32(0))   # process-global: never leave it set
                 self._mark("adam_coef")
         else:
             grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
@@ -654,6 +666,7 @@ class TrainStep:
                                       L.i32(int(self.fp16)), L.ptr(self.abs_sum if l1 > 0 else None), L.f32(l1),
                                       L.ptr(reg), L.stream()), "step_epilogue")
         self.global_step += 1
+        self._stale_params = self._stale_moments = True    # "sharded" mode: see sync_sharded_parameters
         if self.world > 1:
             mse = mse_local.clone()
             dist.all_reduce(mse, group=self.pg)
@@ -690,7 +703,31 @@ class TrainStep:
             return
         no, nd = next_rays[0], next_rays[1]
         nn = next_rays[2] if len(next_rays) > 2 else None
-        self._prefetched = ((no.data_ptr(), nd.data_ptr(), no.shape[0]), march_on_side(no, nd, nn))
+        # the announced tensors are kept (their storage cannot be recycled for another batch meanwhile) together with
+        # their version counters (an in-place refill of a persistent ray buffer is noticed)
+        key = tuple((t_, t_.data_ptr(), tuple(t_.shape), t_._version) if t_ is not None else None for t_ in (no, nd, nn))
+        self._prefetched = (key, march_on_side(no, nd, nn))
+
+    @staticmethod
+    def _prefetch_matches(key, rays_o, rays_d, noises):
+        for k, t_ in zip(key, (rays_o, rays_d, noises)):
+            if (k is None) != (t_ is None):
+                return False
+            if k is not None and (k[1] != t_.data_ptr() or k[2] != tuple(t_.shape) or k[3] != t_._version
+                                  or k[0]._version != k[3] or k[0].dtype != t_.dtype):
+                return False
+        return True
+
+    def _drop_prefetch(self):
+        """Forget a march started for a batch that is not coming: its step_counter slot and local_step are given back
+        (mean_count at the next refresh averages the slots), and the launch stream is ordered behind it."""
+        pre, self._prefetched = self._prefetched, None
+        if pre is None:
+            return
+        (_, (_, ev_sort)) = pre[1]
+        torch.cuda.current_stream().wait_event(ev_sort)
+        self.model.local_step -= 1
+        self.model.step_counter[self.model.local_step % 16].zero_()
 
     def _scaler_probe(self, g0, g1, flag):
         """GradScaler.unscale_'s found_inf over g0 (+ g1) and an optional device flag; [1] float tensor."""
@@ -715,12 +752,26 @@ class TrainStep:
         n0 = self.ll.params[0].shape[-1]
         self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale, None, s0 * n0 * n0, s1 * n0 * n0)
 
-    def sync_sharded_parameters(self):
-        """All-gather the slice-sharded coefficients (call before saving a checkpoint in "sharded" mode)."""
+    def sync_sharded_parameters(self, moments=False):
+        """All-gather the slice-sharded coefficients ("sharded" mode: a rank's Adam pass only updates its own
+        (plane, channel) slices, the others go stale until this runs).  A collective: every rank must call it, in the
+        same order.  moments=True also gathers exp_avg / exp_avg_sq (needed for a full checkpoint).  No-op when
+        nothing was stepped since the last call."""
         if self.dist_mode != "sharded":
             return
+        need_p = self._stale_params
+        need_m = moments and self._stale_moments
+        if not (need_p or need_m):
+            return
         s0, s1 = self._slice_range()
-        for p in self.coef.params + self.ll.params:
-            S = 3 * self.C
-            flat = p.data.view(S, -1)
-            flat.copy_(D.all_gather_slices(flat[s0:s1], self.pg))
+        S = 3 * self.C
+        for flat in (self.coef, self.ll):
+            for k, p in enumerate(flat.params):
+                o, n = flat.offsets[k], flat.sizes[k]
+                bufs = ([flat.data] if need_p else []) + ([flat.m, flat.v] if need_m else [])
+                for buf in bufs:
+                    seg = buf[o:o + n].view(S, -1)
+                    seg.copy_(D.all_gather_slices(seg[s0:s1], self.pg))
+        self._stale_params = False
+        if need_m:
+            self._stale_moments = False

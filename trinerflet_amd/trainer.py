@@ -203,6 +203,8 @@ class Trainer:
         model = self.model
         was_training = model.training
         model.eval()
+        self.ts.sync_sharded_parameters()     # "sharded": planes are rebuilt from every slice below (a collective;
+        #                                       evaluate_one_epoch / test call this on all ranks before striping)
         self.model.encoder.reset_cahce()      # the training loop only refreshes the occupancy window of the planes
         data = pool.image_rays(index, bg_color=self.background_color)
         out = model.render(data["rays_o"].unsqueeze(0), data["rays_d"].unsqueeze(0), staged=True,
@@ -221,6 +223,7 @@ class Trainer:
         striped over the ranks and the two sums all-reduced."""
         meter = PSNRMeter()
         loss = torch.zeros((), dtype=torch.float64, device=self.device)
+        self.ts.sync_sharded_parameters()     # before the ranks take different numbers of images
         for i in range(self.rank, pool.B, self.world):
             pred, _, gt = self.render_image(pool, i, max_steps=max_steps)
             meter.update(pred, gt)
@@ -241,6 +244,7 @@ class Trainer:
         """Render every pose (test_step); returns [B,H,W,3] uint8 on the host and, if a path is given, writes
         binary PPMs there (the reference writes PNG + MP4 through cv2 / imageio, which this build does not carry)."""
         frames = []
+        self.ts.sync_sharded_parameters()
         for i in range(pool.B):
             pred, _, _ = self.render_image(pool, i, max_steps=max_steps)
             frames.append((pred.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy())
@@ -271,7 +275,8 @@ class Trainer:
         return slots
 
     def optimizer_state_dict(self):
-        self.ts.sync_sharded_parameters()
+        """torch.optim.Adam state_dict over model.get_params(lr).  No collective in here: in "sharded" mode the caller
+        (save_checkpoint, on EVERY rank) has gathered parameters and moments before the ranks diverge."""
         opt = self._torch_optimizer()
         slots = self._flat_slots()
         step = self.ts.opt_steps.detach().to("cpu", torch.float32).reshape(())
@@ -326,7 +331,9 @@ class Trainer:
     def save_checkpoint(self, name=None, full=False, remove_old=True):
         if self.ckpt_path is None:
             raise RuntimeError("Trainer was built without a workspace")
-        self.ts.sync_sharded_parameters()
+        # collectives first, on every rank ("sharded": a rank only steps its own (plane, channel) slices and their
+        # moments); only then do the ranks part ways
+        self.ts.sync_sharded_parameters(moments=full)
         if self.rank != 0:
             return None
         if name is None:
