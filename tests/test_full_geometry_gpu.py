@@ -1,0 +1,215 @@
+"""BASELINE.json's configurations at their REAL geometry (README.md:46-58): base / base-light (C = 32, R = 2048,
+scale 32 = five levels of bior6.8, hidden 64, 60 000 rays) and large (C = 48, hidden 128) -- the size-dependent code
+(pipelined IDWT kernels, occupancy window, gradient-support rectangles, 49 k tile bins, > 4 GB buffers, the two-launch
+hidden-128 backward inside TrainStep) against the oracle on what the oracle can afford:
+
+  * the march of all 60 000 rays: per-ray (id, offset, count), counter, every sample position / step bit-exact;
+  * five-level IDWT + adjoint on three (plane, channel) slices of 2048^2 vs the C oracle;
+  * fused field forward / backward on a 100 000-sample subset of the marched samples vs oracle/field.py;
+  * TrainStep with the occupancy window + support chain == TrainStep on whole planes, from an untrained budget
+    (mean_count = 0 first) through a grid refresh.
+Skipped when the device has less than 64 GB free."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref, field as ofield
+from trinerflet_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {"base": (32, 64, 0.4), "large": (48, 128, 0.6)}
+R, SCALE, N, BOUND = 2048, 32, 60000, 1.5
+
+
+def _need_memory():
+    free, _ = torch.cuda.mem_get_info()
+    if free < 64 * 2 ** 30:
+        pytest.skip(f"needs 64 GB of free device memory, {free / 2 ** 30:.0f} GB available")
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _model(dev, cfg, seed=0):
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    C, H, _ = CONFIGS[cfg]
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=BOUND, cuda_ray=True, density_thresh=10, hidden_dim=H,
+                    hidden_dim_color=H, triplane_channels=C, triplane_resolution=R, triplane_wavelet_levels=SCALE,
+                    wavelet_type="bior6.8").to(dev)
+    synthetic.init_field_parameters(m, seed=seed)
+    assert [p.shape[-1] for p in m.encoder.planes_features_wavelet_coefs] == [64, 128, 256, 512, 1024]
+    return m
+
+
+@pytest.fixture(scope="module")
+def rays60k():
+    rng = np.random.default_rng(0)
+    poses = synthetic.hemisphere_poses(100, seed=0)
+    flat = rng.permutation(100 * 800 * 800)[:N]
+    pix = np.stack([flat // (800 * 800), flat % (800 * 800)], -1)
+    o, d = synthetic.get_rays(poses, pix)
+    noise = rng.random(N).astype(np.float32)
+    bf = synthetic.sphere_bitfield(128, 2, BOUND, 0.8, 0.0)
+    return o, d, noise, bf
+
+
+def test_march_60k_rays_bit_exact(cuda, rays60k):
+    from trinerflet_amd import raymarching
+    o, d, noise, bf = rays60k
+    aabb = np.array([-BOUND] * 3 + [BOUND] * 3, np.float32)
+    nears, fars = cref.near_far_from_aabb(o, d, aabb, 0.2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    # first pass: unknown budget (the wrapper's .item() path); second: the budget the running mean would give
+    counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+    x, dd, dl, rr = raymarching.march_rays_train(t(o), t(d), BOUND, t(bf), 2, 128, t(nears), t(fars), counter, -1, True,
+                                                 128, False, 0, 1024, t(noise))
+    total = int(counter[0])
+    assert 3_000_000 < total < 8_000_000                      # the bench's workload (~4.65 M samples)
+    xr, dr, lr, rro, cr = cref.march_rays_train(o, d, BOUND, bf, 2, 128, nears, fars, noise, total + 128)
+    assert np.array_equal(counter.cpu().numpy(), cr) and np.array_equal(rr.cpu().numpy(), rro)
+    assert np.array_equal(x[:total].cpu().numpy(), xr[:total]) and np.array_equal(dl[:total].cpu().numpy(), lr[:total])
+    assert np.array_equal(dd[:total].cpu().numpy(), dr[:total])
+    budget = total * 9 // 10                                   # a budget that drops the last rays
+    counter.zero_()
+    x2, _, dl2, rr2 = raymarching.march_rays_train(t(o), t(d), BOUND, t(bf), 2, 128, t(nears), t(fars), counter, budget,
+                                                   True, 128, False, 0, 1024, t(noise))
+    M = x2.shape[0]
+    xr, dr, lr, rro, cr = cref.march_rays_train(o, d, BOUND, bf, 2, 128, nears, fars, noise, M)
+    assert np.array_equal(rr2.cpu().numpy(), rro) and np.array_equal(counter.cpu().numpy(), cr)
+    assert np.array_equal(x2.cpu().numpy(), xr) and np.array_equal(dl2.cpu().numpy(), lr)
+
+
+@pytest.mark.parametrize("cfg", ["base", "large"])
+def test_five_level_idwt_and_adjoint_slices(cuda, cfg):
+    _need_memory()
+    C = CONFIGS[cfg][0]
+    m = _model(cuda, cfg, seed=1)
+    enc = m.encoder
+    with torch.no_grad():
+        for p in enc.planes_features_wavelet_coefs:
+            p.mul_(4.0)
+    planes = enc.get_planes()
+    assert tuple(planes.shape) == (3, C, R, R)
+    slices = [(0, 0), (1, C // 2), (2, C - 1)]
+    ll = np.stack([enc.planes_features[p, c].detach().cpu().numpy() for p, c in slices])[None]
+    coefs = [np.stack([q[p, c].detach().cpu().numpy() for p, c in slices])[None]
+             for q in enc.planes_features_wavelet_coefs]
+    want = cref.build_planes(ll, coefs, "bior6.8")[0]
+    for k, (p, c) in enumerate(slices):
+        got = planes[p, c].detach().cpu().numpy()
+        assert np.abs(got - want[k]).max() < 5e-6 * np.abs(want[k]).max(), (cfg, p, c)
+    # adjoint through autograd of the module path (the kernels TrainStep also runs)
+    g = torch.Generator(device=cuda).manual_seed(3)
+    cot = torch.zeros_like(planes)
+    for p, c in slices:
+        cot[p, c] = torch.randn(R, R, generator=g, device=cuda)
+    planes.backward(cot)
+    dpl = np.stack([cot[p, c].cpu().numpy() for p, c in slices])[None]
+    dll, dco = cref.build_planes_adj(dpl, 5, "bior6.8")
+    got_ll = np.stack([enc.planes_features.grad[p, c].cpu().numpy() for p, c in slices])
+    assert _rel(got_ll, dll[0]) < 2e-5
+    for lvl, q in enumerate(enc.planes_features_wavelet_coefs):
+        got = np.stack([q.grad[p, c].cpu().numpy() for p, c in slices])
+        assert _rel(got, dco[lvl][0]) < 2e-5, (cfg, lvl)
+    # slices that received no cotangent get exactly zero
+    assert float(enc.planes_features_wavelet_coefs[4].grad[0, 1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", ["base", "large"])
+def test_fused_field_on_marched_subset(cuda, rays60k, cfg):
+    _need_memory()
+    from trinerflet_amd import raymarching
+    from trinerflet_amd.nerf import field as gfield
+    C, H, _ = CONFIGS[cfg]
+    o, d, noise, bf = rays60k
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    m = _model(cuda, cfg, seed=2)
+    with torch.no_grad():
+        for p in m.encoder.planes_features_wavelet_coefs:
+            p.mul_(4.0)
+    m.density_bitfield.copy_(t(bf))
+    nears, fars = raymarching.near_far_from_aabb(t(o), t(d), m.aabb_train, 0.2)
+    counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+    x, dd, dl, rr = raymarching.march_rays_train(t(o), t(d), BOUND, t(bf), 2, 128, nears, fars, counter, -1, True, 128,
+                                                 False, 0, 1024, t(noise))
+    total = int(counter[0])
+    pick = torch.from_numpy(np.sort(np.random.default_rng(1).choice(total, 100_000, replace=False))).to(cuda)
+    xs, ds = x[pick].contiguous(), dd[pick].contiguous()
+    planes = m.encoder.get_planes().detach()
+    tm = m.encoder.get_planes_texel_major()                          # fp16 [3,R,R,C]
+    Ws = [m.sigma_net[0].weight, m.sigma_net[1].weight, m.color_net[0].weight, m.color_net[1].weight,
+          m.color_net[2].weight]
+    packed = gfield.pack_weights(*Ws, C, H)
+    Mx = xs.shape[0]
+    sigma, rgb, feats = gfield.field_forward(tm, xs, ds, packed, BOUND, C, R, H, save_feats=True)
+    # oracle, fp16 operand emulation (fp32 accumulate), planes rounded to fp16 like the sampler's copy
+    pl_o = planes.cpu().requires_grad_(True)
+    W_o = [w.detach().cpu().clone().requires_grad_(True) for w in Ws]
+    s_o, c_o = ofield.field(pl_o, xs.cpu(), ds.cpu(), W_o, BOUND, fp16=True, plane_half=True)
+    np.testing.assert_allclose(rgb.cpu().numpy(), c_o.detach().numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(sigma.cpu().numpy(), s_o.detach().numpy(), rtol=3e-3, atol=1e-6)
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(Mx, generator=g), torch.randn(Mx, 3, generator=g)
+    ((s_o * a).sum() + (c_o * b).sum()).backward()
+    # kernel backward, TrainStep's form: dF as fp16 + tile-sorted reduction into (3,C,R,R)
+    nW = sum(w.numel() for w in Ws)
+    gW = torch.zeros(nW, device=cuda)
+    dfeat = torch.empty(3, Mx, C, dtype=torch.float16, device=cuda)
+    g_cm = torch.empty(3, C, R, R, device=cuda)
+    gfield.field_backward(a.to(cuda), b.to(cuda), sigma, None, feats, xs, ds, packed, BOUND, C, R, H, g_cm, gW,
+                          dfeat=dfeat)
+    gfield.plane_grad_binned(dfeat, xs, BOUND, C, R, g_cm, channel_major=True)
+    off = 0
+    for k, w in enumerate(W_o):
+        e = _rel(gW[off:off + w.numel()].cpu().numpy().reshape(w.shape), w.grad.numpy())
+        assert e < 5e-3, (cfg, k, e)
+        off += w.numel()
+    ref = pl_o.grad.numpy()
+    got = g_cm.cpu().numpy()
+    assert _rel(got, ref) < 5e-3
+    assert np.array_equal(got != 0, ref != 0) or float(np.abs(got[ref == 0]).max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", ["base", "large"])
+def test_trainstep_window_equals_whole_plane(cuda, rays60k, cfg):
+    """Five steps from an untrained sample budget (mean_count = 0: the march's worst-case buffers and the .item()
+    path), one grid refresh at step 4; with the occupancy window + support rectangles vs whole planes."""
+    _need_memory()
+    from trinerflet_amd.train import TrainStep
+    C, H, lam = CONFIGS[cfg]
+    o, d, noise, bf = rays60k
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    gt = t(synthetic.target_colors(d))
+    o_t, d_t, nz, bf_t = t(o), t(d), t(noise), t(bf)
+    base = _model(cuda, cfg, seed=4)
+    base.density_bitfield.copy_(bf_t)
+    res = []
+    for use_roi in (False, True):
+        m = copy.deepcopy(base)
+        ts = TrainStep(m, lr=1e-2, wavelet_regularization=lam, iters=1000, update_extra_interval=4, use_roi=use_roi)
+        ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf_t)
+        m.mean_count = 0
+        losses, Ms = [], []
+        for it in range(5):
+            loss = ts.step(o_t, d_t, gt, noises=nz)
+            losses.append(float(loss))
+            Ms.append(int(ts.last["counter"][0]))
+            if use_roi and it % 4 != 0:
+                assert ts._roi is not None and ts._roi[6] < R and ts._rect_ok and ts._rects[0] is not None
+                assert ts._roi[6] == 1152 and ts._roi[7] == 1152          # the r = 0.8 sphere's window
+        assert all(np.isfinite(losses)) and Ms[0] > 3_000_000 and len(set(Ms)) == 1
+        assert float(ts.last["found_inf"]) == 0.0
+        res.append((losses, [p.detach() for p in m.parameters()], ts))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-4)
+    assert res[0][0][-1] < res[0][0][0]
+    for a, b in zip(res[0][1], res[1][1]):
+        # see tests/test_roi_gpu.py::test_training_with_window_equals_whole_plane_training for the allowance (isolated
+        # coefficients whose gradient sits at rounding level; measured here 1.2e-5 of them over five steps)
+        bad = ((a - b).abs() > 2e-3 + 1e-3 * b.abs())
+        assert int(bad.sum()) <= max(1, int(5e-5 * a.numel())) and float((a - b).abs().max()) < 6e-2, \
+            (cfg, int(bad.sum()), a.numel())

@@ -1,0 +1,246 @@
+"""The HIP path against outputs of the reference's own Python (tests/golden/network_reference.npz, produced in the
+build container by tests/golden/make_golden_network.py: reference NeRFNetwork / NeRFRenderer.run / run_cuda /
+Trainer.train_step / raymarching.py wrappers, imported unmodified; the CUDA-only kernels inside stood in for by the C
+oracle).  Rows of SURVEY.md 8(a): A2 planes, A3 lookup, A4 SH, A5/A6 MLP (F-MLP), A10 run_cuda training glue incl.
+background and depth, A11 inference loop (F-INFER), A13 one optimisation step x2 (F-STEP), A14 run (F-RUN).
+
+Two GPU paths are checked: the fp32 'train-parity' composition (modular: HIP lookup + HIP SH + fp32 Linear, fp32
+planes) at fp32 tolerances, and the default fused path (fp16 planes, fp16 MFMA operands) at BASELINE.json's 1e-3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["W0", "W1", "W2", "W3", "W4"]
+KEYS = ["sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight", "color_net.1.weight", "color_net.2.weight"]
+
+
+@pytest.fixture(scope="module")
+def ref(golden_dir):
+    return np.load(os.path.join(golden_dir, "network_reference.npz"))
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _cfg(ref):
+    C, R, scale, H, N, max_steps = (int(v) for v in ref["cfg"])
+    bound, lam, bg, lr, min_near, dscale = (float(v) for v in ref["cfg_f"])
+    return C, R, scale, H, N, max_steps, bound, lam, bg, lr, min_near
+
+
+def _model(ref, dev, fp32=False, tag="param", suffix=""):
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    C, R, scale, H, N, max_steps, bound, lam, bg, lr, min_near = _cfg(ref)
+    kw = dict(plane_dtype=torch.float32) if fp32 else {}
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=bound, cuda_ray=True, density_scale=1, min_near=min_near,
+                    density_thresh=10, hidden_dim=H, hidden_dim_color=H, triplane_channels=C, triplane_resolution=R,
+                    triplane_wavelet_levels=scale, wavelet_type="bior6.8", **kw).to(dev)
+    m.force_modular = fp32
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    with torch.no_grad():
+        m.encoder.planes_features.copy_(t(ref[f"{tag}/ll{suffix}"]))
+        for i, p in enumerate(m.encoder.planes_features_wavelet_coefs):
+            p.copy_(t(ref[f"{tag}/coef{i}{suffix}"]))
+        sd = dict(m.named_parameters())
+        for k, n in zip(KEYS, NAMES):
+            sd[k].copy_(t(ref[f"{tag}/{n}{suffix}"]))
+    m.density_bitfield.copy_(t(ref["bitfield"]))
+    return m
+
+
+def test_planes(cuda, ref):
+    m = _model(ref, cuda)
+    planes = m.encoder.get_planes().detach().cpu().numpy()
+    assert np.abs(planes - ref["planes"]).max() < 3e-6 * np.abs(ref["planes"]).max()
+
+
+@pytest.mark.parametrize("fp32", [True, False])
+def test_network_forward_and_vjp(cuda, ref, fp32):
+    """F-MLP: reference NeRFNetwork.forward / density / color (network.py:118-214) and its autograd VJP."""
+    m = _model(ref, cuda, fp32=fp32)
+    m.train()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    xyz, dirs = t(ref["mlp/xyz"]), t(ref["mlp/dirs"])
+    sigma, rgb = m(xyz, dirs)
+    s_ref, c_ref = ref["mlp/sigma"], ref["mlp/rgb"]
+    if fp32:
+        np.testing.assert_allclose(sigma.detach().cpu().numpy(), s_ref, rtol=3e-5, atol=1e-7)
+        np.testing.assert_allclose(rgb.detach().cpu().numpy(), c_ref, rtol=0, atol=3e-6)
+    else:   # BASELINE.json: RGB / sigma within 1e-3 fp16 (sigma = exp(logit): relative)
+        assert np.abs(rgb.detach().cpu().numpy() - c_ref).max() < 2e-3
+        rel = np.abs(sigma.detach().cpu().numpy() - s_ref) / s_ref
+        assert np.median(rel) < 1e-3 and rel.max() < 1e-2, (np.median(rel), rel.max())
+    (sigma * t(ref["mlp/cot_sigma"])).sum().add((rgb * t(ref["mlp/cot_rgb"])).sum()).backward()
+    tol = 5e-5 if fp32 else 3e-2     # fused: fp16 planes, fp16 MFMA operands incl. the incoming gradients
+    sd = dict(m.named_parameters())
+    for k, n in enumerate(KEYS):
+        assert _rel(sd[n].grad.cpu().numpy(), ref[f"mlp/dW{k}"]) < tol, (n, _rel(sd[n].grad.cpu().numpy(), ref[f"mlp/dW{k}"]))
+    # planes -> (LL, coefficients) through the adjoint IDWT: compare via <dplanes, dP/dtheta . v> on the LL gradient
+    # of the reference cotangent pushed through the pinned oracle adjoint
+    from oracle import cref
+    dll, dco = cref.build_planes_adj(ref["mlp/dplanes"], 2, "bior6.8")
+    assert _rel(m.encoder.planes_features.grad.cpu().numpy(), dll.reshape(ref["param/ll"].shape)) < (1e-4 if fp32 else 3e-2)
+    for i, p in enumerate(m.encoder.planes_features_wavelet_coefs):
+        assert _rel(p.grad.cpu().numpy(), dco[i].reshape(p.shape)) < (1e-4 if fp32 else 3e-2), i
+    # density() / masked color()
+    with torch.no_grad():
+        dens = m.density(xyz)
+        col = m.color(xyz, dirs, mask=t(ref["mlp/mask"]), geo_feat=t(ref["mlp/geo_feat"]))
+    rel = np.abs(dens["sigma"].cpu().numpy() - ref["mlp/density_sigma"]) / ref["mlp/density_sigma"]
+    assert rel.max() < (3e-5 if fp32 else 1e-2)
+    assert np.abs(dens["geo_feat"].float().cpu().numpy() - ref["mlp/geo_feat"]).max() < (1e-5 if fp32 else 5e-3)
+    assert np.abs(col.cpu().numpy() - ref["mlp/color_masked"]).max() < 1e-5      # fp32 colour MLP on reference geo_feat
+
+
+@pytest.mark.parametrize("tag,steps,ups", [("run64", 64, 0), ("run32u16", 32, 16)])
+def test_run_matches_reference_run(cuda, ref, tag, steps, ups):
+    """F-RUN / A14: NeRFRenderer.run (renderer.py:126-254), with and without hierarchical resampling."""
+    C, R, scale, H, N, max_steps, bound, lam, bg, lr, min_near = _cfg(ref)
+    m = _model(ref, cuda, fp32=True)
+    m.eval()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    with torch.no_grad():
+        out = m.run(t(ref["rays/o"])[None], t(ref["rays/d"])[None], num_steps=steps, upsample_steps=ups, bg_color=bg,
+                    perturb=False)
+    hit = np.isfinite(ref[f"{tag}/depth"])
+    assert not hit.all()
+    # resampled positions come from an inverse-CDF search: a rounding-level change of a weight can move one sample
+    tol = 3e-6 if ups == 0 else 2e-4
+    np.testing.assert_allclose(out["image"][0].cpu().numpy()[hit], ref[f"{tag}/image"][hit], atol=tol)
+    np.testing.assert_allclose(out["weights_sum"].cpu().numpy()[hit], ref[f"{tag}/weights_sum"][hit], atol=tol)
+    np.testing.assert_allclose(out["depth"][0].cpu().numpy()[hit], ref[f"{tag}/depth"][hit], atol=tol)
+    assert np.isnan(out["depth"][0].cpu().numpy()[~hit]).all()
+
+
+@pytest.mark.parametrize("fp32", [True, False])
+def test_inference_branch_matches_reference(cuda, ref, fp32):
+    """F-INFER / A11 + glue: run_cuda eval branch (renderer.py:324-374)."""
+    C, R, scale, H, N, max_steps, bound, lam, bg, lr, min_near = _cfg(ref)
+    m = _model(ref, cuda, fp32=fp32)
+    m.eval()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    with torch.no_grad():
+        out = m.render(t(ref["rays/o"])[None], t(ref["rays/d"])[None], staged=True, bg_color=bg, perturb=False,
+                       dt_gamma=0, max_steps=max_steps, T_thresh=1e-4)
+    hit = np.isfinite(ref["infer/depth"])
+    tol = 1e-5 if fp32 else 2e-3
+    np.testing.assert_allclose(out["image"][0].cpu().numpy(), ref["infer/image"], atol=tol)
+    np.testing.assert_allclose(out["weights_sum"].reshape(-1).cpu().numpy(), ref["infer/weights_sum"], atol=tol)
+    np.testing.assert_allclose(out["depth"][0].cpu().numpy()[hit], ref["infer/depth"][hit], atol=tol)
+    assert np.isnan(out["depth"][0].cpu().numpy()[~hit]).all()
+
+
+@pytest.mark.parametrize("fp32", [True, False])
+def test_training_branch_glue_matches_reference(cuda, ref, fp32):
+    """A10: run_cuda training branch incl. image += (1 - ws) bg and the depth normalisation (renderer.py:317-318),
+    under the sample budget rule, parameters after the reference's two updates."""
+    C, R, scale, H, N, max_steps, bound, lam, bg, lr, min_near = _cfg(ref)
+    m = _model(ref, cuda, fp32=fp32, tag="step1", suffix="_after")
+    m.train()
+    m.mean_count = int(ref["glue/mean_count"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    with torch.no_grad():
+        out = m.render(t(ref["rays/o"])[None], t(ref["rays/d"])[None], staged=False, bg_color=bg, perturb=True,
+                       force_all_rays=False, dt_gamma=0, max_steps=max_steps, noises=t(ref["glue/noises"]))
+    hit = np.isfinite(ref["glue/depth"])
+    tol = 1e-5 if fp32 else 2e-3
+    np.testing.assert_allclose(out["image"][0].cpu().numpy(), ref["glue/image"], atol=tol)
+    np.testing.assert_allclose(out["weights_sum"].cpu().numpy(), ref["glue/weights_sum"], atol=tol)
+    np.testing.assert_allclose(out["depth"][0].cpu().numpy()[hit], ref["glue/depth"][hit], atol=tol)
+    assert np.isnan(out["depth"][0].cpu().numpy()[~hit]).all()
+
+
+def _gt(ref, bg, dev):
+    images = torch.from_numpy(ref["rays/images"][0]).to(dev)
+    return (images[:, :3] * images[:, 3:] + bg * (1 - images[:, 3:])).contiguous()
+
+
+def test_dropin_autograd_step_matches_reference_trainer(cuda, ref):
+    """F-STEP through the drop-in modules as the reference's Trainer drives them (fp32 composition, torch autograd,
+    torch.optim.Adam): loss, prediction, every gradient, every parameter after the update -- both iterations."""
+    C, R, scale, H, N, max_steps, bound, lam, bg, lr, min_near = _cfg(ref)
+    m = _model(ref, cuda, fp32=True)
+    m.train()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    opt = torch.optim.Adam(m.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
+    gt = _gt(ref, bg, cuda)
+    sd = dict(m.named_parameters())
+    pnames = ["encoder.planes_features", "encoder.planes_features_wavelet_coefs.0",
+              "encoder.planes_features_wavelet_coefs.1"] + KEYS
+    gk = ["g_ll", "g_coef0", "g_coef1"] + [f"g_{n}" for n in NAMES]
+    ak = ["ll_after", "coef0_after", "coef1_after"] + [f"{n}_after" for n in NAMES]
+    for it in range(2):
+        m.mean_count = int(ref[f"step{it}/mean_count"])
+        opt.zero_grad()
+        m.encoder.reset_cahce(); m.encoder.get_planes()
+        out = m.render(t(ref["rays/o"])[None], t(ref["rays/d"])[None], staged=False, bg_color=bg, perturb=True,
+                       force_all_rays=False, dt_gamma=0, max_steps=max_steps, noises=t(ref[f"step{it}/noises"]))
+        assert np.array_equal(m.step_counter[(m.local_step - 1) % 16].cpu().numpy(), ref[f"step{it}/counter"])
+        np.testing.assert_allclose(out["image"][0].detach().cpu().numpy(), ref[f"step{it}/pred"], atol=1e-5)
+        mse = ((out["image"][0] - gt) ** 2).mean(-1).mean()
+        wf = m.encoder.get_wavelet_features()
+        tot = sum(v.numel() for v in wf)
+        reg = lam * sum(v.abs().mean() * (v.numel() / tot) for v in wf) / len(wf)
+        assert abs(float(mse) - float(ref[f"step{it}/mse"])) < 1e-5 * float(mse)
+        assert abs(float(reg) - float(ref[f"step{it}/wavelet_reg"])) < 1e-5 * float(reg)
+        (mse + reg).backward()
+        m.encoder.reset_cahce()
+        for n, k in zip(pnames, gk):
+            assert _rel(sd[n].grad.cpu().numpy(), ref[f"step{it}/{k}"]) < 2e-4, (it, n, _rel(sd[n].grad.cpu().numpy(), ref[f"step{it}/{k}"]))
+        opt.step()
+        for n, k, g in zip(pnames, ak, gk):
+            gr = ref[f"step{it}/{g}"]
+            sig = np.abs(gr) > 1e-3 * np.abs(gr).max()          # sign-like early Adam steps: see test_train_gpu.py
+            diff = np.abs(sd[n].detach().cpu().numpy() - ref[f"step{it}/{k}"])
+            assert (diff[sig] > 2e-5).mean() < 5e-3, (it, n)
+            with torch.no_grad():
+                sd[n].copy_(t(ref[f"step{it}/{k}"]))
+
+
+@pytest.mark.parametrize("plane_fp32", [True, False])
+def test_fused_trainstep_matches_reference_trainer(cuda, ref, plane_fp32):
+    """F-STEP through TrainStep (the fused step: C-ABI kernels, fused field fwd/bwd, tile-sorted plane gradient or
+    atomics, adjoint IDWT, fused Adam+L1, GradScaler bookkeeping) -- fp16 MFMA operands, so BASELINE.json's fp16
+    tolerance on values and a relative-L2 bound on gradients."""
+    from trinerflet_amd.train import TrainStep
+    C, R, scale, H, N, max_steps, bound, lam, bg, lr, min_near = _cfg(ref)
+    m = _model(ref, cuda)
+    if plane_fp32:
+        m.encoder.plane_dtype = torch.float32
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    ts = TrainStep(m, lr=lr, wavelet_regularization=lam, iters=100, warmup_steps=0, fp16=True, update_extra_interval=0,
+                   background_color=bg, max_steps=max_steps, init_scale=65536.0)
+    gt = _gt(ref, bg, cuda)
+    flats = [(ts.ll, 0, "g_ll", "ll_after"), (ts.coef, 0, "g_coef0", "coef0_after"), (ts.coef, 1, "g_coef1", "coef1_after")] + \
+            [(ts.mlp, k, f"g_{n}", f"{n}_after") for k, n in enumerate(NAMES)]
+    for it in range(2):
+        m.mean_count = int(ref[f"step{it}/mean_count"])
+        loss = ts.step(t(ref["rays/o"]), t(ref["rays/d"]), gt, noises=t(ref[f"step{it}/noises"]))
+        assert np.array_equal(ts.last["counter"].cpu().numpy(), ref[f"step{it}/counter"])      # exact sample count
+        assert abs(float(ts.last["lr"]) - float(ref[f"step{it}/lr"])) < 1e-9
+        assert np.abs(ts.last["image"].cpu().numpy() - ref[f"step{it}/pred"]).max() < 2e-3
+        assert abs(float(ts.last["mse"]) - float(ref[f"step{it}/mse"])) < 3e-3 * float(ref[f"step{it}/mse"])
+        assert abs(float(ts.last["wavelet_reg"]) - float(ref[f"step{it}/wavelet_reg"])) < 1e-5 * float(ref[f"step{it}/wavelet_reg"])
+        assert abs(float(loss) - float(ref[f"step{it}/loss"])) < 3e-3 * float(ref[f"step{it}/loss"])
+        inv = 1.0 / 65536.0
+        for flat, k, gkey, akey in flats:
+            g = flat.grad_view(k).cpu().numpy() * inv
+            gr = ref[f"step{it}/{gkey}"]
+            if flat is ts.coef:   # TrainStep folds the L1 term into the Adam pass: add it to compare like with like
+                p_before = ref[f"param/coef{k}"] if it == 0 else ref[f"step0/coef{k}_after"]
+                g = g + lam / (2 * ts.coef_numel) * np.sign(p_before)
+            assert _rel(g, gr) < 2e-2, (it, gkey, _rel(g, gr))
+            sig = np.abs(gr) > 1e-2 * np.abs(gr).max()
+            o, n = flat.offsets[k], flat.sizes[k]
+            after = flat.data[o:o + n].cpu().numpy().reshape(gr.shape)
+            diff = np.abs(after - ref[f"step{it}/{akey}"])
+            # an Adam step is lr * m^ / sqrt(v^): a 1-2 % fp16-operand error of the gradient moves it by 1-2e-4
+            assert (diff[sig] > 5e-4).mean() < 1e-2, (it, akey, float((diff[sig] > 5e-4).mean()))
+            with torch.no_grad():
+                flat.data[o:o + n].copy_(t(ref[f"step{it}/{akey}"]).reshape(-1))
