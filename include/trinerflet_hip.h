@@ -400,6 +400,13 @@ TNL_API int tnl_idwt_level_forward_win(const float *x, const float *yh, uint32_t
                                        const int32_t *win, void *stream);
 TNL_API int tnl_idwt_level_backward_win(const float *dout, uint32_t S, uint32_t n, int wave, float *dx, float *dyh,
                                         const int32_t *win, int strided, int32_t *out_rect, void *stream);
+
+/* Levels with n >= walk_min_n (and n % 8 == 0) run the column-walk IDWT / adjoint kernels (a thread owns a column and
+ * slides a register window down the plane: no staged halo tile), smaller ones the LDS-tiled kernels.  Default 512
+ * (0 restores it).  A tuning / test knob (tests force the walk kernels on small planes); process-global, set it
+ * before launching work.  The kernel choice depends on n only, so windowed and whole-plane calls of one level always
+ * take the same kernel (their results are bit-identical). */
+TNL_API int tnl_idwt_set_walk_min_n(uint32_t walk_min_n);
 TNL_API int tnl_adam_l1_step_rect(float *p, float *grad, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n,
                                   uint32_t spp, uint32_t s0, const int32_t *rect, float lr,
                                   const float *opt_step_dev, float beta1, float beta2, float eps, float inv_scale,

@@ -1,0 +1,102 @@
+"""The column-walk IDWT / adjoint kernels (csrc/wavelet.hip k_idwt_fwd_walk / k_idwt_bwd_walk; production use: levels
+with n >= 512) forced onto small planes with tnl_idwt_set_walk_min_n, so that the C oracle can check them in seconds:
+all five wavelets, plane sizes that leave ragged last tiles (n not a multiple of the 120-column tile) and several row
+segments, forward bit-identical to the LDS-tiled kernels, adjoint vs the oracle and the <Ax,y> = <x,A^T y> identity,
+and the occupancy-window / support-rectangle entry points (the tests of tests/test_roi_gpu.py re-run on these kernels).
+The full-size use (n = 512, 1024) is covered by tests/test_full_geometry_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def walk(cuda):
+    from trinerflet_amd import _lib as L
+    L.lib().tnl_idwt_set_walk_min_n(L.u32(8))
+    yield
+    L.lib().tnl_idwt_set_walk_min_n(L.u32(0))
+
+
+def _vol(dev, C, R, scale, wave):
+    from trinerflet_amd.triplaneencoder.triplane_encoder import TriPlaneVolume
+    return TriPlaneVolume(number_of_features=C, plane_resolution=R, inner_multi_res_scale=scale, wavelet_type=wave,
+                          plane_dtype=torch.float32).to(dev)
+
+
+@pytest.mark.parametrize("wave,C,R,scale", [("bior6.8", 3, 512, 4), ("bior6.8", 1, 1008, 2), ("haar", 2, 256, 8),
+                                            ("bior4.4", 1, 320, 2), ("bior2.6", 2, 144, 2), ("bior2.2", 2, 64, 4)])
+def test_walk_kernels_vs_oracle_and_tile_kernels(cuda, wave, C, R, scale):
+    from trinerflet_amd import _lib as L
+    torch.manual_seed(0)
+    vol = _vol(cuda, C, R, scale, wave)
+    with torch.no_grad():
+        vol.planes_features.normal_(0, 0.5)
+        for p in vol.planes_features_wavelet_coefs:
+            p.normal_(0, 0.3)
+    res = {}
+    cot = None
+    for mode, min_n in (("tile", 1 << 20), ("walk", 8)):
+        L.lib().tnl_idwt_set_walk_min_n(L.u32(min_n))
+        try:
+            vol.reset_cahce()
+            vol.zero_grad(set_to_none=True)
+            planes = vol.get_planes()
+            if cot is None:
+                cot = torch.randn_like(planes)
+            planes.backward(cot)
+            res[mode] = (planes.detach().clone(), vol.planes_features.grad.clone(),
+                         [p.grad.clone() for p in vol.planes_features_wavelet_coefs])
+        finally:
+            L.lib().tnl_idwt_set_walk_min_n(L.u32(0))
+    # forward: same FMA order per output as the tile kernels -> the same bits
+    assert torch.equal(res["walk"][0], res["tile"][0])
+    ll = vol.planes_features.detach().cpu().numpy()
+    coefs = [p.detach().cpu().numpy() for p in vol.planes_features_wavelet_coefs]
+    ref = cref.build_planes(ll, coefs, wave)
+    np.testing.assert_allclose(res["walk"][0].cpu().numpy(), ref, rtol=0, atol=3e-6 * np.abs(ref).max())
+    # adjoint: vertical pass first (the tile kernels run the horizontal one first): equal to rounding, both vs the oracle
+    dll, dcoefs = cref.build_planes_adj(cot.cpu().numpy(), len(coefs), wave)
+    np.testing.assert_allclose(res["walk"][1].cpu().numpy(), dll, rtol=0, atol=5e-6 * np.abs(dll).max())
+    for g, d, gt in zip(res["walk"][2], dcoefs, res["tile"][2]):
+        np.testing.assert_allclose(g.cpu().numpy(), d, rtol=0, atol=5e-6 * np.abs(d).max())
+        assert float((g - gt).abs().max()) <= 5e-6 * float(gt.abs().max())
+    planes = res["walk"][0]
+    lhs = (planes.double() * cot.double()).sum().item()
+    rhs = (vol.planes_features.detach().double() * res["walk"][1].double()).sum().item()
+    rhs += sum((p.detach().double() * g.double()).sum().item()
+               for p, g in zip(vol.planes_features_wavelet_coefs, res["walk"][2]))
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+def test_walk_half_output_equals_tile_kernel(cuda):
+    """fp16 output (the finest level's form in TrainStep) and several row segments."""
+    from trinerflet_amd import _lib as L
+    from trinerflet_amd.triplaneencoder import triplane_encoder as te
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 4, 264, 264, generator=g).to(cuda)
+    yh = torch.randn(3, 4, 3, 264, 264, generator=g).to(cuda)
+    outs = []
+    for min_n in (1 << 20, 8):
+        L.lib().tnl_idwt_set_walk_min_n(L.u32(min_n))
+        try:
+            outs.append(te.idwt_level_half(x, yh, 4))
+        finally:
+            L.lib().tnl_idwt_set_walk_min_n(L.u32(0))
+    assert outs[0].dtype == torch.float16 and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("wave", ["bior6.8", "bior2.2", "haar"])
+def test_window_entry_points_on_walk_kernels(cuda, walk, wave):
+    from tests import test_roi_gpu as troi
+    troi.test_forward_and_adjoint_roi_match_whole_plane(cuda, wave)
+
+
+def test_support_chain_on_walk_kernels(cuda, walk):
+    from tests import test_roi_gpu as troi
+    troi.test_support_chain_adjoint_and_rect_adam_match_dense(cuda)
+    troi.test_windowed_rebuild_equals_full_rebuild_inside_the_window(cuda)
+    troi.test_training_with_window_equals_whole_plane_training(cuda)

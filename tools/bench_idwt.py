@@ -7,6 +7,8 @@ from trinerflet_amd.triplaneencoder import triplane_encoder as te
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+if len(sys.argv) > 3:   # walk_min_n: 1048576 forces the LDS-tiled kernels, 8 the column-walk kernels
+    L.lib().tnl_idwt_set_walk_min_n(L.u32(int(sys.argv[3])))
 R, S, wid = 2 * n, 3 * C, 4
 dev = torch.device("cuda:0")
 lib = L.lib()

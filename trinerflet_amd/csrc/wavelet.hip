@@ -279,12 +279,14 @@ k_idwt_bwd(const float* __restrict__ dout, int n, float* __restrict__ dx, float*
 // instructions instead of by occupancy.  HALF_OUT writes the level as fp16 (used for the finest level:
 // the sampler's planes are fp16, so the fp32 copy is never materialised).
 // ---------------------------------------------------------------------------------------------
-constexpr int TPW = 8;  // tiles per workgroup walk
+constexpr int TPW_MAX = 8;  // tiles per workgroup walk (fewer on small levels, where the serial walk of one workgroup,
+                            // not bandwidth, sets the kernel's time: 3 x 75 us of the base step's adjoint were levels <= 256)
 
 
 template <int W, bool HALF_OUT>
 __global__ void __launch_bounds__(NT)
-k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n, void* __restrict__ out, Roi roi) {
+k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n, void* __restrict__ out, Roi roi,
+                int TPW) {
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2, HW = L / 4;
   constexpr int HWA = HW ? 4 : 0;            // staged halo, 16-byte aligned
@@ -442,7 +444,7 @@ struct FuseAdam {
 template <int W, bool FUSE>
 __global__ void __launch_bounds__(NT)
 k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh, FuseAdam fa,
-                Roi roi, Roi orect) {
+                Roi roi, Roi orect, int TPW) {
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2;
   constexpr int KA = (K + 3) / 4 * 4;                 // aligned left halo of the fine tile
@@ -632,6 +634,253 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Walk kernels (large levels, n >= walk_min_n): no staged input tile at all.
+//
+// The vertical pass of a separable filter needs no data from another lane, so a thread OWNS ONE COLUMN and walks down
+// the plane with a rolling register window: every coefficient row is loaded from HBM exactly once per tile (coalesced
+// 256-byte wave rows, the next WB rows already in flight in registers while the current WB are computed) -- the
+// (1 + 8/32)^2 = 1.56x halo over-fetch and the band staging through LDS of the tile kernels above are gone; only the
+// vertical pass's results cross lanes, through an LDS image of WB coarse rows, for the horizontal pass (16-byte LDS
+// reads of a thread's 12 / 24-sample window).  Over-fetch: 8 of 128 columns per tile plus 8 rows per row segment.
+// Same FMA order per output as the tile kernels in the forward direction (bit-identical planes).
+// ---------------------------------------------------------------------------------------------
+constexpr int WB = 8;          // coarse rows per phase
+constexpr int WT = 128;        // forward: threads = staged coarse columns of a tile
+constexpr int WV = WT - 8;     // forward: coarse columns a tile produces (4-column halo each side)
+constexpr int AT = 256;        // adjoint: threads = staged fine columns of a tile
+constexpr int AVC = (AT - 16) / 2;   // adjoint: coarse columns a tile produces (= WV)
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int W, bool HALF_OUT>
+__global__ void __launch_bounds__(WT)
+k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n, void* __restrict__ out, Roi roi,
+                int seg) {
+  constexpr WTaps T = wtaps(W);
+  constexpr int L = T.L, K = (L - 2) / 2, HW = L / 4;
+  static_assert(HW <= 4, "staged halo is 4 coarse samples");
+  constexpr int LSM = WT + 4;                          // mid row stride: 16-byte aligned rows
+  __shared__ __attribute__((aligned(16))) float mid[2][2 * WB][LSM];
+
+  const int tid = threadIdx.x, s = blockIdx.z, m2 = 2 * n;
+  const int pl = roi.rw ? (s + roi.s0) / roi.spp : 0;
+  const int fox = roi.rw ? roi.ox[pl] : 0, foy = roi.rw ? roi.oy[pl] : 0;
+  const bool compact = roi.rw && !roi.strided;
+  const int orow = compact ? roi.rw : m2;
+  const size_t oplane = compact ? (size_t)roi.rh * roi.rw : (size_t)m2 * m2;
+  const int sox = compact ? fox : 0, soy = compact ? foy : 0;
+  const int cx0 = fox / 2, cy0 = foy / 2, cw = roi.rw ? roi.rw / 2 : n, ch = roi.rw ? roi.rh / 2 : n;
+  const int vx0 = cx0 + blockIdx.x * WV, vx1 = min(vx0 + WV, cx0 + cw);        // coarse columns this tile produces
+  const int ry0 = cy0 + blockIdx.y * seg, ry1 = min(ry0 + seg, cy0 + ch);      // coarse rows of this segment
+  if (vx0 >= vx1 || ry0 >= ry1) return;
+  const int c = vx0 - 4 + tid;                                                 // this thread's coarse column
+  const bool col_ok = c >= 0 && c < n && c < vx1 + 4;
+  const size_t nn = (size_t)n * n;
+  const float* b0 = x + (size_t)s * nn + (col_ok ? c : 0);
+  const float* b1 = yh + (size_t)s * 3 * nn + (col_ok ? c : 0);
+  auto ld4 = [&](int r, float& v0, float& v1, float& v2, float& v3) {
+    v0 = v1 = v2 = v3 = 0.f;
+    if (col_ok && r >= 0 && r < n) {
+      const size_t o = (size_t)r * n;
+      v0 = b0[o]; v1 = b1[o]; v2 = b1[nn + o]; v3 = b1[2 * nn + o];
+    }
+  };
+  float w0[2 * WB], w1[2 * WB], w2[2 * WB], w3[2 * WB];      // rows R0-4 .. R0+11 of the four bands
+  float n0[WB], n1[WB], n2[WB], n3[WB];                      // rows R0+12 .. R0+19 (next phase), in flight
+#pragma unroll
+  for (int i = 0; i < 2 * WB; i++) ld4(ry0 - 4 + i, w0[i], w1[i], w2[i], w3[i]);
+#pragma unroll
+  for (int i = 0; i < 2 * WB; i++) w0[i] *= 2.0f;            // the 2* of triplane_encoder.py:379
+  char* const obase = reinterpret_cast<char*>(out);
+  for (int R0 = ry0; R0 < ry1; R0 += WB) {
+    const bool more = R0 + WB < ry1;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < WB; i++) ld4(R0 + 12 + i, n0[i], n1[i], n2[i], n3[i]);
+    }
+    // vertical synthesis of this thread's column: coarse rows R0..R0+7 -> fine rows 2*R0 .. 2*R0+15 of lo and hi
+#pragma unroll
+    for (int m = 0; m < WB; m++) {
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        float lo = 0.f, hi = 0.f;
+#pragma unroll
+        for (int d = -HW; d <= HW; d++) {
+          const int k = e + K - 2 * d;
+          if (k >= 0 && k < L) {
+            const float t0 = T.g0[k], t1 = T.g1[k];
+            if (t0 != 0.f) { lo = fmaf(w0[m + d + 4], t0, lo); hi = fmaf(w2[m + d + 4], t0, hi); }
+            if (t1 != 0.f) { lo = fmaf(w1[m + d + 4], t1, lo); hi = fmaf(w3[m + d + 4], t1, hi); }
+          }
+        }
+        mid[0][2 * m + e][tid] = lo;
+        mid[1][2 * m + e][tid] = hi;
+      }
+    }
+    __syncthreads();
+    // horizontal synthesis + store: 16 fine rows x 30 runs of 4 coarse (8 fine) columns; 32 lanes per row
+#pragma unroll
+    for (int trip = 0; trip < (2 * WB * 32) / WT; trip++) {
+      const int row = trip * (WT / 32) + (tid >> 5), run = tid & 31;
+      const int v = 4 * run, gcol = vx0 + v;
+      if (run < WV / 4 && gcol < vx1) {
+        float wl[12], wh[12];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const v4f a = *reinterpret_cast<const v4f*>(&mid[0][row][v + 4 * q]);
+          const v4f b = *reinterpret_cast<const v4f*>(&mid[1][row][v + 4 * q]);
+#pragma unroll
+          for (int i = 0; i < 4; i++) { wl[4 * q + i] = a[i]; wh[4 * q + i] = b[i]; }
+        }
+        float o[8];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int d = -HW; d <= HW; d++) {
+              const int k = e + K - 2 * d;
+              if (k >= 0 && k < L) {
+                const float t0 = T.g0[k], t1 = T.g1[k];
+                if (t0 != 0.f) acc = fmaf(wl[m + d + 4], t0, acc);
+                if (t1 != 0.f) acc = fmaf(wh[m + d + 4], t1, acc);
+              }
+            }
+            o[2 * m + e] = acc;
+          }
+        }
+        const int gr = 2 * R0 + row, gc = 2 * gcol;
+        const size_t off = (size_t)s * oplane + (size_t)(gr - soy) * orow + (gc - sox);
+        if (HALF_OUT) {
+          typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+          h8 hv;
+#pragma unroll
+          for (int i = 0; i < 8; i++) hv[i] = (_Float16)o[i];
+          *reinterpret_cast<h8*>(obase + off * 2) = hv;
+        } else {
+          float* p = reinterpret_cast<float*>(obase) + off;
+          reinterpret_cast<v4f*>(p)[0] = v4f{o[0], o[1], o[2], o[3]};
+          reinterpret_cast<v4f*>(p)[1] = v4f{o[4], o[5], o[6], o[7]};
+        }
+      }
+    }
+    __syncthreads();
+    // slide the window down by WB rows
+#pragma unroll
+    for (int i = 0; i < WB; i++) {
+      w0[i] = w0[i + WB]; w1[i] = w1[i + WB]; w2[i] = w2[i + WB]; w3[i] = w3[i + WB];
+      w0[i + WB] = 2.0f * n0[i]; w1[i + WB] = n1[i]; w2[i + WB] = n2[i]; w3[i + WB] = n3[i];
+    }
+  }
+}
+
+// Adjoint walk: a thread owns one FINE column of the input gradient and walks down with an 18-row rolling window
+// (vertical analysis: v_lo = g0 . column, v_hi = g1 . column per coarse row), the horizontal analysis of WB coarse
+// rows at a time goes through LDS.  The output region is the gradient-support rectangle `orect` (or the whole plane):
+// every element of it is written -- computed from the input window `roi` (zero outside it) -- nothing outside is.
+template <int W>
+__global__ void __launch_bounds__(AT)
+k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh, Roi roi,
+                Roi orect, int seg) {
+  constexpr WTaps T = wtaps(W);
+  constexpr int L = T.L, K = (L - 2) / 2;
+  constexpr int KA = (K + 3) / 4 * 4, SH = KA - K;       // staged left halo (fine samples), 16-byte aligned
+  static_assert(2 * (AVC - 1) + SH + L <= AT, "tile too narrow for this filter");
+  constexpr int LSA = AT + 4;
+  __shared__ __attribute__((aligned(16))) float mid[2][WB][LSA];
+
+  const int tid = threadIdx.x, s = blockIdx.z, m2 = 2 * n;
+  const int pl = roi.rw ? (s + roi.s0) / roi.spp : (orect.rw ? (s + orect.s0) / orect.spp : 0);
+  const int fox = roi.rw ? roi.ox[pl] : 0, foy = roi.rw ? roi.oy[pl] : 0;
+  const int fw = roi.rw ? roi.rw : m2, fh = roi.rw ? roi.rh : m2;
+  const int sw = (roi.rw && !roi.strided) ? roi.rw : m2;
+  const int sox = roi.strided ? 0 : fox, soy = roi.strided ? 0 : foy;
+  const float* src = dout + (size_t)s * (roi.strided ? (size_t)m2 * m2 : (size_t)fh * fw);
+  const bool has_or = orect.rw != 0;
+  const int ox0 = has_or ? orect.ox[pl] : 0, oy0 = has_or ? orect.oy[pl] : 0;
+  const int ow = has_or ? orect.rw : n, oh = has_or ? orect.rh : n;
+  const int vx0 = ox0 + blockIdx.x * AVC, vx1 = min(vx0 + AVC, ox0 + ow);      // coarse columns this tile produces
+  const int ry0 = oy0 + blockIdx.y * seg, ry1 = min(ry0 + seg, oy0 + oh);      // coarse rows of this segment
+  if (vx0 >= vx1 || ry0 >= ry1) return;
+  const int fc = 2 * vx0 - KA + tid;                                            // this thread's fine column
+  const bool col_ok = fc - fox >= 0 && fc - fox < fw && fc < 2 * vx1 + L;       // inside the input window
+  const float* colp = src + (col_ok ? (fc - sox) : 0);
+  auto ld = [&](int r) -> float {        // fine row r (absolute)
+    const int gr = r - foy;
+    return (col_ok && gr >= 0 && gr < fh) ? colp[(size_t)(r - soy) * sw] : 0.f;
+  };
+  float w[4 * WB];        // fine rows 2*R0-K .. 2*R0-K+31
+  float nx[2 * WB];       // the next 16 rows, in flight
+#pragma unroll
+  for (int i = 0; i < 4 * WB; i++) w[i] = ld(2 * ry0 - K + i);
+  const size_t nn = (size_t)n * n;
+  float* o_ll = dx + (size_t)s * nn;
+  float* o_h = dyh + (size_t)s * 3 * nn;
+  for (int R0 = ry0; R0 < ry1; R0 += WB) {
+    const bool more = R0 + WB < ry1;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 2 * WB; i++) nx[i] = ld(2 * R0 - K + 4 * WB + i);
+    }
+#pragma unroll
+    for (int j = 0; j < WB; j++) {
+      float lo = 0.f, hi = 0.f;
+#pragma unroll
+      for (int k = 0; k < L; k++) {
+        const float t0 = T.g0[k], t1 = T.g1[k];
+        if (t0 != 0.f) lo = fmaf(w[2 * j + k], t0, lo);
+        if (t1 != 0.f) hi = fmaf(w[2 * j + k], t1, hi);
+      }
+      mid[0][j][tid] = lo;
+      mid[1][j][tid] = hi;
+    }
+    __syncthreads();
+    {
+      const int j = tid >> 5, run = tid & 31;            // 8 coarse rows x 30 runs of 4 coarse columns
+      const int v = 4 * run, gcol = vx0 + v, gr = R0 + j;
+      if (run < AVC / 4 && gcol < vx1 && gr < ry1) {
+        float wl[24], wh[24];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          const v4f a = *reinterpret_cast<const v4f*>(&mid[0][j][2 * v + 4 * q]);
+          const v4f b = *reinterpret_cast<const v4f*>(&mid[1][j][2 * v + 4 * q]);
+#pragma unroll
+          for (int i = 0; i < 4; i++) { wl[4 * q + i] = a[i]; wh[4 * q + i] = b[i]; }
+        }
+        v4f r0, r1, r2, r3;
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+          float a = 0.f, b = 0.f, cc = 0.f, d = 0.f;
+#pragma unroll
+          for (int k = 0; k < L; k++) {
+            const float t0 = T.g0[k], t1 = T.g1[k];
+            // ll = (W lo, H lo), yh[0] = (W lo, H hi), yh[1] = (W hi, H lo), yh[2] = (W hi, H hi)
+            if (t0 != 0.f) { a = fmaf(wl[SH + 2 * jj + k], t0, a); b = fmaf(wh[SH + 2 * jj + k], t0, b); }
+            if (t1 != 0.f) { cc = fmaf(wl[SH + 2 * jj + k], t1, cc); d = fmaf(wh[SH + 2 * jj + k], t1, d); }
+          }
+          r0[jj] = 2.0f * a; r1[jj] = b; r2[jj] = cc; r3[jj] = d;
+        }
+        const size_t off = (size_t)gr * n + gcol;
+        if (TNL_IDWT_BWD_NT) {
+          __builtin_nontemporal_store(r0, reinterpret_cast<v4f*>(o_ll + off));
+          __builtin_nontemporal_store(r1, reinterpret_cast<v4f*>(o_h + off));
+          __builtin_nontemporal_store(r2, reinterpret_cast<v4f*>(o_h + nn + off));
+          __builtin_nontemporal_store(r3, reinterpret_cast<v4f*>(o_h + 2 * nn + off));
+        } else {
+          *reinterpret_cast<v4f*>(o_ll + off) = r0;
+          *reinterpret_cast<v4f*>(o_h + off) = r1;
+          *reinterpret_cast<v4f*>(o_h + nn + off) = r2;
+          *reinterpret_cast<v4f*>(o_h + 2 * nn + off) = r3;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2 * WB; i++) { w[i] = w[i + 2 * WB]; w[i + 2 * WB] = nx[i]; }
+  }
+}
+
 // fp16 (3,C,R,R) -> fp16 [3,R,R,C]: 16-byte loads along x, 16-byte stores along the channels
 __global__ void __launch_bounds__(NT)
 k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __restrict__ tm, Roi roi) {
@@ -713,16 +962,41 @@ k_to_channel_major(const float* __restrict__ tm, int C, int R, float* __restrict
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+int g_walk_min_n = 512;   // levels with n >= this (and n % 8 == 0) run the walk kernels; tnl_idwt_set_walk_min_n
+
+// tiles a workgroup of the pipelined tile kernels walks: as many as keep >= ~3000 workgroups in the launch
+inline int pick_tpw(uint32_t ntx, uint32_t nty, uint32_t S) {
+  int tpw = TPW_MAX;
+  while (tpw > 1 && (uint64_t)cdiv(ntx, tpw) * nty * S < 3000) tpw >>= 1;
+  return tpw;
+}
+// coarse rows per workgroup of the walk kernels (multiple of WB)
+inline int pick_seg(uint32_t tiles, uint32_t rows, uint32_t S) {
+  int seg = 256;
+  while (seg > 32 && (uint64_t)tiles * cdiv(rows, seg) * S < 3000) seg >>= 1;
+  return seg;
+}
+
 template <int W>
 int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, void* out, int half_out, hipStream_t st,
                Roi roi = Roi{}) {
-  if (n % 4 == 0) {
-    const dim3 grid = roi.rw ? dim3(cdiv(roi.rw / (2 * TI), TPW), roi.rh / (2 * TI), S)
-                             : dim3(cdiv(cdiv(n, TI), TPW), cdiv(n, TI), S);
+  if (n % 8 == 0 && (int)n >= g_walk_min_n) {
+    const uint32_t cw = roi.rw ? roi.rw / 2 : n, ch = roi.rw ? roi.rh / 2 : n;
+    const uint32_t tiles = cdiv(cw, WV);
+    const int seg = pick_seg(tiles, ch, S);
+    const dim3 grid(tiles, cdiv(ch, seg), S);
     if (half_out)
-      hipLaunchKernelGGL((k_idwt_fwd_pipe<W, true>), grid, dim3(NT), 0, st, x, yh, (int)n, out, roi);
+      hipLaunchKernelGGL((k_idwt_fwd_walk<W, true>), grid, dim3(WT), 0, st, x, yh, (int)n, out, roi, seg);
     else
-      hipLaunchKernelGGL((k_idwt_fwd_pipe<W, false>), grid, dim3(NT), 0, st, x, yh, (int)n, out, roi);
+      hipLaunchKernelGGL((k_idwt_fwd_walk<W, false>), grid, dim3(WT), 0, st, x, yh, (int)n, out, roi, seg);
+  } else if (n % 4 == 0) {
+    const uint32_t ntx = roi.rw ? roi.rw / (2 * TI) : cdiv(n, TI), nty = roi.rw ? roi.rh / (2 * TI) : cdiv(n, TI);
+    const int tpw = pick_tpw(ntx, nty, S);
+    const dim3 grid(cdiv(ntx, tpw), nty, S);
+    if (half_out)
+      hipLaunchKernelGGL((k_idwt_fwd_pipe<W, true>), grid, dim3(NT), 0, st, x, yh, (int)n, out, roi, tpw);
+    else
+      hipLaunchKernelGGL((k_idwt_fwd_pipe<W, false>), grid, dim3(NT), 0, st, x, yh, (int)n, out, roi, tpw);
   } else {
     if (roi.rw) return (int)hipErrorInvalidValue;
     if (half_out) return (int)hipErrorInvalidValue;
@@ -736,8 +1010,8 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
                int32_t* out_rect = nullptr) {
   Roi orect{};
   if (out_rect != nullptr) {
-    // Tiles of coarse outputs the input window reaches (same test as the kernel's hits()), per plane, then grown to a
-    // common size: inside the rectangle every tile is written (computed or zero), outside nothing is.
+    // Tiles of coarse outputs the input window reaches (same test as the tile kernel's hits()), per plane, then grown
+    // to a common size: inside the rectangle every element is written (computed or zero), outside nothing is.
     if (n % 2 != 0 || n % TI != 0) return (int)hipErrorInvalidValue;
     constexpr WTaps T = wtaps(W);
     constexpr int L = T.L, K = (L - 2) / 2, KA = (K + 3) / 4 * 4, SH = KA - K;
@@ -770,10 +1044,17 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
     orect.spp = roi.rw ? roi.spp : (int)(S / 3);
     orect.s0 = roi.s0;
   }
-  if (n % 2 == 0)
-    hipLaunchKernelGGL((k_idwt_bwd_pipe<W, false>), dim3(cdiv(cdiv(n, TI), TPW), cdiv(n, TI), S), dim3(NT), 0, st, dout,
-                       (int)n, dx, dyh, FuseAdam{}, roi, orect);
-  else if (roi.rw)
+  if (n % 8 == 0 && (int)n >= g_walk_min_n) {
+    const uint32_t ow = orect.rw ? orect.rw : n, oh = orect.rw ? orect.rh : n;
+    const uint32_t tiles = cdiv(ow, AVC);
+    const int seg = pick_seg(tiles, oh, S);
+    hipLaunchKernelGGL(k_idwt_bwd_walk<W>, dim3(tiles, cdiv(oh, seg), S), dim3(AT), 0, st, dout, (int)n, dx, dyh, roi,
+                       orect, seg);
+  } else if (n % 2 == 0) {
+    const int tpw = pick_tpw(cdiv(n, TI), cdiv(n, TI), S);
+    hipLaunchKernelGGL((k_idwt_bwd_pipe<W, false>), dim3(cdiv(cdiv(n, TI), tpw), cdiv(n, TI), S), dim3(NT), 0, st, dout,
+                       (int)n, dx, dyh, FuseAdam{}, roi, orect, tpw);
+  } else if (roi.rw)
     return (int)hipErrorInvalidValue;
   else
     hipLaunchKernelGGL(k_idwt_bwd<W>, dim3(cdiv(n, TI), cdiv(n, TI), S), dim3(NT), 0, st, dout, (int)n, dx, dyh);
@@ -783,6 +1064,11 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
 }  // namespace
 
 extern "C" {
+
+int tnl_idwt_set_walk_min_n(uint32_t n) {
+  g_walk_min_n = n == 0 ? 512 : (int)n;
+  return 0;
+}
 
 static int idwt_forward_any(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, void* out,
                             int half_out, void* stream, const int32_t* roi_host = nullptr, int strided = 0) {
@@ -898,10 +1184,11 @@ int tnl_idwt_level_backward_adam(const float* dout, uint32_t S, uint32_t n, int 
   if (S > 65535 || n % 2 != 0 || (dx == nullptr && ll_p == nullptr)) return (int)hipErrorInvalidValue;
   FuseAdam fa{p, m, v, ll_p, ll_m, ll_v, AdamArgs{step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef},
               inv_scale_dev, found_inf, abs_sum};
-  const dim3 grid(cdiv(cdiv(n, TI), TPW), cdiv(n, TI), S);
+  const int tpw = pick_tpw(cdiv(n, TI), cdiv(n, TI), S);
+  const dim3 grid(cdiv(cdiv(n, TI), tpw), cdiv(n, TI), S);
   hipStream_t st = (hipStream_t)stream;
 #define TNL_BWD_ADAM(WW) \
-  hipLaunchKernelGGL((k_idwt_bwd_pipe<WW, true>), grid, dim3(NT), 0, st, dout, (int)n, dx, (float*)nullptr, fa, Roi{}, Roi{})
+  hipLaunchKernelGGL((k_idwt_bwd_pipe<WW, true>), grid, dim3(NT), 0, st, dout, (int)n, dx, (float*)nullptr, fa, Roi{}, Roi{}, tpw)
   switch (wave) {
     case 0: TNL_BWD_ADAM(0); break;
     case 1: TNL_BWD_ADAM(1); break;
