@@ -298,7 +298,8 @@ def main():
                        "sections_ms": {k: round(v, 4) for k, v in sec.items()},
                        "sections_note": "adam_coef: HIP events inside the timed steps; the other sections: an "
                                         "instrumented pass after them (an event at every boundary costs 6-8 us)",
-                       "kernels": kernels},
+                       "kernels": kernels,
+                       "adam_placement": ts.placement},
             "roofline": {"bound": "hbm", "kernel": "k_adam_l1 (fused Adam + wavelet-L1), the step's launches over all "
                                                    "wavelet levels + LL taken together",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

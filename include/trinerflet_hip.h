@@ -407,6 +407,10 @@ TNL_API int tnl_idwt_level_backward_win(const float *dout, uint32_t S, uint32_t 
  * before launching work.  The kernel choice depends on n only, so windowed and whole-plane calls of one level always
  * take the same kernel (their results are bit-identical). */
 TNL_API int tnl_idwt_set_walk_min_n(uint32_t walk_min_n);
+/* Launch-shape knobs of the walk kernels, for A/B measurements (tools/bench_idwt.py); results do not depend on them.
+ * key 1: coarse rows per phase of the forward kernel (4 or 8); key 2: XCD-aware block order (0 / 1);
+ * key 3: coarse rows per workgroup (multiple of 8; 0 = automatic). */
+TNL_API int tnl_idwt_set_tuning(int key, int value);
 TNL_API int tnl_adam_l1_step_rect(float *p, float *grad, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n,
                                   uint32_t spp, uint32_t s0, const int32_t *rect, float lr,
                                   const float *opt_step_dev, float beta1, float beta2, float eps, float inv_scale,

@@ -9,6 +9,9 @@ C = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 if len(sys.argv) > 3:   # walk_min_n: 1048576 forces the LDS-tiled kernels, 8 the column-walk kernels
     L.lib().tnl_idwt_set_walk_min_n(L.u32(int(sys.argv[3])))
+for kv in sys.argv[4:]:  # key=value pairs of tnl_idwt_set_tuning (1: forward rows per phase, 2: XCD order, 3: rows per workgroup)
+    k, v = kv.split("=")
+    assert L.lib().tnl_idwt_set_tuning(int(k), int(v)) == 0
 R, S, wid = 2 * n, 3 * C, 4
 dev = torch.device("cuda:0")
 lib = L.lib()

@@ -20,6 +20,12 @@
 #ifndef TNL_ADAM_UNROLL
 #define TNL_ADAM_UNROLL 2
 #endif
+#ifndef TNL_ADAM_ORDER
+#define TNL_ADAM_ORDER 0   // A/B knob: 0 = p loaded ahead of the found_inf branch, 1 = with g, m, v, 2 = v, m, g, p
+#endif
+#ifndef TNL_ADAM_STORE_ORDER
+#define TNL_ADAM_STORE_ORDER 0
+#endif
 #ifndef TNL_ADAM_BLOCKS
 #define TNL_ADAM_BLOCKS 4096
 #endif
@@ -82,7 +88,9 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
   const uint64_t chunk = TNL_ADAM_PIECE ? (uint64_t)TNL_ADAM_PIECE : (n4 + gridDim.x - 1) / gridDim.x;
   struct Quad { float4 pp, gg, mm, vv; };
   auto load = [&](uint64_t i, Quad& q) {
+#if TNL_ADAM_ORDER == 0
     q.pp = NTMP ? ld_nt(p4 + i) : p4[i];
+#endif
     q.gg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!skip) {
       bool inside = true;
@@ -95,10 +103,23 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
         const int pl = sl >= 2 * rc.spp ? 2 : (sl >= rc.spp ? 1 : 0);
         inside = c >= rc.rx[pl] && c < rc.rx[pl] + rc.rw && r >= rc.ry[pl] && r < rc.ry[pl] + rc.rh;
       }
+#if TNL_ADAM_ORDER == 1
+      q.pp = NTMP ? ld_nt(p4 + i) : p4[i];
+#endif
+#if TNL_ADAM_ORDER == 2
+      q.vv = NTMP ? ld_nt(v4 + i) : v4[i];
+      q.mm = NTMP ? ld_nt(m4 + i) : m4[i];
+      if (inside) q.gg = NTMP ? ld_nt(g4 + i) : g4[i];
+      q.pp = NTMP ? ld_nt(p4 + i) : p4[i];
+#else
       if (inside) q.gg = NTMP ? ld_nt(g4 + i) : g4[i];
       q.mm = NTMP ? ld_nt(m4 + i) : m4[i];
       q.vv = NTMP ? ld_nt(v4 + i) : v4[i];
+#endif
     }
+#if TNL_ADAM_ORDER != 0
+    else { q.pp = NTMP ? ld_nt(p4 + i) : p4[i]; }
+#endif
   };
   auto finish = [&](uint64_t i, Quad& q) {
     if (!skip) {
@@ -106,8 +127,13 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
       adam1(q.pp.y, q.gg.y, q.mm.y, q.vv.y, a, acc);
       adam1(q.pp.z, q.gg.z, q.mm.z, q.vv.z, a, acc);
       adam1(q.pp.w, q.gg.w, q.mm.w, q.vv.w, a, acc);
+#if TNL_ADAM_STORE_ORDER == 0
       if (NTMP) { st_nt(p4 + i, q.pp); st_nt(m4 + i, q.mm); st_nt(v4 + i, q.vv); }
       else { p4[i] = q.pp; m4[i] = q.mm; v4[i] = q.vv; }
+#else
+      if (NTMP) { st_nt(v4 + i, q.vv); st_nt(m4 + i, q.mm); st_nt(p4 + i, q.pp); }
+      else { v4[i] = q.vv; m4[i] = q.mm; p4[i] = q.pp; }
+#endif
     } else {
       acc += fabsf(q.pp.x) + fabsf(q.pp.y) + fabsf(q.pp.z) + fabsf(q.pp.w);
     }

@@ -645,24 +645,45 @@ k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, f
 // reads of a thread's 12 / 24-sample window).  Over-fetch: 8 of 128 columns per tile plus 8 rows per row segment.
 // Same FMA order per output as the tile kernels in the forward direction (bit-identical planes).
 // ---------------------------------------------------------------------------------------------
-constexpr int WB = 8;          // coarse rows per phase
+constexpr int WB = 8;          // coarse rows per phase (adjoint)
+#ifndef TNL_FWD_FB
+#define TNL_FWD_FB 4
+#endif
 constexpr int WT = 128;        // forward: threads = staged coarse columns of a tile
 constexpr int WV = WT - 8;     // forward: coarse columns a tile produces (4-column halo each side)
 constexpr int AT = 256;        // adjoint: threads = staged fine columns of a tile
 constexpr int AVC = (AT - 16) / 2;   // adjoint: coarse columns a tile produces (= WV)
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int W, bool HALF_OUT>
+// Logical (x, y, z) block of a walk kernel.  lg.w == 0: the launch grid is the logical grid.  Otherwise the launch is
+// 1-D, padded to a multiple of 8, and block b is given logical index (b % 8) * (blocks / 8) + b / 8: workgroups are dealt
+// round-robin over the 8 XCDs (MI355X_MICROARCH.md "Workgroup dispatch"), so consecutive logical blocks -- x-neighbour
+// tiles, which share 8 halo columns and the 128-byte lines their unaligned edges straddle -- meet in one XCD's L2.
+struct LGrid { int x, y, z, w; };
+__device__ __forceinline__ bool logical_block(const LGrid& lg, int& bx, int& by, int& bz) {
+  if (lg.w == 0) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; return true; }
+  const unsigned chunk = gridDim.x >> 3;
+  const unsigned id = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+  if (id >= (unsigned)lg.x * lg.y * lg.z) return false;
+  bx = id % lg.x; by = (id / lg.x) % lg.y; bz = id / (lg.x * lg.y);
+  return true;
+}
+
+template <int W, bool HALF_OUT, int FB>
 __global__ void __launch_bounds__(WT)
 k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n, void* __restrict__ out, Roi roi,
-                int seg) {
+                int seg, LGrid lg) {
+  // FB = coarse rows per phase (4 or 8): the rolling window holds FB + 8 rows of the four bands, FB more are in flight
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2, HW = L / 4;
   static_assert(HW <= 4, "staged halo is 4 coarse samples");
+  constexpr int WW = FB + 8;                           // window rows: R0-4 .. R0+FB+3
   constexpr int LSM = WT + 4;                          // mid row stride: 16-byte aligned rows
-  __shared__ __attribute__((aligned(16))) float mid[2][2 * WB][LSM];
+  __shared__ __attribute__((aligned(16))) float mid[2][2 * FB][LSM];
 
-  const int tid = threadIdx.x, s = blockIdx.z, m2 = 2 * n;
+  int bx, by, s;
+  if (!logical_block(lg, bx, by, s)) return;
+  const int tid = threadIdx.x, m2 = 2 * n;
   const int pl = roi.rw ? (s + roi.s0) / roi.spp : 0;
   const int fox = roi.rw ? roi.ox[pl] : 0, foy = roi.rw ? roi.oy[pl] : 0;
   const bool compact = roi.rw && !roi.strided;
@@ -670,8 +691,8 @@ k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n
   const size_t oplane = compact ? (size_t)roi.rh * roi.rw : (size_t)m2 * m2;
   const int sox = compact ? fox : 0, soy = compact ? foy : 0;
   const int cx0 = fox / 2, cy0 = foy / 2, cw = roi.rw ? roi.rw / 2 : n, ch = roi.rw ? roi.rh / 2 : n;
-  const int vx0 = cx0 + blockIdx.x * WV, vx1 = min(vx0 + WV, cx0 + cw);        // coarse columns this tile produces
-  const int ry0 = cy0 + blockIdx.y * seg, ry1 = min(ry0 + seg, cy0 + ch);      // coarse rows of this segment
+  const int vx0 = cx0 + bx * WV, vx1 = min(vx0 + WV, cx0 + cw);        // coarse columns this tile produces
+  const int ry0 = cy0 + by * seg, ry1 = min(ry0 + seg, cy0 + ch);      // coarse rows of this segment
   if (vx0 >= vx1 || ry0 >= ry1) return;
   const int c = vx0 - 4 + tid;                                                 // this thread's coarse column
   const bool col_ok = c >= 0 && c < n && c < vx1 + 4;
@@ -685,22 +706,22 @@ k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n
       v0 = b0[o]; v1 = b1[o]; v2 = b1[nn + o]; v3 = b1[2 * nn + o];
     }
   };
-  float w0[2 * WB], w1[2 * WB], w2[2 * WB], w3[2 * WB];      // rows R0-4 .. R0+11 of the four bands
-  float n0[WB], n1[WB], n2[WB], n3[WB];                      // rows R0+12 .. R0+19 (next phase), in flight
+  float w0[WW], w1[WW], w2[WW], w3[WW];                      // rows R0-4 .. R0+FB+3 of the four bands
+  float n0[FB], n1[FB], n2[FB], n3[FB];                      // rows R0+FB+4 .. R0+2FB+3 (next phase), in flight
 #pragma unroll
-  for (int i = 0; i < 2 * WB; i++) ld4(ry0 - 4 + i, w0[i], w1[i], w2[i], w3[i]);
+  for (int i = 0; i < WW; i++) ld4(ry0 - 4 + i, w0[i], w1[i], w2[i], w3[i]);
 #pragma unroll
-  for (int i = 0; i < 2 * WB; i++) w0[i] *= 2.0f;            // the 2* of triplane_encoder.py:379
+  for (int i = 0; i < WW; i++) w0[i] *= 2.0f;                // the 2* of triplane_encoder.py:379
   char* const obase = reinterpret_cast<char*>(out);
-  for (int R0 = ry0; R0 < ry1; R0 += WB) {
-    const bool more = R0 + WB < ry1;
+  for (int R0 = ry0; R0 < ry1; R0 += FB) {
+    const bool more = R0 + FB < ry1;
     if (more) {
 #pragma unroll
-      for (int i = 0; i < WB; i++) ld4(R0 + 12 + i, n0[i], n1[i], n2[i], n3[i]);
+      for (int i = 0; i < FB; i++) ld4(R0 + FB + 4 + i, n0[i], n1[i], n2[i], n3[i]);
     }
-    // vertical synthesis of this thread's column: coarse rows R0..R0+7 -> fine rows 2*R0 .. 2*R0+15 of lo and hi
+    // vertical synthesis of this thread's column: coarse rows R0..R0+FB-1 -> fine rows 2*R0 .. of lo and hi
 #pragma unroll
-    for (int m = 0; m < WB; m++) {
+    for (int m = 0; m < FB; m++) {
 #pragma unroll
       for (int e = 0; e < 2; e++) {
         float lo = 0.f, hi = 0.f;
@@ -718,9 +739,9 @@ k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n
       }
     }
     __syncthreads();
-    // horizontal synthesis + store: 16 fine rows x 30 runs of 4 coarse (8 fine) columns; 32 lanes per row
+    // horizontal synthesis + store: 2*FB fine rows x 30 runs of 4 coarse (8 fine) columns; 32 lanes per row
 #pragma unroll
-    for (int trip = 0; trip < (2 * WB * 32) / WT; trip++) {
+    for (int trip = 0; trip < (2 * FB * 32) / WT; trip++) {
       const int row = trip * (WT / 32) + (tid >> 5), run = tid & 31;
       const int v = 4 * run, gcol = vx0 + v;
       if (run < WV / 4 && gcol < vx1) {
@@ -766,12 +787,11 @@ k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n
       }
     }
     __syncthreads();
-    // slide the window down by WB rows
+    // slide the window down by FB rows
 #pragma unroll
-    for (int i = 0; i < WB; i++) {
-      w0[i] = w0[i + WB]; w1[i] = w1[i + WB]; w2[i] = w2[i + WB]; w3[i] = w3[i + WB];
-      w0[i + WB] = 2.0f * n0[i]; w1[i + WB] = n1[i]; w2[i + WB] = n2[i]; w3[i + WB] = n3[i];
-    }
+    for (int i = 0; i < 8; i++) { w0[i] = w0[i + FB]; w1[i] = w1[i + FB]; w2[i] = w2[i + FB]; w3[i] = w3[i + FB]; }
+#pragma unroll
+    for (int i = 0; i < FB; i++) { w0[8 + i] = 2.0f * n0[i]; w1[8 + i] = n1[i]; w2[8 + i] = n2[i]; w3[8 + i] = n3[i]; }
   }
 }
 
@@ -782,7 +802,7 @@ k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n
 template <int W>
 __global__ void __launch_bounds__(AT)
 k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh, Roi roi,
-                Roi orect, int seg) {
+                Roi orect, int seg, LGrid lg) {
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2;
   constexpr int KA = (K + 3) / 4 * 4, SH = KA - K;       // staged left halo (fine samples), 16-byte aligned
@@ -790,7 +810,9 @@ k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, f
   constexpr int LSA = AT + 4;
   __shared__ __attribute__((aligned(16))) float mid[2][WB][LSA];
 
-  const int tid = threadIdx.x, s = blockIdx.z, m2 = 2 * n;
+  int bx, by, s;
+  if (!logical_block(lg, bx, by, s)) return;
+  const int tid = threadIdx.x, m2 = 2 * n;
   const int pl = roi.rw ? (s + roi.s0) / roi.spp : (orect.rw ? (s + orect.s0) / orect.spp : 0);
   const int fox = roi.rw ? roi.ox[pl] : 0, foy = roi.rw ? roi.oy[pl] : 0;
   const int fw = roi.rw ? roi.rw : m2, fh = roi.rw ? roi.rh : m2;
@@ -800,8 +822,8 @@ k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, f
   const bool has_or = orect.rw != 0;
   const int ox0 = has_or ? orect.ox[pl] : 0, oy0 = has_or ? orect.oy[pl] : 0;
   const int ow = has_or ? orect.rw : n, oh = has_or ? orect.rh : n;
-  const int vx0 = ox0 + blockIdx.x * AVC, vx1 = min(vx0 + AVC, ox0 + ow);      // coarse columns this tile produces
-  const int ry0 = oy0 + blockIdx.y * seg, ry1 = min(ry0 + seg, oy0 + oh);      // coarse rows of this segment
+  const int vx0 = ox0 + bx * AVC, vx1 = min(vx0 + AVC, ox0 + ow);      // coarse columns this tile produces
+  const int ry0 = oy0 + by * seg, ry1 = min(ry0 + seg, oy0 + oh);      // coarse rows of this segment
   if (vx0 >= vx1 || ry0 >= ry1) return;
   const int fc = 2 * vx0 - KA + tid;                                            // this thread's fine column
   const bool col_ok = fc - fox >= 0 && fc - fox < fw && fc < 2 * vx1 + L;       // inside the input window
@@ -963,6 +985,21 @@ k_to_channel_major(const float* __restrict__ tm, int C, int R, float* __restrict
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 int g_walk_min_n = 512;   // levels with n >= this (and n % 8 == 0) run the walk kernels; tnl_idwt_set_walk_min_n
+int g_fwd_fb = TNL_FWD_FB;   // tnl_idwt_set_tuning(1, 4 | 8): coarse rows per phase of the forward walk kernel
+int g_xcd = 1;               // tnl_idwt_set_tuning(2, 0 | 1): XCD-aware block order of the walk kernels
+int g_seg = 0;               // tnl_idwt_set_tuning(3, rows): rows per workgroup (0 = pick_seg)
+
+// launch geometry of a walk kernel: the logical grid, or its XCD-ordered 1-D form
+inline void walk_grid(uint32_t gx, uint32_t gy, uint32_t gz, dim3& grid, LGrid& lg) {
+  if (g_xcd) {
+    const uint64_t tot = (uint64_t)gx * gy * gz;
+    grid = dim3((uint32_t)((tot + 7) / 8 * 8));
+    lg = LGrid{(int)gx, (int)gy, (int)gz, 1};
+  } else {
+    grid = dim3(gx, gy, gz);
+    lg = LGrid{(int)gx, (int)gy, (int)gz, 0};
+  }
+}
 
 // tiles a workgroup of the pipelined tile kernels walks: as many as keep >= ~3000 workgroups in the launch
 inline int pick_tpw(uint32_t ntx, uint32_t nty, uint32_t S) {
@@ -972,8 +1009,10 @@ inline int pick_tpw(uint32_t ntx, uint32_t nty, uint32_t S) {
 }
 // coarse rows per workgroup of the walk kernels (multiple of WB)
 inline int pick_seg(uint32_t tiles, uint32_t rows, uint32_t S) {
+  // measured at the base size (n = 1024, 96 slices): 64 rows per workgroup beat 128 and 256 by 5-8 % in both
+  // directions (13.8 k workgroups instead of 3.5 k: shorter tails, more row streams in flight)
   int seg = 256;
-  while (seg > 32 && (uint64_t)tiles * cdiv(rows, seg) * S < 3000) seg >>= 1;
+  while (seg > 32 && (uint64_t)tiles * cdiv(rows, seg) * S < 12000) seg >>= 1;
   return seg;
 }
 
@@ -983,12 +1022,15 @@ int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, void* ou
   if (n % 8 == 0 && (int)n >= g_walk_min_n) {
     const uint32_t cw = roi.rw ? roi.rw / 2 : n, ch = roi.rw ? roi.rh / 2 : n;
     const uint32_t tiles = cdiv(cw, WV);
-    const int seg = pick_seg(tiles, ch, S);
-    const dim3 grid(tiles, cdiv(ch, seg), S);
-    if (half_out)
-      hipLaunchKernelGGL((k_idwt_fwd_walk<W, true>), grid, dim3(WT), 0, st, x, yh, (int)n, out, roi, seg);
-    else
-      hipLaunchKernelGGL((k_idwt_fwd_walk<W, false>), grid, dim3(WT), 0, st, x, yh, (int)n, out, roi, seg);
+    const int seg = g_seg ? g_seg : pick_seg(tiles, ch, S);
+    dim3 grid;
+    LGrid lg;
+    walk_grid(tiles, cdiv(ch, seg), S, grid, lg);
+#define TNL_FWD_WALK(HALF, FB) \
+  hipLaunchKernelGGL((k_idwt_fwd_walk<W, HALF, FB>), grid, dim3(WT), 0, st, x, yh, (int)n, out, roi, seg, lg)
+    if (half_out) { if (g_fwd_fb == 4) TNL_FWD_WALK(true, 4); else TNL_FWD_WALK(true, 8); }
+    else { if (g_fwd_fb == 4) TNL_FWD_WALK(false, 4); else TNL_FWD_WALK(false, 8); }
+#undef TNL_FWD_WALK
   } else if (n % 4 == 0) {
     const uint32_t ntx = roi.rw ? roi.rw / (2 * TI) : cdiv(n, TI), nty = roi.rw ? roi.rh / (2 * TI) : cdiv(n, TI);
     const int tpw = pick_tpw(ntx, nty, S);
@@ -1047,9 +1089,11 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
   if (n % 8 == 0 && (int)n >= g_walk_min_n) {
     const uint32_t ow = orect.rw ? orect.rw : n, oh = orect.rw ? orect.rh : n;
     const uint32_t tiles = cdiv(ow, AVC);
-    const int seg = pick_seg(tiles, oh, S);
-    hipLaunchKernelGGL(k_idwt_bwd_walk<W>, dim3(tiles, cdiv(oh, seg), S), dim3(AT), 0, st, dout, (int)n, dx, dyh, roi,
-                       orect, seg);
+    const int seg = g_seg ? g_seg : pick_seg(tiles, oh, S);
+    dim3 grid;
+    LGrid lg;
+    walk_grid(tiles, cdiv(oh, seg), S, grid, lg);
+    hipLaunchKernelGGL(k_idwt_bwd_walk<W>, grid, dim3(AT), 0, st, dout, (int)n, dx, dyh, roi, orect, seg, lg);
   } else if (n % 2 == 0) {
     const int tpw = pick_tpw(cdiv(n, TI), cdiv(n, TI), S);
     hipLaunchKernelGGL((k_idwt_bwd_pipe<W, false>), dim3(cdiv(cdiv(n, TI), tpw), cdiv(n, TI), S), dim3(NT), 0, st, dout,
@@ -1068,6 +1112,15 @@ extern "C" {
 int tnl_idwt_set_walk_min_n(uint32_t n) {
   g_walk_min_n = n == 0 ? 512 : (int)n;
   return 0;
+}
+
+int tnl_idwt_set_tuning(int key, int value) {
+  switch (key) {
+    case 1: if (value != 4 && value != 8) return (int)hipErrorInvalidValue; g_fwd_fb = value; return 0;
+    case 2: g_xcd = value != 0; return 0;
+    case 3: if (value < 0 || value % 8) return (int)hipErrorInvalidValue; g_seg = value; return 0;
+    default: return (int)hipErrorInvalidValue;
+  }
 }
 
 static int idwt_forward_any(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, void* out,

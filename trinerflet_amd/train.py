@@ -67,12 +67,50 @@ class _Flat:
         o, n = self.offsets[k], self.sizes[k]
         return self.grad[o:o + n].view(self.params[k].shape)
 
+    def tune_placement(self, time_pass, spares=5, roles=("data", "v", "m")):
+        """The HBM-bound Adam pass over these four arrays runs 15-20 % slower for some PLACEMENTS of them than for
+        others (tools/adam_regimes.py: same kernel, same data, same virtual spacing; the time follows which physical
+        allocation holds the parameter array -- to a lesser degree the second-moment array -- relative to the others,
+        not any single array, and stays with a set of allocations for their lifetime).  So the placement is chosen by
+        measurement, once: `spares` extra buffers are allocated, each is timed in turn in the role of the parameters
+        (then of v, of m) with the real kernel, and the fastest assignment is kept; the losers go back to the
+        allocator.  time_pass(data, grad, m, v) -> milliseconds must not change the arrays (lr = 0, g = m = v = 0
+        here).  Returns a report dict."""
+        pool = [torch.empty_like(self.data) for _ in range(spares)]
+        cur = {"data": self.data, "m": self.m, "v": self.v}
+        saved = self.data.clone() if "data" in roles else None      # parameters are live: candidates get a copy
+        t0 = time_pass(cur["data"], self.grad, cur["m"], cur["v"])
+        report = {"before_ms": t0, "trials": []}
+        best = t0
+        for role in roles:
+            times = []
+            for k in range(len(pool)):
+                trial = dict(cur)
+                trial[role] = pool[k]
+                if role != "data":
+                    pool[k].zero_()
+                times.append(time_pass(trial["data"], self.grad, trial["m"], trial["v"]))
+            report["trials"].append((role, [round(t, 4) for t in times]))
+            k = min(range(len(pool)), key=lambda i: times[i])
+            if times[k] < 0.98 * best:
+                pool[k], cur[role] = cur[role], pool[k]
+                best = times[k]
+        if cur["data"] is not self.data:
+            cur["data"].copy_(saved)
+            for p, o, n in zip(self.params, self.offsets, self.sizes):
+                p.data = cur["data"][o:o + n].view(p.shape)
+        self.data, self.m, self.v = cur["data"], cur["m"], cur["v"]
+        self.m.zero_(); self.v.zero_()
+        report["after_ms"] = best
+        del pool, saved
+        return report
+
 
 class TrainStep:
     def __init__(self, model, lr=1e-2, wavelet_regularization=0.4, iters=30000, warmup_steps=0,
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
-                 dist_mode=None, process_group=None, binned=True, fuse_adam=False, use_roi=True):
+                 dist_mode=None, process_group=None, binned=True, fuse_adam=False, use_roi=True, tune_placement=None):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
@@ -114,6 +152,11 @@ class TrainStep:
         self.mlp = _Flat(self.Ws)
         assert self.mlp.total == sum(w.numel() for w in self.Ws) or True
         self.coef_numel = sum(self.coef.sizes)
+        # placement of the coefficient arrays chosen by measurement (see _Flat.tune_placement): default for sets large
+        # enough for the Adam pass to be the step's dominant kernel
+        self.placement = None
+        if (tune_placement if tune_placement is not None else self.coef.total >= 64_000_000) and self.coef.total > 0:
+            self.placement = self.coef.tune_placement(self._time_adam_pass)
         # GradScaler state (torch.cuda.amp.GradScaler defaults: 2^16, x2 every 2000 clean steps, x0.5 on inf)
         self.scale = torch.full((1,), init_scale if fp16 else 1.0, dtype=torch.float32, device=dev)
         self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -330,6 +373,25 @@ class TrainStep:
             L.f32(lr_t), L.ptr(self.opt_steps), L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0),
             L.ptr(inv_scale_dev), L.f32(l1_coef), L.ptr(found_inf), L.ptr(abs_sum), L.i32(0), L.stream()),
             "adam_l1_step")
+
+    def _time_adam_pass(self, data, grad, m, v, reps=3):
+        """Milliseconds of one k_adam_l1 pass over whole arrays with lr = 0 (nothing changes when g = m = v = 0)."""
+        one = torch.ones(1, dtype=torch.float32, device=data.device)
+        zero = torch.zeros(1, dtype=torch.float32, device=data.device)
+
+        def run():
+            L.check(L.lib().tnl_adam_l1_step_dev(
+                L.ptr(data), L.ptr(grad), L.ptr(m), L.ptr(v), L.u64(data.numel()), L.f32(0.0), L.ptr(one),
+                L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0), None, L.f32(0.0), L.ptr(zero), None,
+                L.i32(0), L.stream()), "adam_l1_step (placement probe)")
+        run()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            run()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) / reps
 
     def _adam_scalars(self, lr_t):
         # fuse_adam path only: host-side bias correction from the iteration count (equal to the device count unless
@@ -686,14 +748,15 @@ class TrainStep:
         return self._prefetch_mode() == "adam" and next_rays is not None and not self.fuse_adam
 
     def _prefetch_mode(self):
-        """prefetch_at resolved.  Measured with the rays marched once (~1 ms of side work), ms per step for
-        bwd | start | fwd | adam: base 6.04 | 6.00-6.08 | 5.97-5.99 | 6.06-6.17, large 9.91-9.96 | 9.85-10.19 | 10.21 | 10.18,
-        small 3.04 | 2.94 | 3.03 | 3.25 -- all within the Adam pass's own per-process spread except small, whose dense
-        tail (0.5 ms) cannot cover the side work: "auto" starts it at the top of the step there, after the field
-        backward otherwise."""
+        """prefetch_at resolved.  Round-2 measurement at base (dense tail 0.4 + 0.4 + 1.85 ms since the column-walk IDWT
+        kernels; ms per step | Adam pass): bwd 5.39 | 2.06 -- the ~1 ms of side work no longer fits under tile reduction +
+        adjoint and spills into the Adam pass; start 5.54 | 1.84 (the march delays the field forward); fwd 5.27 | 1.84;
+        adam 5.26 | 1.98.  "fwd" (side work beside the two MFMA field kernels, whose waves leave half of each SIMD's
+        registers free) gives the shortest step with the HBM-bound dominant kernel alone on the GPU.  The small
+        configuration (dense tail 0.5 ms) starts it at the top of the step: 2.94 | 3.03 (fwd) | 3.04 (bwd) ms."""
         mode = self.prefetch_at
         if mode == "auto":
-            mode = "start" if self.coef_numel < 100_000_000 else "bwd"
+            mode = "start" if self.coef_numel < 100_000_000 else "fwd"
         return mode
 
     def _prefetch_next(self, next_rays, march_on_side):
