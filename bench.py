@@ -41,18 +41,19 @@ WORKLOADS = {
 }
 
 
-def build(workload, device, dist_mode):
+def build(workload, device, dist_mode, plane_dtype=None, **ts_kwargs):
     from trinerflet_amd import synthetic
     from trinerflet_amd.nerf.network import NeRFNetwork
     from trinerflet_amd.train import TrainStep
     C, R, scale, H, N, lam = WORKLOADS[workload]
+    extra = {} if plane_dtype is None else {"plane_dtype": plane_dtype}
     model = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, density_scale=1, min_near=0.2,
                         density_thresh=10, bg_radius=-1, hidden_dim=H, hidden_dim_color=H,
                         triplane_channels=C, triplane_resolution=R, triplane_wavelet_levels=scale,
-                        wavelet_type="bior6.8").to(device)
+                        wavelet_type="bior6.8", **extra).to(device)
     synthetic.init_field_parameters(model, seed=0)
     ts = TrainStep(model, lr=1e-2, wavelet_regularization=lam, iters=40000, warmup_steps=0, fp16=True,
-                   background_color=0.0, dist_mode=dist_mode)
+                   background_color=0.0, dist_mode=dist_mode, **ts_kwargs)
     ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", ts.prefetch_at)   # "auto" | "bwd" | "adam" (experiments)
     bitfield = torch.from_numpy(synthetic.sphere_bitfield(128, model.cascade, 1.5, 0.8, 0.0)).to(device)
     model.density_bitfield.copy_(bitfield)
@@ -105,14 +106,105 @@ def cpu_baseline(workload):
                       f"measured dense {t['dense_s']:.2f}s ray {t['ray_s']:.2f}s"}
 
 
-def pmc_traffic(workload, world):
-    """HBM bytes of the step's k_adam_l1 launches from the committed rocprofv3 PMC passes
-    (profiles/r01o_pmc_adam.json, made by tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE in separate --pmc runs,
-    gfx950 correction applied); null when no profile exists for this configuration."""
-    path = os.path.join(ROOT, "profiles", "r01o_pmc_adam.json")
-    if workload != "base" or world != 1 or not os.path.exists(path):
-        return None
-    return json.load(open(path))["hbm_bytes_per_launch"]
+PMC_STATIC = os.path.join(ROOT, "profiles", "r02_pmc_adam.json")
+
+
+def pmc_traffic_static(workload, world):
+    """HBM bytes of the step's k_adam_l1 launches from the committed rocprofv3 PMC passes (tools/pmc_summary.py)."""
+    if workload != "base" or world != 1 or not os.path.exists(PMC_STATIC):
+        return None, None
+    return json.load(open(PMC_STATIC))["hbm_bytes_per_launch"], os.path.relpath(PMC_STATIC, ROOT) + " (static)"
+
+
+def pmc_traffic_live(workload, launches_per_step):
+    """HBM bytes per k_adam_l1 launch measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE in separate passes, no trace domain, the program itself after `--`), 2 timed steps each, summed over the
+    step's launches with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts half of a wide streaming
+    read): bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Returns (bytes per step, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    tot = {}
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(td, counter)
+            cmd = [prof, "--pmc", counter, "-d", out, "--output-format", "csv", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "0", "--pmc-child"]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=td)
+            except Exception as e:                                   # noqa: BLE001
+                return None, f"rocprofv3 child failed: {e}"
+            if r.returncode != 0:
+                return None, f"rocprofv3 child rc={r.returncode}: {r.stderr[-300:]}"
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == counter and "k_adam_l1<true" in row["Kernel_Name"]:
+                            vals.append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+            vals = [v for _, v in sorted(vals)]
+            n = len(vals) // launches_per_step
+            if n < 2:
+                return None, f"no k_adam_l1<true> dispatches in the {counter} pass"
+            last = vals[(n - 2) * launches_per_step:n * launches_per_step]     # the child's last two steps (ROI steps)
+            tot[counter] = sum(last) / 2.0
+    return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0, \
+        "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run, (2*FETCH+WRITE)*1024 per step"
+
+
+def time_steps(model, ts, bitfield, batches, mean_count, steps, setup=4):
+    """Seconds per step of `steps` steps after `setup` untimed ones (secondary figures of the bench line)."""
+    nb = len(batches)
+    for i in range(setup):
+        one_step(model, ts, bitfield, batches[i % nb], mean_count, batches[(i + 1) % nb])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one_step(model, ts, bitfield, batches[(setup + i) % nb], mean_count, batches[(setup + i + 1) % nb])
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def variant_ms(workload, device, bitfield_np_unused, batches, mean_count, steps, **kw):
+    """ms per step of a variant configuration (whole planes instead of the occupancy window, fp32 planes): a second
+    model + TrainStep, a whole density-grid period of set-up, then `steps` timed steps that contain no refresh."""
+    model, ts, bitfield, _ = build(workload, device, None, **kw)
+    model.mean_count = mean_count
+    t = time_steps(model, ts, bitfield, batches, mean_count, steps, setup=17)   # past the refresh at step 16
+    del model, ts
+    gc.collect()
+    torch.cuda.empty_cache()
+    return t * 1e3
+
+
+def inference_figure(model, device, max_steps=4096, images=3):
+    """BASELINE config 5's `--test` render: 800 x 800 rays of one pose through run_cuda's inference branch at
+    max_steps = 4096 (renderer.py:324-374), the trained-state planes of the benchmark model."""
+    from trinerflet_amd import synthetic
+    poses = synthetic.hemisphere_poses(images, seed=3)
+    model.eval()
+    model.encoder.reset_cahce()
+    times = []
+    with torch.no_grad():
+        for k in range(images + 1):
+            pix = np.stack([np.full(640000, k % images, np.int64), np.arange(640000)], -1)
+            o, d = synthetic.get_rays(poses, pix)
+            o, d = torch.from_numpy(o).to(device)[None], torch.from_numpy(d).to(device)[None]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    model.train()
+    t = float(np.mean(times[1:]))
+    return {"image": "800x800", "max_steps": max_steps, "ms_per_image": round(t * 1e3, 2), "rays_per_s": 640000 / t,
+            "note": "run_cuda eval branch (device-driven alive-ray loop, the reference's schedule), solid-sphere "
+                    "occupancy, the benchmark's field after its training steps; mean of 3 images after one warm-up"}
 
 
 def main():
@@ -127,7 +219,14 @@ def main():
                     help="nccl (= RCCL, the measured configuration); gloo only to dry-run the N>1 code on one GPU")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (dry-run with --backend gloo)")
     ap.add_argument("--sections", action="store_true", help="print a per-section time breakdown to stderr")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank its own 60 000 rays per step; strong: the 60 000 rays of a step split over the ranks")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary figures (whole-plane / fp32-plane step times, inference, live PMC traffic)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # a rocprofv3 --pmc pass of pmc_traffic_live
     args = ap.parse_args()
+    if args.pmc_child:
+        args.no_extras = args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -155,6 +254,10 @@ def main():
             dist.barrier()
 
     model, ts, bitfield, N = build(args.workload, device, args.dist_mode if world > 1 else None)
+    n_global = N * world
+    if args.scaling == "strong":       # the step's 60 000 rays split over the ranks (the dense work is what shards)
+        n_global = N
+        N = N // world
     batches = make_batches(4, N, rank, device)
 
     # dry run: fixes the per-step sample budget (mean_count) so M is constant
@@ -281,39 +384,89 @@ def main():
         "idwt_adjoint_all_levels": {"GB/s": rate(adj_bytes, "idwt_adjoint")},
     }
 
+    # ---- secondary figures, after the timed region (rank 0's GPU only; skipped by --no-extras and in multi-GPU runs)
+    extras = {}
+    roi_window = None if ts._roi is None else {"origin_x": ts._roi[0:3], "origin_y": ts._roi[3:6], "width": ts._roi[6],
+                                                "height": ts._roi[7], "of": ts.R,
+                                                "note": "bounding window of the occupied cells per plane (r = 0.8 sphere): "
+                                                        "the finest IDWT level, layout change, plane gradient and adjoint "
+                                                        "touch only this window on the 15 of 16 steps without a grid refresh"}
+    traffic, traffic_src = pmc_traffic_static(args.workload, world)
+    if world == 1 and not args.no_extras:
+        extras["inference"] = inference_figure(model, device)
+        live, note = pmc_traffic_live(args.workload, n_launch)
+        if live is not None:
+            traffic, traffic_src = live, note
+        elif traffic_src is not None:
+            traffic_src += f"; live collection unavailable ({note})"
+        plc = ts.placement
+        del ts, model
+        gc.collect()
+        torch.cuda.empty_cache()
+        k = min(args.steps, 12)
+        extras["no_roi_ms_per_step"] = round(variant_ms(args.workload, device, None, batches, mean_count, k, use_roi=False), 4)
+        extras["fp32_planes_ms_per_step"] = round(variant_ms(args.workload, device, None, batches, mean_count, k,
+                                                             plane_dtype=torch.float32), 4)
+        extras["variants_note"] = ("no_roi: every step rebuilds / differentiates whole planes (no occupancy window, no "
+                                   "gradient-support rectangles); fp32_planes: the sampler reads fp32 planes as the "
+                                   "reference's training does (SURVEY F9; implies whole planes); same rays, budget, "
+                                   f"{k} steps without a grid refresh after a 17-step set-up")
+    else:
+        plc = ts.placement
+
     if rank == 0:
         C, R, scale, H, _, lam = WORKLOADS[args.workload]
         ms = elapsed / args.steps * 1e3
+        wire = None
+        if world > 1:
+            S_all = 3 * C
+            if args.dist_mode == "sharded":
+                win = (roi_window["width"] * roi_window["height"]) if roi_window else R * R
+                rs = S_all * win * 4.0 * (world - 1) / world       # reduce-scatter of the fp32 plane-gradient window
+                ag = S_all * win * 2.0 * (world - 1) / world       # all-gather of the rebuilt fp16 planes (window)
+                wire = {"reduce_scatter_plane_grad_bytes": rs, "all_gather_planes_bytes": ag,
+                        "note": "sent per rank and step without a grid refresh (whole planes on refresh steps); "
+                                "plus 54 kB of MLP-gradient all-reduce and three scalars"}
+            else:
+                wire = {"all_reduce_plane_grad_bytes": 2.0 * S_all * R * R * 4.0 * (world - 1) / world}
         out = {
             "metric": "train rays/sec (whole node)", "value": N * world * args.steps / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f16",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: 3x{C}ch x {R}^2 planes, bior6.8 scale {scale}, hidden {H}, "
                                    f"{N} rays/step/GPU, solid-sphere occupancy r=0.8 (re-imposed after each refresh), "
                                    f"fp16 planes + fp16 MFMA MLP, fp32 masters, Adam+L1",
-                       "rays_per_step_per_gpu": N, "samples_per_step_per_gpu": samples_per_step,
+                       "rays_per_step_per_gpu": N, "rays_per_step_global": n_global,
+                       "samples_per_step_per_gpu": samples_per_step,
                        "sample_budget_M": mean_count, "parallelism": f"ray-dp{world}" + (f"+{args.dist_mode}" if world > 1 else ""),
+                       "collectives": None if world == 1 else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                                               "bytes_on_the_wire": wire},
                        "samples_per_sec": samples_per_step * world * args.steps / elapsed,
                        "sections_ms": {k: round(v, 4) for k, v in sec.items()},
                        "sections_note": "adam_coef: HIP events inside the timed steps; the other sections: an "
                                         "instrumented pass after them (an event at every boundary costs 6-8 us)",
                        "kernels": kernels,
-                       "adam_placement": ts.placement},
-            "roofline": {"bound": "hbm", "kernel": "k_adam_l1 (fused Adam + wavelet-L1), the step's launches over all "
-                                                   "wavelet levels + LL taken together",
+                       "roi_window": roi_window,
+                       "adam_placement": plc,
+                       **extras},
+            "roofline": {"bound": "hbm", "kernel": f"k_adam_l1 (fused Adam + wavelet-L1): the step's {n_launch} launches "
+                                                   "(one per wavelet level + LL), byte-weighted",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, world), "algorithmic_bytes_per_launch": adam_bytes,
-                         "avg_launch_ms": adam_ms, "launches_per_step": n_launch,
+                         "traffic": None if traffic is None else traffic / n_launch, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": adam_bytes / n_launch,
+                         "avg_launch_ms": adam_ms / n_launch, "launches_per_step": n_launch,
+                         "per_step": {"algorithmic_bytes": adam_bytes, "traffic_bytes": traffic, "ms": adam_ms},
                          "alone": None if adam_alone_ms != adam_alone_ms else {
-                             "avg_launch_ms": adam_alone_ms, "achieved": adam_bytes / (adam_alone_ms * 1e-3) / 1e9,
+                             "ms_per_step": adam_alone_ms, "achieved": adam_bytes / (adam_alone_ms * 1e-3) / 1e9,
                              "frac": adam_bytes / (adam_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "note": "the same launches with nothing beside them: in the timed steps the next batch's "
-                                     "march + tile sort run underneath the Adam pass by design (the step is 0.2 ms "
-                                     "shorter for it), here they start after the field backward instead"},
+                             "note": "the same launches with nothing beside them (only reported when the step is "
+                                     "configured to run the next batch's march + tile sort underneath the Adam pass)"},
                          "note": "achieved = algorithmic bytes of the step's k_adam_l1 launches / their summed duration "
-                                 "(HIP events on the launch stream); 8000 GB/s is the spec peak, a float4 copy "
-                                 "reaches 6290 GB/s on MI355X (MI355X_MICROARCH.md)"},
+                                 "(HIP events on the launch stream, inside the timed steps) = mean bytes per launch / mean "
+                                 "launch duration; 28 B per coefficient inside a level's gradient-support rectangle, 24 B "
+                                 "outside it (g = 0 is neither stored nor read there); 8000 GB/s is the spec peak, a "
+                                 "float4 copy reaches 6290 GB/s on MI355X (MI355X_MICROARCH.md)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)

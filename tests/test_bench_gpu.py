@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_prints_one_contract_line(cuda):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "3",
-                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--warmup", "1", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600,
+                       cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -28,7 +29,8 @@ def test_bench_prints_one_contract_line(cuda):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
 
 
-def test_bench_two_ranks_on_one_device(cuda):
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_on_one_device(cuda, scaling):
     """The N > 1 code path of bench.py itself (ray shards, slice-sharded dense work, collectives, max-over-ranks
     timing, rank-0 line), launched exactly as the driver does but with both ranks on cuda:0 over gloo -- the only way
     to execute it on a one-GPU box.  RCCL replaces gloo on a real node; the call sequence is the same."""
@@ -38,11 +40,16 @@ def test_bench_two_ranks_on_one_device(cuda):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny",
-           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--backend", "gloo", "--same-device"]
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--backend", "gloo", "--same-device", "--scaling", scaling]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
     assert "dp2" in d["config"]["parallelism"]
+    cfg = d["config"]
+    assert cfg["rays_per_step_global"] == (4096 if scaling == "strong" else 8192)
+    assert cfg["rays_per_step_per_gpu"] * 2 == cfg["rays_per_step_global"]
+    assert cfg["collectives"]["world_size"] == 2 and cfg["collectives"]["backend"] == "gloo"
+    assert cfg["collectives"]["bytes_on_the_wire"]["reduce_scatter_plane_grad_bytes"] > 0
