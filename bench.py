@@ -55,6 +55,8 @@ def build(workload, device, dist_mode, plane_dtype=None, **ts_kwargs):
     ts = TrainStep(model, lr=1e-2, wavelet_regularization=lam, iters=40000, warmup_steps=0, fp16=True,
                    background_color=0.0, dist_mode=dist_mode, **ts_kwargs)
     ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", ts.prefetch_at)   # "auto" | "bwd" | "adam" (experiments)
+    if os.environ.get("TNL_NO_OVERLAP"):      # experiments: march + tile sort in order on the launch stream (kernels alone)
+        ts.overlap_march = False
     bitfield = torch.from_numpy(synthetic.sphere_bitfield(128, model.cascade, 1.5, 0.8, 0.0)).to(device)
     model.density_bitfield.copy_(bitfield)
     return model, ts, bitfield, N

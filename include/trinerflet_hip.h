@@ -189,6 +189,19 @@ TNL_API int tnl_triplane_sample_backward(const float *grad_feats, const float *x
                                          uint32_t N, uint32_t C, uint32_t R, float *grad_tm,
                                          void *stream);
 
+/* F.grid_sample(bilinear, padding_mode='border', align_corners=True) on texel-major planes [3][R][R][C] for the
+ * optional TriPlaneVolume lookups whose coordinates are not the plain axis projection: learn_rotation_axis
+ * (triplane_encoder.py:335-362), lbound_auto_scale (:323-326), the nested zoom planes (:453-483).
+ * grid: [N][3][CG][2] normalised (gx -> W, gy -> H); CG = 1 (one pair per plane) or C (one per channel).
+ * feats: [N][3C].  Backward (grid_sampler_2d_backward semantics): grad_tm [3][R][R][C] fp32 receives atomic adds
+ * (caller zero-fills; NULL = not wanted); grad_grid [N][3][CG][2] (NULL = not wanted; zero-filled by the caller when
+ * CG = 1, where the channels' contributions are added atomically); a clipped coordinate gets zero gradient. */
+TNL_API int tnl_grid_sample_tm_forward(const void *planes_tm, int half_in, const float *grid, uint32_t N, uint32_t C,
+                                       uint32_t CG, uint32_t R, float *feats, void *stream);
+TNL_API int tnl_grid_sample_tm_backward(const void *planes_tm, int half_in, const float *grid,
+                                        const float *grad_feats, uint32_t N, uint32_t C, uint32_t CG, uint32_t R,
+                                        float *grad_tm, float *grad_grid, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused field: NeRFNetwork.forward (reconstruction/nerf/network.py:118-147) = triplane lookup
  * + sigma MLP + trunc_exp (activation.py:5-17) + SH-4 + colour MLP + sigmoid, fp16 MFMA with

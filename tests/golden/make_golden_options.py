@@ -11,6 +11,7 @@ constructor options no README configuration uses:
   cur/         inner_multi_res_scale_current=2                        -> learnable shapes, planes
   partial/     get_planes(max_res / max_scale / get_all_resolutions)  -> shapes and values
   grid/        get_grid_features(4)                                   -> lbound, features, grid
+  wbr22/ wbr68/ wavelet_base_resolution > 0 (bior2.2 at 64^2 / 8, bior6.8 at 128^2 / 8) -> level sizes, planes, forward
 All float32 (as the reference runs), C=2, R=32, scale 4, bior2.2.
 """
 import os
@@ -120,6 +121,20 @@ def main():
     vol.reset_cahce()
     lb, feats, grid = vol.get_grid_features(4)
     out["grid/lbound"], out["grid/features"], out["grid/grid"] = np.array(lb), feats.detach().numpy(), grid.numpy()
+    # wavelet_base_resolution: levels at or below it keep the uncropped analysis size and are synthesised without pad
+    for tag, wv, res, sc, wbr in (("wbr22", "bior2.2", 64, 8, 12), ("wbr68", "bior6.8", 128, 8, 41)):
+        torch.manual_seed(13)
+        vol = TriPlaneVolume(number_of_features=C, plane_resolution=res, inner_multi_res_scale=sc, wavelet_type=wv,
+                             lbound=bound, wavelet_base_resolution=wbr)
+        with torch.no_grad():
+            for p in vol.planes_features_wavelet_coefs:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.3)
+        dump_params(tag, vol)
+        out[f"{tag}/cfg"] = np.array([res, sc, wbr])
+        out[f"{tag}/shapes"] = np.array([p.shape[-1] for p in vol.planes_features_wavelet_coefs] + [vol.planes_features.shape[-1]])
+        out[f"{tag}/planes"] = vol.get_planes().detach().numpy()
+        out[f"{tag}/forward"] = vol(xyz, bound).detach().numpy()
+        print(tag, "level sizes", out[f"{tag}/shapes"], "planes", out[f"{tag}/planes"].shape)
     np.savez_compressed(os.path.join(HERE, "triplane_options_reference.npz"), **out)
     print("wrote", len(out), "arrays;", {k: v.shape for k, v in out.items() if k.startswith(("up/planes", "partial/", "cur/"))})
 

@@ -72,8 +72,9 @@ def test_reference_api_surface():
         assert hasattr(vol, m)
     rot = TriPlaneVolume(number_of_features=16, plane_resolution=512, inner_multi_res_scale=8, learn_rotation_axis=True)
     assert tuple(rot.rotation_matrix.shape) == (16, 3, 3) and not rot.is_plain() and vol.is_plain()
-    with pytest.raises(NotImplementedError):
-        TriPlaneVolume(number_of_features=16, plane_resolution=512, inner_multi_res_scale=8, wavelet_base_resolution=64)
+    # wavelet_base_resolution: the analysis sizes at or below it stay uncropped (triplane_encoder.py:190-196)
+    wbr = TriPlaneVolume(number_of_features=2, plane_resolution=128, inner_multi_res_scale=8, wavelet_base_resolution=41)
+    assert [p.shape[-1] for p in wbr.planes_features_wavelet_coefs] == [28, 40, 64] and wbr.planes_features.shape[-1] == 28
     from trinerflet_amd.nerf.network import NeRFNetwork
     net = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, triplane_channels=16,
                       triplane_resolution=256, triplane_wavelet_levels=4, density_thresh=10)

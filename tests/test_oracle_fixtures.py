@@ -20,6 +20,20 @@ def fx(golden_dir):
     return np.load(os.path.join(golden_dir, "oracle_kernels.npz"))
 
 
+def test_sh4_equals_the_reference_formulas(golden_dir):
+    """oracle SH-4 == the reference kernel's own statements evaluated in fp32 (tests/golden/sh_reference.npz, made by
+    make_golden_sh.py from shencoder.cu where it lies): bit for bit -- A4 is pinned by execution of the reference's
+    arithmetic, not only by restatement."""
+    g = np.load(os.path.join(golden_dir, "sh_reference.npz"))
+    assert np.array_equal(cref.sh4(g["dirs"]), g["out"][:, :16])
+    # and the 64 functions the fixture holds are orthonormal on the sphere (sanity of the fixture itself)
+    rng = np.random.default_rng(0)
+    d = rng.standard_normal((200000, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    assert np.allclose(cref.sh4(d.astype(np.float32)).astype(np.float64).T @ cref.sh4(d.astype(np.float32)) * 4 * np.pi / len(d),
+                       np.eye(16), atol=0.03)
+
+
 def test_sh_and_grid(fx):
     np.testing.assert_array_equal(cref.sh4(fx["sh/dirs"]), fx["sh/out"])
     ax = np.arange(128, dtype=np.int32)

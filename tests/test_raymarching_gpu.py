@@ -240,8 +240,26 @@ def test_sh(cuda):
         dm[:, k] -= eps
         num[:, k] = ((cref.sh4(dp).astype(np.float64) - cref.sh4(dm)) * w.cpu().numpy()).sum(-1) / (2 * eps)
     np.testing.assert_allclose(dt.grad.cpu().numpy(), num, rtol=2e-2, atol=2e-2)
-    with pytest.raises(NotImplementedError):
-        SHEncoder(3, 5)(_t(d, cuda))
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_sh_all_degrees_vs_reference_formulas(cuda, golden_dir, degree):
+    """tests/golden/sh_reference.npz = the reference kernel's own statements (shencoder.cu:48-122 values, :125-354
+    derivatives) evaluated in fp32 by make_golden_sh.py: every degree the reference supports, values and dy_dx."""
+    import os
+    from trinerflet_amd.shencoder import SHEncoder
+    g = np.load(os.path.join(golden_dir, "sh_reference.npz"))
+    n = degree * degree
+    d = _t(g["dirs"], cuda).requires_grad_(True)
+    out = SHEncoder(3, degree)(d)
+    want = g["out"][:, :n]
+    tol = 1e-6 if degree <= 4 else 2e-5            # <= 4: the same polynomials; above: generated by recurrence
+    assert np.abs(out.detach().cpu().numpy() - want).max() <= tol * max(1.0, np.abs(want).max())
+    # derivatives through the dy_dx path: VJP with one-hot cotangents per input axis equals the tables' column sums
+    w = torch.from_numpy(np.random.default_rng(degree).standard_normal((96, n)).astype(np.float32)).to(cuda)
+    (gin,) = torch.autograd.grad(out, d, w)
+    ref = np.stack([(g[k][:, :n] * w.cpu().numpy()).sum(-1) for k in ("dx", "dy", "dz")], -1)
+    assert np.abs(gin.cpu().numpy() - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.gpu

@@ -195,3 +195,28 @@ def test_per_ray_background_equals_constant_background(cuda):
     tr = Trainer("rb", _model(cuda), lr=1e-2, iters=50, num_rays=1024, train_rand_bg=True, fast_training=True)
     tr.train(train, None, max_epochs=2)
     assert np.isfinite(tr.stats["loss"]).all() and tr.global_step == 2 * train.steps_per_epoch(1024)
+
+
+def test_save_triplane_dumps(cuda, tmp_path):
+    """Trainer.save_triplane (utils.py:1600-1661): file set, min-max + contrast normalisation, the wavelet pyramid."""
+    from trinerflet_amd.trainer import Trainer
+    tr = Trainer("t", _model(cuda, R=128, levels=4), workspace=str(tmp_path), use_checkpoint="scratch", lr=1e-2, iters=10,
+                 num_rays=512, fast_training=True)
+    with torch.no_grad():
+        for p in tr.model.encoder.planes_features_wavelet_coefs:
+            p.normal_(0, 0.1)
+    files = tr.save_triplane(all=True, save_wavelet=True)
+    names = sorted(os.path.relpath(f, str(tmp_path)) for f in files)
+    assert len([n for n in names if n.startswith("planes/plane_0_")]) == 3 * 16
+    assert len([n for n in names if n.startswith("planes/wavelet_features/")]) == 3 * 16
+    assert {n.split("/")[1] for n in names if "levels_" in n} == {"levels_0", "levels_1", "levels_2"}
+    # one image against the definition: min-max, then clamp(2x - mean, 0, 1), 8-bit
+    tr.model.encoder.reset_cahce()
+    pl = tr.model.encoder.get_planes()[1, 5].detach().float().cpu()
+    x = (pl - pl.min()) / (pl.max() - pl.min())
+    want = ((2 * x - x.mean()).clamp(0, 1) * 255).round().numpy().astype(np.uint8)
+    raw = open(os.path.join(str(tmp_path), "planes", "plane_0_1_5.pgm"), "rb").read()
+    head, data = raw.split(b"\n", 1)
+    assert head == b"P5 128 128 255" and np.array_equal(np.frombuffer(data, np.uint8).reshape(128, 128), want)
+    w = open(os.path.join(str(tmp_path), "planes", "wavelet_features", "wavelet_features_0_0_0.pgm"), "rb").read()
+    assert w.split(b"\n", 1)[0] == b"P5 128 128 255"          # 32 (LL) -> 64 -> 128 pyramid

@@ -109,6 +109,27 @@ def test_partially_learnable_levels_and_partial_builds(cuda, g):
     _close(feats, g["grid/features"])
 
 
+@pytest.mark.parametrize("tag,wave", [("wbr22", "bior2.2"), ("wbr68", "bior6.8")])
+def test_wavelet_base_resolution(cuda, g, tag, wave):
+    """Levels below wavelet_base_resolution are synthesised without the zero halo (triplane_encoder.py:391-393) and have
+    the uncropped analysis sizes (:190-196): level sizes, planes and lookup vs the reference class."""
+    from trinerflet_amd.triplaneencoder.triplane_encoder import TriPlaneVolume
+    res, sc, wbr = (int(v) for v in g[f"{tag}/cfg"])
+    vol = TriPlaneVolume(number_of_features=C, plane_resolution=res, inner_multi_res_scale=sc, wavelet_type=wave,
+                         lbound=float(g["bound"]), plane_dtype=torch.float32, wavelet_base_resolution=wbr).to(cuda)
+    shapes = [p.shape[-1] for p in vol.planes_features_wavelet_coefs] + [vol.planes_features.shape[-1]]
+    assert shapes == list(g[f"{tag}/shapes"])
+    with torch.no_grad():
+        vol.planes_features.copy_(torch.from_numpy(g[f"{tag}/ll"]))
+        for i, p in enumerate(vol.planes_features_wavelet_coefs):
+            p.copy_(torch.from_numpy(g[f"{tag}/coef{i}"]))
+    _close(vol.get_planes(), g[f"{tag}/planes"])
+    f = vol(torch.from_numpy(g["xyz"]).to(cuda), float(g["bound"]))
+    _close(f, g[f"{tag}/forward"])
+    f.sum().backward()            # the crop is differentiable: every level receives a gradient
+    assert all(float(p.grad.abs().sum()) > 0 for p in vol.planes_features_wavelet_coefs)
+
+
 def test_options_switch_the_fused_path_off_and_still_render(cuda):
     from trinerflet_amd.nerf.network import NeRFNetwork
     m = NeRFNetwork(encoding="triplane_wavelet", bound=1.0, cuda_ray=True, hidden_dim=64, hidden_dim_color=64,

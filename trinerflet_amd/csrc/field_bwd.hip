@@ -26,6 +26,10 @@
 #include "../../include/trinerflet_hip.h"
 #include "field_device.h"
 
+#ifndef TNL_BWD_NW
+#define TNL_BWD_NW 8   // waves per workgroup of the hidden-64 binned backward (4: one wave per SIMD, 8: two)
+#endif
+
 namespace {
 
 // NW waves per workgroup, 32 samples per wave.  The kernel needs ~320 registers per lane (dW accumulators + the
@@ -69,6 +73,14 @@ struct BwdGeom {
   static constexpr int NT0 = G::OB * G::IB0, NT1 = G::OB, NT2 = G::OB, NT3 = G::OB * G::OB, NT4 = G::OB;
   static constexpr int A0 = (NT0 + NW - 1) / NW, A1 = (NT1 + NW - 1) / NW, A2 = (NT2 + NW - 1) / NW,
                        A3 = (NT3 + NW - 1) / NW, A4 = (NT4 + NW - 1) / NW;
+  // GT (8-wave workgroups): the weight-gradient tiles of ALL layers are dealt out together, tile T to wave T % NW
+  // (in the order layer 4, 3, 2, 1, 0), so that a wave holds NSLOT = 2 accumulator tiles (32 registers) instead of one
+  // or two per layer (80-96): with that the kernel fits 256 registers per lane, i.e. two waves per SIMD, which is what
+  // covers the barrier / LDS-latency stalls that made up more than half of the one-wave-per-SIMD kernel's time.
+  static constexpr bool GT = NW >= 8;
+  static constexpr int NTILES = NT0 + NT1 + NT2 + NT3 + NT4;
+  static constexpr int NSLOT = (NTILES + NW - 1) / NW;
+  static constexpr int B4 = 0, B3 = NT4, B2 = B3 + NT3, B1 = B2 + NT2, B0 = B1 + NT1;   // first tile id of each layer
 };
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -100,6 +112,17 @@ __device__ __forceinline__ f32x16 dw_tile(const char* yb, const char* xb, int t0
     acc = MFMA32(a, b, acc);
   }
   return acc;
+}
+
+// GT (global tile ownership): the tiles [BASE, BASE + NT) of one layer, laid out [y block][x block] with NX x blocks;
+// wave wv accumulates those of its slots (tile ids wv, wv + NW, ...) that belong to this layer.  Wave-uniform branches.
+template <int ST, int BLK, int NW, int NSLOT, int BASE, int NT, int NX>
+__device__ __forceinline__ void dw_layer(f32x16 (&dwg)[NSLOT], int wv, const char* Y, const char* X, int t0, int t1) {
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; sl++) {
+    const int t = wv + NW * sl - BASE;
+    if (t >= 0 && t < NT) dwg[sl] = dw_tile<ST>(Y + (t / NX) * BLK, X + (t % NX) * BLK, t0, t1, dwg[sl]);
+  }
 }
 
 // publish an accumulator-layout tile (registers 4q..4q+3 = features 8q + 4h .. + 3 of the lane's sample) into a block
@@ -205,6 +228,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   float* stage = stage_all + (size_t)(ATOMIC ? wv : 0) * 32 * B::STAGE_LD;
 
   f32x16 dw0[B::A0], dw1[B::A1], dw2[B::A2], dw3[B::A3], dw4[B::A4];
+  f32x16 dwg[B::NSLOT];      // GT: this wave's tiles wv, wv + NW, ... of the whole network
+#pragma unroll
+  for (int k = 0; k < B::NSLOT; k++) dwg[k] = zero16();
 #pragma unroll
   for (int k = 0; k < B::A0; k++) dw0[k] = zero16();
 #pragma unroll
@@ -333,10 +359,14 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     // (Every wave accumulates A_l tiles per layer without a branch: behind `if (tile < NT_l)` the accumulators of that
     // block live in VGPRs and are copied into AGPRs and back around the MFMAs, 32 moves per tile and super-tile.  The
     // duplicates cost idle waves a few MFMAs and are dropped when the slabs are written.)
+    if (B::GT) {
+      dw_layer<ST, BLK, NW, B::NSLOT, B::B4, B::NT4, B::NT4>(dwg, wv, Ys, Xs, t0, t1);
+    } else {
 #pragma unroll
     for (int k = 0; k < B::A4; k++) {
       const int t = (wv + NW * k) % B::NT4;   // a wave without a tile of its own repeats another's
       dw4[k] = dw_tile<ST>(Ys, Xs + t * BLK, t0, t1, dw4[k]);
+    }
     }
     // (a gradient tile leaves the registers as soon as it is masked and converted: its two fp16 fragments feed the next
     // layer's MFMAs AND are what the stage receives -- put_frag of fragments 2ib, 2ib+1 writes exactly put_acc's chunks)
@@ -356,10 +386,14 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d4f[ks], h, col);
     __syncthreads();
+    if (B::GT) {
+      dw_layer<ST, BLK, NW, B::NSLOT, B::B3, B::NT3, G::OB>(dwg, wv, Ys, Xs, t0, t1);
+    } else {
 #pragma unroll
     for (int k = 0; k < B::A3; k++) {
       const int t = (wv + NW * k) % B::NT3;   // a wave without a tile of its own repeats another's
       dw3[k] = dw_tile<ST>(Ys + (t / G::OB) * BLK, Xs + (t % G::OB) * BLK, t0, t1, dw3[k]);
+    }
     }
     half8 d3f[G::KH];
 #pragma unroll
@@ -390,10 +424,14 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d3f[ks], h, col);
     __syncthreads();
+    if (B::GT) {
+      dw_layer<ST, BLK, NW, B::NSLOT, B::B2, B::NT2, 1>(dwg, wv, Ys, Xs, t0, t1);
+    } else {
 #pragma unroll
     for (int k = 0; k < B::A2; k++) {
       const int t = (wv + NW * k) % B::NT2;   // a wave without a tile of its own repeats another's
       dw2[k] = dw_tile<ST>(Ys + t * BLK, Xs, t0, t1, dw2[k]);
+    }
     }
     f32x16 dzz = zero16();
 #pragma unroll
@@ -422,10 +460,14 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h1[ks], h, col);
     put_frag<BLK>(Ys, 0, dof, h, col);   // features 0..15 of the block; 16..31 are never used
     __syncthreads();
+    if (B::GT) {
+      dw_layer<ST, BLK, NW, B::NSLOT, B::B1, B::NT1, B::NT1>(dwg, wv, Ys, Xs, t0, t1);
+    } else {
 #pragma unroll
     for (int k = 0; k < B::A1; k++) {
       const int t = (wv + NW * k) % B::NT1;   // a wave without a tile of its own repeats another's
       dw1[k] = dw_tile<ST>(Ys, Xs + t * BLK, t0, t1, dw1[k]);
+    }
     }
     half8 d1f[G::KH];
 #pragma unroll
@@ -454,10 +496,14 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d1f[ks], h, col);
     __syncthreads();
+    if (B::GT) {
+      dw_layer<ST, BLK, NW, B::NSLOT, B::B0, B::NT0, G::IB0>(dwg, wv, Ys, B::EARLY_F ? Fs : Xs, t0, t1);
+    } else {
 #pragma unroll
     for (int k = 0; k < B::A0; k++) {
       const int t = (wv + NW * k) % B::NT0;   // a wave without a tile of its own repeats another's
       dw0[k] = dw_tile<ST>(Ys + (t / G::IB0) * BLK, (B::EARLY_F ? Fs : Xs) + (t % G::IB0) * BLK, t0, t1, dw0[k]);
+    }
     }
     // feature gradient dF^T = W0^T dH1^T
     if (!ATOMIC) {
@@ -525,6 +571,18 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 
   // ---- epilogue: this workgroup's weight-gradient slab
   float* slab = slabs + (size_t)blockIdx.x * G::NW;
+  if (B::GT) {
+#pragma unroll
+    for (int sl = 0; sl < B::NSLOT; sl++) {
+      const int T = wv + NW * sl;
+      if (T < B::B3) slab_tile(slab, G::OFF4, 3, H, 0, T - B::B4, dwg[sl], r, h);
+      else if (T < B::B2) slab_tile(slab, G::OFF3, H, H, (T - B::B3) / G::OB, (T - B::B3) % G::OB, dwg[sl], r, h);
+      else if (T < B::B1) slab_tile<2>(slab, G::OFF2, H, 31, T - B::B2, 0, dwg[sl], r, h);
+      else if (T < B::B0) slab_tile<1>(slab, G::OFF1, 16, H, 0, T - B::B1, dwg[sl], r, h);
+      else if (T < B::NTILES) slab_tile(slab, G::OFF0, H, G::F, (T - B::B0) / G::IB0, (T - B::B0) % G::IB0, dwg[sl], r, h);
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < B::A0; k++) {
     const int t = wv + NW * k;
@@ -654,9 +712,9 @@ int tnl_field_backward(const float* grad_sigma, const float* grad_rgb, const flo
   if (Hd != Hc) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   if (C == 16 && Hd == 64)
-    return launch_bwd<16, 64, 4>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
+    return launch_bwd<16, 64, TNL_BWD_NW>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   if (C == 32 && Hd == 64)
-    return launch_bwd<32, 64, 4>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
+    return launch_bwd<32, 64, TNL_BWD_NW>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   if (C == 48 && Hd == 128)
     return launch_bwd<48, 128, 4>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   return (int)hipErrorInvalidValue;

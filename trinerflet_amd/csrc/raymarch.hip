@@ -872,8 +872,74 @@ k_compact_write(const int* __restrict__ rays_alive, uint32_t n, const int* __res
 }
 
 // ---------------------------------------------------------------------------------------------
-// spherical harmonics (aux_libs/shencoder/src/shencoder.cu:28-68, degree <= 4)
+// spherical harmonics (aux_libs/shencoder/src/shencoder.cu:28-355).  Degrees <= 4 (the hot path's 16 values) are the
+// reference's polynomials term by term; bands l = 4..7 (degrees 5..8) are generated instead of tabulated:
+//   (c_m + i s_m) = (x + i y)^m,   Q_l^m(z) = P_l^m(z) / (1 - z^2)^(m/2) by the three-term recurrence,
+//   Y_l^m = N_l^m Q_l^m c_m (m > 0),  Y_l^-m = N_l^m Q_l^m s_m,  Y_l^0 = N_l^0 Q_l^0,
+//   N_l^m = (-1)^m sqrt(2) K_l^m, N_l^0 = K_l^0, K_l^m = sqrt((2l+1)/(4 pi) (l-m)!/(l+m)!)
+// which expands to exactly the reference's polynomials (pinned by tests/golden/sh_reference.npz: the reference's own
+// statements evaluated in fp32); the optional derivatives come out of the same recurrences carried on
+// (value, d/dx, d/dy, d/dz) quadruples.
 // ---------------------------------------------------------------------------------------------
+struct D4 { float v, x, y, z; };
+__device__ __forceinline__ D4 d4mul(const D4& a, const D4& b) {
+  return D4{a.v * b.v, a.x * b.v + a.v * b.x, a.y * b.v + a.v * b.y, a.z * b.v + a.v * b.z};
+}
+__device__ __forceinline__ D4 d4sub(const D4& a, const D4& b) { return D4{a.v - b.v, a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ D4 d4add(const D4& a, const D4& b) { return D4{a.v + b.v, a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ D4 d4scale(const D4& a, float s) { return D4{a.v * s, a.x * s, a.y * s, a.z * s}; }
+
+// writes entries [16, C*C) of o (and of gx, gy, gz when WITH_GRAD)
+template <bool WITH_GRAD>
+__device__ __forceinline__ void sh_high_bands(float x, float y, float z, uint32_t C, float* o, float* gx, float* gy,
+                                              float* gz) {
+  static constexpr float NRM[4][8] = {
+    {0.84628437532163447f, -0.26761861742291571f, 0.063078313050504001f, -0.016858388283618388f, 0.0059603403376112026f, 0.f, 0.f, 0.f},   // l = 4
+    {0.9356025796273888f, -0.24157154730437169f, 0.045652731285460234f, -0.0093188247511476283f, 0.0021964680580751762f, -0.00069458418713245519f, 0.f, 0.f},   // l = 5
+    {1.0171072362820548f, -0.22195099524523101f, 0.03509353369580661f, -0.0058489222826344353f, 0.0010678622237644956f, -0.00022766899107568562f, 6.5722376641838803e-05f, 0.f},   // l = 6
+    {1.0925484305920792f, -0.20647224590289676f, 0.028097313806030647f, -0.0039735602250741348f, 0.00059903674311141165f, -9.9839457185235285e-05f, 1.9580128477462541e-05f, -5.233009453691466e-06f},   // l = 7
+  };
+  const D4 X{x, 1.f, 0.f, 0.f}, Y{y, 0.f, 1.f, 0.f}, Z{z, 0.f, 0.f, 1.f};
+  D4 c[8], s[8];
+  c[0] = D4{1.f, 0.f, 0.f, 0.f};
+  s[0] = D4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 1; m < 8; m++) {
+    c[m] = d4sub(d4mul(X, c[m - 1]), d4mul(Y, s[m - 1]));
+    s[m] = d4add(d4mul(X, s[m - 1]), d4mul(Y, c[m - 1]));
+  }
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    // Q_m^m = (2m-1)!!, Q_{m+1}^m = (2m+1) z Q_m^m, Q_l^m = ((2l-1) z Q_{l-1}^m - (l+m-1) Q_{l-2}^m) / (l-m)
+    float dfac = 1.f;
+    for (int k = 1; k <= m; k++) dfac *= (float)(2 * k - 1);
+    D4 q2{dfac, 0.f, 0.f, 0.f};                       // Q_m^m
+    D4 q1 = d4scale(Z, (float)(2 * m + 1) * dfac);    // Q_{m+1}^m
+#pragma unroll
+    for (int l = m; l < 8; l++) {
+      D4 q;
+      if (l == m) q = q2;
+      else if (l == m + 1) q = q1;
+      else {
+        q = d4scale(d4sub(d4scale(d4mul(Z, q1), (float)(2 * l - 1)), d4scale(q2, (float)(l + m - 1))), 1.f / (float)(l - m));
+        q2 = q1;
+        q1 = q;
+      }
+      if (l < 4 || (uint32_t)l >= C) continue;
+      const float nrm = NRM[l - 4][m];
+      const int base = l * l + l;
+      const D4 yp = d4scale(d4mul(q, c[m]), nrm);
+      o[base + m] = yp.v;
+      if (WITH_GRAD) { gx[base + m] = yp.x; gy[base + m] = yp.y; gz[base + m] = yp.z; }
+      if (m > 0) {
+        const D4 yn = d4scale(d4mul(q, s[m]), nrm);
+        o[base - m] = yn.v;
+        if (WITH_GRAD) { gx[base - m] = yn.x; gy[base - m] = yn.y; gz[base - m] = yn.z; }
+      }
+    }
+  }
+}
+
 __global__ void k_sh(const float* __restrict__ inputs, float* __restrict__ outputs, uint32_t B, uint32_t C,
                      float* __restrict__ dy_dx) {
   const uint32_t b = threadIdx.x + blockIdx.x * blockDim.x;
@@ -881,7 +947,7 @@ __global__ void k_sh(const float* __restrict__ inputs, float* __restrict__ outpu
   const uint32_t C2 = C * C;
   const float x = inputs[b * 3], y = inputs[b * 3 + 1], z = inputs[b * 3 + 2];
   const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
-  float o[16];
+  float o[64];
   o[0] = 0.28209479177387814f;
   o[1] = -0.48860251190291987f * y;
   o[2] = 0.48860251190291987f * z;
@@ -898,10 +964,14 @@ __global__ void k_sh(const float* __restrict__ inputs, float* __restrict__ outpu
   o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
   o[14] = 1.4453057213202769f * z * (x2 - y2);
   o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+  float gx[64], gy[64], gz[64];
+  if (C > 4) {   // wave-uniform
+    if (dy_dx) sh_high_bands<true>(x, y, z, C, o, gx, gy, gz);
+    else sh_high_bands<false>(x, y, z, C, o, gx, gy, gz);
+  }
   for (uint32_t i = 0; i < C2; i++) outputs[(size_t)b * C2 + i] = o[i];
   if (dy_dx) {
-    // shencoder.cu:125-354 restricted to degree <= 4: d/dx, d/dy, d/dz of each basis function
-    float gx[16], gy[16], gz[16];
+    // shencoder.cu:125-354, degree <= 4 term by term: d/dx, d/dy, d/dz of each basis function
     gx[0] = 0; gy[0] = 0; gz[0] = 0;
     gx[1] = 0; gy[1] = -0.48860251190291987f; gz[1] = 0;
     gx[2] = 0; gy[2] = 0; gz[2] = 0.48860251190291987f;
@@ -1173,7 +1243,7 @@ int tnl_compact_rays(const int32_t* rays_alive, uint32_t n_alive, int32_t* rays_
 
 int tnl_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, float* dy_dx,
                           void* stream) {
-  if (D != 3 || C < 1 || C > 4) return (int)hipErrorInvalidValue;
+  if (D != 3 || C < 1 || C > 8) return (int)hipErrorInvalidValue;
   if (B == 0) return 0;
   hipLaunchKernelGGL(k_sh, dim3(cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, inputs, outputs, B, C, dy_dx);
   return launch_status();
@@ -1182,7 +1252,7 @@ int tnl_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint3
 int tnl_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
                            const float* dy_dx, float* grad_inputs, void* stream) {
   (void)inputs;
-  if (D != 3 || C < 1 || C > 4) return (int)hipErrorInvalidValue;
+  if (D != 3 || C < 1 || C > 8) return (int)hipErrorInvalidValue;
   if (B == 0) return 0;
   hipLaunchKernelGGL(k_sh_backward, dim3(cdiv(B * 3, 256)), dim3(256), 0, (hipStream_t)stream, grad, B, C, dy_dx,
                      grad_inputs);

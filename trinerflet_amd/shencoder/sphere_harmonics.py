@@ -1,7 +1,7 @@
 """Mirror of aux_libs/shencoder/sphere_harmonics.py (reference) on libtrinerflet_hip.so.
 
-SHEncoder(input_dim=3, degree=4).forward(inputs, size=1) -> [..., degree^2]; degrees 1..4 are
-implemented (the hot path uses 4, reconstruction/nerf/network.py:58); higher degrees raise.
+SHEncoder(input_dim=3, degree=4).forward(inputs, size=1) -> [..., degree^2]; degrees 1..8 as in the
+reference (the hot path uses 4, reconstruction/nerf/network.py:58).
 """
 import torch
 import torch.nn as nn
@@ -24,7 +24,7 @@ class _sh_encoder(Function):
         err = L.lib().tnl_sh_encode_forward(L.ptr(inputs), L.ptr(outputs), L.u32(B), L.u32(input_dim), L.u32(degree),
                                             L.ptr(dy_dx), L.stream())
         if err == 1:  # hipErrorInvalidValue
-            raise NotImplementedError("SH encoder: only input_dim == 3 and degree <= 4 are built in this tier")
+            raise ValueError("SH encoder: input_dim must be 3 and degree in [1, 8]")
         L.check(err, "sh_encode_forward")
         ctx.save_for_backward(inputs, dy_dx)
         ctx.dims = [B, input_dim, degree]

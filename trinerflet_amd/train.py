@@ -115,6 +115,9 @@ class TrainStep:
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
             raise NotImplementedError("TrainStep needs a configuration the fused field kernel is built for")
+        if getattr(enc, "wavelet_base_resolution", 0) > 0:
+            raise NotImplementedError("TrainStep assumes level sizes base * 2^i (wavelet_base_resolution = 0, as every "
+                                      "README configuration has it); the module path (autograd) supports the option")
         self.model, self.enc = model, enc
         self.C, self.R, self.H = enc.number_of_features, enc.plane_resolution, model.hidden_dim
         self.J = enc.planes_features_wavelet_all_level

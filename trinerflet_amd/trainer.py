@@ -258,6 +258,81 @@ class Trainer:
         return frames
 
     # ----------------------------------------------------------------------------------------------------------
+    # plane dumps (utils.py:1535-1661 save_tensor / get_wavelet_img / save_triplane)
+    # ----------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _normalised(planes):
+        """utils.py:1618-1623: per (plane, channel) min-max to [0, 1], then torchvision's adjust_contrast(., 2) of a
+        one-channel image = clamp(2 x - mean(x), 0, 1)."""
+        planes = planes.detach().float()
+        flat = planes.reshape(planes.shape[0], planes.shape[1], -1)
+        a = flat.min(dim=-1).values[..., None, None]
+        b = flat.max(dim=-1).values[..., None, None]
+        x = (planes - a) / (b - a)
+        mean = x.mean(dim=(-2, -1), keepdim=True)
+        return (2.0 * x - mean).clamp(0.0, 1.0)
+
+    @staticmethod
+    def wavelet_image(planes_features, coefs):
+        """get_wavelet_img (utils.py:1570-1595): the classic pyramid picture -- normalised LL in the top-left corner, every
+        level's |lh| to its right, |hl| below, |hh| diagonal, each band scaled by its own maximum."""
+        ll = Trainer._normalised(planes_features)
+        for w in coefs:
+            w = w.detach().float().abs()
+            w = w / w.reshape(w.shape[0], w.shape[1], w.shape[2], -1).max(dim=-1).values[..., None, None]
+            top = torch.cat([ll, w[:, :, 0]], dim=3)
+            bottom = torch.cat([w[:, :, 1], w[:, :, 2]], dim=3)
+            ll = torch.cat([top, bottom], dim=2)
+        return ll
+
+    def save_triplane(self, all=False, save_wavelet=False):
+        """Trainer.save_triplane (utils.py:1600-1661): grey images of the reconstructed planes (one random channel per
+        plane, or all), of the nested zoom planes, and optionally of the wavelet pyramid and of every resolution level,
+        under <workspace>/planes.  Written as binary PGM (this build carries no PNG encoder); names, normalisation and
+        contrast as in the reference.  Returns the list of files."""
+        if self.workspace is None:
+            raise RuntimeError("Trainer was built without a workspace")
+        if self.rank != 0:
+            return []
+        enc = self.model.encoder
+        root = os.path.join(self.workspace, "planes")
+        os.makedirs(root, exist_ok=True)
+        rng = np.random.default_rng(self.seed + self.epoch)
+        written = []
+
+        def save_tensor(t, path, prefix="plane"):          # utils.py:1535-1567
+            os.makedirs(path, exist_ok=True)
+            t = t.cpu()
+            for axis in range(t.shape[0]):
+                chans = range(t.shape[1]) if all else [int(rng.integers(t.shape[1]))]
+                for ch in chans:
+                    img = (t[axis, ch] * 255).round().numpy().astype(np.uint8)
+                    f = os.path.join(path, f"{prefix}_{self.epoch}_{axis}_{ch}.pgm")
+                    with open(f, "wb") as fh:
+                        fh.write(f"P5 {img.shape[1]} {img.shape[0]} 255\n".encode())
+                        fh.write(img.tobytes())
+                    written.append(f)
+
+        with torch.no_grad():
+            self.ts.sync_sharded_parameters()
+            enc.reset_cahce()
+            planes = enc.get_planes()
+            upscaled = []
+            if enc.upscale_enabled:
+                planes, upscaled = planes[0], planes[1:]
+            save_tensor(self._normalised(planes), root)
+            for idx, pu in enumerate(upscaled):
+                save_tensor(self._normalised(pu), root, prefix=f"plane_upscaled_{idx}")
+            if save_wavelet:
+                save_tensor(self.wavelet_image(enc.planes_features, enc.get_wavelet_features()),
+                            os.path.join(root, "wavelet_features"), prefix="wavelet_features")
+                enc.reset_cahce()
+                for idx, lv in enumerate(enc.get_planes(get_all_resolutions=True)):
+                    save_tensor(self._normalised(lv), os.path.join(root, f"levels_{idx}"))
+            enc.reset_cahce()
+        return written
+
+    # ----------------------------------------------------------------------------------------------------------
     # checkpoints (utils.py:1390-1532)
     # ----------------------------------------------------------------------------------------------------------
     def _torch_optimizer(self):

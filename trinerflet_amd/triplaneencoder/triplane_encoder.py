@@ -184,6 +184,38 @@ class _Sample(Function):
         return g_tm, None, None
 
 
+class _GridSample(Function):
+    """planes_tm [3,R,R,C], grid [N,3,CG,2] (normalised, gx -> W) -> feats [N,3C]: F.grid_sample(bilinear, border,
+    align_corners=True) of the reference's optional lookups (triplane_encoder.py:323-329,335-362) on the texel-major
+    planes, differentiable w.r.t. the planes and the grid (csrc/triplane.hip)."""
+
+    @staticmethod
+    def forward(ctx, planes_tm, grid):
+        L.require_cuda(planes_tm, grid)
+        grid = grid.to(torch.float32).contiguous()
+        _, R, _, C = planes_tm.shape
+        N, _, CG, _ = grid.shape
+        feats = torch.empty(N, 3 * C, dtype=torch.float32, device=grid.device)
+        L.check(L.lib().tnl_grid_sample_tm_forward(L.ptr(planes_tm), L.i32(int(planes_tm.dtype == torch.float16)),
+                                                   L.ptr(grid), L.u32(N), L.u32(C), L.u32(CG), L.u32(R), L.ptr(feats),
+                                                   L.stream()), "grid_sample_tm_forward")
+        ctx.save_for_backward(planes_tm, grid)
+        return feats
+
+    @staticmethod
+    def backward(ctx, g):
+        planes_tm, grid = ctx.saved_tensors
+        _, R, _, C = planes_tm.shape
+        N, _, CG, _ = grid.shape
+        g = g.to(torch.float32).contiguous()
+        g_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        g_grid = (torch.zeros_like(grid) if CG == 1 else torch.empty_like(grid)) if ctx.needs_input_grad[1] else None
+        L.check(L.lib().tnl_grid_sample_tm_backward(L.ptr(planes_tm), L.i32(int(planes_tm.dtype == torch.float16)),
+                                                    L.ptr(grid), L.ptr(g), L.u32(N), L.u32(C), L.u32(CG), L.u32(R),
+                                                    L.ptr(g_tm), L.ptr(g_grid), L.stream()), "grid_sample_tm_backward")
+        return g_tm, g_grid
+
+
 class _IDWTBuffers(nn.Module):
     """Holds pytorch_wavelets.DWTInverse's filter buffers (g0_col, g1_col, g0_row, g1_row) so that
     reference checkpoints (`encoder.idwt.*` keys) load and save unchanged.  Not used for compute."""
@@ -217,9 +249,6 @@ class TriPlaneVolume(torch.nn.Module):
                  ):
         super().__init__()
         # reference: triplane_encoder.py:27-94
-        if wavelet_base_resolution > 0:
-            # changes the level sizes in a filter-length dependent way (:190-196, :391-393); no configuration uses it
-            raise NotImplementedError("TriPlaneVolume option `wavelet_base_resolution` > 0 is not implemented")
         self.number_of_features = number_of_features
         self.plane_resolution = plane_resolution
         self.init_sigma = init_sigma
@@ -320,12 +349,21 @@ class TriPlaneVolume(torch.nn.Module):
         levels = utils.get_levels(self.inner_wavelet_scale)
         if R % (2 ** levels) != 0:
             raise ValueError('plane_resolution must be divisible by inner_multi_res_scale')
-        base = R // (2 ** levels)
         self.wave_id = WAVELET_IDS[self.wavelet_type]
         self.idwt = _IDWTBuffers(self.wavelet_type)
-        self.planes_features_wavelet_pad = PAD_DICT[self.wavelet_type]
-        self.planes_features_wavelet_yh_shapes = [torch.Size((3, C, 3, base * 2 ** i, base * 2 ** i))
-                                                  for i in range(levels)]
+        pad = self.planes_features_wavelet_pad = PAD_DICT[self.wavelet_type]
+        # Level sizes, fine -> coarse, as the reference's shape probe finds them (:188-203): a zero-mode analysis step
+        # of an n-sample axis gives n/2 + 2*pad samples, cropped back to n/2 -- except at levels whose uncropped size
+        # does not exceed wavelet_base_resolution (default 0: every level is cropped, n_i = base * 2^i).
+        sizes, n = [], R
+        for _ in range(levels):
+            n = (n + 4 * pad + 1) // 2          # floor((n + L - 1) / 2) with L = 4 * pad + 2
+            if pad > 0 and n > self.wavelet_base_resolution:
+                n -= 2 * pad
+            sizes.append(n)
+        sizes = sizes[::-1]
+        base = sizes[0]
+        self.planes_features_wavelet_yh_shapes = [torch.Size((3, C, 3, m, m)) for m in sizes]
         if planes_features is None:
             planes_features = self.init_sigma * torch.randn(3, C, base, base)
         self.planes_features = nn.Parameter(planes_features.clone().detach())
@@ -368,7 +406,14 @@ class TriPlaneVolume(torch.nn.Module):
                 else:   # a level that is not learnable (yet): zero detail coefficients (:387-389)
                     n = x.shape[-1]
                     yh = torch.zeros(x.shape[0], x.shape[1], 3, n, n, dtype=x.dtype, device=x.device)
+                n_in = x.shape[-1]
                 x = _IDWTLevel.apply(x, yh, self.wave_id)
+                if n_in < self.wavelet_base_resolution and self.planes_features_wavelet_pad > 0:
+                    # :391-393: below wavelet_base_resolution the level is synthesised WITHOUT the zero halo of `pad`
+                    # samples: the unpadded transposed convolution is the padded one minus K = (L - 2) / 2 = 2 * pad
+                    # output samples per side (2n - L + 2 instead of 2n), i.e. a crop of the same kernel's result
+                    k = 2 * self.planes_features_wavelet_pad
+                    x = x[..., k:-k, k:-k]
                 current_scale *= 2
             if get_all_resolutions:
                 all_res.append(x)
@@ -425,12 +470,11 @@ class TriPlaneVolume(torch.nn.Module):
         if not self.lbound_auto_scale:
             tm = _ToTexelMajor.apply(plane_features, self.plane_dtype == torch.float16)
             return _Sample.apply(tm, coordinates, float(lbound)).view(coordinates.shape[0], 3, -1)
-        # per-plane learnable zoom of the projected coordinates: torch's grid_sample, as in the reference
-        proj = self._project(plane_axes, coordinates / lbound).transpose(0, 1).unsqueeze(2)      # Np,N,1,2
-        proj = (proj * self.get_lbound_scale().view(-1, 1, 1, 1)).clamp(-1, 1)
-        vals = F.grid_sample(plane_features, proj.to(plane_features.dtype), mode='bilinear', padding_mode='border',
-                             align_corners=True)
-        return vals.permute(2, 0, 1, 3).squeeze(-1)
+        # per-plane learnable zoom of the projected coordinates (:323-326), then the general HIP lookup
+        proj = self._project(plane_axes, coordinates / lbound)                                   # N,Np,2
+        proj = (proj * self.get_lbound_scale().view(1, -1, 1)).clamp(-1, 1)
+        tm = _ToTexelMajor.apply(plane_features, self.plane_dtype == torch.float16)
+        return _GridSample.apply(tm, proj.unsqueeze(2)).view(coordinates.shape[0], 3, -1)
 
     def sample_from_planes_aux_rotation(self, coordinates, plane_features, plane_axes, lbound=1):
         # reference: triplane_encoder.py:335-362: every channel samples its own rotated copy of the three axes
@@ -440,11 +484,9 @@ class TriPlaneVolume(torch.nn.Module):
         rot, _ = torch.linalg.qr(rot)                                                    # C,dim,dim
         axes = torch.matmul(rot.unsqueeze(1), plane_axes.unsqueeze(0)).transpose(0, 1)   # Np,C,dim,dim-1
         axes = axes.reshape(-1, dim, dim - 1)
-        proj = self._project(axes, coordinates / lbound).transpose(0, 1).unsqueeze(2)    # Np*C,N,1,2
-        vals = F.grid_sample(plane_features.reshape(-1, 1, H, W), proj.to(plane_features.dtype), mode='bilinear',
-                             padding_mode='border', align_corners=True)
-        vals = vals.view(Np, C, vals.shape[2], vals.shape[3])
-        return vals.permute(2, 0, 1, 3).squeeze(-1)
+        proj = self._project(axes, coordinates / lbound)                                 # N,Np*C,2
+        tm = _ToTexelMajor.apply(plane_features, self.plane_dtype == torch.float16)
+        return _GridSample.apply(tm, proj.view(coordinates.shape[0], Np, C, 2)).view(coordinates.shape[0], Np, C)
 
     def sample_from_planes(self, coordinates, plane_features=None, lbound=None):
         # reference: triplane_encoder.py:443-484 -> [N, 3, C]
