@@ -55,6 +55,8 @@ def build(workload, device, dist_mode, plane_dtype=None, **ts_kwargs):
     ts = TrainStep(model, lr=1e-2, wavelet_regularization=lam, iters=40000, warmup_steps=0, fp16=True,
                    background_color=0.0, dist_mode=dist_mode, **ts_kwargs)
     ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", ts.prefetch_at)   # "auto" | "bwd" | "adam" (experiments)
+    if os.environ.get("TNL_SIDE_CUS"):        # experiments: CUs the side stream may use
+        ts.side_cus = int(os.environ["TNL_SIDE_CUS"])
     if os.environ.get("TNL_NO_OVERLAP"):      # experiments: march + tile sort in order on the launch stream (kernels alone)
         ts.overlap_march = False
     bitfield = torch.from_numpy(synthetic.sphere_bitfield(128, model.cascade, 1.5, 0.8, 0.0)).to(device)
@@ -255,6 +257,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    if os.environ.get("TNL_MAIN_PRIO"):    # experiments: the step on a high-priority stream, side work on a normal one
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["TNL_MAIN_PRIO"])))
     model, ts, bitfield, N = build(args.workload, device, args.dist_mode if world > 1 else None)
     n_global = N * world
     if args.scaling == "strong":       # the step's 60 000 rays split over the ranks (the dense work is what shards)

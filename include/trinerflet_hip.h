@@ -434,6 +434,13 @@ TNL_API int tnl_adam_l1_step_rect(float *p, float *grad, float *m, float *v, uin
  * tile sort) find wave slots underneath it.  0 (default) = no limit.  Host-side state, not thread-safe. */
 TNL_API int tnl_adam_set_lds_reservation(uint32_t bytes);
 
+/* A HIP stream restricted to the compute units set in `mask` (hipExtStreamCreateWithCUMask; bit i of the n_words
+ * 32-bit words = CU i).  TrainStep runs the next batch's march + tile sort on such a stream (a fraction of the CUs)
+ * so that this latency-bound side work does not take one wave slot of every SIMD of the chip.  No reference
+ * counterpart (the reference launches everything on the default stream). */
+TNL_API int tnl_stream_create_cu_mask(const uint32_t *mask, uint32_t n_words, void **stream);
+TNL_API int tnl_stream_destroy(void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,7 +189,7 @@ def test_trainstep_window_equals_whole_plane(cuda, rays60k, cfg):
     base = _model(cuda, cfg, seed=4)
     base.density_bitfield.copy_(bf_t)
     res = []
-    for use_roi in (False, True):
+    for use_roi in (False, False, True):      # the whole-plane run twice: the yardstick for run-to-run noise
         m = copy.deepcopy(base)
         ts = TrainStep(m, lr=1e-2, wavelet_regularization=lam, iters=1000, update_extra_interval=4, use_roi=use_roi)
         ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf_t)
@@ -204,12 +204,16 @@ def test_trainstep_window_equals_whole_plane(cuda, rays60k, cfg):
                 assert ts._roi[6] == 1152 and ts._roi[7] == 1152          # the r = 0.8 sphere's window
         assert all(np.isfinite(losses)) and Ms[0] > 3_000_000 and len(set(Ms)) == 1
         assert float(ts.last["found_inf"]) == 0.0
-        res.append((losses, [p.detach() for p in m.parameters()], ts))
-    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-4)
+        res.append((losses, [p.detach() for p in m.parameters()]))
+        del ts
+    np.testing.assert_allclose(res[0][0], res[2][0], rtol=2e-4)
     assert res[0][0][-1] < res[0][0][0]
-    for a, b in zip(res[0][1], res[1][1]):
-        # see tests/test_roi_gpu.py::test_training_with_window_equals_whole_plane_training for the allowance (isolated
-        # coefficients whose gradient sits at rounding level; measured here 1.2e-5 of them over five steps)
-        bad = ((a - b).abs() > 2e-3 + 1e-3 * b.abs())
-        assert int(bad.sum()) <= max(1, int(5e-5 * a.numel())) and float((a - b).abs().max()) < 6e-2, \
-            (cfg, int(bad.sum()), a.numel())
+    # The tile reduction sums in the order its bin-fill atomics produced, so two runs of the SAME configuration differ
+    # in the last bits of a gradient, and Adam (eps = 1e-15) turns a gradient at rounding level into a +-lr step: the
+    # windowed run may differ from the whole-plane run by no more than two whole-plane runs differ from each other
+    # (x3 + a floor), never by more than a few steps of lr anywhere.
+    for a, a2, b in zip(res[0][1], res[1][1], res[2][1]):
+        noise = int(((a - a2).abs() > 2e-3 + 1e-3 * a2.abs()).sum())
+        bad = int(((a - b).abs() > 2e-3 + 1e-3 * b.abs()).sum())
+        assert bad <= 3 * noise + max(2, int(1e-5 * a.numel())) and float((a - b).abs().max()) < 6e-2, \
+            (cfg, bad, noise, a.numel())

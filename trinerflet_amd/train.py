@@ -174,6 +174,7 @@ class TrainStep:
         self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
         self.prefetch_at = "auto"   # "start" | "fwd" | "bwd" | "adam" | "auto": where step(next_rays=...) starts the next batch's march
         self._side = None
+        self.side_cus = 0           # > 0: the side stream may only use this many compute units (see _make_side_stream)
         self._prefetched = None     # (key, marched tensors) of a march started for the following call
         self._stale_params = self._stale_moments = False
         self.post_refresh = None    # optional callable run right after every density-grid refresh
@@ -545,7 +546,7 @@ class TrainStep:
         def march_on_side(*a):
             main = torch.cuda.current_stream()
             if self._side is None:
-                self._side = torch.cuda.Stream()
+                self._side = self._make_side_stream()
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 out = march(*a)
@@ -744,6 +745,24 @@ class TrainStep:
         self.last = {'mse': mse, 'wavelet_reg': reg, 'M': M, 'found_inf': found_inf, 'image': pred, 'ws': ws,
                      'depth': depth, 'counter': counter, 'lr': lr_t}
         return loss
+
+    def _make_side_stream(self):
+        """The stream of the next batch's march + tile sort.  side_cus > 0: confined to that many compute units spread
+        evenly over the device (tnl_stream_create_cu_mask), else an ordinary stream."""
+        n = int(self.side_cus)
+        if n <= 0:
+            return torch.cuda.Stream()
+        total = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        n = min(n, total)
+        words = (total + 31) // 32
+        mask = (C_.c_uint32 * words)()
+        for k in range(n):
+            cu = (k * total) // n
+            mask[cu // 32] |= 1 << (cu % 32)
+        out = C_.c_void_p()
+        L.check(L.lib().tnl_stream_create_cu_mask(mask, L.u32(words), C_.byref(out)), "stream_create_cu_mask")
+        self._side_raw = out
+        return torch.cuda.ExternalStream(out.value, device=self.dev)
 
     def _prefetch_under_adam(self, next_rays):
         """Where the next batch's march + tile sort go: right after the field backward (default), or together with the
