@@ -326,7 +326,8 @@ def test_march_fused_tile_count_equals_sort(cuda):
     aabb = torch.tensor([-bound] * 3 + [bound] * 3, device=cuda)
     nears, fars = raymarching.near_far_from_aabb(o, d, aabb, 0.2)
     noise = torch.from_numpy(rng.random(N).astype(np.float32)).to(cuda)
-    nb = 3 * (R // 32) * (R // 8)
+    SUBS = 4                                # BIN_SUBS of csrc/bin_common.h: sub-bins per (plane, tile)
+    nb = 3 * (R // 32) * (R // 8) * SUBS
     ent0 = 3 * (nb + 1) + 1 + (nb + 1023) // 1024 + 8
 
     def parse(ws):

@@ -1077,7 +1077,7 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
                                  uint32_t workspace_words, uint32_t binR, void* sort_workspace, void* stream) {
   if (sort_workspace != nullptr) {   // the tile sort's bin counts (first nb + 1 ints of its workspace) start from zero
     if (binR == 0 || binR % TSX != 0) return (int)hipErrorInvalidValue;
-    const size_t nbins = 3ull * (binR / TSX) * (binR / TSY);
+    const size_t nbins = 3ull * (binR / TSX) * (binR / TSY) * BIN_SUBS;
     hipError_t e = hipMemsetAsync(sort_workspace, 0, (nbins + 1) * sizeof(int), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }

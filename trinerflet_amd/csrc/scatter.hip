@@ -159,7 +159,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
     ty = rem / TNX; tx = rem - ty * TNX;
   }
   const int bin = p * TNX * TNY + ty * TNX + tx;
-  const int beg = offsets[bin], end = offsets[bin + 1];
+  const int beg = offsets[bin * BIN_SUBS], end = offsets[(bin + 1) * BIN_SUBS];   // all sub-bins of the tile
   const int x_lo = tx * TSX, y_lo = ty * TSY;
   // channel-major output addressing: row stride, slice stride and origin of the (possibly compact) window
   const int ow = roi.rw ? roi.rw : R, oh = roi.rw ? roi.rh : R;
@@ -356,7 +356,7 @@ extern "C" {
 // bytes of scratch: counts, offsets(+1), cursor: one int per (plane, tile) each; entries: 12 * M uint32
 uint64_t tnl_plane_grad_binned_workspace(uint32_t M, uint32_t R) {
   if (R % TSX != 0) return 0;
-  const uint64_t nb = 3ull * (R / TSX) * (R / TSY);
+  const uint64_t nb = 3ull * (R / TSX) * (R / TSY) * BIN_SUBS;
   return (3 * nb + 8 + (nb + 1023) / 1024 + 8) * 4 + 12ull * M * 4;
 }
 
@@ -376,7 +376,7 @@ struct SortWs {
 static SortWs sort_ws(void* workspace, uint32_t R) {
   SortWs w;
   const int TNX = R / TSX, TNY = R / TSY;
-  w.nb = 3 * TNX * TNY;
+  w.nb = 3 * TNX * TNY * BIN_SUBS;   // counters: BIN_SUBS sub-bins per (plane, tile), see bin_common.h
   w.nblk = (w.nb + 1023) / 1024;
   w.counts = reinterpret_cast<int*>(workspace);
   w.offsets = w.counts + w.nb + 1;
@@ -437,7 +437,7 @@ int tnl_plane_grad_reduce(const void* dfeat_half, const float* xyz, float bound,
   const int* offsets = w.offsets;
   const uint32_t* entries = w.entries;
   const _Float16* df = reinterpret_cast<const _Float16*>(dfeat_half);
-  const int ntiles = roi.rw ? 3 * (roi.rw / TSX) * (roi.rh / TSY) : w.nb;
+  const int ntiles = roi.rw ? 3 * (roi.rw / TSX) * (roi.rh / TSY) : w.nb / BIN_SUBS;
   if (C == 16)
     hipLaunchKernelGGL(k_tile_accumulate<16>, dim3(ntiles), dim3(NT), 0, st, df, M, xyz, bound, (int)R, TNX, TNY,
                        offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
