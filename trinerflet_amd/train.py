@@ -84,7 +84,11 @@ class _Flat:
         best_t, best = t0, None
         hold = []
         if gbs(t0) < good_gbs:
+            need = (spacing + 2) * self.data.numel() * 4
             for _ in range(candidates):
+                if torch.cuda.mem_get_info(self.data.device)[0] < need:      # never search a device into OOM
+                    report["stopped"] = "free memory"
+                    break
                 cand = torch.empty_like(self.data)
                 hold.append(cand)
                 hold.extend(torch.empty_like(self.data) for _ in range(spacing))     # spacers: move on in address space
