@@ -303,6 +303,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(model, ts, bitfield, batches[(args.warmup + i) % nb], mean_count, batches[(args.warmup + i + 1) % nb])
+    # the optimiser work TrainStep deferred during these steps (coefficients outside the occupancy window's footprint,
+    # replayed in one pass per flush) belongs to them: it is done before the clock stops
+    ts.flush_deferred()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

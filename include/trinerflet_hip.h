@@ -429,6 +429,29 @@ TNL_API int tnl_adam_l1_step_rect(float *p, float *grad, float *m, float *v, uin
                                   const float *opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
                                   const float *inv_scale_dev, float l1_coef, const float *found_inf,
                                   float *abs_sum, void *stream);
+/* Live / deferred split of a level's optimiser pass between two density-grid refreshes (TrainStep; no reference
+ * counterpart -- the reference runs torch.optim.Adam over every coefficient every step, main_nerf.py:119).
+ * A coefficient outside `live` (8 host ints like `rect`: the footprint the windowed plane rebuild reads united with
+ * the gradient's rectangle) is neither read nor reached by a data gradient until the window changes, and its update
+ * p, m, v <- adam(p, l1 sign(p), m, v) depends on nothing but its own three numbers and the step's scalars:
+ *   tnl_adam_l1_step_live   tnl_adam_l1_step_rect restricted to the live rectangle (the gradient is read inside
+ *                           grad_rect, 0 elsewhere); nothing outside `live` is touched.
+ *   tnl_adam_record_step    ring[slot] (4 floats per slot, 16 slots) = this step's {lr / (1 - beta1^t),
+ *                           sqrt(1 - beta2^t), found_inf != 0} from the same device counter, BEFORE the step's
+ *                           epilogue advances it.
+ *   tnl_adam_l1_catchup     replays ring[0 .. count) (count <= 16), oldest first, for every coefficient outside
+ *                           `live`: one 24-byte pass instead of `count`; abs_sums[r] += sum |p| as step r saw it.
+ * The same operations in the same order as the per-step pass: p, m, v are bit-identical after the catch-up. */
+TNL_API int tnl_adam_l1_step_live(float *p, float *grad, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n,
+                                  uint32_t spp, uint32_t s0, const int32_t *live, const int32_t *grad_rect, float lr,
+                                  const float *opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
+                                  const float *inv_scale_dev, float l1_coef, const float *found_inf,
+                                  float *abs_sum, void *stream);
+TNL_API int tnl_adam_record_step(float *ring, int32_t slot, float lr, const float *opt_step_dev, float beta1,
+                                 float beta2, const float *found_inf, void *stream);
+TNL_API int tnl_adam_l1_catchup(float *p, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n, uint32_t spp,
+                                uint32_t s0, const int32_t *live, const float *ring, int32_t count, float beta1,
+                                float beta2, float eps, float l1_coef, float *abs_sums, void *stream);
 /* Dynamic LDS (bytes, <= 64 KB) reserved by every workgroup of the FOLLOWING tnl_adam_l1_* launches of this process:
  * limits the pass to 160 KB / bytes workgroups per CU so that kernels of another stream (the next batch's march and
  * tile sort) find wave slots underneath it.  0 (default) = no limit.  Host-side state, not thread-safe. */

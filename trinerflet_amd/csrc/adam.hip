@@ -185,6 +185,170 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Live / deferred split of one level's pass (TrainStep between two density-grid refreshes).
+// Outside the occupancy window's footprint a coefficient is neither read by the windowed plane rebuild nor reached by
+// a data gradient: its update p, m, v <- adam(p, l1 * sign(p), m, v) is a closed recurrence in its own three
+// numbers and the step's two scalars.  k_adam_l1_live therefore updates only the live rectangle (28 B per coefficient
+// of the window instead of 24-28 B per coefficient of the level), k_adam_record keeps each step's scalars
+// (step size, bias correction, GradScaler skip) in a device ring, and k_adam_l1_catchup later replays the pending
+// steps for everything outside the rectangle in registers: one 24-byte pass per flush instead of one per step, the
+// same operations in the same order -- bit-identical p, m, v.
+// ---------------------------------------------------------------------------------------------
+struct AdamStepRec { float step_size, bias2_sqrt, skip, pad; };
+constexpr int ADAM_REPLAY_MAX = 16;
+
+__global__ void k_adam_record(AdamStepRec* __restrict__ ring, int slot, float lr, const float* __restrict__ opt_step_dev,
+                              float beta1, float beta2, const float* __restrict__ found_inf) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double t = (double)opt_step_dev[0] + 1.0;          // k_adam_l1's expressions
+  AdamStepRec r;
+  r.step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+  r.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
+  r.skip = (found_inf != nullptr && found_inf[0] != 0.f) ? 1.f : 0.f;
+  r.pad = 0.f;
+  ring[slot] = r;
+}
+
+__device__ __forceinline__ int rect_plane(const AdamRect& rc, uint32_t sb) {
+  const int sl = (int)(rc.bands == 3 ? (sb * 0xAAABu) >> 17 : sb) + rc.s0;   // exact sb / 3 for sb < 98304
+  return sl >= 2 * rc.spp ? 2 : (sl >= rc.spp ? 1 : 0);
+}
+
+// live: iteration domain (per plane origin, common size); gr: where the gradient is stored (0 elsewhere)
+__global__ void __launch_bounds__(256)
+k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+               uint32_t rows, AdamArgs a, const float* __restrict__ inv_scale_dev, const float* __restrict__ found_inf,
+               float* __restrict__ abs_sum, const float* __restrict__ opt_step_dev, AdamRect live, AdamRect gr) {
+  {
+    __shared__ float bc[2];
+    if (threadIdx.x == 0) {
+      const double t = (double)opt_step_dev[0] + 1.0;
+      bc[0] = (float)((double)a.step_size / (1.0 - pow((double)a.beta1, t)));
+      bc[1] = (float)sqrt(1.0 - pow((double)a.beta2, t));
+    }
+    __syncthreads();
+    a.step_size = bc[0];
+    a.bias2_sqrt = bc[1];
+  }
+  if (inv_scale_dev != nullptr) a.inv_scale *= inv_scale_dev[0];
+  const bool skip = found_inf != nullptr && found_inf[0] != 0.f;
+  float acc = 0.f;
+  const uint32_t w4 = (uint32_t)live.rw / 4;
+  const uint32_t total = rows * w4;
+  const uint32_t chunk = (total + gridDim.x - 1) / gridDim.x;
+  const uint32_t c0 = blockIdx.x * chunk, c1 = min(c0 + chunk, total);
+  struct Quad { float4 pp, gg, mm, vv; uint64_t e; };
+  auto load = [&](uint32_t i, Quad& q) {
+    const uint32_t row = i / w4, c4 = i - row * w4;
+    const uint32_t sb = row / (uint32_t)live.rh, r = row - sb * (uint32_t)live.rh;
+    const int pl = rect_plane(live, sb);
+    const int x = live.rx[pl] + 4 * (int)c4, y = live.ry[pl] + (int)r;
+    q.e = ((uint64_t)sb << (2 * live.log2n)) + ((uint64_t)y << live.log2n) + (uint64_t)x;
+    q.pp = ld_nt(reinterpret_cast<const float4*>(p + q.e));
+    q.gg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!skip) {
+      const bool inside = x >= gr.rx[pl] && x < gr.rx[pl] + gr.rw && y >= gr.ry[pl] && y < gr.ry[pl] + gr.rh;
+      if (inside) q.gg = ld_nt(reinterpret_cast<const float4*>(g + q.e));
+      q.mm = ld_nt(reinterpret_cast<const float4*>(m + q.e));
+      q.vv = ld_nt(reinterpret_cast<const float4*>(v + q.e));
+    }
+  };
+  auto finish = [&](Quad& q) {
+    if (!skip) {
+      adam1(q.pp.x, q.gg.x, q.mm.x, q.vv.x, a, acc);
+      adam1(q.pp.y, q.gg.y, q.mm.y, q.vv.y, a, acc);
+      adam1(q.pp.z, q.gg.z, q.mm.z, q.vv.z, a, acc);
+      adam1(q.pp.w, q.gg.w, q.mm.w, q.vv.w, a, acc);
+      st_nt(reinterpret_cast<float4*>(p + q.e), q.pp);
+      st_nt(reinterpret_cast<float4*>(m + q.e), q.mm);
+      st_nt(reinterpret_cast<float4*>(v + q.e), q.vv);
+    } else {
+      acc += fabsf(q.pp.x) + fabsf(q.pp.y) + fabsf(q.pp.z) + fabsf(q.pp.w);
+    }
+  };
+  uint32_t i = c0 + threadIdx.x;
+  for (; i + 256 < c1; i += 512) {
+    Quad q0, q1;
+    load(i, q0); load(i + 256, q1);
+    finish(q0); finish(q1);
+  }
+  for (; i < c1; i += 256) { Quad q; load(i, q); finish(q); }
+  if (abs_sum != nullptr) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(abs_sum, part[0] + part[1] + part[2] + part[3]);
+  }
+}
+
+// Replays `count` (<= ADAM_REPLAY_MAX) recorded steps, oldest first, for every coefficient of the level OUTSIDE
+// the live rectangle; abs_sums[r] += sum |p| as step r saw it (the L1 value's deferred share).  ALU-bound (count x two
+// divisions and a square root per coefficient against 24 bytes): two float4 per thread are in flight, the record loop
+// is a real loop (one scalar load per record and 8 coefficients), the per-record |p| sums live in per-thread LDS slots.
+__global__ void __launch_bounds__(256)
+k_adam_l1_catchup(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, uint64_t n, AdamArgs a,
+                  const AdamStepRec* __restrict__ ring, int count, float* __restrict__ abs_sums, AdamRect live) {
+  __shared__ float s_acc[ADAM_REPLAY_MAX][256];
+  const bool sums = abs_sums != nullptr;
+  if (sums)
+    for (int r = 0; r < ADAM_REPLAY_MAX; r++) s_acc[r][threadIdx.x] = 0.f;
+  const uint64_t n4 = n / 4;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
+  const uint64_t chunk = (n4 + gridDim.x - 1) / gridDim.x;
+  const uint64_t c0 = (uint64_t)blockIdx.x * chunk, c1 = min(c0 + chunk, n4);
+  const int nm = (1 << live.log2n) - 1;
+  auto outside = [&](uint64_t i) {
+    const uint64_t e = i * 4;
+    const int c = (int)(e & nm), r0 = (int)((e >> live.log2n) & nm);
+    const int pl = rect_plane(live, (uint32_t)(e >> (2 * live.log2n)));
+    return !(c >= live.rx[pl] && c < live.rx[pl] + live.rw && r0 >= live.ry[pl] && r0 < live.ry[pl] + live.rh);
+  };
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (uint64_t i = c0 + threadIdx.x; i < c1; i += 512) {
+    const uint64_t j = i + 256;
+    const bool oi = outside(i), oj = j < c1 && outside(j);
+    if (!oi && !oj) continue;
+    // a slot that lies inside the rectangle (or past the chunk) is carried along as zeros: p = m = v = 0 stays 0
+    float4 pi = zero, mi = zero, vi = zero, pj = zero, mj = zero, vj = zero;
+    if (oi) { pi = ld_nt(p4 + i); mi = ld_nt(m4 + i); vi = ld_nt(v4 + i); }
+    if (oj) { pj = ld_nt(p4 + j); mj = ld_nt(m4 + j); vj = ld_nt(v4 + j); }
+    for (int r = 0; r < count; r++) {
+      const AdamStepRec rec = ring[r];                      // uniform: a scalar load
+      if (sums)
+        s_acc[r][threadIdx.x] += fabsf(pi.x) + fabsf(pi.y) + fabsf(pi.z) + fabsf(pi.w) +
+                                 fabsf(pj.x) + fabsf(pj.y) + fabsf(pj.z) + fabsf(pj.w);
+      if (rec.skip != 0.f) continue;                        // GradScaler skipped this step: nothing moves
+      a.step_size = rec.step_size;
+      a.bias2_sqrt = rec.bias2_sqrt;
+      float unused = 0.f;
+      adam1(pi.x, 0.f, mi.x, vi.x, a, unused); adam1(pi.y, 0.f, mi.y, vi.y, a, unused);
+      adam1(pi.z, 0.f, mi.z, vi.z, a, unused); adam1(pi.w, 0.f, mi.w, vi.w, a, unused);
+      adam1(pj.x, 0.f, mj.x, vj.x, a, unused); adam1(pj.y, 0.f, mj.y, vj.y, a, unused);
+      adam1(pj.z, 0.f, mj.z, vj.z, a, unused); adam1(pj.w, 0.f, mj.w, vj.w, a, unused);
+    }
+    if (oi) { st_nt(p4 + i, pi); st_nt(m4 + i, mi); st_nt(v4 + i, vi); }
+    if (oj) { st_nt(p4 + j, pj); st_nt(m4 + j, mj); st_nt(v4 + j, vj); }
+  }
+  if (sums) {
+    __shared__ float part[ADAM_REPLAY_MAX][4];
+    for (int r = 0; r < count; r++) {
+      float x = s_acc[r][threadIdx.x];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+      if ((threadIdx.x & 63) == 0) part[r][threadIdx.x >> 6] = x;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < count) atomicAdd(abs_sums + threadIdx.x, part[threadIdx.x][0] + part[threadIdx.x][1] +
+                                                                     part[threadIdx.x][2] + part[threadIdx.x][3]);
+  }
+}
+
 }  // namespace
 
 // Dynamic LDS reserved (not used) by every workgroup of the following Adam launches: caps how many of them a CU holds
@@ -268,4 +432,69 @@ extern "C" int tnl_adam_l1_step_rect(float* p, float* grad, float* m, float* v, 
   rc.bands = (int)bands; rc.spp = (int)spp; rc.s0 = (int)s0;
   return adam_launch(p, grad, m, v, (uint64_t)S * bands * n * n, lr, 1.0f, beta1, beta2, eps, inv_scale, inv_scale_dev,
                      l1_coef, found_inf, abs_sum, 0, opt_step_dev, stream, &rc);
+}
+
+static int fill_rect(AdamRect& rc, const int32_t* h, uint32_t n, uint32_t bands, uint32_t spp, uint32_t s0) {
+  for (int k = 0; k < 3; k++) { rc.rx[k] = h[k]; rc.ry[k] = h[3 + k]; }
+  rc.rw = h[6]; rc.rh = h[7];
+  if (rc.rw % 4 != 0 || rc.rw <= 0 || rc.rh <= 0) return 1;
+  for (int k = 0; k < 3; k++)
+    if (rc.rx[k] % 4 != 0 || rc.rx[k] < 0 || rc.ry[k] < 0 || rc.rx[k] + rc.rw > (int)n || rc.ry[k] + rc.rh > (int)n)
+      return 1;
+  rc.log2n = 0;
+  while ((1u << rc.log2n) < n) rc.log2n++;
+  rc.bands = (int)bands; rc.spp = (int)spp; rc.s0 = (int)s0;
+  return 0;
+}
+
+extern "C" int tnl_adam_record_step(float* ring, int32_t slot, float lr, const float* opt_step_dev, float beta1,
+                                    float beta2, const float* found_inf, void* stream) {
+  if (ring == nullptr || opt_step_dev == nullptr || slot < 0 || slot >= ADAM_REPLAY_MAX) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_adam_record, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<AdamStepRec*>(ring),
+                     (int)slot, lr, opt_step_dev, beta1, beta2, found_inf);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tnl_adam_l1_step_live(float* p, float* grad, float* m, float* v, uint32_t S, uint32_t bands, uint32_t n,
+                                     uint32_t spp, uint32_t s0, const int32_t* live_host, const int32_t* grad_rect_host,
+                                     float lr, const float* opt_step_dev, float beta1, float beta2, float eps,
+                                     float inv_scale, const float* inv_scale_dev, float l1_coef, const float* found_inf,
+                                     float* abs_sum, void* stream) {
+  if (opt_step_dev == nullptr || live_host == nullptr || grad_rect_host == nullptr || n == 0 || (n & (n - 1)) != 0 ||
+      n % 4 != 0 || bands == 0 || spp == 0 || S == 0)
+    return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
+       reinterpret_cast<uintptr_t>(v)) & 15)
+    return (int)hipErrorInvalidValue;
+  AdamRect live, gr;
+  if (fill_rect(live, live_host, n, bands, spp, s0) || fill_rect(gr, grad_rect_host, n, bands, spp, s0))
+    return (int)hipErrorInvalidValue;
+  const uint64_t rows = (uint64_t)S * bands * live.rh, total = rows * (live.rw / 4);
+  if (total >= (1ull << 32)) return (int)hipErrorInvalidValue;
+  AdamArgs a{lr, 1.0f, beta1, beta2, eps, inv_scale, l1_coef};
+  uint64_t blocks = (total + 511) / 512;
+  if (blocks > TNL_ADAM_BLOCKS) blocks = TNL_ADAM_BLOCKS;
+  hipLaunchKernelGGL(k_adam_l1_live, dim3((unsigned)blocks), dim3(256), g_lds_reservation, (hipStream_t)stream, p, grad,
+                     m, v, (uint32_t)rows, a, inv_scale_dev, found_inf, abs_sum, opt_step_dev, live, gr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tnl_adam_l1_catchup(float* p, float* m, float* v, uint32_t S, uint32_t bands, uint32_t n, uint32_t spp,
+                                   uint32_t s0, const int32_t* live_host, const float* ring, int32_t count, float beta1,
+                                   float beta2, float eps, float l1_coef, float* abs_sums, void* stream) {
+  if (count == 0) return 0;
+  if (ring == nullptr || live_host == nullptr || count < 0 || count > ADAM_REPLAY_MAX || n == 0 || (n & (n - 1)) != 0 ||
+      n % 4 != 0 || bands == 0 || spp == 0 || S == 0)
+    return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
+    return (int)hipErrorInvalidValue;
+  AdamRect live;
+  if (fill_rect(live, live_host, n, bands, spp, s0)) return (int)hipErrorInvalidValue;
+  const uint64_t total = (uint64_t)S * bands * n * n;
+  AdamArgs a{0.f, 1.0f, beta1, beta2, eps, 1.0f, l1_coef};
+  uint64_t blocks = (total / 4 + 255) / 256;
+  if (blocks > 4 * TNL_ADAM_BLOCKS) blocks = 4 * TNL_ADAM_BLOCKS;
+  hipLaunchKernelGGL(k_adam_l1_catchup, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, total, a,
+                     reinterpret_cast<const AdamStepRec*>(ring), (int)count, abs_sums, live);
+  return (int)hipGetLastError();
 }

@@ -9,12 +9,30 @@ struct AdamArgs {
 };
 
 __device__ __forceinline__ float adam_sgn(float x) { return (x > 0.f) - (x < 0.f); }
+// c * sign(x) for c >= 0 (sign(+-0) = 0): the magnitude with x's sign bit, or zero -- three instructions
+__device__ __forceinline__ float adam_signed(float c, float x) { return x == 0.f ? 0.f : copysignf(c, x); }
 
+// x / y for finite, non-zero y: hardware reciprocal and one Newton step on the quotient (within 1 ulp of the correctly
+// rounded quotient, 4 instructions instead of the 10 of the IEEE sequence).  The replay of deferred steps
+// (k_adam_l1_catchup) is ALU-bound -- two divisions and a square root per coefficient and step -- and every Adam kernel
+// of this library must compute the same bits, so all of them divide this way; denominators here are
+// sqrt(1 - beta2^t) in (0, 1] and sqrt(v) / that + eps >= eps > 0.
+__device__ __forceinline__ float adam_div(float x, float y) {
+  const float r = __builtin_amdgcn_rcpf(y);
+  const float q = x * r;
+  return fmaf(fmaf(-y, q, x), r, q);
+}
+
+// Every operation is rounded on its own (no multiply-add contraction inside this function beyond the two explicit
+// ones of adam_div), so the update does not depend on which kernel it was inlined into -- the live-rectangle pass and
+// the replay of deferred steps (k_adam_l1_live, k_adam_l1_catchup) must reproduce the whole-level pass bit for bit.
+// sqrt is the hardware's (1 ulp).
 __device__ __forceinline__ void adam1(float& p, float g_in, float& m, float& v, const AdamArgs& a, float& abs_acc) {
+#pragma clang fp contract(off)
   abs_acc += fabsf(p);
-  const float g = g_in * a.inv_scale + a.l1_coef * adam_sgn(p);
+  const float g = g_in * a.inv_scale + adam_signed(a.l1_coef, p);
   m = m + (g - m) * (1.f - a.beta1);
   v = v * a.beta2 + (1.f - a.beta2) * g * g;
-  const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
-  p = p - a.step_size * (m / denom);
+  const float denom = adam_div(__builtin_amdgcn_sqrtf(v), a.bias2_sqrt) + a.eps;
+  p = p - a.step_size * adam_div(m, denom);
 }

@@ -114,7 +114,8 @@ class TrainStep:
     def __init__(self, model, lr=1e-2, wavelet_regularization=0.4, iters=30000, warmup_steps=0,
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
-                 dist_mode=None, process_group=None, binned=True, fuse_adam=False, use_roi=True, tune_placement=None):
+                 dist_mode=None, process_group=None, binned=True, fuse_adam=False, use_roi=True, tune_placement=None,
+                 defer_adam=None):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
@@ -164,6 +165,22 @@ class TrainStep:
         self.placement = None
         if (tune_placement if tune_placement is not None else self.coef.total >= 64_000_000) and self.coef.total > 0:
             self.placement = self.coef.tune_placement(self._time_adam_pass)
+        # defer_adam: between two density-grid refreshes the coefficients outside the occupancy window's footprint are
+        # neither read (windowed plane rebuild) nor reached by a data gradient, and their Adam(+L1) update is a closed
+        # recurrence in their own p, m, v and the step's scalars.  The per-step pass then covers only the live
+        # rectangle of each level; the rest is replayed in registers, all pending steps in one pass, before anything
+        # reads it (next refresh, checkpoint, evaluation, flush_deferred()): bit-identical p, m, v, 1/16 of the bytes.
+        # The L1 value of the deferred coefficients arrives with the replay (deferred_reg / pop_deferred_reg()), so a
+        # step's returned loss carries the live rectangle's share only.  Default: on for large coefficient sets.
+        self.defer_adam = (defer_adam if defer_adam is not None else self.coef.total >= 64_000_000) and self._rect_ok
+        self._ring = torch.zeros(16 * 4, dtype=torch.float32, device=dev)      # csrc/adam.hip AdamStepRec[16]
+        self._ring_sums = torch.zeros(16, dtype=torch.float32, device=dev)
+        self._pending = 0          # recorded steps not yet applied outside the live rectangles
+        self._live = None          # per level the live rectangle (8 ints) or None; fixed while steps are pending
+        self._defer_ctx = None     # (s0, s1, l1) of the pending steps
+        self.deferred_reg = torch.zeros((), dtype=torch.float32, device=dev)   # replayed steps' L1 value, summed
+        self.deferred_steps = 0    # counters for reports
+        self.deferred_flushes = 0
         # GradScaler state (torch.cuda.amp.GradScaler defaults: 2^16, x2 every 2000 clean steps, x0.5 on inf)
         self.scale = torch.full((1,), init_scale if fp16 else 1.0, dtype=torch.float32, device=dev)
         self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -224,6 +241,7 @@ class TrainStep:
     def invalidate_roi(self):
         """Call after changing model.density_bitfield by hand (update_extra_state inside step() is tracked): the
         occupancy window is recomputed and a march already started for the following batch is dropped."""
+        self.flush_deferred()
         self._roi_valid = False
         self._drop_prefetch()
 
@@ -311,6 +329,8 @@ class TrainStep:
         enc = self.enc
         fast = (self.J > 0 and enc.plane_dtype == torch.float16 and self.C % 8 == 0 and self.R % 16 == 0)
         roi = roi and self._roi is not None and self._tm_full is not None
+        if not roi:
+            self.flush_deferred()     # whole planes read every coefficient
         with torch.no_grad():
             wins = self._forward_windows() if roi else [None] * self.J
             if self.dist_mode == "sharded":
@@ -570,6 +590,9 @@ class TrainStep:
             self._drop_prefetch()                       # other rays than announced (or a refresh): marched for nothing
             if self.overlap_march and not refresh and model.mean_count > 0:
                 marched, side = march_on_side(), self._side
+        if self._pending and (refresh or not self._roi_valid):
+            self.flush_deferred()
+            self._mark("adam_catchup")
         if self.use_roi and not refresh and not self._roi_valid:
             self._roi, self._roi_valid = self._compute_roi(), True
         # where the next batch's side work starts (see _prefetch_mode): "start" = here, "fwd" = before the field forward,
@@ -697,7 +720,10 @@ class TrainStep:
                 try:
                     if under_adam:
                         self._prefetch_next(next_rays, march_on_side)
-                    self._adam_levels(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
+                    if self.defer_adam and rects is not None and not refresh:
+                        self._adam_levels_live(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
+                    else:
+                        self._adam_levels(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
                 finally:
                     if under_adam:
                         lib.tnl_adam_set_lds_reservation(L.u32(0))   # process-global: never leave it set
@@ -829,6 +855,114 @@ class TrainStep:
             return (~torch.isfinite(probe)).to(torch.float32)
         return found
 
+    # ------------------------------------------------------------------------------------------
+    # live / deferred split of the coefficient pass (defer_adam)
+    def _live_rects(self, rects):
+        """Per level the rectangle (per plane origin, common size, multiples of 16; the level's own coordinates) holding
+        everything the windowed rebuild reads -- the level's output window halved and grown by 8 (the kernels stage a
+        4-coefficient halo) -- and everything the windowed adjoint writes (rects).  None: the whole level stays live."""
+        wins = self._forward_windows()
+        live = [None] * self.J
+        for lvl in range(self.J):
+            w, r = wins[lvl], rects[lvl]
+            if w is None or r is None:
+                continue
+            n = self.coef.params[lvl].shape[-1]
+
+            def span(o, size, ro, rsize):
+                lo = min(ro, max(o // 2 - 8, 0)) // 16 * 16
+                hi = min((max(ro + rsize, (o + size) // 2 + 8) + 15) // 16 * 16, n)
+                return lo, hi
+            xs = [span(w[p], w[6], r[p], r[6]) for p in range(3)]
+            ys = [span(w[3 + p], w[7], r[3 + p], r[7]) for p in range(3)]
+            rw = max(h - l for l, h in xs)
+            rh = max(h - l for l, h in ys)
+            if rw * rh > 0.8 * n * n:
+                continue
+            live[lvl] = [min(l, n - rw) for l, _ in xs] + [min(l, n - rh) for l, _ in ys] + [rw, rh]
+        return live
+
+    def _adam_levels_live(self, lr_t, l1, found_inf, inv_scale, s0, s1, rects):
+        """_adam_levels over the live rectangles only; the step's scalars are recorded for the replay."""
+        lib = L.lib()
+        ns = s1 - s0
+        if self._pending == 0:
+            self._live = self._live_rects(rects)
+            self._defer_ctx = (s0, s1, l1)
+        assert self._defer_ctx == (s0, s1, l1)
+        if any(lv is not None for lv in self._live):
+            L.check(lib.tnl_adam_record_step(L.ptr(self._ring), L.i32(self._pending), L.f32(lr_t), L.ptr(self.opt_steps),
+                                             L.f32(self.b1), L.f32(self.b2), L.ptr(found_inf), L.stream()),
+                    "adam_record_step")
+        for lvl in range(self.J):
+            n = self.coef.params[lvl].shape[-1]
+            base = self.coef.offsets[lvl] + s0 * 3 * n * n
+            cf = self.coef
+            if self._live[lvl] is None:
+                L.check(lib.tnl_adam_l1_step_rect(
+                    L.ptr(cf.data[base:]), L.ptr(cf.grad[base:]), L.ptr(cf.m[base:]), L.ptr(cf.v[base:]), L.u32(ns),
+                    L.u32(3), L.u32(n), L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*rects[lvl]), L.f32(lr_t),
+                    L.ptr(self.opt_steps), L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0),
+                    L.ptr(inv_scale), L.f32(l1), L.ptr(found_inf), L.ptr(self.abs_sum), L.stream()),
+                    "adam_l1_step_rect")
+            else:
+                L.check(lib.tnl_adam_l1_step_live(
+                    L.ptr(cf.data[base:]), L.ptr(cf.grad[base:]), L.ptr(cf.m[base:]), L.ptr(cf.v[base:]), L.u32(ns),
+                    L.u32(3), L.u32(n), L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*self._live[lvl]),
+                    (C_.c_int32 * 8)(*rects[lvl]), L.f32(lr_t), L.ptr(self.opt_steps), L.f32(self.b1), L.f32(self.b2),
+                    L.f32(self.eps), L.f32(1.0), L.ptr(inv_scale), L.f32(l1), L.ptr(found_inf), L.ptr(self.abs_sum),
+                    L.stream()), "adam_l1_step_live")
+        n0 = self.ll.params[0].shape[-1]
+        ll = self.ll
+        off = s0 * n0 * n0
+        L.check(lib.tnl_adam_l1_step_rect(
+            L.ptr(ll.data[off:]), L.ptr(ll.grad[off:]), L.ptr(ll.m[off:]), L.ptr(ll.v[off:]), L.u32(ns), L.u32(1),
+            L.u32(n0), L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*rects[0]), L.f32(lr_t), L.ptr(self.opt_steps),
+            L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0), L.ptr(inv_scale), L.f32(0.0),
+            L.ptr(found_inf), L.ptr(None), L.stream()), "adam_l1_step_rect")
+        if any(lv is not None for lv in self._live):
+            self._pending += 1
+            self.deferred_steps += 1
+            if self._pending == 16:
+                self.flush_deferred()
+
+    def flush_deferred(self):
+        """Replays the pending steps for the coefficients outside the live rectangles (no-op when none are pending).
+        Called by step() before a refresh / a window change, by rebuild_planes() of whole planes, and by anything that
+        reads the coefficient or moment arrays (checkpoints, evaluation, sync_sharded_parameters)."""
+        if self._pending == 0:
+            return
+        lib = L.lib()
+        s0, s1, l1 = self._defer_ctx
+        ns = s1 - s0
+        self._ring_sums.zero_()
+        for lvl in range(self.J):
+            if self._live[lvl] is None:
+                continue
+            n = self.coef.params[lvl].shape[-1]
+            base = self.coef.offsets[lvl] + s0 * 3 * n * n
+            cf = self.coef
+            L.check(lib.tnl_adam_l1_catchup(
+                L.ptr(cf.data[base:]), L.ptr(cf.m[base:]), L.ptr(cf.v[base:]), L.u32(ns), L.u32(3), L.u32(n),
+                L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*self._live[lvl]), L.ptr(self._ring), L.i32(self._pending),
+                L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(l1), L.ptr(self._ring_sums if l1 > 0 else None),
+                L.stream()), "adam_l1_catchup")
+        if l1 > 0:
+            self.deferred_reg += l1 * self._ring_sums[:self._pending].sum()
+        self._pending = 0
+        self._live = None
+        self.deferred_flushes += 1
+
+    def pop_deferred_reg(self):
+        """The L1 value (wavelet regulariser) of the replayed steps' deferred coefficients, summed over those steps
+        and, in the sharded mode, over the ranks; the accumulator restarts from zero.  Add it to a sum of step losses."""
+        self.flush_deferred()
+        out = self.deferred_reg.clone()
+        self.deferred_reg.zero_()
+        if self.world > 1 and self.dist_mode == "sharded":
+            dist.all_reduce(out, group=self.pg)
+        return out
+
     def _adam_sharded(self, lr_t, l1, found_inf, inv_scale, s0, s1):
         """Each rank updates only its (plane, channel) slices; afterwards parameters are all-gathered so the
         replicas stay identical (needed for checkpoints; the next rebuild_planes only reads the own slices)."""
@@ -845,7 +979,9 @@ class TrainStep:
         """All-gather the slice-sharded coefficients ("sharded" mode: a rank's Adam pass only updates its own
         (plane, channel) slices, the others go stale until this runs).  A collective: every rank must call it, in the
         same order.  moments=True also gathers exp_avg / exp_avg_sq (needed for a full checkpoint).  No-op when
-        nothing was stepped since the last call."""
+        nothing was stepped since the last call.  In every mode it first applies the deferred part of the coefficient
+        pass (flush_deferred): after it the parameter and moment arrays are what a per-step pass would have left."""
+        self.flush_deferred()
         if self.dist_mode != "sharded":
             return
         need_p = self._stale_params

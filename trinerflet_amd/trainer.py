@@ -189,6 +189,7 @@ class Trainer:
                                 next_rays=None if nxt is None else (nxt[0], nxt[1]))
             total += loss.detach()
             cur = nxt
+        total += self.ts.pop_deferred_reg()     # L1 value of the coefficients whose pass TrainStep deferred (defer_adam)
         avg = float(total) / steps                                                  # the epoch's only read-back
         self.stats["loss"].append(avg)
         self.log(f"==> Finished Epoch {self.epoch}, loss {avg:.6f}")
@@ -460,6 +461,8 @@ class Trainer:
         """load_state_dict with the reference's tolerance (strict=False: missing new wavelet levels stay at their
         zero init, utils.py:1481) plus a shape filter: a tensor whose shape changed with the resolution is skipped
         with a warning instead of raising."""
+        if hasattr(self, "ts"):
+            self.ts.flush_deferred()    # pending deferred updates belong to the values about to be replaced
         own = self.model.state_dict()
         ok = {k: v for k, v in sd.items() if k in own and tuple(own[k].shape) == tuple(v.shape)}
         skipped = [k for k in sd if k not in ok]
