@@ -149,12 +149,13 @@ def pmc_traffic_live(workload, launches_per_step):
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if row["Counter_Name"] == counter and "k_adam_l1<true" in row["Kernel_Name"]:
+                        if row["Counter_Name"] == counter and ("k_adam_l1<true" in row["Kernel_Name"] or
+                                                               "k_adam_l1_live" in row["Kernel_Name"]):
                             vals.append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
             vals = [v for _, v in sorted(vals)]
             n = len(vals) // launches_per_step
             if n < 2:
-                return None, f"no k_adam_l1<true> dispatches in the {counter} pass"
+                return None, f"no k_adam_l1<true> / k_adam_l1_live dispatches in the {counter} pass"
             last = vals[(n - 2) * launches_per_step:n * launches_per_step]     # the child's last two steps (ROI steps)
             tot[counter] = sum(last) / 2.0
     return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0, \
@@ -301,6 +302,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    flushes0, deferred0 = ts.deferred_flushes, ts.deferred_steps
     for i in range(args.steps):
         one_step(model, ts, bitfield, batches[(args.warmup + i) % nb], mean_count, batches[(args.warmup + i + 1) % nb])
     # the optimiser work TrainStep deferred during these steps (coefficients outside the occupancy window's footprint,
@@ -316,6 +318,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
+    timed_flushes, timed_deferred = ts.deferred_flushes - flushes0, ts.deferred_steps - deferred0
     # the dominant kernel's time from the HIP events recorded inside the timed region ...
     adam_ms = ts.section_times().get("adam_coef", float("nan"))
     # ... and every section's, for the secondary figures, from an instrumented pass AFTER it (not part of the K steps)
@@ -346,16 +349,41 @@ def main():
     # level's rectangle (24 B there).  TrainStep._rects holds the rectangles of the last non-refresh step.
     S_own = (3 * ts.C) // (world if ts.dist_mode == "sharded" else 1)
     rects = ts._rects if (ts._rect_ok and ts._roi is not None and all(r is not None for r in ts._rects)) else None
-    adam_bytes, n_launch = 0.0, 0
+    # with the live / deferred split (TrainStep.defer_adam) a level's per-step launch covers only its live rectangle;
+    # the coefficients outside it are replayed by k_adam_l1_catchup once per flush (24 B each, reported separately)
+    live = ts.last_live if (ts.defer_adam and rects is not None and ts.last_live is not None) else [None] * ts.J
+    adam_bytes, n_launch, deferred_coefs = 0.0, 0, 0.0
     for lvl in range(ts.J):
         n_l = ts.coef.params[lvl].shape[-1]
         inside = rects[lvl][6] * rects[lvl][7] if rects is not None else n_l * n_l
-        adam_bytes += S_own * 3 * (24.0 * n_l * n_l + 4.0 * inside)
+        domain = live[lvl][6] * live[lvl][7] if live[lvl] is not None else n_l * n_l
+        adam_bytes += S_own * 3 * (24.0 * domain + 4.0 * inside)
+        deferred_coefs += S_own * 3 * float(n_l * n_l - domain)
         n_launch += 1
     n_ll = ts.ll.params[0].shape[-1]
     adam_bytes += S_own * (24.0 * n_ll * n_ll + 4.0 * (rects[0][6] * rects[0][7] if rects is not None else n_ll * n_ll))
     n_launch += 1
+    if ts.defer_adam and rects is not None:
+        n_launch = 2          # all wavelet levels in one k_adam_l1_live launch + the LL launch
     achieved = adam_bytes / (adam_ms * 1e-3) / 1e9 if adam_ms == adam_ms and adam_ms > 0 else float("nan")
+    adam_deferred = None
+    if any(lv is not None for lv in live):
+        cu_ms = sec.get("adam_catchup", float("nan"))
+        all_coefs = float(S_own * 3 * sum(ts.coef.params[lvl].shape[-1] ** 2 for lvl in range(ts.J)))
+        adam_deferred = {
+            "live_rectangles": [None if lv is None else {"level_size": ts.coef.params[k].shape[-1], "origin_x": lv[0:3],
+                                                         "origin_y": lv[3:6], "width": lv[6], "height": lv[7]}
+                                for k, lv in enumerate(live)],
+            "deferred_share_of_coefficients": round(deferred_coefs / all_coefs, 4),
+            "steps_deferred_in_timed_region": timed_deferred, "flushes_in_timed_region": timed_flushes,
+            "catchup": None if cu_ms != cu_ms else {
+                "ms": round(cu_ms, 4), "records": ts.last_flush_records, "bytes": 24.0 * deferred_coefs,
+                "GB/s": round(24.0 * deferred_coefs / (cu_ms * 1e-3) / 1e9, 1)},
+            "note": "coefficients outside a level's live rectangle (what the windowed plane rebuild reads + where the "
+                    "windowed adjoint writes) are neither read nor reached by a data gradient until the occupancy window "
+                    "changes; their Adam(+L1) steps are replayed in registers by k_adam_l1_catchup, all pending steps "
+                    "in one 24-B/coefficient pass (bit-identical p, m, v).  Every replay the timed steps caused runs "
+                    "inside the timed region (the ring holds 16 steps; a flush also precedes the clock's stop)."}
 
     # secondary rooflines (north star: HBM GB/s of the sampling / IDWT kernels, MFMA rate of the MLP), from the same
     # HIP-event sections; bytes and flops are the algorithmic ones of SURVEY.md 8(d) for what each section moves
@@ -458,9 +486,12 @@ def main():
                        "kernels": kernels,
                        "roi_window": roi_window,
                        "adam_placement": plc,
+                       "adam_deferred": adam_deferred,
                        **extras},
-            "roofline": {"bound": "hbm", "kernel": f"k_adam_l1 (fused Adam + wavelet-L1): the step's {n_launch} launches "
-                                                   "(one per wavelet level + LL), byte-weighted",
+            "roofline": {"bound": "hbm", "kernel": f"k_adam_l1 / k_adam_l1_live (fused Adam + wavelet-L1): the step's {n_launch} "
+                                                   "launches (all wavelet levels in one launch restricted to their live "
+                                                   "rectangles + LL; without the deferral one launch per level), "
+                                                   "byte-weighted",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic / n_launch, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": adam_bytes / n_launch,
@@ -474,7 +505,8 @@ def main():
                          "note": "achieved = algorithmic bytes of the step's k_adam_l1 launches / their summed duration "
                                  "(HIP events on the launch stream, inside the timed steps) = mean bytes per launch / mean "
                                  "launch duration; 28 B per coefficient inside a level's gradient-support rectangle, 24 B "
-                                 "outside it (g = 0 is neither stored nor read there); 8000 GB/s is the spec peak, a "
+                                 "outside it (g = 0 is neither stored nor read there), nothing outside a live rectangle "
+                                 "(config.adam_deferred); 8000 GB/s is the spec peak, a "
                                  "float4 copy reaches 6290 GB/s on MI355X (MI355X_MICROARCH.md)"},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -434,19 +434,24 @@ TNL_API int tnl_adam_l1_step_rect(float *p, float *grad, float *m, float *v, uin
  * A coefficient outside `live` (8 host ints like `rect`: the footprint the windowed plane rebuild reads united with
  * the gradient's rectangle) is neither read nor reached by a data gradient until the window changes, and its update
  * p, m, v <- adam(p, l1 sign(p), m, v) depends on nothing but its own three numbers and the step's scalars:
- *   tnl_adam_l1_step_live   tnl_adam_l1_step_rect restricted to the live rectangle (the gradient is read inside
- *                           grad_rect, 0 elsewhere); nothing outside `live` is touched.
+ *   tnl_adam_l1_step_live   ONE launch over n_levels (<= 8) levels of the flat arrays p / grad / m / v: level k
+ *                           starts at element offsets[k], is [S][bands[k]][sizes[k]][sizes[k]], is updated inside
+ *                           live[8k .. 8k+8) only (the whole level: {0,0,0, 0,0,0, n, n}), reads its gradient inside
+ *                           grad_rect[8k ..) (0 elsewhere) and uses l1_coefs[k].  step_rec (may be NULL): the ring
+ *                           slot tnl_adam_record_step wrote for this step -- the bias-corrected scalars are then read
+ *                           instead of being evaluated by every workgroup.  Nothing outside `live` is touched.
  *   tnl_adam_record_step    ring[slot] (4 floats per slot, 16 slots) = this step's {lr / (1 - beta1^t),
  *                           sqrt(1 - beta2^t), found_inf != 0} from the same device counter, BEFORE the step's
  *                           epilogue advances it.
  *   tnl_adam_l1_catchup     replays ring[0 .. count) (count <= 16), oldest first, for every coefficient outside
  *                           `live`: one 24-byte pass instead of `count`; abs_sums[r] += sum |p| as step r saw it.
  * The same operations in the same order as the per-step pass: p, m, v are bit-identical after the catch-up. */
-TNL_API int tnl_adam_l1_step_live(float *p, float *grad, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n,
-                                  uint32_t spp, uint32_t s0, const int32_t *live, const int32_t *grad_rect, float lr,
-                                  const float *opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
-                                  const float *inv_scale_dev, float l1_coef, const float *found_inf,
-                                  float *abs_sum, void *stream);
+TNL_API int tnl_adam_l1_step_live(float *p, float *grad, float *m, float *v, uint32_t S, uint32_t spp, uint32_t s0,
+                                  uint32_t n_levels, const uint64_t *offsets, const uint32_t *sizes,
+                                  const uint32_t *bands, const int32_t *live, const int32_t *grad_rect,
+                                  const float *l1_coefs, float lr, const float *opt_step_dev, const float *step_rec,
+                                  float beta1, float beta2, float eps, float inv_scale, const float *inv_scale_dev,
+                                  const float *found_inf, float *abs_sum, void *stream);
 TNL_API int tnl_adam_record_step(float *ring, int32_t slot, float lr, const float *opt_step_dev, float beta1,
                                  float beta2, const float *found_inf, void *stream);
 TNL_API int tnl_adam_l1_catchup(float *p, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n, uint32_t spp,

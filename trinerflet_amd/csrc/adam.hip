@@ -216,12 +216,32 @@ __device__ __forceinline__ int rect_plane(const AdamRect& rc, uint32_t sb) {
   return sl >= 2 * rc.spp ? 2 : (sl >= rc.spp ? 1 : 0);
 }
 
-// live: iteration domain (per plane origin, common size); gr: where the gradient is stored (0 elsewhere)
+// One launch for all wavelet levels of the step (they share the flat p / g / m / v arrays): per level an iteration
+// domain `live` (per plane origin, common size; the whole level where nothing is deferred) and the rectangle `gr`
+// where the gradient is stored (0 elsewhere).  The small levels no longer pay a launch tail each, and the step's
+// scalars come from the record k_adam_record wrote (same double-precision expressions, evaluated once per step
+// instead of by every workgroup).
+constexpr int ADAM_MAX_SEGS = 8;
+struct LiveSeg {
+  AdamRect live, gr;
+  uint64_t off;            // element offset of the level in the flat arrays
+  uint32_t rows, blocks0;  // S * bands * live.rh ; first workgroup of the segment
+  float l1_coef;
+};
+struct LiveSegs {
+  LiveSeg s[ADAM_MAX_SEGS];
+  int n;
+};
+
 __global__ void __launch_bounds__(256)
 k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-               uint32_t rows, AdamArgs a, const float* __restrict__ inv_scale_dev, const float* __restrict__ found_inf,
-               float* __restrict__ abs_sum, const float* __restrict__ opt_step_dev, AdamRect live, AdamRect gr) {
-  {
+               AdamArgs a, const float* __restrict__ inv_scale_dev, const float* __restrict__ found_inf,
+               float* __restrict__ abs_sum, const float* __restrict__ opt_step_dev,
+               const AdamStepRec* __restrict__ rec, LiveSegs segs) {
+  if (rec != nullptr) {
+    a.step_size = rec->step_size;
+    a.bias2_sqrt = rec->bias2_sqrt;
+  } else {
     __shared__ float bc[2];
     if (threadIdx.x == 0) {
       const double t = (double)opt_step_dev[0] + 1.0;
@@ -234,11 +254,24 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
   }
   if (inv_scale_dev != nullptr) a.inv_scale *= inv_scale_dev[0];
   const bool skip = found_inf != nullptr && found_inf[0] != 0.f;
+  int si = 0;
+#pragma unroll
+  for (int k = 1; k < ADAM_MAX_SEGS; k++)
+    if (k < segs.n && blockIdx.x >= segs.s[k].blocks0) si = k;
+  const LiveSeg& sg = segs.s[si];
+  const AdamRect& live = sg.live;
+  const AdamRect& gr = sg.gr;
+  a.l1_coef = sg.l1_coef;
+  const uint32_t nblk = (si + 1 < segs.n ? segs.s[si + 1].blocks0 : gridDim.x) - sg.blocks0;
   float acc = 0.f;
   const uint32_t w4 = (uint32_t)live.rw / 4;
-  const uint32_t total = rows * w4;
-  const uint32_t chunk = (total + gridDim.x - 1) / gridDim.x;
-  const uint32_t c0 = blockIdx.x * chunk, c1 = min(c0 + chunk, total);
+  const uint32_t total = sg.rows * w4;
+  const uint32_t chunk = (total + nblk - 1) / nblk;
+  const uint32_t c0 = (blockIdx.x - sg.blocks0) * chunk, c1 = min(c0 + chunk, total);
+  float* pb = p + sg.off;
+  const float* gb = g + sg.off;
+  float* mb = m + sg.off;
+  float* vb = v + sg.off;
   struct Quad { float4 pp, gg, mm, vv; uint64_t e; };
   auto load = [&](uint32_t i, Quad& q) {
     const uint32_t row = i / w4, c4 = i - row * w4;
@@ -246,13 +279,13 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
     const int pl = rect_plane(live, sb);
     const int x = live.rx[pl] + 4 * (int)c4, y = live.ry[pl] + (int)r;
     q.e = ((uint64_t)sb << (2 * live.log2n)) + ((uint64_t)y << live.log2n) + (uint64_t)x;
-    q.pp = ld_nt(reinterpret_cast<const float4*>(p + q.e));
+    q.pp = ld_nt(reinterpret_cast<const float4*>(pb + q.e));
     q.gg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!skip) {
       const bool inside = x >= gr.rx[pl] && x < gr.rx[pl] + gr.rw && y >= gr.ry[pl] && y < gr.ry[pl] + gr.rh;
-      if (inside) q.gg = ld_nt(reinterpret_cast<const float4*>(g + q.e));
-      q.mm = ld_nt(reinterpret_cast<const float4*>(m + q.e));
-      q.vv = ld_nt(reinterpret_cast<const float4*>(v + q.e));
+      if (inside) q.gg = ld_nt(reinterpret_cast<const float4*>(gb + q.e));
+      q.mm = ld_nt(reinterpret_cast<const float4*>(mb + q.e));
+      q.vv = ld_nt(reinterpret_cast<const float4*>(vb + q.e));
     }
   };
   auto finish = [&](Quad& q) {
@@ -261,9 +294,9 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
       adam1(q.pp.y, q.gg.y, q.mm.y, q.vv.y, a, acc);
       adam1(q.pp.z, q.gg.z, q.mm.z, q.vv.z, a, acc);
       adam1(q.pp.w, q.gg.w, q.mm.w, q.vv.w, a, acc);
-      st_nt(reinterpret_cast<float4*>(p + q.e), q.pp);
-      st_nt(reinterpret_cast<float4*>(m + q.e), q.mm);
-      st_nt(reinterpret_cast<float4*>(v + q.e), q.vv);
+      st_nt(reinterpret_cast<float4*>(pb + q.e), q.pp);
+      st_nt(reinterpret_cast<float4*>(mb + q.e), q.mm);
+      st_nt(reinterpret_cast<float4*>(vb + q.e), q.vv);
     } else {
       acc += fabsf(q.pp.x) + fabsf(q.pp.y) + fabsf(q.pp.z) + fabsf(q.pp.w);
     }
@@ -455,27 +488,51 @@ extern "C" int tnl_adam_record_step(float* ring, int32_t slot, float lr, const f
   return (int)hipGetLastError();
 }
 
-extern "C" int tnl_adam_l1_step_live(float* p, float* grad, float* m, float* v, uint32_t S, uint32_t bands, uint32_t n,
-                                     uint32_t spp, uint32_t s0, const int32_t* live_host, const int32_t* grad_rect_host,
-                                     float lr, const float* opt_step_dev, float beta1, float beta2, float eps,
-                                     float inv_scale, const float* inv_scale_dev, float l1_coef, const float* found_inf,
-                                     float* abs_sum, void* stream) {
-  if (opt_step_dev == nullptr || live_host == nullptr || grad_rect_host == nullptr || n == 0 || (n & (n - 1)) != 0 ||
-      n % 4 != 0 || bands == 0 || spp == 0 || S == 0)
+extern "C" int tnl_adam_l1_step_live(float* p, float* grad, float* m, float* v, uint32_t S, uint32_t spp, uint32_t s0,
+                                     uint32_t n_levels, const uint64_t* offsets, const uint32_t* sizes,
+                                     const uint32_t* bands, const int32_t* live_host, const int32_t* grad_rect_host,
+                                     const float* l1_coefs, float lr, const float* opt_step_dev, const float* step_rec,
+                                     float beta1, float beta2, float eps, float inv_scale, const float* inv_scale_dev,
+                                     const float* found_inf, float* abs_sum, void* stream) {
+  if ((opt_step_dev == nullptr && step_rec == nullptr) || live_host == nullptr || grad_rect_host == nullptr ||
+      offsets == nullptr || sizes == nullptr || bands == nullptr || l1_coefs == nullptr || n_levels == 0 ||
+      n_levels > ADAM_MAX_SEGS || spp == 0 || S == 0)
     return (int)hipErrorInvalidValue;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
        reinterpret_cast<uintptr_t>(v)) & 15)
     return (int)hipErrorInvalidValue;
-  AdamRect live, gr;
-  if (fill_rect(live, live_host, n, bands, spp, s0) || fill_rect(gr, grad_rect_host, n, bands, spp, s0))
-    return (int)hipErrorInvalidValue;
-  const uint64_t rows = (uint64_t)S * bands * live.rh, total = rows * (live.rw / 4);
-  if (total >= (1ull << 32)) return (int)hipErrorInvalidValue;
-  AdamArgs a{lr, 1.0f, beta1, beta2, eps, inv_scale, l1_coef};
-  uint64_t blocks = (total + 511) / 512;
-  if (blocks > TNL_ADAM_BLOCKS) blocks = TNL_ADAM_BLOCKS;
-  hipLaunchKernelGGL(k_adam_l1_live, dim3((unsigned)blocks), dim3(256), g_lds_reservation, (hipStream_t)stream, p, grad,
-                     m, v, (uint32_t)rows, a, inv_scale_dev, found_inf, abs_sum, opt_step_dev, live, gr);
+  LiveSegs segs;
+  segs.n = (int)n_levels;
+  uint64_t items[ADAM_MAX_SEGS], all = 0;
+  for (uint32_t k = 0; k < n_levels; k++) {
+    const uint32_t n = sizes[k];
+    if (n == 0 || (n & (n - 1)) != 0 || n % 4 != 0 || bands[k] == 0 || offsets[k] % 4 != 0) return (int)hipErrorInvalidValue;
+    LiveSeg& sg = segs.s[k];
+    if (fill_rect(sg.live, live_host + 8 * k, n, bands[k], spp, s0) ||
+        fill_rect(sg.gr, grad_rect_host + 8 * k, n, bands[k], spp, s0))
+      return (int)hipErrorInvalidValue;
+    const uint64_t rows = (uint64_t)S * bands[k] * sg.live.rh;
+    items[k] = rows * (sg.live.rw / 4);
+    if (items[k] >= (1ull << 32)) return (int)hipErrorInvalidValue;
+    sg.off = offsets[k];
+    sg.rows = (uint32_t)rows;
+    sg.l1_coef = l1_coefs[k];
+    all += items[k];
+  }
+  // workgroups dealt in proportion to the levels' float4 counts (512 per workgroup and trip), at least one each
+  uint64_t want = (all + 511) / 512;
+  if (want > TNL_ADAM_BLOCKS) want = TNL_ADAM_BLOCKS;
+  if (want < n_levels) want = n_levels;
+  uint32_t next = 0;
+  for (uint32_t k = 0; k < n_levels; k++) {
+    uint64_t b = (items[k] * want + all - 1) / all;
+    if (b == 0) b = 1;
+    segs.s[k].blocks0 = next;
+    next += (uint32_t)b;
+  }
+  AdamArgs a{lr, 1.0f, beta1, beta2, eps, inv_scale, 0.f};
+  hipLaunchKernelGGL(k_adam_l1_live, dim3(next), dim3(256), g_lds_reservation, (hipStream_t)stream, p, grad, m, v, a,
+                     inv_scale_dev, found_inf, abs_sum, opt_step_dev, reinterpret_cast<const AdamStepRec*>(step_rec), segs);
   return (int)hipGetLastError();
 }
 

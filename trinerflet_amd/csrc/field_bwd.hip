@@ -610,19 +610,31 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   }
 }
 
-// gradW[e] += sum over the workgroups' slabs.  64 elements per workgroup, the slab loop split over 4 threads per element
-// (fixed order: deterministic), so 13.5 k weights give 212 workgroups instead of 53 long serial loops (61 -> ~20 us).
+// gradW[e] += sum over the workgroups' slabs (fixed order: deterministic).  16 elements per workgroup, the slab loop
+// dealt over 16 threads per element with 8 loads in flight each: one or two rounds of memory latency instead of a
+// serial chain of 64 dependent loads per thread (155-180 us inside the step, beside the side stream's kernels).
 __global__ void __launch_bounds__(256)
 k_slab_reduce(const float* __restrict__ slabs, int nslab, int nw, float* __restrict__ gradW) {
-  __shared__ float part[4][64];
-  const int le = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + le;
+  __shared__ float part[16][17];
+  const int le = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + le;
   float s = 0.f;
-  if (e < nw)
-    for (int k = grp; k < nslab; k += 4) s += slabs[(size_t)k * nw + e];
+  if (e < nw) {
+    for (int k0 = grp; k0 < nslab; k0 += 16 * 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) x[u] = k0 + 16 * u < nslab ? slabs[(size_t)(k0 + 16 * u) * nw + e] : 0.f;
+      s += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    }
+  }
   part[grp][le] = s;
   __syncthreads();
-  if (grp == 0 && e < nw) gradW[e] += (part[0][le] + part[1][le]) + (part[2][le] + part[3][le]);
+  if (grp == 0 && e < nw) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) t += part[g][le];
+    gradW[e] += t;
+  }
 }
 
 inline uint32_t bwd_blocks(uint32_t M, uint32_t st = 128) {
@@ -674,7 +686,7 @@ int launch_bwd_impl(const float* gsig, const float* grgb, const float* sigma, co
                                              dfeat, nullptr, blocks, st);
   }
   if (e != 0) return e;
-  hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 63) / 64), dim3(256), 0, st, slabs, (int)blocks, (int)G::NW, gradW);
+  hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 15) / 16), dim3(256), 0, st, slabs, (int)blocks, (int)G::NW, gradW);
   return (int)hipGetLastError();
 }
 

@@ -177,10 +177,12 @@ class TrainStep:
         self._ring_sums = torch.zeros(16, dtype=torch.float32, device=dev)
         self._pending = 0          # recorded steps not yet applied outside the live rectangles
         self._live = None          # per level the live rectangle (8 ints) or None; fixed while steps are pending
+        self.last_live = None
         self._defer_ctx = None     # (s0, s1, l1) of the pending steps
         self.deferred_reg = torch.zeros((), dtype=torch.float32, device=dev)   # replayed steps' L1 value, summed
         self.deferred_steps = 0    # counters for reports
         self.deferred_flushes = 0
+        self.last_flush_records = 0
         # GradScaler state (torch.cuda.amp.GradScaler defaults: 2^16, x2 every 2000 clean steps, x0.5 on inf)
         self.scale = torch.full((1,), init_scale if fp16 else 1.0, dtype=torch.float32, device=dev)
         self.growth_tracker = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -720,7 +722,7 @@ class TrainStep:
                 try:
                     if under_adam:
                         self._prefetch_next(next_rays, march_on_side)
-                    if self.defer_adam and rects is not None and not refresh:
+                    if self.defer_adam and rects is not None:
                         self._adam_levels_live(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
                     else:
                         self._adam_levels(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
@@ -728,6 +730,9 @@ class TrainStep:
                     if under_adam:
                         lib.tnl_adam_set_lds_reservation(L.u32(0))   # process-global: never leave it set
                 self._mark("adam_coef")
+                if self._pending == 16:     # the ring is full (a whole density-grid period at the default interval)
+                    self.flush_deferred()
+                    self._mark("adam_catchup")
         else:
             grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
             F_.field_backward(g_sigma, g_rgb, sigma_field, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
@@ -888,30 +893,25 @@ class TrainStep:
         ns = s1 - s0
         if self._pending == 0:
             self._live = self._live_rects(rects)
+            self.last_live = self._live            # kept after the flush, for reports
             self._defer_ctx = (s0, s1, l1)
         assert self._defer_ctx == (s0, s1, l1)
-        if any(lv is not None for lv in self._live):
-            L.check(lib.tnl_adam_record_step(L.ptr(self._ring), L.i32(self._pending), L.f32(lr_t), L.ptr(self.opt_steps),
-                                             L.f32(self.b1), L.f32(self.b2), L.ptr(found_inf), L.stream()),
-                    "adam_record_step")
-        for lvl in range(self.J):
-            n = self.coef.params[lvl].shape[-1]
-            base = self.coef.offsets[lvl] + s0 * 3 * n * n
-            cf = self.coef
-            if self._live[lvl] is None:
-                L.check(lib.tnl_adam_l1_step_rect(
-                    L.ptr(cf.data[base:]), L.ptr(cf.grad[base:]), L.ptr(cf.m[base:]), L.ptr(cf.v[base:]), L.u32(ns),
-                    L.u32(3), L.u32(n), L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*rects[lvl]), L.f32(lr_t),
-                    L.ptr(self.opt_steps), L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0),
-                    L.ptr(inv_scale), L.f32(l1), L.ptr(found_inf), L.ptr(self.abs_sum), L.stream()),
-                    "adam_l1_step_rect")
-            else:
-                L.check(lib.tnl_adam_l1_step_live(
-                    L.ptr(cf.data[base:]), L.ptr(cf.grad[base:]), L.ptr(cf.m[base:]), L.ptr(cf.v[base:]), L.u32(ns),
-                    L.u32(3), L.u32(n), L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*self._live[lvl]),
-                    (C_.c_int32 * 8)(*rects[lvl]), L.f32(lr_t), L.ptr(self.opt_steps), L.f32(self.b1), L.f32(self.b2),
-                    L.f32(self.eps), L.f32(1.0), L.ptr(inv_scale), L.f32(l1), L.ptr(found_inf), L.ptr(self.abs_sum),
-                    L.stream()), "adam_l1_step_live")
+        slot = self._pending
+        L.check(lib.tnl_adam_record_step(L.ptr(self._ring), L.i32(slot), L.f32(lr_t), L.ptr(self.opt_steps),
+                                         L.f32(self.b1), L.f32(self.b2), L.ptr(found_inf), L.stream()),
+                "adam_record_step")
+        # every level in ONE launch: its live rectangle, or the whole level where nothing is deferred
+        J, cf = self.J, self.coef
+        sizes = [cf.params[lvl].shape[-1] for lvl in range(J)]
+        offs = [cf.offsets[lvl] + s0 * 3 * sizes[lvl] ** 2 for lvl in range(J)]
+        live = [lv if lv is not None else [0, 0, 0, 0, 0, 0, sizes[k], sizes[k]] for k, lv in enumerate(self._live)]
+        flat = lambda rs: (C_.c_int32 * (8 * J))(*[x for r in rs for x in r[:8]])
+        L.check(lib.tnl_adam_l1_step_live(
+            L.ptr(cf.data), L.ptr(cf.grad), L.ptr(cf.m), L.ptr(cf.v), L.u32(ns), L.u32(self.C), L.u32(s0), L.u32(J),
+            (C_.c_uint64 * J)(*offs), (C_.c_uint32 * J)(*sizes), (C_.c_uint32 * J)(*([3] * J)), flat(live), flat(rects),
+            (C_.c_float * J)(*([l1] * J)), L.f32(lr_t), L.ptr(self.opt_steps), L.ptr(self._ring[4 * slot:]),
+            L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0), L.ptr(inv_scale), L.ptr(found_inf),
+            L.ptr(self.abs_sum), L.stream()), "adam_l1_step_live")
         n0 = self.ll.params[0].shape[-1]
         ll = self.ll
         off = s0 * n0 * n0
@@ -923,8 +923,6 @@ class TrainStep:
         if any(lv is not None for lv in self._live):
             self._pending += 1
             self.deferred_steps += 1
-            if self._pending == 16:
-                self.flush_deferred()
 
     def flush_deferred(self):
         """Replays the pending steps for the coefficients outside the live rectangles (no-op when none are pending).
@@ -949,6 +947,7 @@ class TrainStep:
                 L.stream()), "adam_l1_catchup")
         if l1 > 0:
             self.deferred_reg += l1 * self._ring_sums[:self._pending].sum()
+        self.last_flush_records = self._pending
         self._pending = 0
         self._live = None
         self.deferred_flushes += 1
