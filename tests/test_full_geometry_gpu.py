@@ -194,19 +194,26 @@ def test_trainstep_window_equals_whole_plane(cuda, rays60k, cfg):
         ts = TrainStep(m, lr=1e-2, wavelet_regularization=lam, iters=1000, update_extra_interval=4, use_roi=use_roi)
         ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf_t)
         m.mean_count = 0
-        losses, Ms = [], []
+        losses, mses, Ms = [], [], []
         for it in range(5):
             loss = ts.step(o_t, d_t, gt, noises=nz)
             losses.append(float(loss))
+            mses.append(float(ts.last["mse"]))
             Ms.append(int(ts.last["counter"][0]))
             if use_roi and it % 4 != 0:
                 assert ts._roi is not None and ts._roi[6] < R and ts._rect_ok and ts._rects[0] is not None
                 assert ts._roi[6] == 1152 and ts._roi[7] == 1152          # the r = 0.8 sphere's window
         assert all(np.isfinite(losses)) and Ms[0] > 3_000_000 and len(set(Ms)) == 1
         assert float(ts.last["found_inf"]) == 0.0
-        res.append((losses, [p.detach() for p in m.parameters()]))
+        # at this size the windowed run defers the optimiser pass outside the live rectangles (defer_adam): a step's
+        # loss then carries the L1 value of the live coefficients only, the rest arrives with the replay
+        assert ts.defer_adam == bool(use_roi)
+        total = sum(losses) + float(ts.pop_deferred_reg())
+        res.append((losses, [p.detach() for p in m.parameters()], mses, total))
         del ts
-    np.testing.assert_allclose(res[0][0], res[2][0], rtol=2e-4)
+    np.testing.assert_allclose(res[0][2], res[2][2], rtol=2e-4)          # MSE per step
+    np.testing.assert_allclose(res[0][3], res[2][3], rtol=2e-4)          # sum of the losses incl. the deferred L1 share
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-4)
     assert res[0][0][-1] < res[0][0][0]
     # The tile reduction sums in the order its bin-fill atomics produced, so two runs of the SAME configuration differ
     # in the last bits of a gradient, and Adam (eps = 1e-15) turns a gradient at rounding level into a +-lr step: the

@@ -1054,11 +1054,15 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
   if (out_rect != nullptr) {
     // Tiles of coarse outputs the input window reaches (same test as the tile kernel's hits()), per plane, then grown
     // to a common size: inside the rectangle every element is written (computed or zero), outside nothing is.
-    if (n % 2 != 0 || n % TI != 0) return (int)hipErrorInvalidValue;
+    // The column-walk kernel writes any rectangle, so its levels use 8-wide granules instead of the tile kernel's
+    // TI-wide tiles (a tighter rectangle: fewer zeros stored, a smaller live rectangle for the optimiser pass).
+    const bool walk = n % 8 == 0 && (int)n >= g_walk_min_n;
+    const int G = walk ? 8 : TI;
+    if (n % 2 != 0 || n % G != 0) return (int)hipErrorInvalidValue;
     constexpr WTaps T = wtaps(W);
     constexpr int L = T.L, K = (L - 2) / 2, KA = (K + 3) / 4 * 4, SH = KA - K;
-    constexpr int FT = 2 * TI + L - 2, FTA = (2 * TI + L - 2 + SH + 3) / 4 * 4;
-    const int nt = (int)n / TI;
+    const int FT = 2 * G + L - 2, FTA = (2 * G + L - 2 + SH + 3) / 4 * 4;
+    const int nt = (int)n / G;
     int lo[2][3], hi[2][3];
     for (int p = 0; p < 3; p++) {
       const int wo[2] = {roi.rw ? roi.ox[p] : 0, roi.rw ? roi.oy[p] : 0};
@@ -1067,7 +1071,7 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
       for (int d = 0; d < 2; d++) {
         lo[d][p] = nt; hi[d][p] = -1;
         for (int t = 0; t < nt; t++) {
-          const int c0 = 2 * t * TI - ka[d];
+          const int c0 = 2 * t * G - ka[d];
           if (c0 < wo[d] + we[d] && c0 + ft[d] > wo[d]) { lo[d][p] = t < lo[d][p] ? t : lo[d][p]; hi[d][p] = t; }
         }
         if (hi[d][p] < 0) { lo[d][p] = 0; hi[d][p] = 0; }
@@ -1077,11 +1081,11 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
     for (int d = 0; d < 2; d++)
       for (int p = 0; p < 3; p++) ext[d] = (hi[d][p] - lo[d][p] + 1) > ext[d] ? (hi[d][p] - lo[d][p] + 1) : ext[d];
     for (int p = 0; p < 3; p++) {
-      orect.ox[p] = TI * (lo[0][p] + ext[0] > nt ? nt - ext[0] : lo[0][p]);
-      orect.oy[p] = TI * (lo[1][p] + ext[1] > nt ? nt - ext[1] : lo[1][p]);
+      orect.ox[p] = G * (lo[0][p] + ext[0] > nt ? nt - ext[0] : lo[0][p]);
+      orect.oy[p] = G * (lo[1][p] + ext[1] > nt ? nt - ext[1] : lo[1][p]);
       out_rect[p] = orect.ox[p]; out_rect[3 + p] = orect.oy[p];
     }
-    orect.rw = TI * ext[0]; orect.rh = TI * ext[1];
+    orect.rw = G * ext[0]; orect.rh = G * ext[1];
     out_rect[6] = orect.rw; out_rect[7] = orect.rh;
     orect.spp = roi.rw ? roi.spp : (int)(S / 3);
     orect.s0 = roi.s0;
