@@ -172,7 +172,7 @@ class TrainStep:
         # reads it (next refresh, checkpoint, evaluation, flush_deferred()): bit-identical p, m, v, 1/16 of the bytes.
         # The L1 value of the deferred coefficients arrives with the replay (deferred_reg / pop_deferred_reg()), so a
         # step's returned loss carries the live rectangle's share only.  Default: on for large coefficient sets.
-        self.defer_adam = (defer_adam if defer_adam is not None else self.coef.total >= 64_000_000) and self._rect_ok
+        self.defer_adam = (defer_adam if defer_adam is not None else self.coef.total >= 32_000_000) and self._rect_ok
         self._ring = torch.zeros(16 * 4, dtype=torch.float32, device=dev)      # csrc/adam.hip AdamStepRec[16]
         self._ring_sums = torch.zeros(16, dtype=torch.float32, device=dev)
         self._pending = 0          # recorded steps not yet applied outside the live rectangles
