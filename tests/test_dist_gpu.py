@@ -127,10 +127,10 @@ def test_two_ranks_equal_one(cuda, mode):
 
 
 # ---- the occupancy window / gradient-support chain under rank sharding (R = 256: window and rectangles are active)
-def _build_roi(dev):
+def _build_roi(dev, R=256):
     from trinerflet_amd.nerf.network import NeRFNetwork
     m = NeRFNetwork(encoding="triplane_wavelet", bound=1.0, cuda_ray=True, density_thresh=10, hidden_dim=H,
-                    hidden_dim_color=H, triplane_channels=C, triplane_resolution=256, triplane_wavelet_levels=4,
+                    hidden_dim_color=H, triplane_channels=C, triplane_resolution=R, triplane_wavelet_levels=R // 64,
                     wavelet_type="bior6.8").to(dev)
     synthetic.init_field_parameters(m, seed=3)
     m.density_bitfield.copy_(torch.from_numpy(synthetic.sphere_bitfield(128, 1, 1.0, 0.4, 0.0)).to(dev))
@@ -138,7 +138,7 @@ def _build_roi(dev):
     return m
 
 
-def _run_roi(mode, rank, world):
+def _run_roi(mode, rank, world, R=256, defer=None):
     from trinerflet_amd.train import TrainStep
     from trinerflet_amd import distributed as D
     dev = torch.device("cuda:0")
@@ -148,25 +148,33 @@ def _run_roi(mode, rank, world):
     noise = np.random.default_rng(0).random(n).astype(np.float32)
     lo, hi = D.shard_rays(n, world, rank)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev)
-    m = _build_roi(dev)
+    m = _build_roi(dev, R)
     bf = m.density_bitfield.clone()
-    ts = TrainStep(m, lr=1e-2, wavelet_regularization=LAM, iters=1000, fp16=True, update_extra_interval=4, dist_mode=mode)
+    ts = TrainStep(m, lr=1e-2, wavelet_regularization=LAM, iters=1000, fp16=True, update_extra_interval=4, dist_mode=mode,
+                   defer_adam=defer)
     ts.post_refresh = lambda: m.density_bitfield.copy_(bf)          # keep the analytic occupancy
     losses = []
     for it in range(6):
         losses.append(float(ts.step(t(o), t(d), t(gt), noises=t(noise), n_global_rays=n)))
         if it % 4 != 0:
-            assert ts._roi is not None and ts._roi[6] < 256 and ts._rect_ok and ts._rects[0] is not None
+            assert ts._roi is not None and ts._roi[6] < R and ts._rect_ok and ts._rects[0] is not None
+        if defer:
+            assert ts._pending == it % 4 + 1 and any(lv is not None for lv in ts._live)
+            live = [None if lv is None else list(lv) for lv in ts._live]
+    if defer:      # the deferred coefficients' L1 share of the six losses (a collective in the sharded mode)
+        losses.append(float(ts.pop_deferred_reg()))
+        assert ts._pending == 0
     ts.sync_sharded_parameters()
-    return losses, {k: v.detach().cpu().numpy() for k, v in m.named_parameters()}
+    params = {k: v.detach().cpu().numpy() for k, v in m.named_parameters()}
+    return (losses, params, live) if defer else (losses, params)
 
 
-def _roi_worker(rank, port, mode, out):
+def _roi_worker(rank, port, mode, out, R=256, defer=None):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=2)
     try:
         torch.cuda.set_device(0)
-        out[rank] = _run_roi(mode, rank, 2)
+        out[rank] = _run_roi(mode, rank, 2, R, defer)
     finally:
         dist.destroy_process_group()
 
@@ -184,6 +192,36 @@ def test_two_ranks_with_occupancy_window(cuda, mode):
         assert np.array_equal(p0[k], p1[k]), k                       # replicas stay identical
         frac = np.mean(np.abs(p0[k] - ref_params[k]) > 2e-3)         # sign-like Adam steps: see test_two_ranks_equal_one
         assert frac < 2e-2, (k, frac)
+
+
+def test_two_ranks_with_deferred_coefficient_pass(cuda):
+    """TrainStep(defer_adam=True) under slice sharding (R = 512: the two finest levels have live rectangles): every rank
+    replays its own slices; after the gather the replicas are identical, and outside the live rectangles -- where a
+    coefficient's trajectory depends on nothing but its own p, m, v and the steps' scalars -- the two-rank run equals
+    the one-rank run bit for bit."""
+    ref_losses, ref_params, live = _run_roi(None, 0, 1, 512, True)
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_roi_worker, args=(port, "sharded", out, 512, True), nprocs=2, join=True)
+    (l0, p0, live0), (l1, p1, _) = out[0], out[1]
+    assert live0 == live and sum(lv is not None for lv in live) >= 1
+    assert np.allclose(l0, l1, rtol=1e-6) and np.allclose(l0[:6], ref_losses[:6], rtol=3e-3), (l0, l1, ref_losses)
+    assert abs(sum(l0) - sum(ref_losses)) < 3e-3 * abs(sum(ref_losses))
+    for k in ref_params:
+        assert np.array_equal(p0[k], p1[k]), k
+    names = [k for k in ref_params if "wavelet_coefs" in k]
+    assert len(names) == len(live)
+    for k, lv in zip(sorted(names, key=lambda s: int(s.rsplit(".", 1)[1])), live):
+        if lv is None:
+            continue
+        a, b = ref_params[k], p0[k]
+        n = a.shape[-1]
+        outside = np.ones((3, 1, 1, n, n), bool)
+        for p in range(3):
+            outside[p, :, :, lv[3 + p]:lv[3 + p] + lv[7], lv[p]:lv[p] + lv[6]] = False
+        outside = np.broadcast_to(outside, a.shape)
+        assert outside.mean() > 0.2 and np.array_equal(a[outside], b[outside]), k
 
 
 # ---- the Trainer loop on two ranks: rays of every batch split over the ranks, evaluation striped over the images
