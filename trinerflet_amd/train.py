@@ -13,6 +13,14 @@ in what is NOT materialised: no autograd graph, the L1 regulariser never forms |
 tensors, coefficient gradients are unscaled inside the Adam pass, the parameters / Adam moments /
 gradients of all wavelet levels live in three flat buffers so the whole coefficient update is one launch.
 
+Deferred coefficient pass (defer_adam, default for >= 32 M coefficients): between two density-grid
+refreshes the coefficients outside the occupancy window's footprint are updated lazily -- their steps are recorded and
+replayed, bit-identically, before anything inside this package reads them (refresh, window change, rebuild_planes of whole
+planes, checkpoints / evaluation through Trainer, sync_sharded_parameters).  Code that reads or replaces
+model.encoder's coefficient tensors or TrainStep's moment buffers directly must call TrainStep.flush_deferred() first;
+rendering through the occupancy grid is unaffected (it never samples outside the window).  A step's returned loss then
+carries the L1 value of the live coefficients only; pop_deferred_reg() hands out the rest.
+
 Multi-GPU: rays are sharded across ranks, planes and MLP weights replicated.
   mode "allreduce": plane gradients all-reduced (RCCL) before the adjoint; every rank repeats the dense work.
   mode "sharded"  : the 3*C (plane, channel) slices are the shard unit (the IDWT is depthwise): plane gradients
