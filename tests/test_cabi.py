@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     # sizes that pass 4 GB: an untrained occupancy grid lets 60 000 rays take 26 M samples (5 GB of saved features)
     h.tnl_field_feats_save_bytes.restype = ctypes.c_uint64
     assert h.tnl_field_feats_save_bytes(ctypes.c_uint32(26295552), 32, 64) == 26295552 * 96 * 2 > 2 ** 32
-    assert h.tnl_field_feats_save_bytes(ctypes.c_uint32(1000), 48, 128) == 1000 * (144 + 16) * 2
+    assert h.tnl_field_feats_save_bytes(ctypes.c_uint32(1000), 48, 128) == (1024 * 144 + 1000 * 16) * 2   # rows in 32-sample tiles
     h.tnl_field_backward_workspace.restype = ctypes.c_uint64
     assert h.tnl_field_backward_workspace(ctypes.c_uint32(150_000_000), 48, 128, 128) > 2 ** 32
     h.tnl_march_rays_train_workspace_rec.restype = ctypes.c_uint32

@@ -252,7 +252,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     half8 geo;   // PART 1: the sigma net's 16 outputs (fp16 fragment) and sigma, saved by the forward
     float sg;
   };
-  const _Float16* geo_save = feats + (size_t)Mcap * G::F;
+  const _Float16* geo_save = feats + (size_t)((Mcap + 31) / 32 * 32) * G::F;
   auto load_inputs = [&](uint32_t st_, Inputs& in) {
     const uint32_t i_ = st_ * ST + col;
     const bool v_ = i_ < M;
@@ -279,7 +279,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
 #pragma unroll
     for (int ks = 0; ks < G::KS0; ks++) {
-      in.fk[ks] = *reinterpret_cast<const half8*>(feats + (size_t)il_ * G::F + 16 * ks + 8 * h);
+      in.fk[ks] = *reinterpret_cast<const half8*>(feats + feat_slot<G::KS0>(il_, ks, h));
       if (!v_) {
 #pragma unroll
         for (int j = 0; j < 8; j++) in.fk[ks][j] = (_Float16)0.f;
@@ -488,7 +488,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
         if (PART != 2) {
 #pragma unroll
           for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
-          if (valid) fk = *reinterpret_cast<const half8*>(feats + (size_t)il * G::F + 16 * ks + 8 * h);
+          if (valid) fk = *reinterpret_cast<const half8*>(feats + feat_slot<G::KS0>(il, ks, h));
         }
         put_nat<BLK>(Xs, ks, fk, h, col);
       }
@@ -523,7 +523,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
             v[0] = (_Float16)df[4 * q]; v[1] = (_Float16)df[4 * q + 1];
             v[2] = (_Float16)df[4 * q + 2]; v[3] = (_Float16)df[4 * q + 3];
             const int pl = f0 / C, fc = f0 - pl * C;   // 4 consecutive features never straddle planes (C % 4 == 0)
-            // (non-temporal feats loads + dF stores: 1.46 -> 1.86 ms, not used)
+            // (non-temporal feats loads + dF stores: 1.46 -> 1.86 ms, not used.  These 8-byte pieces of a 64-byte row
+            //  cost 3.2x the algorithmic bytes in WRITE_SIZE; staging a wave's 32 x 32 block through a private LDS patch
+            //  so that it leaves as whole rows was measured SLOWER, 0.808 -> 0.843 ms alone: the kernel is not HBM-bound)
             *reinterpret_cast<half4*>(dfeat + ((size_t)pl * Mcap + i) * C + fc) = v;
           }
         }

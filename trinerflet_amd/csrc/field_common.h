@@ -55,6 +55,18 @@ struct FieldGeom {
   static constexpr int NW = OFF4 + 3 * H;
 };
 
+// Saved-feature layout shared by k_field_fwd (writer) and k_field_bwd (reader): blocked by the 32-sample tile a
+// wavefront owns, [tile][k-step][sample in tile][16 halfs], so that ONE store instruction of the forward (all lanes,
+// one k-step) covers 1 KB of contiguous memory -- eight whole 128-byte lines.  With the row-major [M][F] layout the
+// six k-steps of a row were six 32-byte pieces stored microseconds apart under the gathers' cache traffic: the
+// partially written lines were evicted and re-fetched, rocprofv3 counted 3.3x the algorithmic bytes in WRITE_SIZE.
+// The buffer holds ceil(M / 32) * 32 rows.
+template <int KS0>
+__device__ __forceinline__ size_t feat_slot(uint32_t i, int ks, int h) {
+  return ((((size_t)(i >> 5) * KS0 + ks) * 32 + (i & 31)) * 16) + 8 * h;
+}
+
+
 // Source element of packed half `idx` (= (frag*64 + lane)*8 + j): returns the index into the
 // concatenated fp32 weights, or -1 for a structural zero.
 template <int C, int H>

@@ -42,7 +42,7 @@ def field_forward(planes_tm, xyz, dirs, packed, bound, C, R, H, save_feats=False
         # [M,3C] features; for hidden 128 the 16 sigma-net outputs per sample follow in the same allocation (kept alive by
         # the view) for the colour half of the split backward
         nb = L.lib().tnl_field_feats_save_bytes(L.u32(M), L.u32(C), L.u32(H))
-        feats = torch.empty(nb // 2, dtype=torch.float16, device=dev)[:M * 3 * C].view(M, 3 * C)
+        feats = torch.empty(nb // 2, dtype=torch.float16, device=dev)   # opaque: blocked by 32-sample tiles (field_common.h)
     L.check(L.lib().tnl_field_forward(L.ptr(planes_tm), L.i32(int(planes_tm.dtype == torch.float16)), L.ptr(xyz),
                                       L.ptr(dirs), L.f32(bound), L.u32(M), L.u32(C), L.u32(R), L.u32(H), L.u32(H),
                                       L.ptr(packed), L.ptr(sigma), L.ptr(second), L.ptr(feats), L.ptr(m_actual), L.stream()),
