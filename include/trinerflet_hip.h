@@ -49,6 +49,11 @@ TNL_API int tnl_morton3D_invert(const int32_t *indices, uint32_t N, int32_t *coo
 /* raymarching.h:11 packbits ; kernel raymarching.cu:268-289.  grid:[8N] fp32 -> bitfield:[N] u8 */
 TNL_API int tnl_packbits(const float *grid, uint32_t N, float density_thresh, uint8_t *bitfield,
                          void *stream);
+/* The same with the threshold min(density_thresh, *mean_density_dev) taken on the device (renderer.py:531-533 reads the
+ * mean density back to the host between the grid update and packbits; here the read-back waits until everything of the
+ * refresh is enqueued). */
+TNL_API int tnl_packbits_dev(const float *grid, uint32_t N, float density_thresh, const float *mean_density_dev,
+                             uint8_t *bitfield, void *stream);
 
 /* Bounding box, in cell coordinates, of the occupied cells of each cascade of a Morton-ordered bitfield
  * (the layout tnl_packbits writes): bounds[c] = {min x, y, z, max x, y, z} int32, preset by the caller to

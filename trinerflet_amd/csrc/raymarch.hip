@@ -299,7 +299,8 @@ k_occupancy_bounds(const uint8_t* __restrict__ bitfield, uint32_t bytes_per_casc
 
 // One thread packs 4 output bytes from 32 floats read as 8 x float4 (coalesced 128 B per lane).
 __global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thresh,
-                           uint8_t* __restrict__ bitfield) {
+                           uint8_t* __restrict__ bitfield, const float* __restrict__ thresh_dev) {
+  if (thresh_dev != nullptr) thresh = fminf(thresh, thresh_dev[0]);   // min(density_thresh, mean density), renderer.py:533
   const uint32_t q = threadIdx.x + blockIdx.x * blockDim.x;  // group of 4 bytes
   const uint32_t n0 = q * 4;
   if (n0 >= N) return;
@@ -1058,7 +1059,16 @@ int tnl_occupancy_bounds(const uint8_t* bitfield, uint32_t bytes_per_cascade, ui
 int tnl_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream) {
   if (N == 0) return 0;
   hipLaunchKernelGGL(k_packbits, dim3(cdiv(cdiv(N, 4), 256)), dim3(256), 0, (hipStream_t)stream, grid, N,
-                     density_thresh, bitfield);
+                     density_thresh, bitfield, (const float*)nullptr);
+  return launch_status();
+}
+
+int tnl_packbits_dev(const float* grid, uint32_t N, float density_thresh, const float* mean_density_dev, uint8_t* bitfield,
+                     void* stream) {
+  if (N == 0) return 0;
+  if (mean_density_dev == nullptr) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_packbits, dim3(cdiv(cdiv(N, 4), 256)), dim3(256), 0, (hipStream_t)stream, grid, N,
+                     density_thresh, bitfield, mean_density_dev);
   return launch_status();
 }
 

@@ -349,34 +349,48 @@ class NeRFRenderer(nn.Module):
             for cas in range(self.cascade):
                 coords = torch.randint(0, H, (N, 3), device=dev)
                 indices = raymarching.morton3D(coords).long()
-                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
-                if occ_indices.shape[0] > 0:     # identical on every rank (the grids are), so the sizes agree
-                    pick = torch.randint(0, occ_indices.shape[0], [N], dtype=torch.long, device=dev)
-                    occ_indices = occ_indices[pick]
-                    occ_coords = raymarching.morton3D_invert(occ_indices)
-                    indices = torch.cat([indices, occ_indices], dim=0)
-                    coords = torch.cat([coords, occ_coords], dim=0)
+                # N occupied cells drawn uniformly with replacement (renderer.py:501-507: nonzero -> randint -> index), without
+                # the read-back of the occupied count: the k-th occupied cell is where the running count reaches k + 1.
+                # No occupied cell at all (the reference then adds no picks): the picks go to a spare slot behind the grid.
+                running = torch.cumsum(self.density_grid[cas] > 0, 0)
+                n_occ = running[-1]
+                k = (torch.rand(N, device=dev, dtype=torch.float64) * n_occ).long().clamp_(max=(n_occ - 1).clamp(min=0))
+                occ_indices = torch.searchsorted(running, k + 1)
+                occ_indices = torch.where(n_occ > 0, occ_indices, torch.full_like(occ_indices, H ** 3))
+                occ_coords = raymarching.morton3D_invert(occ_indices.clamp(max=H ** 3 - 1))
+                indices = torch.cat([indices, occ_indices], dim=0)
+                coords = torch.cat([coords, occ_coords], dim=0)
                 xyzs = 2 * coords.float() / (H - 1) - 1
                 bound = min(2 ** cas, self.bound)
                 half_grid_size = bound / H
                 xyzs = xyzs * (bound - half_grid_size)
                 xyzs = xyzs + (torch.rand_like(xyzs) * 2 - 1) * half_grid_size
                 dens = self.density(xyzs)['sigma'].reshape(-1).detach().float() * self.density_scale
+                tmp_c = -torch.ones(H ** 3 + 1, dtype=tmp_grid.dtype, device=dev)   # + the spare slot of the picks above
                 if world == 1:
-                    tmp_grid[cas, indices] = dens
+                    tmp_c[indices] = dens
                 else:
                     # a cell drawn twice keeps the larger value (index assignment would keep an arbitrary one,
                     # possibly a different one on each rank; the grids must stay bit-identical across ranks)
-                    tmp_grid[cas].scatter_reduce_(0, gather(indices), gather(dens), reduce="amax", include_self=True)
+                    tmp_c.scatter_reduce_(0, gather(indices), gather(dens), reduce="amax", include_self=True)
+                tmp_grid[cas] = tmp_c[:H ** 3]
+        # The same values as the reference's masked assignment / .item() / packbits / .item() sequence, with ONE host
+        # read-back at the end instead of five (three of them hidden in the boolean-mask indexing): every kernel of the
+        # refresh is enqueued before the host waits, the threshold min(density_thresh, mean) is taken on the device.
         valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
-        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.density_grid.copy_(torch.where(valid_mask, torch.maximum(self.density_grid * decay, tmp_grid),
+                                            self.density_grid))
+        mean_dev = torch.mean(self.density_grid.clamp(min=0)).reshape(1).float()
         self.iter_density += 1
-        density_thresh = min(self.mean_density, self.density_thresh)
-        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+        L.check(L.lib().tnl_packbits_dev(L.ptr(self.density_grid), L.u32(self.density_bitfield.numel()),
+                                         L.f32(self.density_thresh), L.ptr(mean_dev), L.ptr(self.density_bitfield),
+                                         L.stream()), "packbits_dev")
         total_step = min(16, self.local_step)
+        csum = self.step_counter[:total_step, 0].sum().reshape(1).double() if total_step > 0 else mean_dev.double() * 0
+        mean_h, csum_h = torch.cat([mean_dev.double(), csum]).tolist()       # the refresh's one read-back (both exact in fp64)
+        self.mean_density = mean_h
         if total_step > 0:
-            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+            self.mean_count = int(csum_h / total_step)
         self.local_step = 0
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):

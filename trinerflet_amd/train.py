@@ -113,6 +113,34 @@ class _Flat:
             self.data = best
         else:
             best_t = t0
+        # Still slow with every candidate in the parameter role (seen: twelve candidates, all 2.21-2.22 ms, in the first
+        # process on a box): then one of the OTHER three arrays sits badly.  The buffers already held are timed in the
+        # roles of exp_avg, exp_avg_sq and the gradient in turn, the fastest adopted each time.
+        if gbs(best_t) < good_gbs and hold:
+            report["other_roles"] = {}
+            for role in ("m", "v", "grad"):
+                if gbs(best_t) >= good_gbs:
+                    break
+                cur = {"m": self.m, "v": self.v, "grad": self.grad}
+                pick_t, pick = best_t, None
+                tried = []
+                for cand in hold:
+                    if cand is self.data or any(cand is t_ for t_ in cur.values()):
+                        continue
+                    cand.zero_()          # the timing pass leaves p alone only while g = m = v = 0
+                    args = dict(cur)
+                    args[role] = cand
+                    t = time_pass(self.data, args["grad"], args["m"], args["v"])
+                    tried.append(round(t, 4))
+                    if t < pick_t:
+                        pick_t, pick = t, cand
+                    if len(tried) >= candidates or gbs(pick_t) >= good_gbs:
+                        break
+                report["other_roles"][role] = tried
+                if pick is not None and pick_t < 0.98 * best_t:
+                    pick.copy_(cur[role])
+                    setattr(self, role, pick)
+                    best_t = pick_t
         report["after_ms"], report["after_GBs"] = round(best_t, 4), round(gbs(best_t), 1)
         del hold
         return report
