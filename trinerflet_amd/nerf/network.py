@@ -143,6 +143,21 @@ class NeRFNetwork(NeRFRenderer):
         sigma, geo_feat = self._sigma_mlp(x)
         return {'sigma': sigma, 'geo_feat': geo_feat}
 
+    def density_sigma(self, x):
+        """sigma of density() without the 15 geo features (the density-grid refresh needs nothing else; the fused
+        kernel then skips their 60 bytes per sample of scattered stores).  No reference counterpart."""
+        if self._fused_ok() and not torch.is_grad_enabled():
+            enc = self.encoder
+            tm = enc.get_planes_texel_major()
+            packed = _field.pack_weights(self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight,
+                                         self.color_net[1].weight, self.color_net[2].weight, enc.number_of_features,
+                                         self.hidden_dim)
+            x = x.detach().to(torch.float32).contiguous()
+            sigma, _, _ = _field.field_forward(tm, x, None, packed, float(self.bound), enc.number_of_features,
+                                               enc.plane_resolution, self.hidden_dim, geo_out=False)
+            return sigma
+        return self.density(x)['sigma']
+
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
         # network.py:186-214 (masked colour query)
         if mask is not None:

@@ -334,6 +334,9 @@ class NeRFRenderer(nn.Module):
         H = self.grid_size
         rank, world, gather = shard if shard is not None else (0, 1, None)
         tmp_grid = -torch.ones_like(self.density_grid)
+        # sigma only (network.density_sigma) unless density() has been replaced on the instance (tests do)
+        sigma_only = getattr(self, "density_sigma", None) if "density" not in self.__dict__ else None
+        sigma_of = sigma_only if sigma_only is not None else (lambda p_: self.density(p_)['sigma'])
         if self.iter_density < 16:  # full refresh: every cell of every cascade
             cells = self._cells()
             c0, c1 = cells.shape[0] * rank // world, cells.shape[0] * (rank + 1) // world
@@ -342,7 +345,7 @@ class NeRFRenderer(nn.Module):
                 half_grid_size = bound / H
                 xyzs = cells[c0:c1] * (bound - half_grid_size)
                 xyzs = xyzs + (torch.rand_like(xyzs) * 2 - 1) * half_grid_size
-                dens = self.density(xyzs)['sigma'].reshape(-1).detach().float() * self.density_scale
+                dens = sigma_of(xyzs).reshape(-1).detach().float() * self.density_scale
                 tmp_grid[cas] = dens if world == 1 else gather(dens)
         else:  # partial refresh: H^3/4 uniform cells + H^3/4 currently occupied cells per cascade
             N = H ** 3 // 4 // world
@@ -365,7 +368,7 @@ class NeRFRenderer(nn.Module):
                 half_grid_size = bound / H
                 xyzs = xyzs * (bound - half_grid_size)
                 xyzs = xyzs + (torch.rand_like(xyzs) * 2 - 1) * half_grid_size
-                dens = self.density(xyzs)['sigma'].reshape(-1).detach().float() * self.density_scale
+                dens = sigma_of(xyzs).reshape(-1).detach().float() * self.density_scale
                 tmp_c = -torch.ones(H ** 3 + 1, dtype=tmp_grid.dtype, device=dev)   # + the spare slot of the picks above
                 if world == 1:
                     tmp_c[indices] = dens
