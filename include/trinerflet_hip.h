@@ -222,7 +222,7 @@ TNL_API int tnl_field_pack(const float *W0, const float *W1, const float *W2, co
 /* sigma:[M] rgb:[M,3] fp32.  feats_save (tnl_field_feats_save_bytes(M, C, Hd) bytes, may be NULL) keeps
  * the interpolated features for the backward pass (fp16, opaque: ceil(M/32)*32 rows of 3C blocked by the 32-sample
  * tile a wavefront owns, [tile][16-channel step][sample][16], so that each store instruction of the forward covers
- * whole 128-byte lines -- a row-major [M,3C] buffer cost 3.3x its bytes in HBM writes), followed for hidden 128 by the 16
+ * whole 128-byte lines instead of 32-byte pieces of 32 different rows), followed for hidden 128 by the 16
  * sigma-net outputs per sample (fp16 [M,16]) that the colour half of the split backward starts from.  dirs == NULL or rgb == NULL: density only (NeRFNetwork.density,
  * network.py:149-166); with dirs == NULL and rgb != NULL, rgb receives the 15 geo features ([M,15]).
  * m_actual (device int32, may be NULL): rows >= min(M, *m_actual) are skipped -- march_rays_train's

@@ -519,7 +519,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
         // 64-byte row.  The two lanes of a sample trade two pieces each (v_permlane32_swap: lanes r and r + 32), after
         // which lane (r, h) holds features 32 ib + 16h .. +15 -- 32 contiguous bytes, two 16-byte stores instead of
         // four 8-byte ones (an 8-byte-per-lane store costs 2.7x the fabric time per byte of a 16-byte one,
-        // MI355X_MICROARCH.md; rocprofv3 counted 3.2x the algorithmic bytes in WRITE_SIZE for the 8-byte form).
+        // MI355X_MICROARCH.md): 0.808 -> 0.77 ms alone.
         // (Measured and not kept: non-temporal feats loads + dF stores, 1.46 -> 1.86 ms; the block staged through a
         //  private LDS patch so that it leaves as whole rows, 0.808 -> 0.843 ms alone -- the kernel is not HBM-bound.)
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
