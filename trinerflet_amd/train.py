@@ -574,7 +574,7 @@ class TrainStep:
         self._mark("begin")
         refresh = self.update_extra_interval > 0 and self.global_step % self.update_extra_interval == 0
 
-        def march(o=rays_o, d=rays_d, nz=noises):
+        def march(o=rays_o, d=rays_d, nz=noises, sort_stream=None):
             nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_train, model.min_near)
             counter = model.step_counter[model.local_step % 16]
             counter.zero_()
@@ -594,7 +594,20 @@ class TrainStep:
             # tile reduction) rides behind it on the same stream and gets its own event
             ev_march = torch.cuda.Event()
             ev_march.record()
-            # the tile sort of the plane gradient needs only the positions: it rides with the march (side stream)
+            # the tile sort of the plane gradient needs only the positions: it rides with the march (side stream); an
+            # in-order march (refresh steps: the bitfield has just changed) hands its scan + fill passes to sort_stream,
+            # beside the field forward
+            if fused_sort and sort_stream is not None:
+                assert out[0].shape[0] == mc
+                sort_stream.wait_event(ev_march)
+                with torch.cuda.stream(sort_stream):
+                    F_.plane_grad_sort_counted(sort_ws, out[0], float(model.bound), R, counter)
+                    ev_sort = torch.cuda.Event()
+                    ev_sort.record()
+                for t_ in (counter, *out, sort_ws):
+                    if torch.is_tensor(t_):
+                        t_.record_stream(sort_stream)
+                return (counter, *out, sort_ws), (ev_march, ev_sort)
             if fused_sort:
                 assert out[0].shape[0] == mc
                 F_.plane_grad_sort_counted(sort_ws, out[0], float(model.bound), R, counter)
@@ -658,8 +671,15 @@ class TrainStep:
                 self._roi, self._roi_valid = self._compute_roi(), True
             self._mark("grid_refresh")
         packed = F_.pack_weights(*self.Ws, C, H)
+        sort_beside = False
         if side is None:
-            marched = march()
+            if self.overlap_march and self.binned and R % 32 == 0 and model.mean_count > 0:
+                if self._side is None:
+                    self._side = self._make_side_stream()
+                marched = march(sort_stream=self._side)      # samples in order, sort passes beside the field forward
+                sort_beside = True
+            else:
+                marched = march()
         marched, (ev_march, ev_sort) = marched
         if side is not None:
             torch.cuda.current_stream().wait_event(ev_march)
@@ -733,7 +753,7 @@ class TrainStep:
             under_adam = self._prefetch_under_adam(next_rays)
             if not under_adam and not early:
                 self._prefetch_next(next_rays, march_on_side)
-            if side is not None:
+            if side is not None or sort_beside:
                 torch.cuda.current_stream().wait_event(ev_sort)
             F_.plane_grad_reduce(sort_ws, dfeat, xyzs, float(model.bound), C, R, g_cm, channel_major=True,
                                  nonfinite_flag=self.nonfinite, roi=self._roi10() if roi is not None else None)
