@@ -100,3 +100,56 @@ def test_support_chain_on_walk_kernels(cuda, walk):
     troi.test_support_chain_adjoint_and_rect_adam_match_dense(cuda)
     troi.test_windowed_rebuild_equals_full_rebuild_inside_the_window(cuda)
     troi.test_training_with_window_equals_whole_plane_training(cuda)
+
+
+@pytest.mark.parametrize("wave", ["bior6.8", "bior4.4", "haar"])
+def test_walk_adjoint_rectangles_random_windows(cuda, walk, wave):
+    """The column-walk adjoint writes 8-wide granules of its gradient-support rectangle (the tile kernels 32-wide
+    tiles): for random windows, two levels deep (compact window -> rectangle -> strided window -> rectangle), the
+    rectangle holds the dense adjoint of the zero-extended gradient bit for bit, the dense result is exactly zero
+    outside it, and nothing outside it is written."""
+    import ctypes
+    from trinerflet_amd import _lib as L
+    from trinerflet_amd.triplaneencoder import triplane_encoder as te
+    lib = L.lib()
+    C, n1 = 4, 64
+    S, R = 3 * C, 4 * n1
+    wid = te.WAVELET_IDS[wave]
+    rng = np.random.default_rng(7)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for trial in range(6):
+        rw, rh = int(rng.choice([64, 128])), int(rng.choice([64, 128]))
+        ox = [int(rng.integers(0, (R - rw) // 64 + 1)) * 64 for _ in range(3)]
+        oy = [int(rng.integers(0, (R - rh) // 64 + 1)) * 64 for _ in range(3)]
+        gc = torch.randn(S, rh, rw, generator=g).to(cuda)
+        gfull = torch.zeros(3, C, R, R, device=cuda)
+        for p in range(3):
+            gfull[p, :, oy[p]:oy[p] + rh, ox[p]:ox[p] + rw] = gc.view(3, C, rh, rw)[p]
+        ref, src = [], gfull.view(S, R, R)
+        for n in (2 * n1, n1):
+            dx = torch.empty(S, n, n, device=cuda)
+            dyh = torch.empty(S, 3, n, n, device=cuda)
+            L.check(lib.tnl_idwt_level_backward(L.ptr(src), L.u32(S), L.u32(n), L.i32(wid), L.ptr(dx), L.ptr(dyh),
+                                                L.stream()), "bwd")
+            ref.append((dx, dyh))
+            src = dx
+        win, strided, src = ox + oy + [rw, rh, C, 0], 0, gc
+        for lvl, n in enumerate((2 * n1, n1)):
+            dx = torch.full((S, n, n), 123.0, device=cuda)
+            dyh = torch.full((S, 3, n, n), 123.0, device=cuda)
+            rect = (ctypes.c_int32 * 8)()
+            L.check(lib.tnl_idwt_level_backward_win(L.ptr(src), L.u32(S), L.u32(n), L.i32(wid), L.ptr(dx), L.ptr(dyh),
+                                                    L.roi_array(win), L.i32(strided), rect, L.stream()), "bwd_win")
+            rect = list(rect)
+            assert rect[6] % 8 == 0 and rect[7] % 8 == 0 and all(v % 4 == 0 for v in rect[:3])
+            for p in range(3):
+                ys, xs = slice(rect[3 + p], rect[3 + p] + rect[7]), slice(rect[p], rect[p] + rect[6])
+                sl = slice(p * C, (p + 1) * C)
+                assert torch.equal(dx[sl, ys, xs], ref[lvl][0][sl, ys, xs]), (wave, trial, lvl, p)
+                assert torch.equal(dyh[sl, :, ys, xs], ref[lvl][1][sl, :, ys, xs]), (wave, trial, lvl, p)
+                mask = torch.ones(n, n, dtype=torch.bool, device=cuda)
+                mask[ys, xs] = False
+                assert bool((dx[sl][:, mask] == 123.0).all()) and bool((dyh[sl][:, :, mask] == 123.0).all())
+                assert float(ref[lvl][0][sl][:, mask].abs().sum()) == 0, (wave, trial, lvl, p, rect, win)
+                assert float(ref[lvl][1][sl][:, :, mask].abs().sum()) == 0, (wave, trial, lvl, p, rect, win)
+            win, strided, src = rect + [C, 0], 1, dx
