@@ -454,6 +454,7 @@ def main():
     if rank == 0:
         C, R, scale, H, _, lam = WORKLOADS[args.workload]
         ms = elapsed / args.steps * 1e3
+        survey_bytes = (44 + 2) * 3.0 * C * R * R + samples_per_step * (12 * C * 2 + 48 * C + 64) + 64.0 * N
         wire = None
         if world > 1:
             S_all = 3 * C
@@ -480,6 +481,13 @@ def main():
                        "collectives": None if world == 1 else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                                                "bytes_on_the_wire": wire},
                        "samples_per_sec": samples_per_step * world * args.steps / elapsed,
+                       # SURVEY.md 8(d)'s byte count of the REFERENCE's step (every coefficient rebuilt, differentiated and
+                       # updated every step: (44 + e) P + M (12 C e + 48 C + 64) + 64 N) over this step's time
+                       "survey_step": {"bytes": survey_bytes, "TB/s_equivalent": round(survey_bytes / (ms * 1e-3) / 1e12, 3),
+                                       "of_8_TB/s": round(survey_bytes / (ms * 1e-3) / 8e12, 3),
+                                       "note": "bytes the reference's formulation of one step moves per GPU (SURVEY.md "
+                                               "8(d), e = 2) divided by the measured step time; the step itself moves "
+                                               "fewer (occupancy window, live rectangles of the optimiser pass)"},
                        "sections_ms": {k: round(v, 4) for k, v in sec.items()},
                        "sections_note": "adam_coef: HIP events inside the timed steps; the other sections: an "
                                         "instrumented pass after them (an event at every boundary costs 6-8 us)",
