@@ -190,3 +190,31 @@ def test_planes_get_gradient_right_after_a_grid_refresh(cuda):
     g = m.encoder.planes_features.grad
     assert g is not None and float(g.abs().sum()) > 0
     assert float(m.encoder.planes_features_wavelet_coefs[0].grad.abs().sum()) > 0
+
+
+def test_partial_refresh_picks_occupied_cells_without_a_read_back(cuda):
+    """Partial refresh (renderer.py:494-520): H^3/4 uniform cells + H^3/4 draws from the currently occupied cells per
+    cascade.  The occupied draws are made from the running count of occupied cells (no nonzero() read-back): every
+    occupied cell of a small occupied set is hit, nothing but uniform draws happens when no cell is occupied."""
+    m = _model(cuda)
+    H, cas = m.grid_size, m.cascade
+    m.density = lambda xyz: {"sigma": torch.full((xyz.shape[0],), 7.0, device=xyz.device), "geo_feat": None}
+    g = torch.Generator(device="cpu").manual_seed(5)
+    occ = torch.randperm(H ** 3, generator=g)[:1000].to(cuda)
+    m.density_grid.zero_()
+    m.density_grid[:, occ] = 1.0
+    m.iter_density = 16
+    torch.manual_seed(1)
+    m.update_extra_state()
+    grid = m.density_grid
+    assert bool((grid[:, occ] == 7.0).all())                       # each of the 1000 occupied cells was drawn (524 288 draws)
+    touched = (grid == 7.0).sum(1).cpu().numpy()
+    N = H ** 3 // 4
+    assert (touched >= 1000).all() and (touched <= N + 1000).all() and (touched > 0.85 * N).all()
+    assert bool(((grid == 7.0) | (grid == 0.0)).all())             # untouched cells keep max(0 * 0.95, -1 -> invalid) = 0
+    # nothing occupied: only the uniform draws, and no out-of-range write
+    m.density_grid.zero_()
+    m.iter_density = 16
+    m.update_extra_state()
+    touched = (m.density_grid == 7.0).sum(1).cpu().numpy()
+    assert (touched <= N).all() and (touched > 0.85 * N).all()
