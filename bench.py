@@ -194,20 +194,25 @@ def inference_figure(model, device, max_steps=4096, images=3):
     poses = synthetic.hemisphere_poses(images, seed=3)
     model.eval()
     model.encoder.reset_cahce()
-    times = []
+    times, wide = [], []
     with torch.no_grad():
         for k in range(images + 1):
             pix = np.stack([np.full(640000, k % images, np.int64), np.arange(640000)], -1)
             o, d = synthetic.get_rays(poses, pix)
             o, d = torch.from_numpy(o).to(device)[None], torch.from_numpy(d).to(device)[None]
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            model.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps)
-            torch.cuda.synchronize()
-            times.append(time.perf_counter() - t0)
+            for min_step, acc in ((1, times), (8, wide)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                model.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, infer_min_step=min_step)
+                torch.cuda.synchronize()
+                acc.append(time.perf_counter() - t0)
     model.train()
-    t = float(np.mean(times[1:]))
+    t, tw = float(np.mean(times[1:])), float(np.mean(wide[1:]))
     return {"image": "800x800", "max_steps": max_steps, "ms_per_image": round(t * 1e3, 2), "rays_per_s": 640000 / t,
+            "wide_iterations": {"ms_per_image": round(tw * 1e3, 2), "rays_per_s": 640000 / tw,
+                                "note": "render(..., infer_min_step=8): the same per-ray sample sequences in an eighth of "
+                                        "the iterations; identical pixels for rays that end before the max_steps cap "
+                                        "(tests/test_renderer_gpu.py)"},
             "note": "run_cuda eval branch (device-driven alive-ray loop, the reference's schedule), solid-sphere "
                     "occupancy, the benchmark's field after its training steps; mean of 3 images after one warm-up"}
 
