@@ -951,11 +951,12 @@ class TrainStep:
         """_adam_levels over the live rectangles only; the step's scalars are recorded for the replay."""
         lib = L.lib()
         ns = s1 - s0
+        if self._pending and self._defer_ctx != (s0, s1, l1):
+            self.flush_deferred()                  # the regulariser's weight (or the slice range) changed: new period
         if self._pending == 0:
             self._live = self._live_rects(rects)
             self.last_live = self._live            # kept after the flush, for reports
             self._defer_ctx = (s0, s1, l1)
-        assert self._defer_ctx == (s0, s1, l1)
         slot = self._pending
         L.check(lib.tnl_adam_record_step(L.ptr(self._ring), L.i32(slot), L.f32(lr_t), L.ptr(self.opt_steps),
                                          L.f32(self.b1), L.f32(self.b2), L.ptr(found_inf), L.stream()),
