@@ -171,6 +171,7 @@ def time_steps(model, ts, bitfield, batches, mean_count, steps, setup=4):
     t0 = time.perf_counter()
     for i in range(steps):
         one_step(model, ts, bitfield, batches[(setup + i) % nb], mean_count, batches[(setup + i + 1) % nb])
+    ts.flush_deferred()      # deferred optimiser work of these steps belongs to them
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps
 
@@ -449,6 +450,16 @@ def main():
         extras["no_roi_ms_per_step"] = round(variant_ms(args.workload, device, None, batches, mean_count, k, use_roi=False), 4)
         extras["fp32_planes_ms_per_step"] = round(variant_ms(args.workload, device, None, batches, mean_count, k,
                                                              plane_dtype=torch.float32), 4)
+        # the other two README configurations at their full geometry: one density-grid period (16 steps, its refresh and the
+        # replay of the deferred optimiser pass inside) after a 17-step set-up, same rays and sample budget
+        others = {}
+        for wl in ("small", "large"):
+            if wl == args.workload:
+                continue
+            t_ms = variant_ms(wl, device, None, batches, mean_count, 16)
+            others[wl] = {"ms_per_step": round(t_ms, 4), "rays_per_s": N / (t_ms * 1e-3),
+                          "config": "3x{}ch x {}^2, scale {}, hidden {}".format(*WORKLOADS[wl][:4])}
+        extras["other_workloads"] = others
         extras["variants_note"] = ("no_roi: every step rebuilds / differentiates whole planes (no occupancy window, no "
                                    "gradient-support rectangles); fp32_planes: the sampler reads fp32 planes as the "
                                    "reference's training does (SURVEY F9; implies whole planes); same rays, budget, "
