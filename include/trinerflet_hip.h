@@ -383,7 +383,11 @@ TNL_API int tnl_ray_batch(const float *poses, const float *intrinsics_host, uint
  *                           iterations: identical colours for every ray that ends before the max_steps cap; buffers
  *                           then need min_step * N + 128 rows); rows = n_alive*n_step
  *   tnl_march_rays_dev      tnl_march_rays for the first n_alive entries of rays_alive; zero-fills the n_alive*n_step
- *                           sample rows it owns first (raymarching.py:337-339); noises may be NULL (no perturbation)
+ *                           sample rows it owns first (raymarching.py:337-339); noises may be NULL (no perturbation).
+ *                           t_scratch (rows_cap floats, rows_cap = the row capacity of xyzs / dirs / deltas; may be
+ *                           NULL): the march then only records each sample's t and a second kernel writes the rows with
+ *                           one thread per row -- the same bits, contiguous stores instead of 16 scattered 4-byte
+ *                           stores per sample
  *   tnl_composite_rays_dev  tnl_composite_rays
  *   tnl_compact_rays_dev    ordered compaction of the survivors into rays_alive_out, then step += n_step and
  *                           n_alive = survivors; workspace: (N + 255) / 256 + 2 int32
@@ -394,7 +398,8 @@ TNL_API int tnl_infer_plan(int32_t *state, uint32_t N, uint32_t max_steps, uint3
 TNL_API int tnl_march_rays_dev(const int32_t *state, uint32_t N, const int32_t *rays_alive, const float *rays_t,
                                const float *rays_o, const float *rays_d, float bound, float dt_gamma,
                                uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t *grid, const float *fars,
-                               float *xyzs, float *dirs, float *deltas, const float *noises, void *stream);
+                               float *xyzs, float *dirs, float *deltas, const float *noises, float *t_scratch,
+                               uint32_t rows_cap, void *stream);
 TNL_API int tnl_composite_rays_dev(const int32_t *state, uint32_t N, float T_thresh, int32_t *rays_alive,
                                    float *rays_t, const float *sigmas, const float *rgbs, const float *deltas,
                                    float *weights_sum, float *depth, float *image, void *stream);

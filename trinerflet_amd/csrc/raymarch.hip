@@ -764,6 +764,84 @@ __global__ void k_march_rays_dev(const InferState* __restrict__ st, const int* _
   march_run<true, WIDE, false>(m, t, fars[index], n_step, xo, dro, dlo);
 }
 
+// The same iteration with line-shaped stores: k_march_rays_dev writes every sample from the lane that marched it, 8 + 8
+// scattered 4-byte stores per sample and lane (zero fill + values; each store instruction scatters 64 pieces, each its own
+// fabric write) -- 60 % of an 800 x 800 render at max_steps 4096.  Here the march only records the sample's t (staged
+// through LDS, written as whole rows of the block), and k_emit_rays_dev computes the samples with one thread per ROW,
+// consecutive threads = consecutive rows: every store instruction covers contiguous memory.  The expressions are
+// march_run's probe() / take() on the same operands (as in k_march_train_emit): bit-identical rows.
+template <bool WIDE>
+__global__ void __launch_bounds__(128)
+k_march_rays_rec_dev(const InferState* __restrict__ st, const int* __restrict__ rays_alive,
+                     const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                     const float* __restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                     uint32_t H, const uint8_t* __restrict__ grid, const float* __restrict__ fars,
+                     const float* __restrict__ noises, float* __restrict__ tscr) {
+  __shared__ float sh_t[128][9];
+  __shared__ int sh_c[128];
+  const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+  const uint32_t n_alive = (uint32_t)st->n_alive, n_step = (uint32_t)st->n_step;
+  if (blockIdx.x * 128u >= n_alive) return;
+  int cnt = 0;
+  if (n < n_alive) {
+    const int index = rays_alive[n];
+    MarchCtx m;
+    march_init(m, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, grid);
+    float t = rays_t[index];
+    const float nz = noises != nullptr ? noises[n] : 0.f;
+    t = fmaf(clampf_(t * dt_gamma, m.dt_min, m.dt_max), nz, t);
+    cnt = (int)march_run<false, WIDE, false, true>(m, t, fars[index], n_step, nullptr, nullptr, nullptr,
+                                                   &sh_t[threadIdx.x][0]);
+  }
+  sh_c[threadIdx.x] = cnt;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * 128 * n_step;
+  const uint32_t rows_here = min(128u, n_alive - blockIdx.x * 128u) * n_step;
+  for (uint32_t i = threadIdx.x; i < rows_here; i += 128) {
+    const uint32_t nl = i / n_step, k = i - nl * n_step;
+    tscr[base + i] = (int)k < sh_c[nl] ? sh_t[nl][k] : -1.f;     // t > 0 always (min_near): -1 = the ray has no k-th sample
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_emit_rays_dev(const InferState* __restrict__ st, const int* __restrict__ rays_alive, const float* __restrict__ rays_t,
+                const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound, float dt_gamma,
+                uint32_t max_steps, uint32_t C, uint32_t H, const float* __restrict__ noises,
+                const float* __restrict__ tscr, float* __restrict__ xyzs, float* __restrict__ dirs,
+                float* __restrict__ deltas) {
+  const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+  const uint32_t n_step = (uint32_t)st->n_step;
+  if (i >= (uint32_t)st->rows) return;
+  const float t = tscr[i];
+  float px = 0.f, py = 0.f, pz = 0.f, ddx = 0.f, ddy = 0.f, ddz = 0.f, d0 = 0.f, d1 = 0.f;
+  if (t >= 0.f) {     // rows a ray does not reach stay zero (raymarching.py:337-339): composite_rays stops at deltas == 0
+    const uint32_t n = i / n_step, k = i - n * n_step;
+    const int index = rays_alive[n];
+    MarchCtx m;
+    march_init(m, rays_o + (size_t)index * 3, rays_d + (size_t)index * 3, bound, dt_gamma, max_steps, C, H, nullptr);
+    auto step_dt = [&](float tt) { return m.fast ? m.dt0 : clampf_(tt * m.dt_gamma, m.dt_min, m.dt_max); };
+    const float dt = step_dt(t);
+    float last_t;
+    if (k == 0) {
+      last_t = rays_t[index];
+      const float nz = noises != nullptr ? noises[n] : 0.f;
+      last_t = fmaf(clampf_(last_t * dt_gamma, m.dt_min, m.dt_max), nz, last_t);
+    } else {
+      const float tp = tscr[i - 1];
+      last_t = tp + step_dt(tp);
+    }
+    px = clampf_(fmaf(t, m.dx, m.ox), -m.bound, m.bound);
+    py = clampf_(fmaf(t, m.dy, m.oy), -m.bound, m.bound);
+    pz = clampf_(fmaf(t, m.dz, m.oz), -m.bound, m.bound);
+    ddx = m.dx; ddy = m.dy; ddz = m.dz;
+    d0 = dt;
+    d1 = (t + dt) - last_t;
+  }
+  xyzs[(size_t)i * 3 + 0] = px; xyzs[(size_t)i * 3 + 1] = py; xyzs[(size_t)i * 3 + 2] = pz;
+  dirs[(size_t)i * 3 + 0] = ddx; dirs[(size_t)i * 3 + 1] = ddy; dirs[(size_t)i * 3 + 2] = ddz;
+  deltas[(size_t)i * 2 + 0] = d0; deltas[(size_t)i * 2 + 1] = d1;
+}
+
 __global__ void k_composite_rays_dev(const InferState* __restrict__ st, float T_thresh, int* __restrict__ rays_alive,
                                      float* __restrict__ rays_t, const float* __restrict__ sigmas,
                                      const float* __restrict__ rgbs, const float* __restrict__ deltas,
@@ -1205,14 +1283,27 @@ int tnl_infer_plan(int32_t* state, uint32_t N, uint32_t max_steps, uint32_t min_
 int tnl_march_rays_dev(const int32_t* state, uint32_t N, const int32_t* rays_alive, const float* rays_t,
                        const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
                        uint32_t C, uint32_t H, const uint8_t* grid, const float* fars, float* xyzs, float* dirs,
-                       float* deltas, const float* noises, void* stream) {
+                       float* deltas, const float* noises, float* t_scratch, uint32_t rows_cap, void* stream) {
   if (N == 0) return 0;
   const InferState* st = reinterpret_cast<const InferState*>(state);
+  hipStream_t s_ = (hipStream_t)stream;
+  if (t_scratch != nullptr) {
+    // record + emit: line-shaped stores (see k_march_rays_rec_dev); rows <= 8 N
+    if (wide_bitfield(grid, C, H))
+      hipLaunchKernelGGL(k_march_rays_rec_dev<true>, dim3(cdiv(N, 128)), dim3(128), 0, s_, st, rays_alive, rays_t, rays_o,
+                         rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, noises, t_scratch);
+    else
+      hipLaunchKernelGGL(k_march_rays_rec_dev<false>, dim3(cdiv(N, 128)), dim3(128), 0, s_, st, rays_alive, rays_t, rays_o,
+                         rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, noises, t_scratch);
+    hipLaunchKernelGGL(k_emit_rays_dev, dim3(cdiv(rows_cap, 256)), dim3(256), 0, s_, st, rays_alive, rays_t, rays_o, rays_d,
+                       bound, dt_gamma, max_steps, C, H, noises, t_scratch, xyzs, dirs, deltas);
+    return launch_status();
+  }
   if (wide_bitfield(grid, C, H))
-    hipLaunchKernelGGL(k_march_rays_dev<true>, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, st, rays_alive,
+    hipLaunchKernelGGL(k_march_rays_dev<true>, dim3(cdiv(N, 128)), dim3(128), 0, s_, st, rays_alive,
                        rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
   else
-    hipLaunchKernelGGL(k_march_rays_dev<false>, dim3(cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, st, rays_alive,
+    hipLaunchKernelGGL(k_march_rays_dev<false>, dim3(cdiv(N, 128)), dim3(128), 0, s_, st, rays_alive,
                        rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
   return launch_status();
 }

@@ -245,6 +245,7 @@ class NeRFRenderer(nn.Module):
         xyzs = torch.empty(cap, 3, dtype=torch.float32, device=dev)
         dirs = torch.empty(cap, 3, dtype=torch.float32, device=dev)
         deltas = torch.empty(cap, 2, dtype=torch.float32, device=dev)
+        t_scratch = torch.empty(cap, dtype=torch.float32, device=dev)     # the march's record of the samples' t
         cws = torch.empty((N + 255) // 256 + 2, dtype=torch.int32, device=dev)
         noises = torch.rand(N, dtype=torch.float32, device=dev) if perturb else None
         rows = state[3:4]
@@ -256,7 +257,7 @@ class NeRFRenderer(nn.Module):
                 L.ptr(state), L.u32(N), L.ptr(alive[0]), L.ptr(rays_t), L.ptr(rays_o), L.ptr(rays_d),
                 L.f32(self.bound), L.f32(dt_gamma), L.u32(max_steps), L.u32(self.cascade), L.u32(self.grid_size),
                 L.ptr(self.density_bitfield), L.ptr(fars), L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas),
-                L.ptr(nz), L.stream()), "march_rays_dev")
+                L.ptr(nz), L.ptr(t_scratch), L.u32(cap), L.stream()), "march_rays_dev")
             sigmas, rgbs = self.field_rows(xyzs, dirs, rows)
             if self.density_scale != 1:
                 sigmas = self.density_scale * sigmas
