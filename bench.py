@@ -267,6 +267,8 @@ def main():
     if os.environ.get("TNL_MAIN_PRIO"):    # experiments: the step on a high-priority stream, side work on a normal one
         torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["TNL_MAIN_PRIO"])))
     model, ts, bitfield, N = build(args.workload, device, args.dist_mode if world > 1 else None)
+    if os.environ.get("TNL_CLIP_FAR") == "1":      # A/B: march only to the exit from the occupied box (TrainStep.clip_far)
+        ts.clip_far = True
     n_global = N * world
     if args.scaling == "strong":       # the step's 60 000 rays split over the ranks (the dense work is what shards)
         n_global = N

@@ -62,6 +62,19 @@ TNL_API int tnl_packbits_dev(const float *grid, uint32_t N, float density_thresh
 TNL_API int tnl_occupancy_bounds(const uint8_t *bitfield, uint32_t bytes_per_cascade, uint32_t cascades,
                                  int32_t *bounds, void *stream);
 
+/* No sample can lie outside the box of the occupied cells, and `far` only enters the march's loop conditions: marching
+ * with min(far, the ray's exit from that box) gives the same samples to the bit, without the probe chain through the
+ * empty cells behind the object (no reference counterpart; the reference marches every ray to its far).
+ *   tnl_occupied_box  box[6] (device) = world-space {min xyz, max xyz} of the occupied cells of all cascades grown by one
+ *                     cell; faces within a cell of the volume boundary are +-inf (positions are clamped there); an
+ *                     empty bitfield gives an empty box.  bounds_scratch: 6 * cascades int32 (device).
+ *   tnl_clip_fars     fars_out[n] = min(fars[n], exit of ray n from the box), -FLT_MAX for a ray that misses it.
+ * The box belongs to the bitfield it was computed from: recompute it whenever the bitfield changes. */
+TNL_API int tnl_occupied_box(const uint8_t *bitfield, uint32_t bytes_per_cascade, uint32_t cascades, uint32_t H,
+                             float bound, int32_t *bounds_scratch, float *box, void *stream);
+TNL_API int tnl_clip_fars(const float *rays_o, const float *rays_d, const float *fars, const float *box, uint32_t N,
+                          float *fars_out, void *stream);
+
 /* Number of int32 scratch words tnl_march_rays_train needs for N rays: the minimum (the samples are then written
  * by a second march of every ray), and the size with which the count pass can record each sample's t
  * (+ N * max_steps floats; 0 if that exceeds 32 bits) so that the samples are written from the record instead --

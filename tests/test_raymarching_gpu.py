@@ -349,3 +349,50 @@ def test_march_fused_tile_count_equals_sort(cuda):
         for b in np.flatnonzero(np.diff(off_a))[::7]:
             assert np.array_equal(np.sort(ent_a[off_a[b]:off_a[b + 1]]), np.sort(ent_b[off_b[b]:off_b[b + 1]]))
         assert np.array_equal(np.sort(ent_a), np.sort(ent_b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["ball", "shell", "offset_box", "touching_boundary", "empty"])
+def test_far_clipped_to_the_occupied_box_gives_the_same_samples(cuda, rays, shape):
+    """tnl_occupied_box + tnl_clip_fars: the training march with far = min(far, exit of the occupied cells' box) against
+    the march to the real far -- identical rays / samples / counts -- for several occupancies (a box away from the
+    centre, cells on the volume boundary where positions are clamped, nothing occupied at all)."""
+    from trinerflet_amd import raymarching
+    o, d, aabb, nears, fars = rays
+    if shape in ("ball", "shell"):
+        bf = scene.sphere_bitfield(HG, CAS, BOUND, 0.8, 0.7 if shape == "shell" else 0.0)
+    else:
+        grid = np.zeros((CAS, HG, HG, HG), bool)
+        if shape == "offset_box":
+            grid[0, 70:100, 20:50, 60:90] = True
+            grid[1, 40:50, 80:90, 64:70] = True
+        elif shape == "touching_boundary":
+            grid[0, 100:128, 50:80, 0:30] = True            # cascade 0 spans [-1, 1]: its last cells are interior of the volume
+            grid[1, 118:128, 60:70, 60:70] = True           # cascade 1 reaches the volume boundary (x = +1.5)
+        bf = np.zeros((CAS, HG ** 3 // 8), np.uint8)
+        ax = np.arange(HG)
+        cells = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+        mort = cref.morton3D(cells.astype(np.int32))
+        for c in range(CAS):
+            flat = np.zeros(HG ** 3, bool)
+            flat[mort] = grid[c].reshape(-1)
+            bf[c] = np.packbits(flat, bitorder="little")
+        bf = bf.reshape(-1)
+    N = o.shape[0]
+    noises = _t(np.random.default_rng(5).random(N).astype(np.float32), cuda)
+    bits = _t(bf, cuda)
+    box = raymarching.occupied_box(bits, CAS, HG, BOUND)
+    fars_c = raymarching.clip_fars(_t(o, cuda), _t(d, cuda), _t(fars, cuda), box)
+    assert bool((fars_c <= _t(fars, cuda)).all())
+    outs = []
+    for f in (_t(fars, cuda), fars_c):
+        counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+        out = raymarching.march_rays_train(_t(o, cuda), _t(d, cuda), BOUND, bits, CAS, HG, _t(nears, cuda), f, counter,
+                                           -1, True, -1, True, 0, 1024, noises)
+        outs.append([t.clone() for t in out] + [counter.clone()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    total = int(outs[0][4][0])
+    assert (total == 0) == (shape == "empty")
+    if shape != "empty":
+        assert float((fars_c < _t(fars, cuda)).float().mean()) > 0.5      # the clipping is real

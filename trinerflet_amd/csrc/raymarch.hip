@@ -1134,6 +1134,91 @@ int tnl_occupancy_bounds(const uint8_t* bitfield, uint32_t bytes_per_cascade, ui
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// No sample can lie outside the box of the occupied cells: a ray that has left it is done, and the march need not probe
+// its way through the empty cells between the object and `far` (one dependent bitfield load chain per cell: the slowest
+// lane of nearly every wavefront of every inference iteration, and the tail of every training ray).  `far` only enters the
+// march's loop conditions, so the callers simply pass min(far, exit of the box): the samples are the same to the bit.
+// (The ENTRY into the box cannot be used the same way: where the march lands after a skip depends, in the last bit, on
+// the cell it skipped from.)
+//   k_occupied_box: world-space box of the occupied cells of all cascades from tnl_occupancy_bounds' cell bounds, grown
+//   by one cell; a face within one cell of the volume's boundary is opened to infinity (positions are clamped to the
+//   volume there, raymarching.cu:367-369, so a ray never really leaves through it).  No occupied cell: an empty box.
+//   k_clip_fars: fars_out[n] = min(fars[n], slab exit of ray n), or -FLT_MAX if the ray misses the box.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_init_bounds(int* __restrict__ bounds, int cascades, int H) {   // {H + 1 x3, -1 x3} per cascade
+  const int i = threadIdx.x;
+  if (i < cascades * 6) bounds[i] = (i % 6) < 3 ? H + 1 : -1;
+}
+
+__global__ void k_occupied_box(const int* __restrict__ bounds, int cascades, int H, float bound, float* __restrict__ box) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float INF = __builtin_inff();
+  float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
+  for (int k = 0; k < cascades; k++) {
+    if (bounds[k * 6 + 3] < 0) continue;
+    const float sk = fminf(exp2f((float)k), bound), cell = 2.f * sk / (float)H;
+    for (int a = 0; a < 3; a++) {
+      lo[a] = fminf(lo[a], ((float)bounds[k * 6 + a] / (float)H * 2.f - 1.f) * sk - cell);
+      hi[a] = fmaxf(hi[a], ((float)(bounds[k * 6 + 3 + a] + 1) / (float)H * 2.f - 1.f) * sk + cell);
+    }
+  }
+  const float edge = 2.f * bound / (float)H;
+  for (int a = 0; a < 3; a++) {
+    if (lo[a] <= hi[a]) {
+      if (lo[a] <= -bound + edge) lo[a] = -INF;
+      if (hi[a] >= bound - edge) hi[a] = INF;
+    }
+    box[a] = lo[a];
+    box[3 + a] = hi[a];
+  }
+}
+
+__global__ void k_clip_fars(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                            const float* __restrict__ fars, const float* __restrict__ box, uint32_t N,
+                            float* __restrict__ out) {
+  const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+  if (n >= N) return;
+  const float FMAX = 3.402823466e+38f;
+  float t_in = -FMAX, t_out = FMAX;
+  bool miss = false;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float o = rays_o[(size_t)n * 3 + a], d = rays_d[(size_t)n * 3 + a], lo = box[a], hi = box[3 + a];
+    if (lo > hi) miss = true;                       // empty box
+    if (d == 0.f) {
+      if (o < lo || o > hi) miss = true;
+    } else {
+      const float t1 = (lo - o) / d, t2 = (hi - o) / d;
+      t_in = fmaxf(t_in, fminf(t1, t2));
+      t_out = fminf(t_out, fmaxf(t1, t2));
+    }
+  }
+  if (t_in > t_out) miss = true;
+  out[n] = miss ? -FMAX : fminf(fars[n], t_out);
+}
+
+int tnl_occupied_box(const uint8_t* bitfield, uint32_t bytes_per_cascade, uint32_t cascades, uint32_t H, float bound,
+                     int32_t* bounds_scratch, float* box, void* stream) {
+  if (bitfield == nullptr || bounds_scratch == nullptr || box == nullptr || cascades == 0 || cascades > 16 || H == 0)
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(128), 0, st, bounds_scratch, (int)cascades, (int)H);
+  hipLaunchKernelGGL(k_occupancy_bounds, dim3(min(cdiv(bytes_per_cascade, 256u), 256u), cascades), dim3(256), 0, st,
+                     bitfield, bytes_per_cascade, cascades, bounds_scratch);
+  hipLaunchKernelGGL(k_occupied_box, dim3(1), dim3(64), 0, st, bounds_scratch, (int)cascades, (int)H, bound, box);
+  return (int)hipGetLastError();
+}
+
+int tnl_clip_fars(const float* rays_o, const float* rays_d, const float* fars, const float* box, uint32_t N,
+                  float* fars_out, void* stream) {
+  if (N == 0) return 0;
+  if (box == nullptr) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_clip_fars, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, fars, box, N,
+                     fars_out);
+  return (int)hipGetLastError();
+}
+
 int tnl_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream) {
   if (N == 0) return 0;
   hipLaunchKernelGGL(k_packbits, dim3(cdiv(cdiv(N, 4), 256)), dim3(256), 0, (hipStream_t)stream, grid, N,

@@ -158,6 +158,12 @@ class NeRFRenderer(nn.Module):
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d,
                                                      self.aabb_train if self.training else self.aabb_infer,
                                                      self.min_near)
+        # the march stops at the ray's exit from the box of the occupied cells (no sample lies behind it: the same samples
+        # to the bit, raymarching.clip_fars); the depth normalisation below keeps the box's far (renderer.py:318)
+        fars_aabb = fars
+        if getattr(self, "clip_far_to_occupancy", True):
+            fars = raymarching.clip_fars(rays_o, rays_d, fars, raymarching.occupied_box(
+                self.density_bitfield, self.cascade, self.grid_size, self.bound))
         if bg_color is None:
             bg_color = 1
         results = {}
@@ -172,7 +178,7 @@ class NeRFRenderer(nn.Module):
             sigmas = self.density_scale * sigmas
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            depth = torch.clamp(depth - nears, min=0) / (fars_aabb - nears)
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             results['weights_sum'] = weights_sum
@@ -182,7 +188,7 @@ class NeRFRenderer(nn.Module):
                                                                 max_steps, T_thresh,
                                                                 min_step=kwargs.get("infer_min_step", 1))
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            depth = torch.clamp(depth - nears, min=0) / (fars_aabb - nears)
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             weights_sum = weights_sum.view(*prefix)
@@ -212,7 +218,7 @@ class NeRFRenderer(nn.Module):
                 n_alive = int(n_out.item())
                 step += n_step
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            depth = torch.clamp(depth - nears, min=0) / (fars_aabb - nears)
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             weights_sum = weights_sum.view(*prefix)

@@ -10,7 +10,7 @@ from torch.autograd import Function
 
 from .. import _lib as L
 
-__all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits",
+__all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "occupied_box", "clip_fars",
            "march_rays_train", "composite_rays_train", "march_rays", "composite_rays", "compact_rays"]
 
 
@@ -263,3 +263,25 @@ def compact_rays(rays_alive, n_alive=None):
     L.check(L.lib().tnl_compact_rays(L.ptr(rays_alive), L.u32(n_alive), L.ptr(out), L.ptr(n_out), L.ptr(ws),
                                      L.stream()), "compact_rays")
     return out, n_out
+
+
+def occupied_box(density_bitfield, cascade, H, bound):
+    """Device tensor [6]: world-space box of the occupied cells of `density_bitfield` grown by one cell (csrc/raymarch.hip
+    k_occupied_box); faces at the volume boundary are infinite.  Valid for this bitfield only.  No host read-back."""
+    bits = density_bitfield.contiguous().view(cascade, -1)
+    dev = bits.device
+    scratch = torch.empty(cascade * 6, dtype=torch.int32, device=dev)
+    box = torch.empty(6, dtype=torch.float32, device=dev)
+    L.check(L.lib().tnl_occupied_box(L.ptr(bits), L.u32(bits.shape[1]), L.u32(cascade), L.u32(H), L.f32(bound),
+                                     L.ptr(scratch), L.ptr(box), L.stream()), "occupied_box")
+    return box
+
+
+def clip_fars(rays_o, rays_d, fars, box):
+    """fars limited to each ray's exit from `box` (occupied_box): marching up to that value finds the same samples, to
+    the bit, as marching up to `fars` -- no occupied cell lies behind it -- without probing the empty cells there."""
+    rays_o, rays_d, fars = _f32c(rays_o).view(-1, 3), _f32c(rays_d).view(-1, 3), _f32c(fars)
+    out = torch.empty_like(fars)
+    L.check(L.lib().tnl_clip_fars(L.ptr(rays_o), L.ptr(rays_d), L.ptr(fars), L.ptr(box), L.u32(fars.numel()), L.ptr(out),
+                                  L.stream()), "clip_fars")
+    return out
