@@ -161,7 +161,7 @@ class NeRFRenderer(nn.Module):
         # the march stops at the ray's exit from the box of the occupied cells (no sample lies behind it: the same samples
         # to the bit, raymarching.clip_fars); the depth normalisation below keeps the box's far (renderer.py:318)
         fars_aabb = fars
-        if getattr(self, "clip_far_to_occupancy", True):
+        if getattr(self, "clip_far_to_occupancy", True) and not self.training:     # (no gain for the training march)
             fars = raymarching.clip_fars(rays_o, rays_d, fars, raymarching.occupied_box(
                 self.density_bitfield, self.cascade, self.grid_size, self.bound))
         if bg_color is None:
