@@ -19,7 +19,7 @@ o, d = synthetic.get_rays(poses, pix)
 o, d = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
 with torch.no_grad():
     for max_steps in (1024, 4096):
-        for dev_loop, min_step in ((False, 1), (True, 1), (True, 8), (True, 16), (True, 32), (True, 64)):
+        for dev_loop, min_step in ((False, 1), (True, 1), (True, 8)):
             for rep in range(3):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
