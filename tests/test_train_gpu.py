@@ -285,3 +285,38 @@ def test_step_state_kernels_match_gradscaler(cuda):
     L.check(lib.tnl_step_epilogue(L.ptr(fi_t), L.ptr(steps_k), L.ptr(s_k), L.ptr(t_k), L.f32(2.0), L.f32(0.5),
                                   L.i32(interval), L.i32(0), L.ptr(None), L.f32(0.25), L.ptr(reg), L.stream()), "epilogue")
     assert torch.equal(s_k, s_t) and float(reg) == 0.0     # update_scale = 0 (fp32 training): scale untouched
+
+
+def test_fused_adam_l1_against_torch_optim_adam(cuda):
+    """tnl_adam_l1_step (csrc/adam_common.h adam1: every operation rounded on its own, reciprocal + Newton division,
+    hardware square root) against torch.optim.Adam on the same gradients + the L1 term's sign gradient, six steps,
+    eps = 1e-15 as the reference configures it (main_nerf.py:119): parameters and both moments to a few ulp."""
+    import trinerflet_amd._lib as L
+    lib = L.lib()
+    n, lr, b1, b2, eps, l1 = 1 << 20, 1e-2, 0.9, 0.99, 1e-15, 3e-7
+    g = torch.Generator(device="cpu").manual_seed(8)
+    p0 = (torch.randn(n, generator=g) * 0.05).to(cuda)
+    p0[::13] = 0.0
+    grads = [(torch.randn(n, generator=g) * 10 ** float(torch.randint(-6, 1, (1,), generator=g))).to(cuda) for _ in range(6)]
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=lr, betas=(b1, b2), eps=eps)
+    p, m, v = p0.clone(), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    steps = torch.zeros(1, device=cuda)
+    zero = torch.zeros(1, device=cuda)
+    G = 0.0
+    for k, gk in enumerate(grads):
+        G = max(G, float(gk.abs().max()))
+        ref.grad = gk + l1 * torch.sign(ref.detach())
+        opt.step()
+        L.check(lib.tnl_adam_l1_step_dev(L.ptr(p), L.ptr(gk.clone()), L.ptr(m), L.ptr(v), L.u64(n), L.f32(lr), L.ptr(steps),
+                                         L.f32(b1), L.f32(b2), L.f32(eps), L.f32(1.0), None, L.f32(l1), L.ptr(zero), None,
+                                         L.i32(0), L.stream()), "adam_l1_step_dev")
+        steps += 1
+        st = opt.state[ref]
+        for got, want, name in ((p, ref.detach(), "p"), (m, st["exp_avg"], "m"), (v, st["exp_avg_sq"], "v")):
+            err = (got - want).abs()
+            # p: the update is lr * m_hat / (sqrt(v_hat) + eps) ~ lr; a few ulp of THAT (3e-6 * lr) per step on top of the parameter's own
+            # m, v: torch's lerp / addcmul fuse a multiply-add here and there: an ulp of the largest term that went in
+            tol = 4e-7 * want.abs() + {"p": 3e-6 * lr * (k + 1), "m": 1e-7 * G, "v": 1e-7 * G * G}[name]
+            bad = int((err > tol).sum())
+            assert bad == 0, (k, name, bad, float(err.max()), float((err / (want.abs() + 1e-30)).max()))

@@ -403,7 +403,7 @@ static int adam_launch(float* p, float* grad, float* m, float* v, uint64_t n, fl
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
        reinterpret_cast<uintptr_t>(v)) & 15)
     return (int)hipErrorInvalidValue;
-  AdamArgs a{step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef};
+  AdamArgs a = make_adam_args(step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef);
   uint64_t blocks = (n / 4 + 255) / 256;
   if (blocks > TNL_ADAM_BLOCKS) blocks = TNL_ADAM_BLOCKS;
   if (blocks == 0) blocks = 1;
@@ -530,7 +530,7 @@ extern "C" int tnl_adam_l1_step_live(float* p, float* grad, float* m, float* v, 
     segs.s[k].blocks0 = next;
     next += (uint32_t)b;
   }
-  AdamArgs a{lr, 1.0f, beta1, beta2, eps, inv_scale, 0.f};
+  AdamArgs a = make_adam_args(lr, 1.0f, beta1, beta2, eps, inv_scale, 0.f);
   hipLaunchKernelGGL(k_adam_l1_live, dim3(next), dim3(256), g_lds_reservation, (hipStream_t)stream, p, grad, m, v, a,
                      inv_scale_dev, found_inf, abs_sum, opt_step_dev, reinterpret_cast<const AdamStepRec*>(step_rec), segs);
   return (int)hipGetLastError();
@@ -548,7 +548,7 @@ extern "C" int tnl_adam_l1_catchup(float* p, float* m, float* v, uint32_t S, uin
   AdamRect live;
   if (fill_rect(live, live_host, n, bands, spp, s0)) return (int)hipErrorInvalidValue;
   const uint64_t total = (uint64_t)S * bands * n * n;
-  AdamArgs a{0.f, 1.0f, beta1, beta2, eps, 1.0f, l1_coef};
+  AdamArgs a = make_adam_args(0.f, 1.0f, beta1, beta2, eps, 1.0f, l1_coef);
   uint64_t blocks = (total / 4 + 255) / 256;
   if (blocks > 4 * TNL_ADAM_BLOCKS) blocks = 4 * TNL_ADAM_BLOCKS;
   hipLaunchKernelGGL(k_adam_l1_catchup, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, total, a,

@@ -3,10 +3,27 @@
 //   m.lerp_(g, 1-b1) ; v.mul_(b2).addcmul_(g, g, 1-b2) ; denom = sqrt(v)/sqrt(bc2) + eps ; p.addcdiv_(m, denom, -lr/bc1)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 struct AdamArgs {
   float step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef;
+  float omb1, omb2;   // 1 - beta1, 1 - beta2 as torch forms them: in double, from the decimal beta, then to fp32
 };
+
+// torch.optim.Adam takes its betas as Python doubles and hands (1 - beta) to the fp32 kernels as a double scalar:
+// 1 - 0.99 = 0.010000000000000009 -> 0.01f.  The C ABI carries the betas as floats, and 1.f - 0.99f = 0.0099999905 --
+// 9.3e-7 off, in every coefficient's second moment.  The float is taken back to the decimal it was written as (7
+// significant digits, the shortest that round-trips for any beta a user types), the subtraction is done in double.
+static inline float adam_one_minus(float beta) {
+  char buf[32];
+  snprintf(buf, sizeof(buf), "%.7g", (double)beta);
+  return (float)(1.0 - strtod(buf, nullptr));
+}
+static inline AdamArgs make_adam_args(float step_size, float bias2_sqrt, float beta1, float beta2, float eps, float inv_scale,
+                                      float l1_coef) {
+  return AdamArgs{step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef, adam_one_minus(beta1), adam_one_minus(beta2)};
+}
 
 __device__ __forceinline__ float adam_sgn(float x) { return (x > 0.f) - (x < 0.f); }
 // c * sign(x) for c >= 0 (sign(+-0) = 0): the magnitude with x's sign bit, or zero -- three instructions
@@ -31,8 +48,8 @@ __device__ __forceinline__ void adam1(float& p, float g_in, float& m, float& v, 
 #pragma clang fp contract(off)
   abs_acc += fabsf(p);
   const float g = g_in * a.inv_scale + adam_signed(a.l1_coef, p);
-  m = m + (g - m) * (1.f - a.beta1);
-  v = v * a.beta2 + (1.f - a.beta2) * g * g;
+  m = m + (g - m) * a.omb1;
+  v = v * a.beta2 + a.omb2 * g * g;
   const float denom = adam_div(__builtin_amdgcn_sqrtf(v), a.bias2_sqrt) + a.eps;
   p = p - a.step_size * adam_div(m, denom);
 }

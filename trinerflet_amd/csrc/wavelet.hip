@@ -1239,7 +1239,7 @@ int tnl_idwt_level_backward_adam(const float* dout, uint32_t S, uint32_t n, int 
                                  float l1_coef, const float* found_inf, float* abs_sum, void* stream) {
   if (S == 0 || n == 0) return 0;
   if (S > 65535 || n % 2 != 0 || (dx == nullptr && ll_p == nullptr)) return (int)hipErrorInvalidValue;
-  FuseAdam fa{p, m, v, ll_p, ll_m, ll_v, AdamArgs{step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef},
+  FuseAdam fa{p, m, v, ll_p, ll_m, ll_v, make_adam_args(step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef),
               inv_scale_dev, found_inf, abs_sum};
   const int tpw = pick_tpw(cdiv(n, TI), cdiv(n, TI), S);
   const dim3 grid(cdiv(cdiv(n, TI), tpw), cdiv(n, TI), S);
