@@ -63,8 +63,8 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
     __shared__ float bc[2];
     if (threadIdx.x == 0) {
       const double t = (double)opt_step_dev[0] + 1.0;
-      bc[0] = (float)((double)a.step_size / (1.0 - pow((double)a.beta1, t)));
-      bc[1] = (float)sqrt(1.0 - pow((double)a.beta2, t));
+      bc[0] = (float)((double)a.step_size / (1.0 - pow(a.b1d, t)));
+      bc[1] = (float)sqrt(1.0 - pow(a.b2d, t));
     }
     __syncthreads();
     a.step_size = bc[0];
@@ -200,12 +200,12 @@ struct AdamStepRec { float step_size, bias2_sqrt, skip, pad; };
 constexpr int ADAM_REPLAY_MAX = 16;
 
 __global__ void k_adam_record(AdamStepRec* __restrict__ ring, int slot, float lr, const float* __restrict__ opt_step_dev,
-                              float beta1, float beta2, const float* __restrict__ found_inf) {
+                              double beta1, double beta2, const float* __restrict__ found_inf) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double t = (double)opt_step_dev[0] + 1.0;          // k_adam_l1's expressions
   AdamStepRec r;
-  r.step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
-  r.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, t));
+  r.step_size = (float)((double)lr / (1.0 - pow(beta1, t)));
+  r.bias2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
   r.skip = (found_inf != nullptr && found_inf[0] != 0.f) ? 1.f : 0.f;
   r.pad = 0.f;
   ring[slot] = r;
@@ -245,8 +245,8 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
     __shared__ float bc[2];
     if (threadIdx.x == 0) {
       const double t = (double)opt_step_dev[0] + 1.0;
-      bc[0] = (float)((double)a.step_size / (1.0 - pow((double)a.beta1, t)));
-      bc[1] = (float)sqrt(1.0 - pow((double)a.beta2, t));
+      bc[0] = (float)((double)a.step_size / (1.0 - pow(a.b1d, t)));
+      bc[1] = (float)sqrt(1.0 - pow(a.b2d, t));
     }
     __syncthreads();
     a.step_size = bc[0];
@@ -484,7 +484,7 @@ extern "C" int tnl_adam_record_step(float* ring, int32_t slot, float lr, const f
                                     float beta2, const float* found_inf, void* stream) {
   if (ring == nullptr || opt_step_dev == nullptr || slot < 0 || slot >= ADAM_REPLAY_MAX) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(k_adam_record, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<AdamStepRec*>(ring),
-                     (int)slot, lr, opt_step_dev, beta1, beta2, found_inf);
+                     (int)slot, lr, opt_step_dev, adam_decimal(beta1), adam_decimal(beta2), found_inf);
   return (int)hipGetLastError();
 }
 

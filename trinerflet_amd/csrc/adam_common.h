@@ -9,20 +9,23 @@
 struct AdamArgs {
   float step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef;
   float omb1, omb2;   // 1 - beta1, 1 - beta2 as torch forms them: in double, from the decimal beta, then to fp32
+  double b1d, b2d;    // the decimal betas in double, for the bias corrections 1 - beta^t (Python doubles in torch)
 };
 
 // torch.optim.Adam takes its betas as Python doubles and hands (1 - beta) to the fp32 kernels as a double scalar:
 // 1 - 0.99 = 0.010000000000000009 -> 0.01f.  The C ABI carries the betas as floats, and 1.f - 0.99f = 0.0099999905 --
 // 9.3e-7 off, in every coefficient's second moment.  The float is taken back to the decimal it was written as (7
 // significant digits, the shortest that round-trips for any beta a user types), the subtraction is done in double.
-static inline float adam_one_minus(float beta) {
+static inline double adam_decimal(float beta) {
   char buf[32];
   snprintf(buf, sizeof(buf), "%.7g", (double)beta);
-  return (float)(1.0 - strtod(buf, nullptr));
+  return strtod(buf, nullptr);
 }
+static inline float adam_one_minus(float beta) { return (float)(1.0 - adam_decimal(beta)); }
 static inline AdamArgs make_adam_args(float step_size, float bias2_sqrt, float beta1, float beta2, float eps, float inv_scale,
                                       float l1_coef) {
-  return AdamArgs{step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef, adam_one_minus(beta1), adam_one_minus(beta2)};
+  return AdamArgs{step_size, bias2_sqrt, beta1, beta2, eps, inv_scale, l1_coef, adam_one_minus(beta1), adam_one_minus(beta2),
+                  adam_decimal(beta1), adam_decimal(beta2)};
 }
 
 __device__ __forceinline__ float adam_sgn(float x) { return (x > 0.f) - (x < 0.f); }
