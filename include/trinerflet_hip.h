@@ -394,7 +394,8 @@ TNL_API int tnl_ray_batch(const float *poses, const float *intrinsics_host, uint
  *   tnl_infer_plan          n_alive = 0 once step >= max_steps; n_step = max(min(N / n_alive, 8), min_step) (min_step = 1 is
  *                           the reference's rule; up to 8 regroups the same sample sequences into fewer, wider
  *                           iterations: identical colours for every ray that ends before the max_steps cap; buffers
- *                           then need min_step * N + 128 rows); rows = n_alive*n_step
+ *                           then need min_step * N + 128 rows); rows = n_alive*n_step.  min_step > 8 returns
+ *                           hipErrorInvalidValue (n_step is at most 8 everywhere in this loop)
  *   tnl_march_rays_dev      tnl_march_rays for the first n_alive entries of rays_alive; zero-fills the n_alive*n_step
  *                           sample rows it owns first (raymarching.py:337-339); noises may be NULL (no perturbation).
  *                           t_scratch (rows_cap floats, rows_cap = the row capacity of xyzs / dirs / deltas; may be

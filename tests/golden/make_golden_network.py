@@ -249,12 +249,16 @@ def _sphere_bitfield(cascade, H, bound, radius):
     return cref.packbits(grid, 0.5), grid
 
 
-def main():
+def import_reference(check_adjoint=True):
+    """Installs the stand-ins of the module docstring and imports the reference's own modules from /root/reference,
+    unmodified.  Returns (NeRFNetwork, nerf.utils, get_params, the `_raymarching` stand-in).  Also used by
+    make_golden_grid.py."""
     sys.meta_path.append(_Finder())
     adapter = types.ModuleType("pytorch_wavelets")
     adapter.DWTForward, adapter.DWTInverse = mgr.DWTForward, DWTInverse
     sys.modules["pytorch_wavelets"] = adapter
-    _check_adjoint()
+    if check_adjoint:
+        _check_adjoint()
     rm_native = sys.modules["_raymarching"] = _oracle_raymarching()
     sys.modules["_shencoder"] = _oracle_shencoder()
     torch.Tensor.cuda = lambda self, *a, **k: self
@@ -267,6 +271,17 @@ def main():
     import raymarching as ref_rm
     assert ref_rm.raymarching._backend is rm_native and NeRFNetwork.__module__ == "nerf.network"
     assert sys.modules["nerf.network"].__file__.startswith(REF)
+    return NeRFNetwork, U, get_params, rm_native
+
+
+MODEL_KEYS = ['triplane_channels', 'triplane_resolution', 'triplane_wavelet_levels', 'wavelet_type', 'hidden_dim',
+              'hidden_dim_color', 'hidden_dim_bg', 'learn_rotation_axis', 'dropout', 'inner_bound', 'lbound_auto_scale',
+              'upscale_ratio_bound', 'upscale_levels', 'density_blob_scale', 'density_blob_std', 'mlp_weight_decay',
+              'wavelet_base_resolution', 'nerfacc_renderer']
+
+
+def main():
+    NeRFNetwork, U, get_params, rm_native = import_reference()
 
     out = {}
     torch.manual_seed(0)
@@ -280,10 +295,7 @@ def main():
     for k, v in list(vars(opt).items()):                      # main_nerf.py:172-205: stage 0 of the list-valued flags
         if isinstance(v, list) and len(v) == 1:
             setattr(opt, k, v[0])
-    keys = ['triplane_channels', 'triplane_resolution', 'triplane_wavelet_levels', 'wavelet_type', 'hidden_dim',
-            'hidden_dim_color', 'hidden_dim_bg', 'learn_rotation_axis', 'dropout', 'inner_bound', 'lbound_auto_scale',
-            'upscale_ratio_bound', 'upscale_levels', 'density_blob_scale', 'density_blob_std', 'mlp_weight_decay',
-            'wavelet_base_resolution', 'nerfacc_renderer']
+    keys = MODEL_KEYS
     model = NeRFNetwork(encoding="triplane_wavelet", bound=opt.bound, cuda_ray=True, density_scale=opt.density_scale,
                         min_near=opt.min_near, density_thresh=opt.density_thresh, bg_radius=opt.bg_radius,
                         **{k: vars(opt)[k] for k in keys})

@@ -224,3 +224,114 @@ def test_trainstep_window_equals_whole_plane(cuda, rays60k, cfg):
         bad = int(((a - b).abs() > 2e-3 + 1e-3 * b.abs()).sum())
         assert bad <= 3 * noise + max(2, int(1e-5 * a.numel())) and float((a - b).abs().max()) < 6e-2, \
             (cfg, bad, noise, a.numel())
+
+
+def _render_model(cuda, bf):
+    """The large configuration with a medium dense enough that rays end by transmittance as well as by leaving the box."""
+    m = _model(cuda, "large", seed=6)
+    with torch.no_grad():
+        m.sigma_net[1].weight[0].add_(0.35)
+    m.density_bitfield.copy_(torch.from_numpy(bf).to(cuda))
+    m.eval()
+    return m
+
+
+def test_test_render_4096_steps_large_geometry_vs_oracle_loop(cuda, rays60k):
+    """BASELINE config 5's `--test` render (main_nerf.py:190-194: max_steps = 4096; renderer.py:324-374) at the LARGE
+    geometry (C = 48, R = 2048, hidden 128) on a 4 096-ray subset:
+      (i)  the device-driven loop against the ORACLE loop (C march_rays / composite_rays, the reference's n_step rule and
+           compaction) evaluating the same field through the same HIP kernel: survivors per iteration exact, image /
+           weights / depth to fp32 rounding -- march, composite, compaction and loop policy at max_steps = 4096;
+      (ii) against the oracle loop with the CPU field in the kernel's operand precision (fp16 planes / operands, fp32
+           accumulation): image within north_star's 1e-3, survivor counts within 0.5 % of the rays per iteration (a ray
+           whose transmittance crosses T_thresh inside an fp16 rounding may end one iteration apart)."""
+    _need_memory()
+    from tests.test_reference_pins import oracle_infer_loop
+    o, d, _, bf = rays60k
+    n = 4096
+    o, d = np.ascontiguousarray(o[:n]), np.ascontiguousarray(d[:n])
+    m = _render_model(cuda, bf)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    bg = 1.0
+    with torch.no_grad():
+        out = m.render(t(o)[None], t(d)[None], staged=True, bg_color=bg, perturb=False, dt_gamma=0, max_steps=4096,
+                       T_thresh=1e-4)
+    aabb = np.array([-BOUND] * 3 + [BOUND] * 3, np.float32)
+    nears, fars = cref.near_far_from_aabb(o, d, aabb, 0.2)
+
+    def finish(ws, dep, img):
+        return img + (1 - ws)[:, None] * bg, np.clip(dep - nears, 0, None) / (fars - nears)
+
+    # (i) same field function (the HIP kernel) inside the oracle's loop
+    def field_hip(x, dd):
+        with torch.no_grad():
+            s, c = m(t(x), t(dd))
+        return s.float().cpu().numpy(), c.float().cpu().numpy()
+    ws, dep, img, hist = oracle_infer_loop(o, d, nears, fars, bf, BOUND, 4096, field_hip)
+    image, depth = finish(ws, dep, img)
+    assert len(hist) > 300 and hist[0] < n and 0.05 * n < sum(w > 0.5 for w in ws) < 0.5 * n, (len(hist), hist[:4])
+    ended_by_T = int(((ws > 1 - 2e-4)).sum())
+    assert ended_by_T > 50, ended_by_T                      # transmittance-terminated rays exist
+    got = out["image"][0].cpu().numpy()
+    np.testing.assert_allclose(got, image, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["weights_sum"].reshape(-1).cpu().numpy(), ws, rtol=0, atol=2e-5)
+    hit = np.isfinite(depth)
+    np.testing.assert_allclose(out["depth"][0].cpu().numpy()[hit], depth[hit], rtol=0, atol=2e-5)
+    # the host-driven loop reports the survivors per iteration: they must equal the oracle's, iteration by iteration
+    alive_log = []
+    import trinerflet_amd.raymarching as rm
+    real = rm.compact_rays
+
+    def logging_compact(rays_alive, n_alive):
+        res = real(rays_alive, n_alive)
+        alive_log.append(int(res[1].item()))
+        return res
+    rm.compact_rays = logging_compact
+    try:
+        with torch.no_grad():
+            host = m.render(t(o)[None], t(d)[None], staged=True, bg_color=bg, perturb=False, dt_gamma=0, max_steps=4096,
+                            T_thresh=1e-4, device_loop=False)
+    finally:
+        rm.compact_rays = real
+    assert alive_log == hist, (len(alive_log), len(hist), [(i, a, b) for i, (a, b) in enumerate(zip(alive_log, hist)) if a != b][:5])
+    assert torch.equal(host["image"], out["image"]) and torch.equal(host["weights_sum"], out["weights_sum"])
+
+    # (ii) the oracle's own field in the kernel's operand precision
+    planes = m.encoder.get_planes().detach().cpu()
+    W = [w.detach().cpu() for w in (m.sigma_net[0].weight, m.sigma_net[1].weight, m.color_net[0].weight,
+                                    m.color_net[1].weight, m.color_net[2].weight)]
+    pl16 = planes.half().float()
+
+    def field_cpu(x, dd):
+        with torch.no_grad():
+            s, c = ofield.field(pl16, torch.from_numpy(x), torch.from_numpy(dd), W, BOUND, fp16=True)
+        return s.numpy(), c.numpy()
+    ws2, dep2, img2, hist2 = oracle_infer_loop(o, d, nears, fars, bf, BOUND, 4096, field_cpu)
+    image2, depth2 = finish(ws2, dep2, img2)
+    err = np.abs(got - image2).max()
+    assert err < 1e-3, err
+    assert np.abs(out["weights_sum"].reshape(-1).cpu().numpy() - ws2).max() < 1e-3
+    k = min(len(hist), len(hist2))
+    assert abs(len(hist) - len(hist2)) <= 2 and np.abs(np.array(hist[:k]) - np.array(hist2[:k])).max() <= 0.005 * n
+
+
+def test_test_render_800x800_device_loop_equals_host_loop_large_geometry(cuda):
+    """The full 800 x 800 image of BASELINE config 5 at max_steps = 4096, large geometry: the device-driven loop (state on
+    the device, iterations enqueued back to back) produces the image of the host-driven loop (one survivor count read back
+    per iteration, the reference's structure) bit for bit."""
+    _need_memory()
+    bf = synthetic.sphere_bitfield(128, 2, BOUND, 0.8, 0.0)
+    m = _render_model(cuda, bf)
+    poses = synthetic.hemisphere_poses(3, seed=7)
+    pix = np.stack([np.full(640000, 1), np.arange(640000)], -1)
+    o, d = synthetic.get_rays(poses, pix)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    with torch.no_grad():
+        dev = m.render(t(o)[None], t(d)[None], staged=True, bg_color=1.0, perturb=False, max_steps=4096, T_thresh=1e-4)
+        host = m.render(t(o)[None], t(d)[None], staged=True, bg_color=1.0, perturb=False, max_steps=4096, T_thresh=1e-4,
+                        device_loop=False)
+    assert torch.equal(dev["image"], host["image"])
+    assert torch.equal(dev["weights_sum"], host["weights_sum"])
+    assert torch.equal(torch.nan_to_num(dev["depth"]), torch.nan_to_num(host["depth"]))
+    ws = dev["weights_sum"].reshape(-1)
+    assert 0.1 < float((ws > 0.5).float().mean()) < 0.4                # the ball covers about a quarter of the image

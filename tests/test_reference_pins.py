@@ -93,6 +93,46 @@ def test_render_run_matches_reference_run(ref):
     assert np.isnan(out["depth"].numpy()[~hit]).all()
 
 
+def test_composite_oracle_equals_reference_run_weights(ref):
+    """The C restatement of composite_rays_train_forward (raymarching.cu:501-577) against an output of the REFERENCE's
+    own Python: with T_thresh = 0 the kernel's recurrence (alpha = 1 - exp(-sigma dt), w = alpha T, T *= 1 - alpha)
+    is the cumprod compositing of NeRFRenderer.run (renderer.py:206-229), so the weights_sum / image / depth the
+    reference's run() produced for the 64-step fixture (run64/*, make_golden_network.py) must come out of the oracle
+    kernel fed with the same sigma / rgb / dt -- sigma and rgb from the oracle field, itself pinned to the reference's
+    NeRFNetwork above."""
+    _, _, _, _, _, _, bound, _, bg, _, min_near = _cfg(ref)
+    _, _, W = _params(ref)
+    o, d = torch.from_numpy(ref["rays/o"]), torch.from_numpy(ref["rays/d"])
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = (torch.from_numpy(a) for a in cref.near_far_from_aabb(o.numpy(), d.numpy(), aabb, min_near))
+    hit = np.isfinite(ref["run64/depth"])
+    N, S = o.shape[0], 64
+    nr, fr = nears.unsqueeze(-1), fars.unsqueeze(-1)
+    z = nr + (fr - nr) * torch.linspace(0.0, 1.0, S).unsqueeze(0).expand(N, S)                    # renderer.py:150-151
+    xyz = (o.unsqueeze(-2) + d.unsqueeze(-2) * z.unsqueeze(-1)).clamp(-bound, bound)
+    dt = torch.cat([z[:, 1:] - z[:, :-1], ((fr - nr) / S).expand(N, 1)], -1)                      # :198-199
+    with torch.no_grad():
+        sig, rgb = ofield.field(torch.from_numpy(ref["planes"]), xyz.reshape(-1, 3),
+                                d.view(N, 1, 3).expand(N, S, 3).reshape(-1, 3), W, bound)
+    sig, rgb = sig.view(N, S).numpy(), rgb.view(N, S, 3).numpy()
+    # run() evaluates colour only where weight > 1e-4 and leaves zeros elsewhere (:213-219)
+    a = 1 - np.exp(-dt.numpy().astype(np.float64) * sig)
+    w = a * np.cumprod(np.concatenate([np.ones((N, 1)), 1 - a + 1e-15], 1), 1)[:, :-1]
+    rgb = np.where((w > 1e-4)[..., None], rgb, 0).astype(np.float32)
+    # kernel inputs: deltas[:,0] = dt of the alpha, deltas[:,1] = t-differences whose running sum is the depth's t (= z)
+    tdiff = np.concatenate([z[:, :1].numpy(), (z[:, 1:] - z[:, :-1]).numpy()], 1)
+    deltas = np.stack([dt.numpy(), tdiff], -1).reshape(-1, 2).astype(np.float32)
+    rays = np.stack([np.arange(N), np.arange(N) * S, np.full(N, S)], 1).astype(np.int32)
+    keep = np.nonzero(hit)[0]
+    ws, dep, img = cref.composite_rays_train_forward(sig.reshape(-1).astype(np.float32), rgb.reshape(-1, 3), deltas, rays, 0.0)
+    image = img + (1 - ws)[:, None] * bg
+    depth = (dep - nears.numpy() * ws) / (fars.numpy() - nears.numpy())                           # sum w (z - near) / (far - near)
+    np.testing.assert_allclose(ws[keep], ref["run64/weights_sum"][keep], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(image[keep], ref["run64/image"][keep], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(depth[keep], ref["run64/depth"][keep], rtol=0, atol=2e-5)
+    assert float(ws[keep].max()) - float(ws[keep].min()) > 0.1 and len(keep) >= 250
+
+
 class _OracleComposite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sig, rgb, deltas, rays):

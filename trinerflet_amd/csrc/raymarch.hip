@@ -1360,6 +1360,8 @@ int tnl_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_
 }
 
 int tnl_infer_plan(int32_t* state, uint32_t N, uint32_t max_steps, uint32_t min_step, void* stream) {
+  // n_step never exceeds 8 (the record kernel's LDS rows hold 8 samples + pad): a larger min_step is a caller error
+  if (min_step > 8) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(k_infer_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<InferState*>(state), N,
                      max_steps, (int)min_step);
   return launch_status();

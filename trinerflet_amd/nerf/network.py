@@ -185,3 +185,8 @@ class NeRFNetwork(NeRFRenderer):
             {'params': self.color_net.parameters(), 'lr': lr, **extra},
         ]
         return params
+
+
+# the density() the sigma-only fused form of the grid refresh stands for (renderer._sigma_for_grid): a subclass that
+# overrides density() is queried through its own
+NeRFNetwork._stock_density = NeRFNetwork.density

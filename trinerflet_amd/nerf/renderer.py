@@ -329,21 +329,40 @@ class NeRFRenderer(nn.Module):
                     count[cas, c0:c0 + chunk] += mask.sum(0)
         self.density_grid[count == 0] = -1
 
+    def _sigma_for_grid(self):
+        """The density the grid refresh queries: self.density(x)['sigma'] (renderer.py:487,511).  The stock network's
+        sigma-only fused form (network.density_sigma) is taken only when density() is the stock one -- a subclass or an
+        instance that overrides density() (custom density, activation, scale) is queried through ITS density()."""
+        stock = getattr(type(self), "_stock_density", None)
+        fast = getattr(self, "density_sigma", None)
+        if fast is not None and stock is not None and "density" not in self.__dict__ \
+                and getattr(type(self).density, "__func__", type(self).density) is stock:
+            return fast
+        return lambda p_: self.density(p_)['sigma']
+
     @torch.no_grad()
-    def update_extra_state(self, decay=0.95, S=128, shard=None):
+    def update_extra_state(self, decay=0.95, S=128, shard=None, draws=None):
         # reference: renderer.py:448-542.  shard=(rank, world, gather): multi-GPU refresh (SURVEY.md 8(e)): every
         # rank evaluates 1/world of the cells (full refresh: a contiguous block of the Morton-ordered cell list;
         # partial refresh: 1/world of the uniform and of the occupied picks) and `gather` (rank-ordered all-gather
         # along dim 0) completes the candidate grid identically on every rank.
+        # draws: explicit random draws for seeded parity runs (None = torch's RNG as in the reference), a dict with
+        #   "noise":  per cascade the in-cell jitter in [0,1) (torch.rand_like of renderer.py:484,509), [cells,3] in the
+        #             order the cells are evaluated here (full refresh: Morton order; partial: uniform picks, then occupied),
+        #   "coords": per cascade the uniform picks [N,3] (torch.randint of :494),
+        #   "occ_k":  per cascade the ranks [N] of the occupied picks (torch.randint(0, n_occupied, [N]) of :499).
         if not self.cuda_ray:
             return
         dev = self.density_bitfield.device
         H = self.grid_size
         rank, world, gather = shard if shard is not None else (0, 1, None)
         tmp_grid = -torch.ones_like(self.density_grid)
-        # sigma only (network.density_sigma) unless density() has been replaced on the instance (tests do)
-        sigma_only = getattr(self, "density_sigma", None) if "density" not in self.__dict__ else None
-        sigma_of = sigma_only if sigma_only is not None else (lambda p_: self.density(p_)['sigma'])
+        sigma_of = self._sigma_for_grid()
+
+        def jitter(cas, xyzs):
+            if draws is not None and draws.get("noise") is not None:
+                return draws["noise"][cas].to(dev, torch.float32)
+            return torch.rand_like(xyzs)
         if self.iter_density < 16:  # full refresh: every cell of every cascade
             cells = self._cells()
             c0, c1 = cells.shape[0] * rank // world, cells.shape[0] * (rank + 1) // world
@@ -351,20 +370,26 @@ class NeRFRenderer(nn.Module):
                 bound = min(2 ** cas, self.bound)
                 half_grid_size = bound / H
                 xyzs = cells[c0:c1] * (bound - half_grid_size)
-                xyzs = xyzs + (torch.rand_like(xyzs) * 2 - 1) * half_grid_size
+                xyzs = xyzs + (jitter(cas, xyzs) * 2 - 1) * half_grid_size
                 dens = sigma_of(xyzs).reshape(-1).detach().float() * self.density_scale
                 tmp_grid[cas] = dens if world == 1 else gather(dens)
         else:  # partial refresh: H^3/4 uniform cells + H^3/4 currently occupied cells per cascade
             N = H ** 3 // 4 // world
             for cas in range(self.cascade):
-                coords = torch.randint(0, H, (N, 3), device=dev)
+                if draws is not None and draws.get("coords") is not None:
+                    coords = draws["coords"][cas].to(dev)
+                else:
+                    coords = torch.randint(0, H, (N, 3), device=dev)
                 indices = raymarching.morton3D(coords).long()
                 # N occupied cells drawn uniformly with replacement (renderer.py:501-507: nonzero -> randint -> index), without
                 # the read-back of the occupied count: the k-th occupied cell is where the running count reaches k + 1.
                 # No occupied cell at all (the reference then adds no picks): the picks go to a spare slot behind the grid.
                 running = torch.cumsum(self.density_grid[cas] > 0, 0)
                 n_occ = running[-1]
-                k = (torch.rand(N, device=dev, dtype=torch.float64) * n_occ).long().clamp_(max=(n_occ - 1).clamp(min=0))
+                if draws is not None and draws.get("occ_k") is not None:
+                    k = draws["occ_k"][cas].to(dev).long()
+                else:
+                    k = (torch.rand(N, device=dev, dtype=torch.float64) * n_occ).long().clamp_(max=(n_occ - 1).clamp(min=0))
                 occ_indices = torch.searchsorted(running, k + 1)
                 occ_indices = torch.where(n_occ > 0, occ_indices, torch.full_like(occ_indices, H ** 3))
                 occ_coords = raymarching.morton3D_invert(occ_indices.clamp(max=H ** 3 - 1))
@@ -374,7 +399,7 @@ class NeRFRenderer(nn.Module):
                 bound = min(2 ** cas, self.bound)
                 half_grid_size = bound / H
                 xyzs = xyzs * (bound - half_grid_size)
-                xyzs = xyzs + (torch.rand_like(xyzs) * 2 - 1) * half_grid_size
+                xyzs = xyzs + (jitter(cas, xyzs) * 2 - 1) * half_grid_size
                 dens = sigma_of(xyzs).reshape(-1).detach().float() * self.density_scale
                 tmp_c = -torch.ones(H ** 3 + 1, dtype=tmp_grid.dtype, device=dev)   # + the spare slot of the picks above
                 if world == 1:

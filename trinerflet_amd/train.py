@@ -217,6 +217,16 @@ class TrainStep:
         self._defer_ctx = None     # (s0, s1, l1) of the pending steps
         self.deferred_reg = torch.zeros((), dtype=torch.float32, device=dev)   # replayed steps' L1 value, summed
         self.deferred_steps = 0    # counters for reports
+        # model.state_dict() / torch.save(model.state_dict()) read the coefficient tensors directly: the deferred part
+        # catches up first (flush_deferred is not a collective).  A weak reference: the hook must not keep this object alive.
+        import weakref
+        me = weakref.ref(self)
+
+        def _flush_before_state_dict(module, prefix, keep_vars):
+            ts = me()
+            if ts is not None and ts.model is module:
+                ts.flush_deferred()
+        self._sd_hook = model.register_state_dict_pre_hook(_flush_before_state_dict)
         self.deferred_flushes = 0
         self.last_flush_records = 0
         # clip_far: march each ray only to its exit from the occupied cells' box (raymarching.clip_fars: the same samples
@@ -900,7 +910,9 @@ class TrainStep:
         # the announced tensors are kept (their storage cannot be recycled for another batch meanwhile) together with
         # their version counters (an in-place refill of a persistent ray buffer is noticed)
         key = tuple((t_, t_.data_ptr(), tuple(t_.shape), t_._version) if t_ is not None else None for t_ in (no, nd, nn))
-        self._prefetched = (key, march_on_side(no, nd, nn))
+        # the ring slot the march takes (run_cuda's local_step rule), so that a dropped prefetch gives back exactly it
+        slot_step = model.local_step
+        self._prefetched = (key, march_on_side(no, nd, nn), slot_step)
 
     @staticmethod
     def _prefetch_matches(key, rays_o, rays_d, noises):
@@ -920,8 +932,11 @@ class TrainStep:
             return
         (_, (_, ev_sort)) = pre[1]
         torch.cuda.current_stream().wait_event(ev_sort)
-        self.model.local_step -= 1
-        self.model.step_counter[self.model.local_step % 16].zero_()
+        # only if nothing moved the ring meanwhile (a manual update_extra_state() resets local_step to 0: the slot then
+        # belongs to a finished period and mean_count has already been taken)
+        if self.model.local_step == pre[2] + 1:
+            self.model.local_step -= 1
+            self.model.step_counter[self.model.local_step % 16].zero_()
 
     def _scaler_probe(self, g0, g1, flag):
         """GradScaler.unscale_'s found_inf over g0 (+ g1) and an optional device flag; [1] float tensor."""

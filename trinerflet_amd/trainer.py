@@ -293,6 +293,8 @@ class Trainer:
         contrast as in the reference.  Returns the list of files."""
         if self.workspace is None:
             raise RuntimeError("Trainer was built without a workspace")
+        # a collective in "sharded" mode (flush + all-gather): on EVERY rank, before the ranks diverge (as save_checkpoint)
+        self.ts.sync_sharded_parameters()
         if self.rank != 0:
             return []
         enc = self.model.encoder
@@ -315,7 +317,6 @@ class Trainer:
                     written.append(f)
 
         with torch.no_grad():
-            self.ts.sync_sharded_parameters()
             enc.reset_cahce()
             planes = enc.get_planes()
             upscaled = []
@@ -353,6 +354,7 @@ class Trainer:
     def optimizer_state_dict(self):
         """torch.optim.Adam state_dict over model.get_params(lr).  No collective in here: in "sharded" mode the caller
         (save_checkpoint, on EVERY rank) has gathered parameters and moments before the ranks diverge."""
+        self.ts.flush_deferred()      # not a collective: the deferred coefficients / moments catch up before they are read
         opt = self._torch_optimizer()
         slots = self._flat_slots()
         step = self.ts.opt_steps.detach().to("cpu", torch.float32).reshape(())
