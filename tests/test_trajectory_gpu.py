@@ -1,0 +1,58 @@
+"""north_star: "PSNR within 0.1 dB of reference" at a README geometry, on a REAL trajectory.
+
+Base configuration (README.md:46-58: C = 32, R = 2048, scale 32, hidden 64, 60 000 rays) from an untrained occupancy
+grid (mark_untrained_grid, real refreshes every 16 steps, nothing re-imposed), 512 steps on the analytic sphere scene,
+twice on the same batches / perturbation noise / refresh draws:
+  * the fused fp16-plane TrainStep (the bench's headline path: occupancy window, live rectangles, deferred optimiser pass),
+  * the loop the reference's Trainer runs (utils.py:1134-1175) on the drop-in modules with fp32 planes: autograd,
+    torch.optim.Adam(eps 1e-15), torch GradScaler, LambdaLR(decay_function).
+Held-out PSNR (PSNRMeter semantics, utils.py:245-285; 4 unseen cameras) must agree within 0.1 dB.
+tools/trajectory.py is the same code as a script; bench.py reports the fused run as config.trajectory."""
+import importlib.util
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _traj():
+    spec = importlib.util.spec_from_file_location("tnl_trajectory", os.path.join(ROOT, "tools", "trajectory.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_base_geometry_fused_fp16_vs_reference_loop_fp32_psnr(cuda):
+    free, _ = torch.cuda.mem_get_info()
+    if free < 96 * 2 ** 30:
+        pytest.skip(f"needs 96 GB of free device memory, {free / 2 ** 30:.0f} GB available")
+    T = _traj()
+    steps = int(os.environ.get("TNL_TRAJ_STEPS", "512"))
+    scene = T.make_scene(cuda)
+    batches = T.batches_of(scene[0], steps, 60000)
+    fused = T.run_fused("base", cuda, steps, 60000, scene, batches)
+    fused.pop("_model")
+    torch.cuda.empty_cache()
+    ref = T.run_reference_loop("base", cuda, steps, 60000, scene, batches)
+    ref.pop("_model")
+    rep = {"fused": fused, "reference_loop": ref,
+           "psnr_difference_db": round(fused["held_out_psnr_db"] - ref["held_out_psnr_db"], 4)}
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "trajectory_base.json"), "w") as f:
+            json.dump(rep, f, indent=1)
+    msg = (f"fused fp16 planes {fused['held_out_psnr_db']:.3f} dB vs reference loop fp32 planes "
+           f"{ref['held_out_psnr_db']:.3f} dB; fused {fused['wall_ms_per_step']:.2f} ms/step over the trajectory "
+           f"({fused['second_half_ms_per_step']:.2f} in its second half), reference loop {ref['wall_ms_per_step']:.1f} ms/step; "
+           f"window {fused['window_first_last']}, samples/step {fused['samples_per_step_first_last']}")
+    print(msg)
+    assert fused["held_out_psnr_db"] > 25.0 and ref["held_out_psnr_db"] > 25.0, msg
+    assert abs(rep["psnr_difference_db"]) < 0.1, msg
+    # the trajectory really moved: the sample count fell by more than 3x from the untrained grid and a window formed
+    assert fused["samples_per_step_first_last"][1] * 3 < fused["samples_per_step_first_last"][0], msg
+    assert fused["window_first_last"][1] is not None and fused["deferred_steps"] > steps // 2, msg

@@ -1,0 +1,221 @@
+"""A real training trajectory at a README geometry (VERDICT r02 "What's missing" 2 and 3; reference loop:
+reconstruction/nerf/utils.py:1134-1175 with the refresh at :1144-1146, configs README.md:46-58, PSNR as
+utils.py:245-285 measures it).
+
+From an UNTRAINED occupancy grid (mark_untrained_grid, then real update_extra_state refreshes every 16 steps -- nothing
+re-imposed, the sample budget follows the ring of step counters) the analytic sphere scene is trained for `steps`
+steps of 60 000 rays twice, on the same batches and the same perturbation noise:
+
+  fused      TrainStep (the product's step: fp16 planes, occupancy window, live rectangles, deferred optimiser pass),
+             timed step by step with HIP events;
+  reference  the loop the reference's Trainer runs, on the drop-in modules: planes rebuilt in fp32 outside autocast
+             (utils.py:1138-1140), autograd through lookup / MLP / composite, torch.optim.Adam(eps 1e-15), torch
+             GradScaler, LambdaLR(decay_function), update_extra_state every 16 steps.
+
+Reports held-out PSNR of both (mean of per-image PSNRs over unseen cameras), the fused run's ms/step over the whole
+trajectory and per 16-step period, and the occupancy window / sample count over time.
+
+    PYTHONPATH=. python tools/trajectory.py [--workload base|large|small] [--steps 512] [--skip-reference]
+
+bench.py imports run_fused() for `config.trajectory`; tests/test_trajectory_gpu.py asserts the 0.1 dB bar.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GEOM = {  # channels, resolution, wavelet scale, hidden, lambda (README.md:46-58)
+    "base": (32, 2048, 32, 64, 0.4),
+    "large": (48, 2048, 32, 128, 0.6),
+    "small": (16, 1024, 16, 64, 0.2),
+    "tiny": (16, 256, 4, 64, 0.2),
+}
+
+
+def make_scene(device, n_train=36, n_valid=4, hw=400, seed=0):
+    """Analytic opaque sphere (alpha 1 on the ball, 0 elsewhere), Blender-style cameras: pools of training and held-out
+    pixels on the device."""
+    from trinerflet_amd import synthetic
+    from trinerflet_amd.raypool import RayPool
+    poses, intr, images = synthetic.sphere_dataset(n_cams=n_train + n_valid, H=hw, W=hw, seed=seed)
+    train = RayPool(poses[n_valid:], intr, hw, hw, images[n_valid:], device=device)
+    valid = RayPool(poses[:n_valid], intr, hw, hw, images[:n_valid], device=device)
+    return train, valid
+
+
+def make_model(workload, device, plane_dtype=None, seed=0):
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    C, R, scale, H, lam = GEOM[workload]
+    extra = {} if plane_dtype is None else {"plane_dtype": plane_dtype}
+    torch.manual_seed(seed)
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, density_scale=1, min_near=0.2,
+                    density_thresh=10, bg_radius=-1, hidden_dim=H, hidden_dim_color=H, triplane_channels=C,
+                    triplane_resolution=R, triplane_wavelet_levels=scale, wavelet_type="bior6.8", **extra).to(device)
+    return m, lam
+
+
+def batches_of(pool, steps, num_rays, seed=0):
+    """The first `steps` batches of consecutive epochs of the pool (train_one_epoch2's order) + one noise vector each."""
+    g = torch.Generator(device=pool.device)
+    g.manual_seed(seed)
+    per_epoch = pool.total // num_rays
+    out = []
+    for k in range(steps):
+        ep, idx = divmod(k, per_epoch)
+        if idx == 0:
+            pool.shuffle(seed * 1000003 + ep + 1)
+        b = pool.batch(idx, num_rays, bg_color=0.0)
+        out.append((b["rays_o"], b["rays_d"], b["gt_rgb"], torch.rand(num_rays, device=pool.device, generator=g)))
+    return out
+
+
+@torch.no_grad()
+def held_out_psnr(model, pool, max_steps=1024):
+    """PSNRMeter semantics (utils.py:245-285): per image -10 log10(mean squared error), averaged over the images."""
+    model.eval()
+    model.encoder.reset_cahce()
+    vals = []
+    for i in range(pool.B):
+        data = pool.image_rays(i, bg_color=0.0)
+        out = model.render(data["rays_o"][None], data["rays_d"][None], staged=True, bg_color=0.0, perturb=False,
+                           dt_gamma=0, max_steps=max_steps)
+        mse = ((out["image"].reshape(-1, 3) - data["gt_rgb"]) ** 2).mean()
+        vals.append(float(-10.0 * torch.log10(mse)))
+    model.train()
+    return float(np.mean(vals))
+
+
+def run_fused(workload, device, steps=512, num_rays=60000, scene=None, batches=None, seed=0, ts_kwargs=None):
+    """The product's training loop from an untrained grid; returns a report dict (and the model under "_model")."""
+    from trinerflet_amd.train import TrainStep
+    train, valid = scene if scene is not None else make_scene(device)
+    model, lam = make_model(workload, device, seed=seed)
+    ts = TrainStep(model, lr=1e-2, wavelet_regularization=lam, iters=steps, warmup_steps=0, fp16=True,
+                   background_color=0.0, **(ts_kwargs or {}))
+    model.mark_untrained_grid(train.poses, train.intrinsics)
+    ts.invalidate_roi()
+    if batches is None:
+        batches = batches_of(train, steps, num_rays, seed)
+    torch.manual_seed(1234)                 # the refreshes' jitter / picks (the same stream in the reference loop)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    counters, windows = [], []
+    total = torch.zeros((), device=device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs[0].record()
+    for k, (o, d, gt, nz) in enumerate(batches):
+        nxt = batches[k + 1] if k + 1 < steps else None
+        total += ts.step(o, d, gt, noises=nz, next_rays=None if nxt is None else (nxt[0], nxt[1], nxt[3]))
+        evs[k + 1].record()
+        counters.append(ts.last["counter"])
+        windows.append(None if ts._roi is None else (ts._roi[6], ts._roi[7]))
+    total += ts.pop_deferred_reg()          # flushes the deferred optimiser work: it belongs to these steps
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(steps)])
+    M = np.array([int(c[0]) for c in torch.stack(counters).cpu()])
+    R = GEOM[workload][1]
+    periods = [{"steps": f"{a}-{min(a + 16, steps) - 1}", "ms_per_step": round(float(ms[a:a + 16].mean()), 3),
+                "refresh_step_ms": round(float(ms[a]), 3), "samples_per_step": int(M[a + 1:a + 16].mean()) if a + 1 < steps else int(M[a]),
+                "window": windows[min(a + 1, steps - 1)]} for a in range(0, steps, 16)]
+    psnr = held_out_psnr(model, valid)
+    tail = slice(steps // 2, steps)
+    return {
+        "workload": workload, "steps": steps, "rays_per_step": num_rays, "plane_size": R,
+        "wall_ms_per_step": round(wall / steps * 1e3, 4), "rays_per_s": num_rays * steps / wall,
+        "event_ms_per_step_mean": round(float(ms.mean()), 4),
+        "second_half_ms_per_step": round(float(ms[tail].mean()), 4),
+        "second_half_samples_per_step": int(M[tail].mean()),
+        "first_period_ms_per_step": round(float(ms[:16].mean()), 3),
+        "samples_per_step_first_last": [int(M[0]), int(M[-1])],
+        "window_first_last": [windows[1] if steps > 1 else windows[0], windows[-1]],
+        "deferred_steps": ts.deferred_steps, "deferred_flushes": ts.deferred_flushes,
+        "loss_sum": float(total), "final_mse": float(ts.last["mse"]), "held_out_psnr_db": round(psnr, 4),
+        "periods": periods, "_model": model,
+        "note": "from an untrained grid (mark_untrained_grid), real density-grid refreshes every 16 steps, no re-imposed "
+                "occupancy; analytic sphere scene, 36 training + 4 held-out cameras of 400 x 400; ms per step from HIP "
+                "events around every step, wall clock around the whole run incl. the closing flush of the deferred pass",
+    }
+
+
+def run_reference_loop(workload, device, steps=512, num_rays=60000, scene=None, batches=None, seed=0):
+    """The reference Trainer's loop (train_one_epoch2 + train_step, fp16=True: autocast around the render, planes built
+    in fp32 outside it) on the drop-in modules, fp32 planes."""
+    from trinerflet_amd.train import lr_factor
+    train, valid = scene if scene is not None else make_scene(device)
+    model, lam = make_model(workload, device, plane_dtype=torch.float32, seed=seed)
+    model.mark_untrained_grid(train.poses, train.intrinsics)
+    model.train()
+    if batches is None:
+        batches = batches_of(train, steps, num_rays, seed)
+    opt = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)            # main_nerf.py:119
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: lr_factor(k, steps, 0))        # main_nerf.py:129
+    scaler = torch.amp.GradScaler("cuda")
+    torch.manual_seed(1234)
+    enc = model.encoder
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    M = []
+    for k, (o, d, gt, nz) in enumerate(batches):
+        enc.reset_cahce()
+        enc.get_planes()                                                                     # utils.py:1138-1140
+        if k % 16 == 0:
+            model.update_extra_state()                                                       # utils.py:1144-1146
+        opt.zero_grad(set_to_none=True)
+        out = model.render(o[None], d[None], staged=False, bg_color=0.0, perturb=True, force_all_rays=False, noises=nz,
+                           dt_gamma=0, max_steps=1024)
+        loss = ((out["image"][0] - gt) ** 2).mean()                                         # utils.py:595 (MSE mean)
+        wf = enc.get_wavelet_features()                                                      # utils.py:639-655
+        tot = sum(v.numel() for v in wf)
+        loss = loss + lam * sum(v.abs().mean() * (v.numel() / tot) for v in wf) / len(wf)
+        enc.reset_cahce()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        sched.step()
+        M.append(model.step_counter[(model.local_step - 1) % 16, 0])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    M = torch.stack(M).cpu().numpy()
+    psnr = held_out_psnr(model, valid)
+    return {"workload": workload, "steps": steps, "wall_ms_per_step": round(wall / steps * 1e3, 3),
+            "samples_per_step_first_last": [int(M[0]), int(M[-1])], "held_out_psnr_db": round(psnr, 4), "_model": model}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="base", choices=sorted(GEOM))
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--rays", type=int, default=60000)
+    ap.add_argument("--skip-reference", action="store_true")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    scene = make_scene(dev)
+    batches = batches_of(scene[0], args.steps, args.rays)
+    fused = run_fused(args.workload, dev, args.steps, args.rays, scene, batches)
+    fused.pop("_model")
+    torch.cuda.empty_cache()
+    rep = {"fused": fused}
+    if not args.skip_reference:
+        ref = run_reference_loop(args.workload, dev, args.steps, args.rays, scene, batches)
+        ref.pop("_model")
+        rep["reference_loop"] = ref
+        rep["psnr_difference_db"] = round(fused["held_out_psnr_db"] - ref["held_out_psnr_db"], 4)
+    s = json.dumps(rep, indent=1)
+    print(s)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(s + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -299,8 +299,15 @@ class NeRFRenderer(nn.Module):
             H = self.grid_size
             idx = torch.arange(H ** 3, dtype=torch.int32, device=self.density_bitfield.device)
             coords = raymarching.morton3D_invert(idx)
-            self._morton_xyz = 2 * coords.float() / (H - 1) - 1
+            self._morton_xyz = self._cell_centres(coords)
         return self._morton_xyz
+
+    def _cell_centres(self, coords):
+        """2 * c / (H - 1) - 1 (renderer.py:416,475) with a TRUE division: torch's GPU kernel for `tensor / python_scalar`
+        multiplies by the scalar's reciprocal, which differs from the reference's CPU-or-CUDA quotient in the last bit for
+        one cell coordinate in nine; dividing by a tensor takes the correctly rounded path."""
+        den = torch.full((1,), float(self.grid_size - 1), dtype=torch.float32, device=coords.device)
+        return 2 * coords.float() / den - 1
 
     @torch.no_grad()
     def mark_untrained_grid(self, poses, intrinsic, S=64):
@@ -395,7 +402,7 @@ class NeRFRenderer(nn.Module):
                 occ_coords = raymarching.morton3D_invert(occ_indices.clamp(max=H ** 3 - 1))
                 indices = torch.cat([indices, occ_indices], dim=0)
                 coords = torch.cat([coords, occ_coords], dim=0)
-                xyzs = 2 * coords.float() / (H - 1) - 1
+                xyzs = self._cell_centres(coords)
                 bound = min(2 ** cas, self.bound)
                 half_grid_size = bound / H
                 xyzs = xyzs * (bound - half_grid_size)
