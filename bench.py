@@ -13,8 +13,11 @@ Synthetic inputs per SURVEY.md 8(d): 100 hemisphere cameras (800x800), seeded ra
 occupancy r=0.8 re-imposed after each grid refresh (the refresh itself runs and is timed), seeded field.
 Weak scaling: every rank processes its own 60 000 rays per step; value = rays of all ranks / max-rank time.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the dominant kernel: the
-fused Adam+L1 pass over the 402 M wavelet coefficients, HBM-bound, 28 B/parameter) and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` -- the section of the step with the
+largest per-step time (found by an instrumented pass before the timed steps, then timed with HIP events inside them),
+its binding roof (HBM bytes or MFMA flops, whichever takes longer at peak), `roofline.top` = the three longest
+sections with algorithmic bytes / flops, fraction and counter traffic, the step's actual traffic, this box's measured
+copy bandwidth -- and `cpu_baseline`.  `config.trajectory`: 512 steps from an untrained grid (tools/trajectory.py).
 """
 import argparse
 import gc
@@ -31,6 +34,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak (MI355X_MICROARCH.md; the headline figures with 2:1 sparsity are not used)
+
+# section -> the mark that precedes it in TrainStep.step (a section is timed between two consecutive marks)
+SECTION_PREV = {"idwt_fwd": "begin", "field_fwd": "march", "field_bwd": "composite_bwd", "plane_grad_binned": "field_bwd",
+                "idwt_adjoint": "scaler_probe", "adam_coef": "idwt_adjoint"}
+# section -> substrings of the kernel names launched inside it (for the rocprofv3 counter passes and profiles/)
+SECTION_KERNELS = {"field_fwd": ["k_field_fwd"], "field_bwd": ["k_field_bwd", "k_slab_reduce"],
+                   "adam_coef": ["k_adam_l1_live", "k_adam_l1<true", "k_adam_record"],
+                   "plane_grad_binned": ["k_tile_accumulate"], "idwt_fwd": ["k_idwt_fwd", "k_to_texel_major"],
+                   "idwt_adjoint": ["k_idwt_bwd"]}
 
 WORKLOADS = {
     # name: (channels, resolution, wavelet scale, hidden, rays, lambda)
@@ -92,39 +105,40 @@ def one_step(model, ts, bitfield, batch, mean_count, next_batch=None):
 
 
 def cpu_baseline(workload):
-    """Reference operator set on the host cores, bounded sample (see oracle/torch_baseline.py)."""
+    """Reference operator set on the host cores (oracle/torch_baseline.py), BASELINE.md section 3's procedure: the dense
+    part (plane rebuild, its backward, regulariser, Adam) at the FULL plane size, the per-ray part on a reduced ray count
+    scaled linearly; one warm-up step, then the median of 3 timed steps (section 3 asks for >= 5; 3 keeps the default run
+    within minutes -- the dense part alone is ~10 s per step at base)."""
     from oracle import torch_baseline as tb
     C, R, scale, H, N, lam = WORKLOADS[workload]
     # torch's CPU kernels stop scaling (and then regress) well before the 256 hardware threads of the GPU box's
     # host: 32 threads measured fastest there (8: 1.38 s, 16: 1.23 s, 32: 1.10 s, 64: 1.92 s for the same sample)
     cores = min(os.cpu_count() or 1, 32)
-    # dense part at 1/4 of the plane area (R/2), per-ray part on N/10 rays; both scale linearly
-    Rs, Ns = max(R // 2, 64 * 2), max(N // 10, 64)
-    ss = max(scale // 2, 2)
-    t = tb.time_step(C, Rs, ss, H, Ns, lam=lam, threads=cores)
-    dense = t["dense_s"] * (R / Rs) ** 2
-    ray = t["ray_s"] * (N / Ns)
+    Ns = max(N // 20, 64)
+    t = tb.time_step(C, R, scale, H, Ns, lam=lam, threads=cores, repeats=3, warmup=1)
+    dense, ray = t["dense_s"], t["ray_s"] * (N / Ns)
     return {"value": N / (dense + ray), "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"torch-CPU fp32 step: dense part (IDWT fwd+bwd, L1, Adam) at R={Rs} scaled x{(R / Rs) ** 2:.0f}; "
-                      f"per-ray part (512 uniform steps/ray, renderer.run semantics) on {Ns} rays scaled x{N / Ns:.0f}; "
-                      f"measured dense {t['dense_s']:.2f}s ray {t['ray_s']:.2f}s"}
+            "samples_per_s": N * 512 / (dense + ray),
+            "split_s": {"dense_full_size": round(dense, 3), "per_ray_scaled": round(ray, 3)},
+            "sample": f"torch-CPU fp32 step, 1 warm-up + median of 3: dense part (IDWT fwd+bwd, L1, Adam over "
+                      f"{3 * C * R * R / 1e6:.0f} M coefficients) at the full R={R}: {[round(v, 2) for v in t['dense_all_s']]} s; "
+                      f"per-ray part (512 uniform steps/ray, renderer.run semantics, on the full-size planes) on {Ns} rays "
+                      f"scaled x{N / Ns:.0f}: {[round(v, 2) for v in t['ray_all_s']]} s"}
 
 
-PMC_STATIC = os.path.join(ROOT, "profiles", "r02_pmc_adam.json")
+def _short(name):
+    import re
+    m = re.search(r"(k_[a-z0-9_]+)", name)
+    return m.group(1) if m else name[:48]
 
 
-def pmc_traffic_static(workload, world):
-    """HBM bytes of the step's k_adam_l1 launches from the committed rocprofv3 PMC passes (tools/pmc_summary.py)."""
-    if workload != "base" or world != 1 or not os.path.exists(PMC_STATIC):
-        return None, None
-    return json.load(open(PMC_STATIC))["hbm_bytes_per_launch"], os.path.relpath(PMC_STATIC, ROOT) + " (static)"
-
-
-def pmc_traffic_live(workload, launches_per_step):
-    """HBM bytes per k_adam_l1 launch measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and
-    WRITE_SIZE in separate passes, no trace domain, the program itself after `--`), 2 timed steps each, summed over the
-    step's launches with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts half of a wide streaming
-    read): bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Returns (bytes per step, note) or (None, reason)."""
+def pmc_traffic_live(workload):
+    """HBM traffic counters of EVERY kernel of a steady-state step, measured NOW: two child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes as the guide prescribes, no trace domain, the
+    program itself after `--`).  The window is the child's last two steps (no grid refresh inside), delimited by the
+    k_step_epilogue dispatches.  Returns ({kernel: {"FETCH_SIZE": KB per step, "WRITE_SIZE": KB per step}}, note) or
+    (None, reason).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half the bytes of a wide
+    coalesced read, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; the raw sum is reported beside it."""
     import csv
     import glob
     import shutil
@@ -133,7 +147,7 @@ def pmc_traffic_live(workload, launches_per_step):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None, "rocprofv3 not found"
-    tot = {}
+    per = {}
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(td, counter)
@@ -145,21 +159,40 @@ def pmc_traffic_live(workload, launches_per_step):
                 return None, f"rocprofv3 child failed: {e}"
             if r.returncode != 0:
                 return None, f"rocprofv3 child rc={r.returncode}: {r.stderr[-300:]}"
-            vals = []
+            rows = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if row["Counter_Name"] == counter and ("k_adam_l1<true" in row["Kernel_Name"] or
-                                                               "k_adam_l1_live" in row["Kernel_Name"]):
-                            vals.append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
-            vals = [v for _, v in sorted(vals)]
-            n = len(vals) // launches_per_step
-            if n < 2:
-                return None, f"no k_adam_l1<true> / k_adam_l1_live dispatches in the {counter} pass"
-            last = vals[(n - 2) * launches_per_step:n * launches_per_step]     # the child's last two steps (ROI steps)
-            tot[counter] = sum(last) / 2.0
-    return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0, \
-        "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run, (2*FETCH+WRITE)*1024 per step"
+                        if row["Counter_Name"] == counter:
+                            rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], float(row["Counter_Value"])))
+            rows.sort()
+            ends = [i for i, kn, _ in rows if "k_step_epilogue" in kn]
+            if len(ends) < 3:
+                return None, f"no step boundaries in the {counter} pass"
+            lo, hi = ends[-3], ends[-1]
+            for i, kn, v in rows:
+                if lo < i <= hi:
+                    per.setdefault(_short(kn), {}).setdefault(counter, 0.0)
+                    per[_short(kn)][counter] += v / 2.0
+    return per, ("live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (separate passes), the child's last "
+                 "two steps; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per the guide's gfx950 correction")
+
+
+def copy_bandwidth(device, nbytes=1 << 30, reps=10):
+    """What this box's memory system gives a plain streaming copy (16 B per lane, tnl_copy_probe): GB/s of read + write."""
+    from trinerflet_amd import _lib as L
+    a = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    b = torch.empty_like(a)
+    run = lambda: L.check(L.lib().tnl_copy_probe(L.ptr(a), L.ptr(b), L.u64(nbytes), L.stream()), "copy_probe")
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    e1.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def time_steps(model, ts, bitfield, batches, mean_count, steps, setup=4):
@@ -190,12 +223,15 @@ def variant_ms(workload, device, bitfield_np_unused, batches, mean_count, steps,
 
 def inference_figure(model, device, max_steps=4096, images=3):
     """BASELINE config 5's `--test` render: 800 x 800 rays of one pose through run_cuda's inference branch at
-    max_steps = 4096 (renderer.py:324-374), the trained-state planes of the benchmark model."""
+    max_steps = 4096 (renderer.py:324-374), the trained-state planes of the benchmark model.  SURVEY.md 8(d)
+    "Inference unit": bytes = samples * (12*C*e + 48) + sum over iterations of n_alive * (4 + 4 + 20*2)."""
     from trinerflet_amd import synthetic
+    import trinerflet_amd.raymarching as rm
     poses = synthetic.hemisphere_poses(images, seed=3)
     model.eval()
     model.encoder.reset_cahce()
     times, wide = [], []
+    sched = []
     with torch.no_grad():
         for k in range(images + 1):
             pix = np.stack([np.full(640000, k % images, np.int64), np.arange(640000)], -1)
@@ -207,15 +243,65 @@ def inference_figure(model, device, max_steps=4096, images=3):
                 model.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, infer_min_step=min_step)
                 torch.cuda.synchronize()
                 acc.append(time.perf_counter() - t0)
+            if k == images:
+                # the schedule of that image (iterations, survivors, samples): the host-driven loop runs the same
+                # iterations (bit-identical image, tests/test_renderer_gpu.py) and passes them through march_rays
+                real = rm.march_rays
+
+                def logging_march(n_alive, n_step, *a, **kw):
+                    sched.append((int(n_alive), int(n_step)))
+                    return real(n_alive, n_step, *a, **kw)
+                rm.march_rays = logging_march
+                try:
+                    model.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, device_loop=False)
+                finally:
+                    rm.march_rays = real
     model.train()
     t, tw = float(np.mean(times[1:])), float(np.mean(wide[1:]))
+    C = model.encoder.number_of_features
+    e = 2 if model.encoder.plane_dtype == torch.float16 else 4
+    samples = float(sum(a * b for a, b in sched))
+    alive = float(sum(a for a, _ in sched))
+    nbytes = samples * (12 * C * e + 48) + alive * 48.0
+    H = model.hidden_dim
+    mac = 3 * C * H + 16 * H + 31 * H + H * H + 3 * H
     return {"image": "800x800", "max_steps": max_steps, "ms_per_image": round(t * 1e3, 2), "rays_per_s": 640000 / t,
+            "iterations": len(sched), "samples_per_image": samples, "samples_per_s": samples / t,
+            "sum_n_alive_over_iterations": alive,
+            "algorithmic_bytes": nbytes, "GB/s": round(nbytes / t / 1e9, 1), "frac_of_8_TB/s": round(nbytes / t / 8e12, 4),
+            "mlp_TFLOP/s": round(2.0 * mac * samples / t / 1e12, 1),
+            "bound_note": "SURVEY.md 8(d) inference unit: samples * (12*C*e + 48) + sum_iterations n_alive * 48 bytes over the "
+                          "image time; the loop is bound by its iteration count (each iteration = plan + march + field + "
+                          "composite + compaction launches over a shrinking ray set), not by bytes -- see wide_iterations",
             "wide_iterations": {"ms_per_image": round(tw * 1e3, 2), "rays_per_s": 640000 / tw,
+                                "GB/s": round(nbytes / tw / 1e9, 1), "frac_of_8_TB/s": round(nbytes / tw / 8e12, 4),
                                 "note": "render(..., infer_min_step=8): the same per-ray sample sequences in an eighth of "
                                         "the iterations; identical pixels for rays that end before the max_steps cap "
                                         "(tests/test_renderer_gpu.py)"},
             "note": "run_cuda eval branch (device-driven alive-ray loop, the reference's schedule), solid-sphere "
-                    "occupancy, the benchmark's field after its training steps; mean of 3 images after one warm-up"}
+                    "occupancy, the benchmark's field after its training steps; mean of 3 images after one warm-up; "
+                    "rocprofv3 summary: profiles/r03_infer_kernel_stats.csv"}
+
+
+def trajectory_figure(workload, device, steps=512):
+    """config.trajectory: the fused step on a REAL trajectory (tools/trajectory.py): untrained grid -> real refreshes,
+    occupancy window and sample budget as they evolve, held-out PSNR at the end."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tnl_trajectory", os.path.join(ROOT, "tools", "trajectory.py"))
+    T = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(T)
+    if workload not in T.GEOM:
+        return None
+    rep = T.run_fused(workload, device, steps, WORKLOADS[workload][4])
+    rep.pop("_model")
+    periods = rep.pop("periods")
+    rep["per_16_steps"] = {"ms_per_step": [p["ms_per_step"] for p in periods],
+                           "refresh_step_ms": [p["refresh_step_ms"] for p in periods],
+                           "samples_per_step": [p["samples_per_step"] for p in periods],
+                           "window": [p["window"] for p in periods]}
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rep
 
 
 def main():
@@ -293,19 +379,28 @@ def main():
     # paths -- sample-budget update, partial ROI rebuild -- has happened once), then park the long-lived Python objects
     # in the permanent generation so that a generation-2 collection (10-20 ms with the torch module tree) cannot land
     # inside the timed steps.  The W warm-up steps and the K timed steps follow unchanged; the timed window still
-    # contains its grid refresh (every 16th step).
+    # contains its grid refresh (every 16th step).  The set-up steps are instrumented (a HIP event at every section
+    # boundary): they tell which section of the step is the longest, i.e. which one the timed steps put events around.
+    ts.section_events, ts.section_names = [], None
     for i in range(16):
         one_step(model, ts, bitfield, batches[i % nb], mean_count, batches[(i + 1) % nb])
     torch.cuda.synchronize()
+    pre = ts.section_times()
+    dominant = max(SECTION_PREV, key=lambda k: pre.get(k, 0.0))
+    if os.environ.get("TNL_BENCH_SECTION") in SECTION_PREV:          # experiments: force the section timed live
+        dominant = os.environ["TNL_BENCH_SECTION"]
+    ts.section_events = None
     gc.collect()
     gc.freeze()
     for i in range(args.warmup):
         one_step(model, ts, bitfield, batches[i % nb], mean_count, batches[(i + 1) % nb])
 
-    # HIP events on the launch stream inside the timed steps: only the two boundaries around the dominant kernel's
+    # HIP events on the launch stream inside the timed steps: only the two boundaries around the dominant section's
     # launches (every recorded boundary costs the stream 6-8 us; all of them together were 1.3 % of a step)
     ts.section_events = []
-    ts.section_names = {"idwt_adjoint", "scaler_probe", "adam_coef"}
+    ts.section_names = {SECTION_PREV[dominant], dominant}
+    if dominant == "idwt_fwd":
+        ts.section_names.add("adam_catchup")          # a replay of the deferred pass may sit between "begin" and the rebuild
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -327,31 +422,20 @@ def main():
     elapsed = float(tmax.item())
 
     timed_flushes, timed_deferred = ts.deferred_flushes - flushes0, ts.deferred_steps - deferred0
-    # the dominant kernel's time from the HIP events recorded inside the timed region ...
-    adam_ms = ts.section_times().get("adam_coef", float("nan"))
-    # ... and every section's, for the secondary figures, from an instrumented pass AFTER it (not part of the K steps)
+    # the dominant section's time from the HIP events recorded inside the timed region ...
+    dom_ms = ts.section_times().get(dominant, float("nan"))
+    # ... and every section's, for the other figures, from an instrumented pass AFTER it (not part of the K steps)
     ts.section_events, ts.section_names = [], None
     for i in range(min(args.steps, 16)):
         j = args.warmup + args.steps + i
         one_step(model, ts, bitfield, batches[j % nb], mean_count, batches[(j + 1) % nb])
     torch.cuda.synchronize()
     sec = ts.section_times()
-    sec["adam_coef"] = adam_ms
-    # If the step starts the next batch's march + tile sort together with the Adam launches (TrainStep.prefetch_at =
-    # "adam"), the figure above is the kernel sharing the GPU with them; then also the kernel by itself: the same steps
-    # with the side work started after the field backward instead (nothing runs beside Adam).
-    adam_alone_ms = float("nan")
-    if ts._prefetch_under_adam(((),)):
-        ts.section_events, ts.section_names = [], {"idwt_adjoint", "scaler_probe", "adam_coef"}
-        ts.prefetch_at = "bwd"
-        for i in range(min(args.steps, 16)):
-            j = args.warmup + args.steps + 16 + i
-            one_step(model, ts, bitfield, batches[j % nb], mean_count, batches[(j + 1) % nb])
-        torch.cuda.synchronize()
-        adam_alone_ms = ts.section_times().get("adam_coef", float("nan"))
-        ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", "auto")
+    sec_instrumented_dominant = sec.get(dominant)
+    if dom_ms == dom_ms:
+        sec[dominant] = dom_ms
+    ts.section_events = None
     samples_per_step = float(np.mean(counts))
-    P_coef = ts.coef_numel if ts.dist_mode != "sharded" else ts.coef_numel // world
     # algorithmic bytes of the step's Adam launches (one per wavelet level + LL): 16 B read (p, g, m, v) + 12 B
     # written (p, m, v) per coefficient; with the gradient-support chain g is neither stored nor read outside each
     # level's rectangle (24 B there).  TrainStep._rects holds the rectangles of the last non-refresh step.
@@ -373,7 +457,6 @@ def main():
     n_launch += 1
     if ts.defer_adam and rects is not None:
         n_launch = 2          # all wavelet levels in one k_adam_l1_live launch + the LL launch
-    achieved = adam_bytes / (adam_ms * 1e-3) / 1e9 if adam_ms == adam_ms and adam_ms > 0 else float("nan")
     adam_deferred = None
     if any(lv is not None for lv in live):
         cu_ms = sec.get("adam_catchup", float("nan"))
@@ -393,8 +476,7 @@ def main():
                     "in one 24-B/coefficient pass (bit-identical p, m, v).  Every replay the timed steps caused runs "
                     "inside the timed region (the ring holds 16 steps; a flush also precedes the clock's stop)."}
 
-    # secondary rooflines (north star: HBM GB/s of the sampling / IDWT kernels, MFMA rate of the MLP), from the same
-    # HIP-event sections; bytes and flops are the algorithmic ones of SURVEY.md 8(d) for what each section moves
+    # algorithmic bytes / flops per section for what each section moves
     Cc, Rr, Hh = ts.C, ts.R, ts.H
     Ms = samples_per_step
     e_pl = 2 if model.encoder.plane_dtype == torch.float16 else 4
@@ -412,22 +494,45 @@ def main():
         rect = rects[lvl][6] * rects[lvl][7] if rects is not None else (m // 2) ** 2
         adj_bytes += S_own * (win_area(lvl, m) * 4.0 + 4.0 * rect * 4.0)   # gradient window in, 4 bands out
     fwd_bytes += (3 * Cc // (world if ts.dist_mode == "sharded" else 1)) * win_area(ts.J - 1, Rr) * 2 * e_pl  # layout
-
-    def rate(nbytes, key):
-        t = sec.get(key, float("nan"))
-        return round(nbytes / (t * 1e-3) / 1e9, 1) if t == t and t > 0 else None
-    kernels = {
-        "field_fwd": {"GB/s": rate(Ms * (12 * Cc * e_pl + 48 + 6 * Cc), "field_fwd"),
-                      "mfma_TFLOP/s": rate(2.0 * mac * Ms / 1e3, "field_fwd"),
-                      "note": "gather 12*C*e + 48 B/sample + 6*C B/sample of saved features; 2*MAC flops/sample"},
-        "field_bwd": {"GB/s": rate(Ms * (6 * Cc + 6 * Cc + 40), "field_bwd"),
-                      "mfma_TFLOP/s": rate(6.0 * mac * Ms / 1e3, "field_bwd"),
-                      "note": "features in, fp16 dF out; recompute + dX + dW = 6*MAC flops/sample; "
-                              "dense fp16 MFMA peak 2500 TFLOP/s"},
-        "plane_grad_reduce": {"GB/s": rate(Ms * 3 * (2 * Cc + 12 + 4.4) + 3 * Cc * win_area(ts.J - 1, Rr) * 4, "plane_grad_binned")},
-        "idwt_forward_all_levels_plus_layout": {"GB/s": rate(fwd_bytes, "idwt_fwd")},
-        "idwt_adjoint_all_levels": {"GB/s": rate(adj_bytes, "idwt_adjoint")},
+    spec = {
+        "field_fwd": {"bytes": Ms * (12 * Cc * e_pl + 48 + 6 * Cc), "flops": 2.0 * mac * Ms,
+                      "per_unit": "per sample: gather 12*C*e + 48 B + 6*C B of saved features; 2*MAC flops (MAC = 13 440 at base)"},
+        "field_bwd": {"bytes": Ms * (6 * Cc + 6 * Cc + 40), "flops": 6.0 * mac * Ms,
+                      "per_unit": "per sample: 6*C B features in + 6*C B fp16 dF out + 40 B (xyz, dir, g_sigma, g_rgb); "
+                                  "recompute + dX + dW = 6*MAC flops"},
+        "adam_coef": {"bytes": adam_bytes, "flops": 0.0,
+                      "per_unit": "per live coefficient: 28 B inside the gradient rectangle, 24 B outside it; nothing outside a live rectangle"},
+        "plane_grad_binned": {"bytes": Ms * 3 * (2 * Cc + 12 + 4.4) + 3 * Cc * win_area(ts.J - 1, Rr) * 4, "flops": 0.0,
+                              "per_unit": "per sample and plane: 2*C B dF + 12 B position + 4.4 B list entries; + 4 B per window texel and channel stored"},
+        "idwt_fwd": {"bytes": fwd_bytes, "flops": 0.0,
+                     "per_unit": "per computed output texel and slice: 4 B of input bands + e (finest) or 4 B out, + 2*e for the texel-major layout pass"},
+        "idwt_adjoint": {"bytes": adj_bytes, "flops": 0.0,
+                         "per_unit": "per slice: 4 B per gradient-window texel in + 16 B per coefficient-rectangle position out"},
     }
+    launches = {"field_fwd": 1, "field_bwd": 2, "adam_coef": n_launch + 1, "plane_grad_binned": 1,
+                "idwt_fwd": ts.J + 1, "idwt_adjoint": ts.J}
+
+    def roof(name, ms_):
+        """The binding roof of a section: the longer of bytes / HBM peak and flops / MFMA peak."""
+        sp = spec[name]
+        if not (ms_ == ms_ and ms_ > 0):
+            return None
+        t_hbm = sp["bytes"] / (HBM_PEAK_GBS * 1e9)
+        t_mfma = sp["flops"] / (MFMA_PEAK_TFLOPS * 1e12)
+        bound = "mfma" if t_mfma > t_hbm else "hbm"
+        gbs = sp["bytes"] / (ms_ * 1e-3) / 1e9
+        tfl = sp["flops"] / (ms_ * 1e-3) / 1e12
+        out = {"section": name, "kernels": SECTION_KERNELS[name], "ms_per_step": round(ms_, 4), "bound": bound,
+               "achieved": tfl if bound == "mfma" else gbs, "peak": MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
+               "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+               "frac": (tfl / MFMA_PEAK_TFLOPS) if bound == "mfma" else (gbs / HBM_PEAK_GBS),
+               "algorithmic_bytes": sp["bytes"], "algorithmic_flops": sp["flops"], "per_unit": sp["per_unit"],
+               "GB/s": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+        if sp["flops"] > 0:
+            out["mfma_TFLOP/s"] = round(tfl, 1)
+            out["frac_mfma"] = round(tfl / MFMA_PEAK_TFLOPS, 4)
+        return out
+    kernels = {k: roof(k, sec.get(k, float("nan"))) for k in spec}
 
     # ---- secondary figures, after the timed region (rank 0's GPU only; skipped by --no-extras and in multi-GPU runs)
     extras = {}
@@ -436,15 +541,13 @@ def main():
                                                 "note": "bounding window of the occupied cells per plane (r = 0.8 sphere): "
                                                         "the finest IDWT level, layout change, plane gradient and adjoint "
                                                         "touch only this window on the 15 of 16 steps without a grid refresh"}
-    traffic, traffic_src = pmc_traffic_static(args.workload, world)
+    pmc, pmc_src = None, "not collected (--no-extras or multi-GPU run)"
+    copy_gbs = None
+    plc = ts.placement
     if world == 1 and not args.no_extras:
+        copy_gbs = copy_bandwidth(device)
         extras["inference"] = inference_figure(model, device)
-        live, note = pmc_traffic_live(args.workload, n_launch)
-        if live is not None:
-            traffic, traffic_src = live, note
-        elif traffic_src is not None:
-            traffic_src += f"; live collection unavailable ({note})"
-        plc = ts.placement
+        pmc, pmc_src = pmc_traffic_live(args.workload)
         del ts, model
         gc.collect()
         torch.cuda.empty_cache()
@@ -466,8 +569,22 @@ def main():
                                    "gradient-support rectangles); fp32_planes: the sampler reads fp32 planes as the "
                                    "reference's training does (SURVEY F9; implies whole planes); same rays, budget, "
                                    f"{k} steps without a grid refresh after a 17-step set-up")
-    else:
-        plc = ts.placement
+        extras["trajectory"] = trajectory_figure(args.workload, device)
+
+    def traffic_of(name):
+        """Counter traffic of a section's kernels per step: (corrected bytes, raw bytes, per kernel) or None."""
+        if pmc is None:
+            return None
+        f = w = 0.0
+        per = {}
+        for kn, v in pmc.items():
+            if any(sub.replace("<true", "") in kn for sub in SECTION_KERNELS[name]):
+                f += v.get("FETCH_SIZE", 0.0)
+                w += v.get("WRITE_SIZE", 0.0)
+                per[kn] = {"FETCH_SIZE_KB": round(v.get("FETCH_SIZE", 0.0), 1), "WRITE_SIZE_KB": round(v.get("WRITE_SIZE", 0.0), 1)}
+        if not per:
+            return None
+        return {"bytes": (2.0 * f + w) * 1024.0, "bytes_uncorrected": (f + w) * 1024.0, "per_kernel": per}
 
     if rank == 0:
         C, R, scale, H, _, lam = WORKLOADS[args.workload]
@@ -485,6 +602,31 @@ def main():
                                 "plus 54 kB of MLP-gradient all-reduce and three scalars"}
             else:
                 wire = {"all_reduce_plane_grad_bytes": 2.0 * S_all * R * R * 4.0 * (world - 1) / world}
+        # the three longest sections, each with its binding roof and its counter traffic
+        ranked = sorted((k for k in kernels if kernels[k] is not None), key=lambda k: -kernels[k]["ms_per_step"])
+        top = []
+        for k in ranked[:3]:
+            e = dict(kernels[k])
+            tr = traffic_of(k)
+            e["traffic"] = None if tr is None else tr["bytes"]
+            e["traffic_uncorrected"] = None if tr is None else tr["bytes_uncorrected"]
+            e["traffic_per_kernel"] = None if tr is None else tr["per_kernel"]
+            e["traffic_over_algorithmic"] = None if tr is None else round(tr["bytes"] / e["algorithmic_bytes"], 3)
+            top.append(e)
+        dom = dict(kernels[dominant]) if kernels.get(dominant) else {}
+        dtr = traffic_of(dominant)
+        n_dom = launches[dominant]
+        step_traffic = None
+        if pmc is not None:
+            fsum = sum(v.get("FETCH_SIZE", 0.0) for v in pmc.values())
+            wsum = sum(v.get("WRITE_SIZE", 0.0) for v in pmc.values())
+            step_traffic = {"bytes": (2.0 * fsum + wsum) * 1024.0, "bytes_uncorrected": (fsum + wsum) * 1024.0,
+                            "TB/s": round((2.0 * fsum + wsum) * 1024.0 / (ms * 1e-3) / 1e12, 3),
+                            "TB/s_uncorrected": round((fsum + wsum) * 1024.0 / (ms * 1e-3) / 1e12, 3),
+                            "note": "sum over every kernel of a steady-state step (main and side stream) of the rocprofv3 "
+                                    "counters, over ms_per_step (which also carries 1/16 of a refresh step and the replay "
+                                    "of the deferred pass, whose bytes are not in this sum); the factor 2 on FETCH_SIZE is "
+                                    "calibrated for 16-B/lane streaming reads, the gather kernels lie between the two figures"}
         out = {
             "metric": "train rays/sec (whole node)", "value": N * world * args.steps / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -506,34 +648,42 @@ def main():
                                        "note": "bytes the reference's formulation of one step moves per GPU (SURVEY.md "
                                                "8(d), e = 2) divided by the measured step time; the step itself moves "
                                                "fewer (occupancy window, live rectangles of the optimiser pass)"},
+                       "step_actual_traffic": step_traffic,
                        "sections_ms": {k: round(v, 4) for k, v in sec.items()},
-                       "sections_note": "adam_coef: HIP events inside the timed steps; the other sections: an "
+                       "sections_note": f"{dominant}: HIP events inside the timed steps; the other sections: an "
                                         "instrumented pass after them (an event at every boundary costs 6-8 us)",
                        "kernels": kernels,
                        "roi_window": roi_window,
                        "adam_placement": plc,
                        "adam_deferred": adam_deferred,
                        **extras},
-            "roofline": {"bound": "hbm", "kernel": f"k_adam_l1 / k_adam_l1_live (fused Adam + wavelet-L1): the step's {n_launch} "
-                                                   "launches (all wavelet levels in one launch restricted to their live "
-                                                   "rectangles + LL; without the deferral one launch per level), "
-                                                   "byte-weighted",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if traffic is None else traffic / n_launch, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": adam_bytes / n_launch,
-                         "avg_launch_ms": adam_ms / n_launch, "launches_per_step": n_launch,
-                         "per_step": {"algorithmic_bytes": adam_bytes, "traffic_bytes": traffic, "ms": adam_ms},
-                         "alone": None if adam_alone_ms != adam_alone_ms else {
-                             "ms_per_step": adam_alone_ms, "achieved": adam_bytes / (adam_alone_ms * 1e-3) / 1e9,
-                             "frac": adam_bytes / (adam_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "note": "the same launches with nothing beside them (only reported when the step is "
-                                     "configured to run the next batch's march + tile sort underneath the Adam pass)"},
-                         "note": "achieved = algorithmic bytes of the step's k_adam_l1 launches / their summed duration "
-                                 "(HIP events on the launch stream, inside the timed steps) = mean bytes per launch / mean "
-                                 "launch duration; 28 B per coefficient inside a level's gradient-support rectangle, 24 B "
-                                 "outside it (g = 0 is neither stored nor read there), nothing outside a live rectangle "
-                                 "(config.adam_deferred); 8000 GB/s is the spec peak, a "
-                                 "float4 copy reaches 6290 GB/s on MI355X (MI355X_MICROARCH.md)"},
+            "roofline": {"bound": dom.get("bound"), "kernel": f"{' + '.join(SECTION_KERNELS[dominant])} (section '{dominant}' of the "
+                                                              f"step: its {n_dom} launch(es) per step)",
+                         "why_this_kernel": "the section with the largest per-step time in the instrumented set-up pass: "
+                                            + ", ".join(f"{k} {pre.get(k, float('nan')):.3f} ms" for k in sorted(SECTION_PREV, key=lambda k: -pre.get(k, 0.0))),
+                         "achieved": dom.get("achieved"), "peak": dom.get("peak"), "unit": dom.get("unit"), "frac": dom.get("frac"),
+                         "traffic": None if dtr is None else dtr["bytes"] / n_dom,
+                         "traffic_uncorrected": None if dtr is None else dtr["bytes_uncorrected"] / n_dom,
+                         "traffic_source": pmc_src,
+                         "algorithmic_bytes_per_launch": spec[dominant]["bytes"] / n_dom,
+                         "algorithmic_flops_per_launch": spec[dominant]["flops"] / n_dom,
+                         "avg_launch_ms": dom_ms / n_dom, "launches_per_step": n_dom,
+                         "per_step": {"algorithmic_bytes": spec[dominant]["bytes"], "algorithmic_flops": spec[dominant]["flops"],
+                                      "traffic_bytes": None if dtr is None else dtr["bytes"], "ms": dom_ms,
+                                      "ms_instrumented_pass": sec_instrumented_dominant,
+                                      "GB/s": dom.get("GB/s"), "frac_hbm": dom.get("frac_hbm"),
+                                      "mfma_TFLOP/s": dom.get("mfma_TFLOP/s"), "frac_mfma": dom.get("frac_mfma")},
+                         "per_unit": spec[dominant]["per_unit"],
+                         "top": top,
+                         "measured_copy_GB/s": None if copy_gbs is None else round(copy_gbs, 1),
+                         "measured_copy_note": "tnl_copy_probe: 1 GiB float4 non-temporal streaming copy on this box, read + "
+                                               "write bytes over HIP-event time (the guide's figure: 6290 GB/s); peaks: HBM3E "
+                                               "8000 GB/s spec, dense fp16 MFMA 2500 TFLOP/s",
+                         "note": "bound = the roof that takes longer at peak for the section's algorithmic bytes and flops "
+                                 "(SURVEY.md 8(d) per-unit figures x the units one step processes); achieved = those over "
+                                 "the section's duration measured with HIP events on the launch stream inside the timed "
+                                 "steps (the section's launches back to back, per launch = / launches_per_step); "
+                                 "field_bwd includes its k_slab_reduce launch (weight-gradient slabs)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)

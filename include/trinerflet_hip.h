@@ -347,6 +347,11 @@ TNL_API int tnl_mse_loss(const float *image, const float *weights_sum, const flo
                          const float *bg_rays, uint32_t N, float inv_norm, const float *scale_dev, float *pred,
                          float *grad_pred, float *grad_weights_sum, float *mse_accum, void *stream);
 
+/* Measurement aid (bench.py): streaming copy of `bytes` (a multiple of 16) from src to dst, 16 bytes per lane,
+ * non-temporal -- what this box's memory system gives a plain copy, printed beside the 8 TB/s HBM3E spec.  No
+ * reference counterpart. */
+TNL_API int tnl_copy_probe(const void *src, void *dst, uint64_t bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Scalar bookkeeping of one optimisation step (csrc/stepstate.hip), replacing torch.cuda.amp.GradScaler's
  * unscale_/step/update bookkeeping and the wavelet-L1 value (reconstruction/nerf/utils.py:1158-1166, :641-655)

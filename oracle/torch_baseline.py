@@ -62,9 +62,11 @@ def render_run(planes, W, rays_o, rays_d, nears, fars, bound, num_steps=512, bg=
     return image
 
 
-def time_step(C, R, scale, H, N, wave="bior6.8", lam=0.4, bound=1.5, threads=None, repeats=1):
-    """One full optimisation step (rebuild planes + render + backward + Adam) at the given size.
-    Returns dict with seconds for the dense part (planes fwd+bwd, reg, Adam) and the per-ray part."""
+def time_step(C, R, scale, H, N, wave="bior6.8", lam=0.4, bound=1.5, threads=None, repeats=3, warmup=1):
+    """Full optimisation steps (rebuild planes + render + backward + Adam) at the given size: `warmup` untimed steps,
+    then the MEDIAN over `repeats` timed ones (BASELINE.md section 3's procedure) of the seconds spent in the dense part
+    (planes forward + backward, regulariser, Adam -- independent of the ray count) and in the per-ray part (render,
+    loss, backward down to the plane gradient -- proportional to N up to the plane gradient's zero fill)."""
     from trinerflet_amd import synthetic
     if threads:
         torch.set_num_threads(threads)
@@ -76,7 +78,7 @@ def time_step(C, R, scale, H, N, wave="bior6.8", lam=0.4, bound=1.5, threads=Non
     gt = torch.from_numpy(synthetic.target_colors(d))
     o, d, nears, fars = map(torch.from_numpy, (o, d, nears, fars))
     res = {"dense_s": [], "ray_s": []}
-    for _ in range(repeats):
+    for it in range(warmup + repeats):
         opt.zero_grad(set_to_none=True)
         t0 = time.perf_counter()
         planes = ofield.build_planes_torch(ll, coefs, wave)
@@ -91,6 +93,10 @@ def time_step(C, R, scale, H, N, wave="bior6.8", lam=0.4, bound=1.5, threads=Non
         reg.backward()
         opt.step()
         t3 = time.perf_counter()
-        res["dense_s"].append((t1 - t0) + (t3 - t2))
-        res["ray_s"].append(t2 - t1)
-    return {k: float(np.median(v)) for k, v in res.items()}
+        del planes, pl, image, mse, reg
+        if it >= warmup:
+            res["dense_s"].append((t1 - t0) + (t3 - t2))
+            res["ray_s"].append(t2 - t1)
+    out = {k: float(np.median(v)) for k, v in res.items()}
+    out["dense_all_s"], out["ray_all_s"] = res["dense_s"], res["ray_s"]
+    return out

@@ -26,7 +26,13 @@ def test_bench_prints_one_contract_line(cuda):
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert (rf["bound"], rf["unit"], rf["peak"]) in (("hbm", "GB/s", 8000.0), ("mfma", "TFLOP/s", 2500.0))
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
+    # the line names the section with the largest per-step time and carries the three longest with their roofs
+    assert len(rf["top"]) == 3 and rf["top"][0]["ms_per_step"] >= rf["top"][1]["ms_per_step"] >= rf["top"][2]["ms_per_step"]
+    for e in rf["top"]:
+        assert e["bound"] in ("hbm", "mfma") and e["algorithmic_bytes"] > 0 and 0 < e["frac"] < 1
+    assert rf["kernel"].split(" ")[0] in rf["top"][0]["kernels"][0] or rf["top"][0]["section"] in rf["kernel"]
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])

@@ -115,7 +115,7 @@ def run_fused(workload, device, steps=512, num_rays=60000, scene=None, batches=N
         nxt = batches[k + 1] if k + 1 < steps else None
         total += ts.step(o, d, gt, noises=nz, next_rays=None if nxt is None else (nxt[0], nxt[1], nxt[3]))
         evs[k + 1].record()
-        counters.append(ts.last["counter"])
+        counters.append(ts.last["counter"].clone())     # a slot of the 16-entry ring: reused
         windows.append(None if ts._roi is None else (ts._roi[6], ts._roi[7]))
     total += ts.pop_deferred_reg()          # flushes the deferred optimiser work: it belongs to these steps
     torch.cuda.synchronize()
