@@ -156,7 +156,7 @@ int launch_fwd(const void* planes, int half_in, const float* xyz, const float* d
   if (blocks > 2048) blocks = 2048;
   const half8* pk = reinterpret_cast<const half8*>(packed);
   _Float16* fs = reinterpret_cast<_Float16*>(feats_save);
-  _Float16* gs = (H > 64 && fs != nullptr) ? fs + (size_t)((M + 31) / 32 * 32) * G::F : nullptr;   // see tnl_field_feats_save_bytes
+  _Float16* gs = (split_backward<H>() && fs != nullptr) ? fs + (size_t)((M + 31) / 32 * 32) * G::F : nullptr;   // see tnl_field_feats_save_bytes
 #define TNL_LAUNCH(HP, DO, SV)                                                                                        \
   hipLaunchKernelGGL((k_field_fwd<C, H, HP, DO, SV>), dim3(blocks), dim3(FWD_THREADS), (DO ? G::F2 : G::NF) * 1024, st, \
                      planes, xyz, dirs, bound, M, (int)R, pk, sigma, rgb, fs, gs, m_actual)
@@ -187,7 +187,7 @@ uint32_t tnl_field_packed_bytes(uint32_t C, uint32_t Hd, uint32_t Hc) {
 uint64_t tnl_field_feats_save_bytes(uint32_t M, uint32_t C, uint32_t Hd) {
   // [ceil(M/32)*32][3C] blocked by 32-sample tiles (field_common.h feat_slot) + [M][16] sigma-net outputs at hidden 128;
   // 5 GB at the 26 M samples of an untrained grid: 64-bit
-  return ((uint64_t)((M + 31) / 32) * 32 * 3 * C + (uint64_t)M * (Hd > 64 ? 16 : 0)) * 2;
+  return ((uint64_t)((M + 31) / 32) * 32 * 3 * C + (uint64_t)M * ((Hd > 64 || TNL_SPLIT_H64) ? 16 : 0)) * 2;
 }
 
 int tnl_field_pack(const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, uint32_t C,

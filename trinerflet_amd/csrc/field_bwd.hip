@@ -29,6 +29,13 @@
 #ifndef TNL_BWD_NW
 #define TNL_BWD_NW 8   // waves per workgroup of the hidden-64 binned backward (4: one wave per SIMD, 8: two)
 #endif
+#ifndef TNL_BWD_MODE
+#define TNL_BWD_MODE 0   // hidden-64 binned backward: 0 shared stages (NW waves in lock step), 1 per-wave weight gradients,
+#endif                   // 2 two staggered 4-wave teams -- see BwdGeom.  Round-3 measurements at base, kernel alone (ms):
+                         // mode 0 0.77-0.78 | mode 1 0.83 | mode 2 stagger 0: 0.75, stagger 3 / 5 / 7: 0.94 / 0.91 / 0.93
+#ifndef TNL_BWD_STAGGER
+#define TNL_BWD_STAGGER 0   // MODE 2: barriers by which the second team trails the first (10 per super-tile)
+#endif
 
 namespace {
 
@@ -36,17 +43,41 @@ namespace {
 // recomputed chain), i.e. one wave per SIMD; its waves wait 42 % of the time (SQ_WAIT_ANY) and issue 36 %.  An 8-wave
 // variant capped at 256 registers (two waves per SIMD) still spills ~120 dwords per lane to scratch -- the first one,
 // when the kernel needed 480 registers, ran 1.9x SLOWER (2.72 vs 1.46 ms) -- so NW = 4.
-template <int C, int H, int NW, bool ATOMIC, int PART = 0>
+//
+// PW ("per wave", round 3): every wave accumulates ALL weight-gradient tiles of the network for ITS OWN 32 samples
+// (K = 32 per tile: two MFMAs), through a private stage image in LDS.  No wave ever reads what another wave staged,
+// so the sample loop contains no workgroup barrier at all -- the five-to-ten s_barrier per 256-sample super-tile of the
+// shared-stage forms (54 % of the wave cycles parked, profiles/r02f_pmc_sq1.txt) disappear; LDS operations of one wave
+// execute in order, so staging and transposed read-back need no synchronisation.  Price: 16 accumulator tiles = 256
+// registers per lane (AGPR half of the unified file), i.e. one wave per SIMD, four waves per workgroup sharing the
+// fragment table in LDS.  MEASURED: 0.83 ms against mode 0's 0.77 -- 1 205 instructions and 86 s_waitcnt per 32-sample
+// tile with nothing else on the SIMD to cover a single wait: the kernel is bound by the latency of its dependent chain
+// (layer -> convert -> stage -> transposed read -> MFMA), not by its barriers.
+//
+// MODE 2 ("teams", round 3): the 8 waves form two teams of 4 (waves 4t .. 4t+3 = one per SIMD), each with its own stage
+// set, its own 128-sample half of the super-tile and its own complete set of weight-gradient tiles (4 per wave, 254
+// registers: still two waves per SIMD).  The teams run the same code with the same number of barriers per super-tile,
+// the second one TNL_BWD_STAGGER barriers behind the first: every s_barrier stays a workgroup barrier (stronger than
+// the team needs), but the two waves that share a SIMD are now in DIFFERENT phases of the layer sequence -- one in an
+// MFMA chain while the other converts / stages / waits on LDS -- instead of both stalling in the same place.
+// MEASURED: the stagger LOSES (0.91-0.94 ms against 0.75 without it): with workgroup-wide barriers every interval lasts
+// as long as the LONGER of the two phases that share it, and the sum of those maxima exceeds the sum of the phases.
+// Without a stagger the team form is 3 % faster than mode 0 alone (4 tiles per wave, 128-sample stages), equal in the step.
+template <int C, int H, int NW, bool ATOMIC, int PART = 0, int MODE = 0>
 struct BwdGeom {
   using G = FieldGeom<C, H>;
+  static constexpr bool PW = MODE == 1, TM = MODE == 2;
+  static constexpr bool PWv = PW;
   static constexpr int BW_WAVES = NW;
   static constexpr int BW_THREADS = 64 * NW;
-  static constexpr int ST = 32 * NW;      // samples per super-tile
+  static constexpr int ST = 32 * NW;      // samples per super-tile (of the workgroup)
+  static constexpr int SS = PW ? 32 : (TM ? ST / 2 : ST); // samples per stage image (PW: the wave's own 32, TM: the team's)
+  static constexpr int COPIES = PW ? NW : (TM ? 2 : 1);
   // A stage image holds fp16 [32-feature block][sample][32 features]: 64-byte rows whose eight 8-byte chunks are
   // XOR-swizzled with the row (img_off), so that a lane stores four consecutive features of its sample with one
   // ds_write_b64 and the weight-gradient MFMA reads both operands (8 samples of one feature per lane) with the
   // transposing ds_read_b64_tr_b16, all conflict-free.
-  static constexpr int BLK = ST * 64;     // bytes per 32-feature block
+  static constexpr int BLK = SS * 64;     // bytes per 32-feature block
   // features staged once per super-tile in their own LDS region (binned mode).  PART 2 (sigma half of the split launch)
   // instead keeps them in registers and stages them into the X region for layer 0, which leaves room for its 80
   // weight fragments in LDS.
@@ -66,8 +97,10 @@ struct BwdGeom {
   static constexpr size_t FS_BYTES = EARLY_F && PART != 1 ? (size_t)G::IB0 * BLK : 0;
   // Double-buffered X / Y stages (layers alternate between the two pairs): the barrier that protected a stage from
   // the next layer's writes disappears, one barrier per layer remains.  Only where it fits next to the weights.
-  static constexpr bool DB = EARLY_F && 2 * (XS_BYTES + YS_BYTES) + FS_BYTES + W_BYTES <= 160 * 1024;
-  static constexpr size_t BASE_BYTES = (DB ? 2 : 1) * (XS_BYTES + YS_BYTES) + STAGE_BYTES + FS_BYTES;
+  // (hidden 64 split by layer: single-buffered, so that TWO workgroups fit a CU -- independent barriers, 2 waves per SIMD)
+  static constexpr bool DB = !PW && !TM && !(H == 64 && PART != 0) && EARLY_F && 2 * (XS_BYTES + YS_BYTES) + FS_BYTES + W_BYTES <= 160 * 1024;
+  static constexpr size_t COPY_BYTES = (DB ? 2 : 1) * (XS_BYTES + YS_BYTES) + FS_BYTES;   // one stage set (PW: one per wave)
+  static constexpr size_t BASE_BYTES = COPIES * COPY_BYTES + STAGE_BYTES;
   static constexpr bool LDSW = BASE_BYTES + W_BYTES <= 160 * 1024;  // weights cached in LDS when they fit
   static constexpr size_t LDS_BYTES = BASE_BYTES + (LDSW ? W_BYTES : 0);
   static constexpr int NT0 = G::OB * G::IB0, NT1 = G::OB, NT2 = G::OB, NT3 = G::OB * G::OB, NT4 = G::OB;
@@ -77,9 +110,13 @@ struct BwdGeom {
   // (in the order layer 4, 3, 2, 1, 0), so that a wave holds NSLOT = 2 accumulator tiles (32 registers) instead of one
   // or two per layer (80-96): with that the kernel fits 256 registers per lane, i.e. two waves per SIMD, which is what
   // covers the barrier / LDS-latency stalls that made up more than half of the one-wave-per-SIMD kernel's time.
-  static constexpr bool GT = NW >= 8;
+#ifndef TNL_BWD_GT_MIN
+#define TNL_BWD_GT_MIN 8
+#endif
+  static constexpr bool GT = NW >= TNL_BWD_GT_MIN || PW || TM;
   static constexpr int NTILES = NT0 + NT1 + NT2 + NT3 + NT4;
-  static constexpr int NSLOT = (NTILES + NW - 1) / NW;
+  static constexpr int TW = PW ? 1 : (TM ? NW / 2 : NW);   // waves the tiles are dealt over (PW: every wave holds them all)
+  static constexpr int NSLOT = (NTILES + TW - 1) / TW;
   static constexpr int B4 = 0, B3 = NT4, B2 = B3 + NT3, B1 = B2 + NT2, B0 = B1 + NT1;   // first tile id of each layer
 };
 
@@ -177,27 +214,38 @@ __device__ __forceinline__ void slab_tile(float* slab, int off, int out_dim, int
 //            and hand the gradient of the 16 sigma-net outputs (dO, 32 B per sample) to
 //   PART 2 = sigma net: recompute layer 0 only, backward through layers 1, 0, weight gradients of W0, W1, dF.
 // Each part holds 6 weight-gradient tiles per wave and half the chain; PART 0 = everything in one launch (hidden 64).
-template <int C, int H, int NW, bool ATOMIC, int PART>
-__global__ void __launch_bounds__(64 * NW)
+template <int C, int H, int NW, bool ATOMIC, int PART, int MODE>
+__global__ void __launch_bounds__(64 * NW, (H == 64 && PART != 0) ? 2 : 1)
 k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, const float* __restrict__ sigma,
             const _Float16* __restrict__ feats,
             const float* __restrict__ xyz, const float* __restrict__ dirs, float bound, uint32_t M, int R,
             const half8* __restrict__ packed, float* __restrict__ grad_tm, float* __restrict__ slabs,
             const int32_t* __restrict__ m_actual, _Float16* __restrict__ dfeat, _Float16* __restrict__ dO) {
   using G = FieldGeom<C, H>;
-  using B = BwdGeom<C, H, NW, ATOMIC, PART>;
+  using B = BwdGeom<C, H, NW, ATOMIC, PART, MODE>;
+  constexpr bool PW = B::PW, TM = B::TM;
   static_assert(PART == 0 || !ATOMIC, "the split launch exists for the binned mode only");
+  static_assert(MODE == 0 || (PART == 0 && !ATOMIC), "per-wave / team weight gradients: single-launch binned mode");
   constexpr bool DO_COL = PART != 2, DO_SIG = PART != 1;
-  constexpr int BW_THREADS = B::BW_THREADS, ST = B::ST, BLK = B::BLK;
+  constexpr int BW_THREADS = B::BW_THREADS, ST = B::ST, BLK = B::BLK, SS = B::SS;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile ownership tests become scalar branches
   const uint32_t Mcap = M;   // row capacity: the plane stride of the plane-major dfeat output
   if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr size_t XY = B::XS_BYTES + B::YS_BYTES;
-  char* const Xb[2] = {smem, smem + (B::DB ? XY : 0)};
-  char* const Yb[2] = {smem + B::XS_BYTES, smem + (B::DB ? XY : 0) + B::XS_BYTES};
+  const int team = TM ? wv / B::TW : 0;
+  char* const sbase = smem + (PW ? (size_t)wv : (size_t)team) * B::COPY_BYTES;   // PW / TM: the wave's / team's own stage set
+  char* const Xb[2] = {sbase, sbase + (B::DB ? XY : 0)};
+  char* const Yb[2] = {sbase + B::XS_BYTES, sbase + (B::DB ? XY : 0) + B::XS_BYTES};
   float* stage_all = reinterpret_cast<float*>(smem + (B::DB ? 2 : 1) * XY);
-  char* Fs = smem + (B::DB ? 2 : 1) * XY + B::STAGE_BYTES;
-  auto sync_stage = [&]() { if (!B::DB) __syncthreads(); };   // stage reuse barrier, not needed when double-buffered
+  char* Fs = PW ? sbase + XY : smem + (B::DB ? 2 : 1) * XY + B::STAGE_BYTES;
+  // stage published -> stage read.  PW: writer and reader are the same wave, whose LDS operations execute in order:
+  // only the compiler has to keep them in order (a wavefront-scope fence emits no instruction).
+  auto stage_ready = [&]() {
+    if (PW) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+  };
+  auto sync_stage = [&]() { if (!B::DB && !PW) __syncthreads(); };   // stage reuse barrier (shared stages, single-buffered)
   const half8* w = packed;    // forward fragments (and, outside PART 2, all of them)
   const half8* wH = packed;   // layers 3, 4 forward and 4, 3, 2 transposed
   const half8* wT = packed;   // transposed fragments of layers 1 and 0
@@ -219,8 +267,10 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   __syncthreads();
 
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile ownership tests become scalar branches
-  const int col = 32 * wv + r;
+  const int col = 32 * wv + r;             // this lane's sample within the workgroup's super-tile
+  constexpr int TW = B::TW;                // waves the weight-gradient tiles are dealt over
+  const int tw = PW ? 0 : (TM ? wv % TW : wv);
+  const int scol = PW ? r : (TM ? 32 * tw + r : col);   // ... and its row in the stage images
   // transposed-read offsets of the weight-gradient operands: lane 4q + p of a 16-lane group addresses sample row q of
   // the block, chunk p of the group's 16 features
   const int tq = (lane & 15) >> 2, tc = 4 * ((lane >> 4) & 1) + (lane & 3);
@@ -289,6 +339,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   constexpr bool PREFETCH = PART != 1;   // the colour half of hidden 128 is register-bound: its 44 B of inputs are read in place
   Inputs nxt;
   if (PREFETCH && blockIdx.x < nst) load_inputs(blockIdx.x, nxt);
+  if (TM && team == 1) {      // the second team trails by TNL_BWD_STAGGER barriers (made up by the first team after the loop)
+    for (int k = 0; k < TNL_BWD_STAGGER; k++) __syncthreads();
+  }
   for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
     if (!B::LDSW || PART == 1) {
       // Weight fragments read from global memory (L2) inside the loop: the 8 layer-2 fragments of PART 1, and all 180
@@ -313,7 +366,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     // publish the features for the layer-0 weight gradient now (they are in registers); read after the last barrier
     if (B::EARLY_F && DO_SIG) {
 #pragma unroll
-      for (int ks = 0; ks < G::KS0; ks++) put_nat<BLK>(Fs, ks, in.fk[ks], h, col);
+      for (int ks = 0; ks < G::KS0; ks++) put_nat<BLK>(Fs, ks, in.fk[ks], h, scol);
     }
 
     // ---- recompute the forward chain from the saved fp16 features
@@ -353,19 +406,19 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     const half8 dz4f = acc_to_frag<false>(dz4, 0);
     Xs = Xb[0]; Ys = Yb[0];
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h4[ks], h, col);
-    put_acc<1>(Ys, dz4, h, col);   // rows 0..7 (rgb logits' gradient in rows 0..2); the rest of the block is never used
-    __syncthreads();
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h4[ks], h, scol);
+    put_acc<1>(Ys, dz4, h, scol);   // rows 0..7 (rgb logits' gradient in rows 0..2); the rest of the block is never used
+    stage_ready();
     // (Every wave accumulates A_l tiles per layer without a branch: behind `if (tile < NT_l)` the accumulators of that
     // block live in VGPRs and are copied into AGPRs and back around the MFMAs, 32 moves per tile and super-tile.  The
     // duplicates cost idle waves a few MFMAs and are dropped when the slabs are written.)
     if (B::GT) {
-      dw_layer<ST, BLK, NW, B::NSLOT, B::B4, B::NT4, B::NT4>(dwg, wv, Ys, Xs, t0, t1);
+      dw_layer<SS, BLK, TW, B::NSLOT, B::B4, B::NT4, B::NT4>(dwg, tw, Ys, Xs, t0, t1);
     } else {
 #pragma unroll
     for (int k = 0; k < B::A4; k++) {
       const int t = (wv + NW * k) % B::NT4;   // a wave without a tile of its own repeats another's
-      dw4[k] = dw_tile<ST>(Ys, Xs + t * BLK, t0, t1, dw4[k]);
+      dw4[k] = dw_tile<SS>(Ys, Xs + t * BLK, t0, t1, dw4[k]);
     }
     }
     // (a gradient tile leaves the registers as soon as it is masked and converted: its two fp16 fragments feed the next
@@ -382,17 +435,17 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     // ---- layer 3
     Xs = Xb[1]; Ys = Yb[1];
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h3[ks], h, col);
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h3[ks], h, scol);
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d4f[ks], h, col);
-    __syncthreads();
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d4f[ks], h, scol);
+    stage_ready();
     if (B::GT) {
-      dw_layer<ST, BLK, NW, B::NSLOT, B::B3, B::NT3, G::OB>(dwg, wv, Ys, Xs, t0, t1);
+      dw_layer<SS, BLK, TW, B::NSLOT, B::B3, B::NT3, G::OB>(dwg, tw, Ys, Xs, t0, t1);
     } else {
 #pragma unroll
     for (int k = 0; k < B::A3; k++) {
       const int t = (wv + NW * k) % B::NT3;   // a wave without a tile of its own repeats another's
-      dw3[k] = dw_tile<ST>(Ys + (t / G::OB) * BLK, Xs + (t % G::OB) * BLK, t0, t1, dw3[k]);
+      dw3[k] = dw_tile<SS>(Ys + (t / G::OB) * BLK, Xs + (t % G::OB) * BLK, t0, t1, dw3[k]);
     }
     }
     half8 d3f[G::KH];
@@ -418,19 +471,19 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
         for (int j = 0; j < 8; j++) geo[j] = (_Float16)ch.o8[j];
       }
-      put_nat<BLK>(Xs, 0, sh_frag(dx, dy, dz, h), h, col);
-      put_frag<BLK>(Xs, 1, geo, h, col);
+      put_nat<BLK>(Xs, 0, sh_frag(dx, dy, dz, h), h, scol);
+      put_frag<BLK>(Xs, 1, geo, h, scol);
     }
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d3f[ks], h, col);
-    __syncthreads();
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d3f[ks], h, scol);
+    stage_ready();
     if (B::GT) {
-      dw_layer<ST, BLK, NW, B::NSLOT, B::B2, B::NT2, 1>(dwg, wv, Ys, Xs, t0, t1);
+      dw_layer<SS, BLK, TW, B::NSLOT, B::B2, B::NT2, 1>(dwg, tw, Ys, Xs, t0, t1);
     } else {
 #pragma unroll
     for (int k = 0; k < B::A2; k++) {
       const int t = (wv + NW * k) % B::NT2;   // a wave without a tile of its own repeats another's
-      dw2[k] = dw_tile<ST>(Ys + t * BLK, Xs, t0, t1, dw2[k]);
+      dw2[k] = dw_tile<SS>(Ys + t * BLK, Xs, t0, t1, dw2[k]);
     }
     }
     f32x16 dzz = zero16();
@@ -457,16 +510,16 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     // ---- layer 1: X = H1, dY = dO in chain-slot order (slot 15 = the logit's gradient; slab_tile<1> maps the rows back)
     Xs = Xb[1]; Ys = Yb[1];
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h1[ks], h, col);
-    put_frag<BLK>(Ys, 0, dof, h, col);   // features 0..15 of the block; 16..31 are never used
-    __syncthreads();
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h1[ks], h, scol);
+    put_frag<BLK>(Ys, 0, dof, h, scol);   // features 0..15 of the block; 16..31 are never used
+    stage_ready();
     if (B::GT) {
-      dw_layer<ST, BLK, NW, B::NSLOT, B::B1, B::NT1, B::NT1>(dwg, wv, Ys, Xs, t0, t1);
+      dw_layer<SS, BLK, TW, B::NSLOT, B::B1, B::NT1, B::NT1>(dwg, tw, Ys, Xs, t0, t1);
     } else {
 #pragma unroll
     for (int k = 0; k < B::A1; k++) {
       const int t = (wv + NW * k) % B::NT1;   // a wave without a tile of its own repeats another's
-      dw1[k] = dw_tile<ST>(Ys, Xs + t * BLK, t0, t1, dw1[k]);
+      dw1[k] = dw_tile<SS>(Ys, Xs + t * BLK, t0, t1, dw1[k]);
     }
     }
     half8 d1f[G::KH];
@@ -490,19 +543,19 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
           for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
           if (valid) fk = *reinterpret_cast<const half8*>(feats + feat_slot<G::KS0>(il, ks, h));
         }
-        put_nat<BLK>(Xs, ks, fk, h, col);
+        put_nat<BLK>(Xs, ks, fk, h, scol);
       }
     }
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d1f[ks], h, col);
-    __syncthreads();
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d1f[ks], h, scol);
+    stage_ready();
     if (B::GT) {
-      dw_layer<ST, BLK, NW, B::NSLOT, B::B0, B::NT0, G::IB0>(dwg, wv, Ys, B::EARLY_F ? Fs : Xs, t0, t1);
+      dw_layer<SS, BLK, TW, B::NSLOT, B::B0, B::NT0, G::IB0>(dwg, tw, Ys, B::EARLY_F ? Fs : Xs, t0, t1);
     } else {
 #pragma unroll
     for (int k = 0; k < B::A0; k++) {
       const int t = (wv + NW * k) % B::NT0;   // a wave without a tile of its own repeats another's
-      dw0[k] = dw_tile<ST>(Ys + (t / G::IB0) * BLK, (B::EARLY_F ? Fs : Xs) + (t % G::IB0) * BLK, t0, t1, dw0[k]);
+      dw0[k] = dw_tile<SS>(Ys + (t / G::IB0) * BLK, (B::EARLY_F ? Fs : Xs) + (t % G::IB0) * BLK, t0, t1, dw0[k]);
     }
     }
     // feature gradient dF^T = W0^T dH1^T
@@ -590,15 +643,18 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     }
     }  // DO_SIG
-    __syncthreads();  // Xs/Ys are rewritten by the next super-tile
+    if (!PW) __syncthreads();  // Xs/Ys are rewritten by the next super-tile (PW: by the same wave, in order)
   }
 
+  if (TM && team == 0) {
+    for (int k = 0; k < TNL_BWD_STAGGER; k++) __syncthreads();
+  }
   // ---- epilogue: this workgroup's weight-gradient slab
-  float* slab = slabs + (size_t)blockIdx.x * G::NW;
+  float* slab = slabs + (size_t)(PW ? blockIdx.x * NW + wv : (TM ? blockIdx.x * 2 + team : blockIdx.x)) * G::NW;   // one per wave / team
   if (B::GT) {
 #pragma unroll
     for (int sl = 0; sl < B::NSLOT; sl++) {
-      const int T = wv + NW * sl;
+      const int T = tw + TW * sl;
       if (T < B::B3) slab_tile(slab, G::OFF4, 3, H, 0, T - B::B4, dwg[sl], r, h);
       else if (T < B::B2) slab_tile(slab, G::OFF3, H, H, (T - B::B3) / G::OB, (T - B::B3) % G::OB, dwg[sl], r, h);
       else if (T < B::B1) slab_tile<2>(slab, G::OFF2, H, 31, T - B::B2, 0, dwg[sl], r, h);
@@ -661,40 +717,41 @@ k_slab_reduce(const float* __restrict__ slabs, int nslab, int nw, float* __restr
   }
 }
 
-inline uint32_t bwd_blocks(uint32_t M, uint32_t st = 128) {
+inline uint32_t bwd_blocks(uint32_t M, uint32_t st = 128, uint32_t cap = 256) {
   uint32_t nst = (M + st - 1) / st;
-  return nst < 256 ? nst : 256;
+  return nst < cap ? nst : cap;
 }
 
 // hidden 128 runs as two launches (see PART above); the dO hand-over buffer follows the slabs in the workspace
 template <int C, int H, bool ATOMIC>
-constexpr bool split_launch() { return H > 64 && !ATOMIC; }
+constexpr bool split_launch() { return split_backward<H>() && !ATOMIC; }
 
-template <int C, int H, int NW, bool ATOMIC, int PART>
+template <int C, int H, int NW, bool ATOMIC, int PART, int MODE = 0>
 int launch_bwd_part(const float* gsig, const float* grgb, const float* sigma, const void* feats, const float* xyz, const float* dirs,
                     float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* slabs,
                     const int32_t* m_actual, void* dfeat, _Float16* dO, uint32_t blocks, hipStream_t st) {
-  using B = BwdGeom<C, H, NW, ATOMIC, PART>;
+  using B = BwdGeom<C, H, NW, ATOMIC, PART, MODE>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd<C, H, NW, ATOMIC, PART>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd<C, H, NW, ATOMIC, PART, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)B::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_field_bwd<C, H, NW, ATOMIC, PART>), dim3(blocks), dim3(B::BW_THREADS), B::LDS_BYTES, st, gsig,
+  hipLaunchKernelGGL((k_field_bwd<C, H, NW, ATOMIC, PART, MODE>), dim3(blocks), dim3(B::BW_THREADS), B::LDS_BYTES, st, gsig,
                      grgb, sigma, reinterpret_cast<const _Float16*>(feats), xyz, dirs, bound, M, (int)R,
                      reinterpret_cast<const half8*>(packed), grad_tm, slabs, m_actual,
                      reinterpret_cast<_Float16*>(dfeat), dO);
   return 0;
 }
 
-template <int C, int H, int NW, bool ATOMIC>
+template <int C, int H, int NW, bool ATOMIC, int MODE = 0>
 int launch_bwd_impl(const float* gsig, const float* grgb, const float* sigma, const void* feats, const float* xyz, const float* dirs,
                     float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW,
                     void* workspace, const int32_t* m_actual, void* dfeat, hipStream_t st) {
   using G = FieldGeom<C, H>;
-    const uint32_t blocks = bwd_blocks(M, 32 * NW);
+  // persistent workgroups: one per CU, two where two fit (hidden 64 split by layer)
+  const uint32_t blocks = bwd_blocks(M, 32 * NW, (H == 64 && split_launch<C, H, ATOMIC>()) ? 512 : 256);
   float* slabs = reinterpret_cast<float*>(workspace);
   int e;
   if constexpr (split_launch<C, H, ATOMIC>()) {
@@ -706,11 +763,12 @@ int launch_bwd_impl(const float* gsig, const float* grgb, const float* sigma, co
     e = launch_bwd_part<C, H, NW, ATOMIC, 2>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, slabs, m_actual,
                                              dfeat, dO, blocks, st);
   } else {
-    e = launch_bwd_part<C, H, NW, ATOMIC, 0>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, slabs, m_actual,
-                                             dfeat, nullptr, blocks, st);
+    e = launch_bwd_part<C, H, NW, ATOMIC, 0, MODE>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, slabs, m_actual,
+                                                 dfeat, nullptr, blocks, st);
   }
   if (e != 0) return e;
-  hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 15) / 16), dim3(256), 0, st, slabs, (int)blocks, (int)G::NW, gradW);
+  hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 15) / 16), dim3(256), 0, st, slabs, (int)(MODE == 1 ? blocks * NW : (MODE == 2 ? blocks * 2 : blocks)),
+                     (int)G::NW, gradW);
   return (int)hipGetLastError();
 }
 
@@ -718,9 +776,20 @@ template <int C, int H, int NWB>
 int launch_bwd(const float* gsig, const float* grgb, const float* sigma, const void* feats, const float* xyz, const float* dirs,
                float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW, void* workspace,
                const int32_t* m_actual, void* dfeat, hipStream_t st) {
-  if (dfeat != nullptr)
-    return launch_bwd_impl<C, H, NWB, false>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
-                                             m_actual, dfeat, st);
+  if (dfeat != nullptr) {
+    if constexpr (TNL_SPLIT_H64 && H == 64)       // two launches split by layer, 4-wave workgroups, two per CU
+      return launch_bwd_impl<C, H, 4, false, 0>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW,
+                                                workspace, m_actual, dfeat, st);
+    else if constexpr (TNL_BWD_MODE == 1 && H == 64)   // per-wave weight gradients: 4 waves per workgroup, one per SIMD, no barriers
+      return launch_bwd_impl<C, H, 4, false, 1>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW,
+                                                workspace, m_actual, dfeat, st);
+    else if constexpr (TNL_BWD_MODE == 2 && H == 64)   // two staggered teams of four waves
+      return launch_bwd_impl<C, H, 8, false, 2>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW,
+                                                workspace, m_actual, dfeat, st);
+    else
+      return launch_bwd_impl<C, H, NWB, false>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
+                                               m_actual, dfeat, st);
+  }
   return launch_bwd_impl<C, H, 4, true>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
                                         m_actual, dfeat, st);
 }
@@ -732,8 +801,8 @@ extern "C" {
 uint64_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint32_t Hc) {
   if (Hd != Hc || M == 0) return 0;
   const uint32_t blocks = bwd_blocks(M);
-  if (C == 16 && Hd == 64) return (uint64_t)blocks * FieldGeom<16, 64>::NW * 4;
-  if (C == 32 && Hd == 64) return (uint64_t)blocks * FieldGeom<32, 64>::NW * 4;
+  if (C == 16 && Hd == 64) return (uint64_t)blocks * FieldGeom<16, 64>::NW * 4 * 4 + (uint64_t)M * 32;   // x4: one slab per wave (PW); + dO (split)
+  if (C == 32 && Hd == 64) return (uint64_t)blocks * FieldGeom<32, 64>::NW * 4 * 4 + (uint64_t)M * 32;
   if (C == 48 && Hd == 128) return (uint64_t)blocks * FieldGeom<48, 128>::NW * 4 + (uint64_t)M * 32;   // + the dO hand-over (split launch)
   return 0;
 }

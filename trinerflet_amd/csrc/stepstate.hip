@@ -73,7 +73,7 @@ __global__ void k_step_epilogue(const float* __restrict__ found_inf, float* __re
   reg[0] = abs_sum != nullptr ? abs_sum[0] * l1_coef : 0.f;
 }
 
-// Streaming copy, 16 bytes per lane, one contiguous chunk per workgroup (the access shape of the coefficient pass):
+// Streaming copy, 16 bytes per lane, one 4-KB piece per workgroup (6.3 TB/s in tools/micro/copy_shapes.py):
 // bench.py measures with it what this box's memory system gives a plain copy, to print beside the 8 TB/s spec.
 typedef float v4f_probe __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
@@ -130,7 +130,7 @@ extern "C" int tnl_stream_destroy(void* stream) {
 extern "C" int tnl_copy_probe(const void* src, void* dst, uint64_t bytes, void* stream) {
   const uint64_t n4 = bytes / 16;
   if (n4 == 0) return 0;
-  const uint32_t per_block = 256 * 16;                       // 64 KB per workgroup
+  const uint32_t per_block = 256;                            // one 4-KB piece per workgroup: the shape that streams fastest
   const uint64_t blocks = (n4 + per_block - 1) / per_block;
   hipLaunchKernelGGL(k_copy_probe, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
                      reinterpret_cast<const v4f_probe*>(src), reinterpret_cast<v4f_probe*>(dst), n4, per_block);
