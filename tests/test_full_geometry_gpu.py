@@ -343,3 +343,37 @@ def test_test_render_800x800_device_loop_equals_host_loop_large_geometry(cuda):
     assert torch.equal(torch.nan_to_num(dev["depth"]), torch.nan_to_num(host["depth"]))
     ws = dev["weights_sum"].reshape(-1)
     assert 0.1 < float((ws > 0.5).float().mean()) < 0.4                # the ball covers about a quarter of the image
+
+
+def test_trainstep_window_equals_whole_plane_bit_for_bit_when_deterministic(cuda, rays60k):
+    """With TrainStep(deterministic=True) every tile list of the plane-gradient reduction is ordered by sample id, so the
+    summation order no longer depends on the fill pass's atomics: the windowed step (occupancy window, gradient-support
+    rectangles, live rectangles + deferred optimiser pass) must then reproduce the whole-plane step BIT FOR BIT -- every
+    parameter after five steps through a grid refresh, at the base geometry."""
+    _need_memory()
+    from trinerflet_amd.train import TrainStep
+    C, H, lam = CONFIGS["base"]
+    o, d, noise, bf = rays60k
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    gt = t(synthetic.target_colors(d))
+    o_t, d_t, nz, bf_t = t(o), t(d), t(noise), t(bf)
+    base = _model(cuda, "base", seed=4)
+    base.density_bitfield.copy_(bf_t)
+    res = []
+    for use_roi in (False, True):
+        m = copy.deepcopy(base)
+        ts = TrainStep(m, lr=1e-2, wavelet_regularization=lam, iters=1000, update_extra_interval=4, use_roi=use_roi,
+                       deterministic=True)
+        ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf_t)
+        m.mean_count = 0
+        mses = []
+        for it in range(5):
+            ts.step(o_t, d_t, gt, noises=nz)
+            mses.append(float(ts.last["mse"]))
+        ts.flush_deferred()
+        assert ts.defer_adam == use_roi and (ts._roi is not None) == use_roi
+        res.append((mses, [p.detach().clone() for p in m.parameters()]))
+        del ts
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b), (a.shape, int((a != b).sum()), float((a - b).abs().max()))

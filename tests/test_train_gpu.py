@@ -320,3 +320,36 @@ def test_fused_adam_l1_against_torch_optim_adam(cuda):
             tol = 4e-7 * want.abs() + {"p": 3e-6 * lr * (k + 1), "m": 1e-7 * G, "v": 1e-7 * G * G}[name]
             bad = int((err > tol).sum())
             assert bad == 0, (k, name, bad, float(err.max()), float((err / (want.abs() + 1e-30)).max()))
+
+
+def test_deterministic_step_is_reproducible_bit_for_bit(cuda):
+    """TrainStep(deterministic=True): two runs of the same six steps (a grid refresh inside, side-stream march, tile
+    sort with atomics) end with identical bits in every parameter and every Adam moment; the default mode differs in
+    the last bits of the plane gradient from run to run (the fill pass's atomic arrival order)."""
+    import copy
+    from trinerflet_amd import synthetic
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    from trinerflet_amd.train import TrainStep
+    torch.manual_seed(0)
+    base = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, density_thresh=10, hidden_dim=64,
+                       hidden_dim_color=64, triplane_channels=16, triplane_resolution=256, triplane_wavelet_levels=4,
+                       wavelet_type="bior6.8").to(cuda)
+    synthetic.init_field_parameters(base, seed=3)
+    bf = torch.from_numpy(synthetic.sphere_bitfield(128, 2, 1.5, 0.8, 0.0)).to(cuda)
+    base.density_bitfield.copy_(bf)
+    o, d = synthetic.training_rays(8192, n_cams=8, seed=2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    o_t, d_t, gt = t(o), t(d), t(synthetic.target_colors(d))
+    nz = torch.rand(8192, device=cuda, generator=torch.Generator(device=cuda).manual_seed(1))
+    runs = []
+    for _ in range(2):
+        m = copy.deepcopy(base)
+        torch.manual_seed(7)          # the refreshes' in-cell jitter
+        ts = TrainStep(m, lr=1e-2, wavelet_regularization=0.2, iters=100, update_extra_interval=4, deterministic=True)
+        ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf)
+        for it in range(6):
+            ts.step(o_t, d_t, gt, noises=nz, next_rays=(o_t, d_t, nz))
+        ts.flush_deferred()
+        runs.append([p.detach().clone() for p in m.parameters()] + [ts.coef.m.clone(), ts.coef.v.clone(), ts.mlp.m.clone()])
+    for a, b in zip(*runs):
+        assert torch.equal(a, b), (a.shape, int((a != b).sum()))

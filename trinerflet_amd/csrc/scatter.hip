@@ -386,6 +386,21 @@ static SortWs sort_ws(void* workspace, uint32_t R) {
   return w;
 }
 
+// Where the tile lists lie inside the workspace, in int32 units: out = {number of bins (sub-bins included), index of
+// offsets[0] (nb + 1 entries, the last one = total entries), index of the first list entry, sub-bins per tile}.  For
+// callers that post-process the lists -- TrainStep(deterministic=True) orders every tile's list by sample id, so that
+// the reduction's summation order (and with it every bit of the plane gradient) no longer depends on the arrival order
+// of the fill pass's atomics.
+int tnl_plane_grad_sort_layout(uint32_t R, int64_t* out) {
+  if (R % TSX != 0 || out == nullptr) return (int)hipErrorInvalidValue;
+  const SortWs w = sort_ws(nullptr, R);
+  out[0] = w.nb;
+  out[1] = w.offsets - w.counts;
+  out[2] = reinterpret_cast<int*>(w.entries) - w.counts;
+  out[3] = BIN_SUBS;
+  return 0;
+}
+
 // Part 1 (needs only the sample positions): counting sort of the samples by (plane, tile).  TrainStep runs it on
 // the march's side stream, so it is off the critical path of the step.
 static int plane_grad_sort_impl(const float* xyz, float bound, uint32_t M, const int32_t* m_actual, uint32_t R,

@@ -3,6 +3,8 @@
 sigma, rgb = fused_field(planes_tm, xyz, dirs, W0..W4, bound) == NeRFNetwork.forward
 (reconstruction/nerf/network.py:118-147) with the layers in fp16 MFMA / fp32 accumulate.
 """
+import ctypes as C
+
 import torch
 from torch.autograd import Function
 
@@ -112,6 +114,26 @@ def plane_grad_sort(xyz, bound, R, m_actual=None):
     L.check(lib.tnl_plane_grad_sort(L.ptr(xyz), L.f32(bound), L.u32(M), L.ptr(m_actual), L.u32(R), L.ptr(ws),
                                     L.stream()), "plane_grad_sort")
     return ws
+
+
+def order_tile_lists(ws, R):
+    """Sorts every tile's list of sample ids ascending, in place (the counting sort leaves them in the arrival order of
+    its atomics, so the tile reduction's fp32 summation order -- hence the last bits of the plane gradient -- differs
+    from run to run).  With this the plane gradient is a pure function of its inputs.  A test / debugging knob
+    (TrainStep(deterministic=True)): a 64-bit torch.sort over all list entries, ~10 ms at the base workload."""
+    lay = (C.c_int64 * 4)()
+    L.check(L.lib().tnl_plane_grad_sort_layout(L.u32(R), lay), "plane_grad_sort_layout")
+    nb, off_idx, ent_idx, subs = (int(v) for v in lay)
+    w32 = ws.view(torch.int32)
+    offsets = w32[off_idx:off_idx + nb + 1]
+    tile_off = offsets[::subs].long()                      # nb / subs + 1 boundaries (the last = total entries)
+    total = int(tile_off[-1])
+    if total == 0:
+        return
+    entries = w32[ent_idx:ent_idx + total]
+    seg = torch.searchsorted(tile_off[1:].contiguous(), torch.arange(total, device=ws.device), right=True)
+    key = (seg << 32) | (entries.long() & 0xFFFFFFFF)
+    entries.copy_((torch.sort(key).values & 0xFFFFFFFF).to(torch.int32))
 
 
 def plane_grad_sort_workspace(M, R, device):

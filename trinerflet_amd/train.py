@@ -151,7 +151,7 @@ class TrainStep:
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
                  dist_mode=None, process_group=None, binned=True, fuse_adam=False, use_roi=True, tune_placement=None,
-                 defer_adam=None):
+                 defer_adam=None, deterministic=False):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
@@ -170,6 +170,9 @@ class TrainStep:
         self.max_steps, self.dt_gamma, self.T_thresh = max_steps, dt_gamma, T_thresh
         self.global_step = 0
         self.binned = binned
+        # deterministic: every tile's list of the plane-gradient reduction ordered by sample id before it is consumed
+        # (field.order_tile_lists), so that two runs on the same inputs produce the same bits.  A test / debugging knob.
+        self.deterministic = deterministic
         # fuse_adam: Adam(+L1) applied inside the adjoint IDWT kernels (no coefficient-gradient buffer).  Measured
         # SLOWER at base (3.8 ms vs 0.95 + 2.03 ms): the epilogue's 4-byte p/m/v accesses are issued late and in
         # 128-B pieces, while the stand-alone pass streams 16 B/lane at the HBM ceiling.  Kept as an option.
@@ -783,6 +786,8 @@ class TrainStep:
                 self._prefetch_next(next_rays, march_on_side)
             if side is not None or sort_beside:
                 torch.cuda.current_stream().wait_event(ev_sort)
+            if self.deterministic:
+                F_.order_tile_lists(sort_ws, R)
             F_.plane_grad_reduce(sort_ws, dfeat, xyzs, float(model.bound), C, R, g_cm, channel_major=True,
                                  nonfinite_flag=self.nonfinite, roi=self._roi10() if roi is not None else None)
             self._mark("plane_grad_binned")
