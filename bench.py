@@ -511,7 +511,9 @@ def main():
         "idwt_adjoint": {"bytes": adj_bytes, "flops": 0.0,
                          "per_unit": "per slice: 4 B per gradient-window texel in + 16 B per coefficient-rectangle position out"},
     }
-    launches = {"field_fwd": 1, "field_bwd": 2, "adam_coef": n_launch + 1, "plane_grad_binned": 1,
+    # launches of the section's main kernel(s) per step (small helper launches inside a section -- k_slab_reduce,
+    # k_adam_record -- are in its time but not counted as launches of the kernel)
+    launches = {"field_fwd": 1, "field_bwd": 1, "adam_coef": n_launch, "plane_grad_binned": 1,
                 "idwt_fwd": ts.J + 1, "idwt_adjoint": ts.J}
 
     def roof(name, ms_):

@@ -116,14 +116,22 @@ class NeRFNetwork(NeRFRenderer):
         return sigma, self._color_mlp(d, geo_feat)
 
     @torch.no_grad()
-    def field_rows(self, xyzs, dirs, m_actual):
+    def packed_weights(self):
+        """The five weight matrices as fp16 MFMA fragments (field_common.h); a render loop packs them once."""
+        enc = self.encoder
+        return _field.pack_weights(self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight,
+                                   self.color_net[1].weight, self.color_net[2].weight, enc.number_of_features,
+                                   self.hidden_dim)
+
+    @torch.no_grad()
+    def field_rows(self, xyzs, dirs, m_actual, packed=None):
         """sigma, rgb of the first m_actual[0] rows (device int32) of fixed-capacity buffers: the inference loop's
-        field query when its sizes live on the device (NeRFRenderer.run_cuda).  Fused path only."""
+        field query when its sizes live on the device (NeRFRenderer.run_cuda).  Fused path only.  packed: the result of
+        packed_weights() (the loop's weights do not change between its iterations)."""
         enc = self.encoder
         tm = enc.get_planes_texel_major()
-        packed = _field.pack_weights(self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight,
-                                     self.color_net[1].weight, self.color_net[2].weight, enc.number_of_features,
-                                     self.hidden_dim)
+        if packed is None:
+            packed = self.packed_weights()
         sigma, rgb, _ = _field.field_forward(tm, xyzs, dirs, packed, float(self.bound), enc.number_of_features,
                                              enc.plane_resolution, self.hidden_dim, m_actual=m_actual)
         return sigma, rgb

@@ -255,6 +255,7 @@ class NeRFRenderer(nn.Module):
         cws = torch.empty((N + 255) // 256 + 2, dtype=torch.int32, device=dev)
         noises = torch.rand(N, dtype=torch.float32, device=dev) if perturb else None
         rows = state[3:4]
+        packed = self.packed_weights()     # once per render, not once per iteration (one 5-us launch each: 2.6 % of an image)
 
         def iteration(nz):
             L.check(lib.tnl_infer_plan(L.ptr(state), L.u32(N), L.u32(max_steps), L.u32(min_step), L.stream()),
@@ -264,7 +265,7 @@ class NeRFRenderer(nn.Module):
                 L.f32(self.bound), L.f32(dt_gamma), L.u32(max_steps), L.u32(self.cascade), L.u32(self.grid_size),
                 L.ptr(self.density_bitfield), L.ptr(fars), L.ptr(xyzs), L.ptr(dirs), L.ptr(deltas),
                 L.ptr(nz), L.ptr(t_scratch), L.u32(cap), L.stream()), "march_rays_dev")
-            sigmas, rgbs = self.field_rows(xyzs, dirs, rows)
+            sigmas, rgbs = self.field_rows(xyzs, dirs, rows, packed)
             if self.density_scale != 1:
                 sigmas = self.density_scale * sigmas
             L.check(lib.tnl_composite_rays_dev(
