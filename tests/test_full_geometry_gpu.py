@@ -374,6 +374,8 @@ def test_trainstep_window_equals_whole_plane_bit_for_bit_when_deterministic(cuda
         assert ts.defer_adam == use_roi and (ts._roi is not None) == use_roi
         res.append((mses, [p.detach().clone() for p in m.parameters()]))
         del ts
-    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
-    for a, b in zip(res[0][1], res[1][1]):
-        assert torch.equal(a, b), (a.shape, int((a != b).sum()), float((a - b).abs().max()))
+    # (the reported MSE is a float-atomic sum over the rays: equal to rounding, not to the bit; the gradients do not read it)
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-6)
+    bad = [(tuple(a.shape), int((a != b).sum()), float((a - b).abs().max())) for a, b in zip(res[0][1], res[1][1])
+           if not torch.equal(a, b)]
+    assert not bad, bad
