@@ -100,6 +100,7 @@ def run_fused(workload, device, steps=512, num_rays=60000, scene=None, batches=N
     model, lam = make_model(workload, device, seed=seed)
     ts = TrainStep(model, lr=1e-2, wavelet_regularization=lam, iters=steps, warmup_steps=0, fp16=True,
                    background_color=0.0, **(ts_kwargs or {}))
+    ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", ts.prefetch_at)      # experiments
     model.mark_untrained_grid(train.poses, train.intrinsics)
     ts.invalidate_roi()
     if batches is None:
@@ -122,6 +123,8 @@ def run_fused(workload, device, steps=512, num_rays=60000, scene=None, batches=N
     wall = time.perf_counter() - t0
     ms = np.array([evs[k].elapsed_time(evs[k + 1]) for k in range(steps)])
     M = np.array([int(c[0]) for c in torch.stack(counters).cpu()])
+    if os.environ.get("TNL_TRAJ_PRINT_STEPS"):
+        print("ms per step:", [round(float(v), 2) for v in ms[:int(os.environ["TNL_TRAJ_PRINT_STEPS"])]], file=sys.stderr)
     R = GEOM[workload][1]
     periods = [{"steps": f"{a}-{min(a + 16, steps) - 1}", "ms_per_step": round(float(ms[a:a + 16].mean()), 3),
                 "refresh_step_ms": round(float(ms[a]), 3), "samples_per_step": int(M[a + 1:a + 16].mean()) if a + 1 < steps else int(M[a]),
@@ -133,6 +136,8 @@ def run_fused(workload, device, steps=512, num_rays=60000, scene=None, batches=N
         "wall_ms_per_step": round(wall / steps * 1e3, 4), "rays_per_s": num_rays * steps / wall,
         "event_ms_per_step_mean": round(float(ms.mean()), 4),
         "second_half_ms_per_step": round(float(ms[tail].mean()), 4),
+        "after_step_64_ms_per_step": round(float(ms[64:].mean()), 4) if steps > 64 else None,
+        "slowest_steps_ms": sorted((round(float(v), 1) for v in ms), reverse=True)[:4],
         "second_half_samples_per_step": int(M[tail].mean()),
         "first_period_ms_per_step": round(float(ms[:16].mean()), 3),
         "samples_per_step_first_last": [int(M[0]), int(M[-1])],
@@ -142,7 +147,10 @@ def run_fused(workload, device, steps=512, num_rays=60000, scene=None, batches=N
         "periods": periods, "_model": model,
         "note": "from an untrained grid (mark_untrained_grid), real density-grid refreshes every 16 steps, no re-imposed "
                 "occupancy; analytic sphere scene, 36 training + 4 held-out cameras of 400 x 400; ms per step from HIP "
-                "events around every step, wall clock around the whole run incl. the closing flush of the deferred pass",
+                "events around every step, wall clock around the whole run incl. the closing flush of the deferred pass. "
+                "The first periods allocate their multi-GB sample buffers (26 M samples per step from the untrained grid): "
+                "single steps of 50-550 ms there are hipMalloc calls of the caching allocator (slowest_steps_ms), which vary "
+                "with the allocator's state; after_step_64_ms_per_step excludes them",
     }
 
 

@@ -253,6 +253,7 @@ class TrainStep:
         self._mark_seq = 0
         self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
         self.prefetch_at = "auto"   # "start" | "fwd" | "bwd" | "adam" | "auto": where step(next_rays=...) starts the next batch's march
+        self.adam_reserve = False   # experiments: limit the Adam pass's residency (LDS reservation) whenever side work may run beside it
         self._side = None
         self.side_cus = 0           # > 0: the side stream may only use this many compute units (see _make_side_stream)
         self._prefetched = None     # (key, marched tensors) of a march started for the following call
@@ -807,7 +808,8 @@ class TrainStep:
                 # large coefficient sets: the next batch's march + tile sort start together with the Adam pass, whose
                 # workgroups are limited to 4 per CU (an unused 40-KB LDS reservation) so that the side stream finds
                 # wave slots; the tile reduction and the adjoint above then ran undisturbed
-                lib.tnl_adam_set_lds_reservation(L.u32(40960 if under_adam else 0))
+                reserve = under_adam or (self.adam_reserve and next_rays is not None)
+                lib.tnl_adam_set_lds_reservation(L.u32(40960 if reserve else 0))
                 try:
                     if under_adam:
                         self._prefetch_next(next_rays, march_on_side)
@@ -816,7 +818,7 @@ class TrainStep:
                     else:
                         self._adam_levels(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
                 finally:
-                    if under_adam:
+                    if reserve:
                         lib.tnl_adam_set_lds_reservation(L.u32(0))   # process-global: never leave it set
                 self._mark("adam_coef")
                 if self._pending == 16:     # the ring is full (a whole density-grid period at the default interval)
@@ -899,10 +901,15 @@ class TrainStep:
         adjoint and spills into the Adam pass; start 5.54 | 1.84 (the march delays the field forward); fwd 5.27 | 1.84;
         adam 5.26 | 1.98.  "fwd" (side work beside the two MFMA field kernels, whose waves leave half of each SIMD's
         registers free) gives the shortest step with the HBM-bound dominant kernel alone on the GPU.  The small
-        configuration (dense tail 0.5 ms) starts it at the top of the step: 2.94 | 3.03 (fwd) | 3.04 (bwd) ms."""
+        configuration (dense tail 0.5 ms) starts it at the top of the step: 2.94 | 3.03 (fwd) | 3.04 (bwd) ms.
+        Round 3 (the side work is down to ~1 ms alone since the rays are marched once and the sort's hot counters are split):
+        "bwd" -- the side work under tile reduction + adjoint + Adam, the two MFMA field kernels alone on the GPU -- wins
+        again: base 4.19-4.25 against 4.28-4.35 ms for "fwd" over eight alternating runs on one box (field forward 0.83 ->
+        0.77, backward 0.90 -> 0.76, tile reduction 0.47 -> 0.40, Adam 0.84 -> 0.99), small 2.22 against 2.25-2.27
+        ("start"), large a tie (7.75-7.93); capping the Adam pass's residency beside it (adam_reserve) loses 0.1 ms."""
         mode = self.prefetch_at
         if mode == "auto":
-            mode = "start" if self.coef_numel < 100_000_000 else "fwd"
+            mode = "bwd"
         return mode
 
     def _prefetch_next(self, next_rays, march_on_side):
