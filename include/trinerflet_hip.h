@@ -105,6 +105,16 @@ TNL_API int tnl_march_rays_train_binned(const float *rays_o, const float *rays_d
                                  const float *fars, float *xyzs, float *dirs, float *deltas,
                                  int32_t *rays, int32_t *counter, const float *noises,
                                  int32_t *workspace, uint32_t workspace_words, uint32_t R, void *sort_workspace, void *stream);
+/* The same in two calls (no reference counterpart): phase 1 = the count pass only (the serial per-ray walk that records
+ * every sample's t), phase 2 = ray records, sample emission with the tile counts, counter -- from what phase 1 left in
+ * `workspace`.  Identical arguments to both calls; record-path workspace (tnl_march_rays_train_workspace_rec) required.
+ * Lets a caller run the latency-bound walk and the wide passes at different points of its schedule. */
+TNL_API int tnl_march_rays_train_binned_phase(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,
+                                              float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                              uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs,
+                                              float *deltas, int32_t *rays, int32_t *counter, const float *noises,
+                                              int32_t *workspace, uint32_t workspace_words, uint32_t R,
+                                              void *sort_workspace, int phase, void *stream);
 
 /* raymarching.h:14 composite_rays_train_forward ; kernel raymarching.cu:501-577.
  * One 64-lane wavefront per ray; transmittance by a wavefront product scan. */

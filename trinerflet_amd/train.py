@@ -253,6 +253,7 @@ class TrainStep:
         self._mark_seq = 0
         self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
         self.prefetch_at = "auto"   # "start" | "fwd" | "bwd" | "adam" | "auto": where step(next_rays=...) starts the next batch's march
+        self.split_phase2_at = "pg"  # prefetch_at = "split": phase 2 after the field backward ("bwd") or after the tile reduction ("pg")
         self.adam_reserve = False   # experiments: limit the Adam pass's residency (LDS reservation) whenever side work may run beside it
         self._side = None
         self.side_cus = 0           # > 0: the side stream may only use this many compute units (see _make_side_stream)
@@ -660,6 +661,51 @@ class TrainStep:
                 t_.record_stream(main)
             return out
 
+        # "split" placement: the next batch's march in two phases on the side stream (tnl_march_rays_train_binned_phase) --
+        # the count pass (a serial walk per ray: ~940 waves of pure latency that fit beside the field kernels' waves)
+        # before the field forward, the wide passes (ray records, emission + tile counts, tile sort) after the field
+        # backward, so that they are done before the Adam pass starts.
+        def march_phase1(o, d, nz):
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = self._make_side_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_train, model.min_near)
+                counter = model.step_counter[model.local_step % 16]
+                counter.zero_()
+                model.local_step += 1
+                mc = model.mean_count + (128 - model.mean_count % 128)
+                Nn = o.shape[0]
+                st = dict(
+                    counter=counter, mc=mc, nears=nears, fars=fars, o=o.contiguous(), d=d.contiguous(),
+                    nz=nz.contiguous() if nz is not None else torch.rand(Nn, dtype=torch.float32, device=self.dev),
+                    xyzs=torch.empty(mc, 3, dtype=torch.float32, device=self.dev),
+                    dirs=torch.empty(mc, 3, dtype=torch.float32, device=self.dev),
+                    deltas=torch.empty(mc, 2, dtype=torch.float32, device=self.dev),
+                    rays=torch.empty(Nn, 3, dtype=torch.int32, device=self.dev),
+                    sort_ws=F_.plane_grad_sort_workspace(mc, R, self.dev))
+                nws = lib.tnl_march_rays_train_workspace_rec(L.u32(Nn), L.u32(self.max_steps))
+                assert nws > 0
+                st["ws"], st["nws"] = torch.empty(nws, dtype=torch.int32, device=self.dev), nws
+                self._march_phase(st, 1)
+            return st
+
+        def march_phase2(st):
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)         # not before the launch stream got here (after the field backward)
+            with torch.cuda.stream(self._side):
+                self._march_phase(st, 2)
+                ev_march = torch.cuda.Event()
+                ev_march.record()
+                F_.plane_grad_sort_counted(st["sort_ws"], st["xyzs"], float(model.bound), R, st["counter"])
+                ev_sort = torch.cuda.Event()
+                ev_sort.record()
+            out = (st["counter"], st["xyzs"], st["dirs"], st["deltas"], st["rays"], st["sort_ws"])
+            for t_ in out:
+                t_.record_stream(main)
+            return out, (ev_march, ev_sort)
+
         # The march (one ray per lane, latency-bound, ~1/8 of the chip's wave slots) depends only on the rays and
         # the occupancy bitfield, not on the planes: it runs on a side stream underneath the HBM-bound plane
         # rebuild.  On grid-refresh steps the bitfield changes first, so there the march stays in order.
@@ -680,6 +726,10 @@ class TrainStep:
         # where the next batch's side work starts (see _prefetch_mode): "start" = here, "fwd" = before the field forward,
         # "bwd" = after the field backward, "adam" = together with the Adam pass
         pf = self._prefetch_mode()
+        split = pf == "split" and self._can_split_prefetch(next_rays)
+        if pf == "split" and not split:
+            pf = "bwd"
+        phase1 = None
         early = pf in ("start", "fwd") and not refresh
         if early and pf == "start":
             self._prefetch_next(next_rays, march_on_side)
@@ -720,6 +770,10 @@ class TrainStep:
         self._mark("march")
         if early and pf == "fwd":
             self._prefetch_next(next_rays, march_on_side)
+        if split:
+            slot_step = model.local_step
+            phase1 = (self._prefetch_key(next_rays), march_phase1(next_rays[0], next_rays[1],
+                                                                  next_rays[2] if len(next_rays) > 2 else None), slot_step)
         # rows past counter[0] are the zero padding of the sample budget: skipped on the device
         sigma, rgb, feats = F_.field_forward(tm, xyzs, dirs, packed, float(model.bound), C, R, H, save_feats=True,
                                              m_actual=counter)
@@ -783,7 +837,10 @@ class TrainStep:
             # is time-sliced in); started under Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms
             # stay exposed.  At the small configuration (dense tail 0.5 ms) 1 ms of the march stays exposed either way.
             under_adam = self._prefetch_under_adam(next_rays)
-            if not under_adam and not early:
+            if phase1 is not None and self.split_phase2_at == "bwd":
+                self._prefetched = (phase1[0], march_phase2(phase1[1]), phase1[2])
+                phase1 = None
+            elif phase1 is None and not under_adam and not early:
                 self._prefetch_next(next_rays, march_on_side)
             if side is not None or sort_beside:
                 torch.cuda.current_stream().wait_event(ev_sort)
@@ -792,6 +849,9 @@ class TrainStep:
             F_.plane_grad_reduce(sort_ws, dfeat, xyzs, float(model.bound), C, R, g_cm, channel_major=True,
                                  nonfinite_flag=self.nonfinite, roi=self._roi10() if roi is not None else None)
             self._mark("plane_grad_binned")
+            if phase1 is not None:          # split_phase2_at == "pg": the wide passes beside adjoint + Adam
+                self._prefetched = (phase1[0], march_phase2(phase1[1]), phase1[2])
+                phase1 = None
             if self.world > 1:
                 dist.all_reduce(self.mlp.grad, group=self.pg)
             # GradScaler probe BEFORE the dense backward, so that the optimiser can be fused into it: the plane
@@ -906,7 +966,12 @@ class TrainStep:
         "bwd" -- the side work under tile reduction + adjoint + Adam, the two MFMA field kernels alone on the GPU -- wins
         again: base 4.19-4.25 against 4.28-4.35 ms for "fwd" over eight alternating runs on one box (field forward 0.83 ->
         0.77, backward 0.90 -> 0.76, tile reduction 0.47 -> 0.40, Adam 0.84 -> 0.99), small 2.22 against 2.25-2.27
-        ("start"), large a tie (7.75-7.93); capping the Adam pass's residency beside it (adam_reserve) loses 0.1 ms."""
+        ("start"), large a tie (7.75-7.93); capping the Adam pass's residency beside it (adam_reserve) loses 0.1 ms.
+        "split" (tnl_march_rays_train_binned_phase: the count pass before the field forward, the wide passes -- emission,
+        tile counts, tile sort -- after the field backward or after the tile reduction) was built to get the side work out
+        from under the Adam pass: Adam does run clean then (0.99 -> 0.84 ms), but the wide passes cost whatever they run
+        beside 0.23-0.28 ms (tile reduction 0.41 -> 0.65, or adjoint 0.37 -> 0.65) against the 0.15 ms they cost Adam, and
+        the count pass costs the field forward 0.06: 4.39-4.44 against 4.23-4.35 ms per step.  Kept as an option."""
         mode = self.prefetch_at
         if mode == "auto":
             mode = "bwd"
@@ -919,12 +984,37 @@ class TrainStep:
             return
         no, nd = next_rays[0], next_rays[1]
         nn = next_rays[2] if len(next_rays) > 2 else None
-        # the announced tensors are kept (their storage cannot be recycled for another batch meanwhile) together with
-        # their version counters (an in-place refill of a persistent ray buffer is noticed)
-        key = tuple((t_, t_.data_ptr(), tuple(t_.shape), t_._version) if t_ is not None else None for t_ in (no, nd, nn))
+        key = self._prefetch_key(next_rays)
         # the ring slot the march takes (run_cuda's local_step rule), so that a dropped prefetch gives back exactly it
         slot_step = model.local_step
         self._prefetched = (key, march_on_side(no, nd, nn), slot_step)
+
+    @staticmethod
+    def _prefetch_key(next_rays):
+        # the announced tensors are kept (their storage cannot be recycled for another batch meanwhile) together with
+        # their version counters (an in-place refill of a persistent ray buffer is noticed)
+        no, nd = next_rays[0], next_rays[1]
+        nn = next_rays[2] if len(next_rays) > 2 else None
+        return tuple((t_, t_.data_ptr(), tuple(t_.shape), t_._version) if t_ is not None else None for t_ in (no, nd, nn))
+
+    def _can_split_prefetch(self, next_rays):
+        """The two-phase side work needs the fused tile count (fixed sample budget, binned mode), a following batch and
+        no refresh in between; the far clip is not part of it."""
+        model = self.model
+        next_refresh = self.update_extra_interval > 0 and (self.global_step + 1) % self.update_extra_interval == 0
+        this_refresh = self.update_extra_interval > 0 and self.global_step % self.update_extra_interval == 0
+        return (next_rays is not None and self.overlap_march and not next_refresh and not this_refresh
+                and model.mean_count > 0 and self.binned and self.R % 32 == 0 and not self.clip_far
+                and model.mean_count + 128 < 2 ** 31)
+
+    def _march_phase(self, st, phase):
+        model = self.model
+        L.check(L.lib().tnl_march_rays_train_binned_phase(
+            L.ptr(st["o"]), L.ptr(st["d"]), L.ptr(model.density_bitfield), L.f32(model.bound), L.f32(self.dt_gamma),
+            L.u32(self.max_steps), L.u32(st["o"].shape[0]), L.u32(model.cascade), L.u32(model.grid_size), L.u32(st["mc"]),
+            L.ptr(st["nears"]), L.ptr(st["fars"]), L.ptr(st["xyzs"]), L.ptr(st["dirs"]), L.ptr(st["deltas"]),
+            L.ptr(st["rays"]), L.ptr(st["counter"]), L.ptr(st["nz"]), L.ptr(st["ws"]), L.u32(st["nws"]), L.u32(self.R),
+            L.ptr(st["sort_ws"]), L.i32(phase), L.stream()), "march_rays_train_binned_phase")
 
     @staticmethod
     def _prefetch_matches(key, rays_o, rays_d, noises):
