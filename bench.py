@@ -68,6 +68,8 @@ def build(workload, device, dist_mode, plane_dtype=None, **ts_kwargs):
     ts = TrainStep(model, lr=1e-2, wavelet_regularization=lam, iters=40000, warmup_steps=0, fp16=True,
                    background_color=0.0, dist_mode=dist_mode, **ts_kwargs)
     ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", ts.prefetch_at)   # "auto" | "bwd" | "adam" (experiments)
+    if os.environ.get("TNL_LIVE_ALIGN"):      # experiments: column granule of the live rectangles
+        ts.live_col_align = int(os.environ["TNL_LIVE_ALIGN"])
     if os.environ.get("TNL_SPLIT_P2"):        # experiments: where phase 2 of the split side work starts
         ts.split_phase2_at = os.environ["TNL_SPLIT_P2"]
     if os.environ.get("TNL_ADAM_RESERVE"):    # experiments: Adam pass with reduced residency beside the side work

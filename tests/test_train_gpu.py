@@ -353,3 +353,52 @@ def test_deterministic_step_is_reproducible_bit_for_bit(cuda):
         runs.append([p.detach().clone() for p in m.parameters()] + [ts.coef.m.clone(), ts.coef.v.clone(), ts.mlp.m.clone()])
     for a, b in zip(*runs):
         assert torch.equal(a, b), (a.shape, int((a != b).sum()))
+
+
+def test_trainstep_with_wavelet_base_resolution(cuda):
+    """SURVEY 8(f) rank 4 tail: TrainStep on an encoder with wavelet_base_resolution > 0 (triplane_encoder.py:391-393: the
+    levels below it keep the uncropped analysis size and are synthesised without the zero halo).  The level sizes are
+    then not base * 2^i: the dense rebuild crops those levels and its adjoint zero-pads.  Checked against the module path
+    (the same encoder through autograd): prediction, loss and every coefficient / LL gradient of one step."""
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    from trinerflet_amd.train import TrainStep
+    torch.manual_seed(0)
+    base = NeRFNetwork(encoding="triplane_wavelet", bound=BOUND, cuda_ray=True, density_thresh=10, hidden_dim=H,
+                       hidden_dim_color=H, triplane_channels=C, triplane_resolution=128, triplane_wavelet_levels=8,
+                       wavelet_type="bior6.8", wavelet_base_resolution=48).to(cuda)
+    sizes = [p.shape[-1] for p in base.encoder.planes_features_wavelet_coefs]
+    assert sizes != [16, 32, 64] and sizes[-1] == 64, sizes           # the coarse levels have the uncropped sizes
+    with torch.no_grad():
+        g = torch.Generator(device=cuda).manual_seed(1)
+        base.encoder.planes_features.copy_(0.1 * torch.randn(base.encoder.planes_features.shape, device=cuda, generator=g))
+        for i, p in enumerate(base.encoder.planes_features_wavelet_coefs):
+            p.copy_(0.05 * 0.5 ** i * torch.randn(p.shape, device=cuda, generator=g))
+    bf = torch.from_numpy(synthetic.sphere_bitfield(128, 2, BOUND, 0.8, 0.3)).to(cuda)
+    base.density_bitfield.copy_(bf)
+    o, d = synthetic.training_rays(1024, n_cams=4, seed=5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    o_t, d_t, gt = t(o), t(d), t(synthetic.target_colors(d))
+    nz = torch.rand(1024, device=cuda, generator=torch.Generator(device=cuda).manual_seed(2))
+    # fused step
+    m1 = copy.deepcopy(base)
+    ts = TrainStep(m1, lr=1e-2, wavelet_regularization=0.0, iters=100, fp16=True, update_extra_interval=0, init_scale=65536.0)
+    assert not ts.use_roi and ts.base_res == 48
+    m1.mean_count = 0
+    ts.step(o_t, d_t, gt, noises=nz)
+    # module path
+    m2 = copy.deepcopy(base)
+    m2.train()
+    m2.mean_count = 0
+    m2.encoder.reset_cahce(); m2.encoder.get_planes()
+    out = m2.render(o_t[None], d_t[None], staged=False, bg_color=0, perturb=True, force_all_rays=False, noises=nz,
+                    dt_gamma=0, max_steps=1024)
+    mse = ((out["image"][0] - gt) ** 2).mean()
+    (mse * 65536.0).backward()          # the loss scale of GradScaler: the fp16 backward operands underflow without it
+    assert np.abs(ts.last["image"].cpu().numpy() - out["image"][0].detach().cpu().numpy()).max() < 1e-5
+    assert abs(float(ts.last["mse"]) - float(mse)) < 1e-5 * float(mse)
+    inv = 1.0 / 65536.0
+    errs = {"LL": _relerr(ts.ll.grad.cpu().numpy() * inv, m2.encoder.planes_features.grad.cpu().numpy().reshape(-1) * inv)}
+    for i, p in enumerate(m2.encoder.planes_features_wavelet_coefs):
+        errs[i] = _relerr(ts.coef.grad_view(i).cpu().numpy() * inv, p.grad.cpu().numpy() * inv)
+        assert float(p.grad.abs().sum()) > 0
+    assert all(e < 2e-2 for e in errs.values()), errs

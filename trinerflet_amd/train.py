@@ -156,9 +156,12 @@ class TrainStep:
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
             raise NotImplementedError("TrainStep needs a configuration the fused field kernel is built for")
-        if getattr(enc, "wavelet_base_resolution", 0) > 0:
-            raise NotImplementedError("TrainStep assumes level sizes base * 2^i (wavelet_base_resolution = 0, as every "
-                                      "README configuration has it); the module path (autograd) supports the option")
+        # wavelet_base_resolution > 0 (triplane_encoder.py:391-393: the levels below it keep their uncropped analysis size
+        # and are synthesised without the zero halo = a crop of the padded kernel's output by 2 * pad per side): the
+        # level sizes are then not base * 2^i, so the occupancy window / rectangle machinery stays off and the dense
+        # rebuild crops (its adjoint zero-pads) those levels.  No README configuration uses the option.
+        self.base_res = int(getattr(enc, "wavelet_base_resolution", 0) or 0)
+        self.crop_k = 2 * int(getattr(enc, "planes_features_wavelet_pad", 0) or 0)
         self.model, self.enc = model, enc
         self.C, self.R, self.H = enc.number_of_features, enc.plane_resolution, model.hidden_dim
         self.J = enc.planes_features_wavelet_all_level
@@ -182,7 +185,7 @@ class TrainStep:
         # that window (compact arrays).  Refresh steps rebuild whole planes (the grid update queries density
         # everywhere).  Results are bit-identical to the whole-plane step.
         self.use_roi = (use_roi and binned and not fuse_adam and self.J > 0 and self.R % 64 == 0 and self.C % 8 == 0
-                        and enc.plane_dtype == torch.float16)
+                        and enc.plane_dtype == torch.float16 and self.base_res == 0)
         self._roi = None          # 8 ints {ox[3], oy[3], rw, rh} or None (whole planes)
         self._roi_valid = False   # False: recompute from the bitfield before it is used
         self._tm_full = None      # persistent fp16 [3,R,R,C]; the ROI steps refresh its window in place
@@ -253,6 +256,7 @@ class TrainStep:
         self._mark_seq = 0
         self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
         self.prefetch_at = "auto"   # "start" | "fwd" | "bwd" | "adam" | "auto": where step(next_rays=...) starts the next batch's march
+        self.live_col_align = 32    # column granule of the live rectangles (see _live_rects)
         self.split_phase2_at = "pg"  # prefetch_at = "split": phase 2 after the field backward ("bwd") or after the tile reduction ("pg")
         self.adam_reserve = False   # experiments: limit the Adam pass's residency (LDS reservation) whenever side work may run beside it
         self._side = None
@@ -384,6 +388,16 @@ class TrainStep:
                 "idwt_level_forward_win")
         return out
 
+    def _cropped(self, lvl):
+        """Level lvl (input size n) is one of the uncropped-size levels of wavelet_base_resolution > 0."""
+        return self.base_res > 0 and self.crop_k > 0 and self.coef.params[lvl].shape[-1] < self.base_res
+
+    def _crop(self, x, lvl):
+        if not self._cropped(lvl):
+            return x
+        k = self.crop_k
+        return x[..., k:-k, k:-k].contiguous()
+
     def rebuild_planes(self, roi=False):
         """encoder.reset_cahce(); encoder.get_planes() of utils.py:1138-1140, outside autograd.
         roi=True (step() between grid refreshes): only the occupancy window of the finest level is rebuilt and
@@ -408,6 +422,7 @@ class TrainStep:
                         x = self._idwt_level_win(x, yh, wins[lvl])
                     else:
                         x = _IDWTLevel.apply(x, yh, enc.wave_id)
+                    x = self._crop(x, lvl)
                 planes = x
             if roi:
                 enc.last_used_planes = None
@@ -445,6 +460,7 @@ class TrainStep:
                 x = self._idwt_level_win(x, yh, wins[lvl], s0)
             else:
                 x = _IDWTLevel.apply(x, yh, enc.wave_id)
+            x = self._crop(x, lvl)
         if roi:
             return D.all_gather_slices(x.reshape(s1 - s0, self._roi[7], self._roi[6]), self.pg)
         mine = x.reshape(s1 - s0, self.R, self.R)
@@ -512,6 +528,8 @@ class TrainStep:
             lr_t, l1, found_inf, inv_scale = fuse
             step_size, bias2_sqrt = self._adam_scalars(lr_t)
         for lvl in reversed(range(self.J)):
+            if self._cropped(lvl):       # the level's output was cropped by k per side: its gradient is zero there
+                g = torch.nn.functional.pad(g, (self.crop_k,) * 4)
             n = (R >> (self.J - lvl)) if roi is not None else g.shape[-1] // 2
             per = 3 * n * n
             dx = torch.empty(ns, n, n, dtype=torch.float32, device=self.dev) if lvl > 0 else None
@@ -1073,7 +1091,7 @@ class TrainStep:
                 return lo, hi
             # rows start on 128-byte lines (a row piece that ends inside a line costs the whole line: measured 4.7 vs
             # 5.6 TB/s with 8-aligned columns); any 8 rows
-            xs = [span(w[p], w[6], r[p], r[6], 32) for p in range(3)]
+            xs = [span(w[p], w[6], r[p], r[6], self.live_col_align) for p in range(3)]
             ys = [span(w[3 + p], w[7], r[3 + p], r[7], 8) for p in range(3)]
             rw = max(h - l for l, h in xs)
             rh = max(h - l for l, h in ys)
