@@ -1091,7 +1091,7 @@ class TrainStep:
                 return lo, hi
             # rows start on 128-byte lines (a row piece that ends inside a line costs the whole line: measured 4.7 vs
             # 5.6 TB/s with 8-aligned columns); any 8 rows
-            xs = [span(w[p], w[6], r[p], r[6], self.live_col_align) for p in range(3)]
+            xs = [span(w[p], w[6], r[p], r[6], getattr(self, "live_col_align", 32)) for p in range(3)]
             ys = [span(w[3 + p], w[7], r[3 + p], r[7], 8) for p in range(3)]
             rw = max(h - l for l, h in xs)
             rh = max(h - l for l, h in ys)
