@@ -442,6 +442,17 @@ def main():
     sec_instrumented_dominant = sec.get(dominant)
     if dom_ms == dom_ms:
         sec[dominant] = dom_ms
+    # the same sections with NOTHING beside them (the next batch's march + tile sort in order on the launch stream
+    # instead of on the side stream): what each kernel does alone, for `roofline.alone` and `kernels[*].alone_ms`
+    ts.section_events, ts.section_names = [], None
+    ts._drop_prefetch()
+    ts.overlap_march = False
+    for i in range(min(args.steps, 8)):
+        j = args.warmup + args.steps + 16 + i
+        one_step(model, ts, bitfield, batches[j % nb], mean_count, None)
+    torch.cuda.synchronize()
+    sec_alone = ts.section_times()
+    ts.overlap_march = not os.environ.get("TNL_NO_OVERLAP")
     ts.section_events = None
     samples_per_step = float(np.mean(counts))
     # algorithmic bytes of the step's Adam launches (one per wavelet level + LL): 16 B read (p, g, m, v) + 12 B
@@ -543,6 +554,11 @@ def main():
             out["frac_mfma"] = round(tfl / MFMA_PEAK_TFLOPS, 4)
         return out
     kernels = {k: roof(k, sec.get(k, float("nan"))) for k in spec}
+    for k in kernels:
+        a = roof(k, sec_alone.get(k, float("nan")))
+        if kernels[k] is not None and a is not None:
+            kernels[k]["alone_ms"] = a["ms_per_step"]
+            kernels[k]["alone_frac"] = round(a["frac"], 4)
 
     # ---- secondary figures, after the timed region (rank 0's GPU only; skipped by --no-extras and in multi-GPU runs)
     extras = {}
@@ -684,6 +700,10 @@ def main():
                                       "GB/s": dom.get("GB/s"), "frac_hbm": dom.get("frac_hbm"),
                                       "mfma_TFLOP/s": dom.get("mfma_TFLOP/s"), "frac_mfma": dom.get("frac_mfma")},
                          "per_unit": spec[dominant]["per_unit"],
+                         "alone": None if not dom.get("alone_ms") else {
+                             "ms_per_step": dom["alone_ms"], "frac": dom["alone_frac"],
+                             "note": "the same section in steps whose side work (the next batch's march + tile sort) runs "
+                                     "in order on the launch stream instead of beside it: the kernel by itself"},
                          "top": top,
                          "measured_copy_GB/s": None if copy_gbs is None else round(copy_gbs, 1),
                          "measured_copy_note": "tnl_copy_probe: 1 GiB float4 non-temporal streaming copy on this box, read + "
