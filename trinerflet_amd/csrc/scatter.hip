@@ -46,13 +46,20 @@ k_bin(const float* __restrict__ xyz, float bound, uint32_t M, const int32_t* __r
 // exclusive scan of the bin counts; also leaves a copy as the fill cursors.  Two tiny launches: (1) each
 // workgroup scans 1024 consecutive counts (coalesced) and publishes its total; (2) every workgroup adds the totals
 // of the workgroups before it (<= 48 values at R = 2048).  A single-workgroup version took 107 us of pure latency.
-__global__ void __launch_bounds__(1024)
+// (256 threads x 4 counts per workgroup since round 3: a 1024-thread workgroup needs a whole CU's worth of free wave
+//  slots, and on the side stream, beside the Adam pass's 4096 workgroups, the 5-us kernel waited ~190 us for them --
+//  profiles/r03b_step_timeline.txt -- holding back the fill pass behind it.  The step time did not move: 4.26-4.31 vs
+//  4.22-4.31 ms over four alternating runs.)
+__global__ void __launch_bounds__(256)
 k_scan_local(const int* __restrict__ counts, int nb, int* __restrict__ offsets, int* __restrict__ block_tot) {
-  __shared__ int wsum[16];
-  const int i = blockIdx.x * 1024 + threadIdx.x;
+  __shared__ int wsum[4];
+  const int i0 = blockIdx.x * 1024 + 4 * threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int v = i < nb ? counts[i] : 0;
-  int incl = v;
+  int v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = i0 + k < nb ? counts[i0 + k] : 0;
+  const int mine = v[0] + v[1] + v[2] + v[3];
+  int incl = mine;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int u = __shfl_up(incl, off);
@@ -62,16 +69,21 @@ k_scan_local(const int* __restrict__ counts, int nb, int* __restrict__ offsets, 
   __syncthreads();
   int b = 0, tot = 0;
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
+  for (int k = 0; k < 4; k++) {
     const int w = wsum[k];
     if (k < wv) b += w;
     tot += w;
   }
-  if (i < nb) offsets[i] = b + incl - v;
+  int run = b + incl - mine;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (i0 + k < nb) offsets[i0 + k] = run;
+    run += v[k];
+  }
   if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
 }
 
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 k_scan_fix(int nb, int nblk, const int* __restrict__ block_tot, int* __restrict__ offsets, int* __restrict__ cursor) {
   __shared__ int s_base;
   if (threadIdx.x < 64) {
@@ -82,11 +94,14 @@ k_scan_fix(int nb, int nblk, const int* __restrict__ block_tot, int* __restrict_
     if (threadIdx.x == 0) s_base = part;
   }
   __syncthreads();
-  const int i = blockIdx.x * 1024 + threadIdx.x;
-  if (i < nb) {
-    const int o = offsets[i] + s_base;
-    offsets[i] = o;
-    cursor[i] = o;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int i = blockIdx.x * 1024 + 4 * threadIdx.x + k;
+    if (i < nb) {
+      const int o = offsets[i] + s_base;
+      offsets[i] = o;
+      cursor[i] = o;
+    }
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) offsets[nb] = s_base + block_tot[nblk - 1];
 }
@@ -417,8 +432,8 @@ static int plane_grad_sort_impl(const float* xyz, float bound, uint32_t M, const
                          w.counts, w.entries);
     }
   }
-  hipLaunchKernelGGL(k_scan_local, dim3(w.nblk), dim3(1024), 0, st, w.counts, w.nb, w.offsets, w.block_tot);
-  hipLaunchKernelGGL(k_scan_fix, dim3(w.nblk), dim3(1024), 0, st, w.nb, w.nblk, w.block_tot, w.offsets, w.cursor);
+  hipLaunchKernelGGL(k_scan_local, dim3(w.nblk), dim3(256), 0, st, w.counts, w.nb, w.offsets, w.block_tot);
+  hipLaunchKernelGGL(k_scan_fix, dim3(w.nblk), dim3(256), 0, st, w.nb, w.nblk, w.block_tot, w.offsets, w.cursor);
   if (M > 0) {
     hipLaunchKernelGGL(k_bin<true>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
                        w.cursor, w.entries);
