@@ -93,11 +93,13 @@ def held_out_psnr(model, pool, max_steps=1024):
     return float(np.mean(vals))
 
 
-def run_fused(workload, device, steps=512, num_rays=60000, scene=None, batches=None, seed=0, ts_kwargs=None):
-    """The product's training loop from an untrained grid; returns a report dict (and the model under "_model")."""
+def run_fused(workload, device, steps=512, num_rays=60000, scene=None, batches=None, seed=0, ts_kwargs=None,
+              plane_dtype=None):
+    """The product's training loop from an untrained grid; returns a report dict (and the model under "_model").
+    plane_dtype=torch.float32: the fused step on fp32 planes (the reference's training precision; whole planes)."""
     from trinerflet_amd.train import TrainStep
     train, valid = scene if scene is not None else make_scene(device)
-    model, lam = make_model(workload, device, seed=seed)
+    model, lam = make_model(workload, device, plane_dtype=plane_dtype, seed=seed)
     ts = TrainStep(model, lr=1e-2, wavelet_regularization=lam, iters=steps, warmup_steps=0, fp16=True,
                    background_color=0.0, **(ts_kwargs or {}))
     ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", ts.prefetch_at)      # experiments
@@ -204,20 +206,33 @@ def main():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--rays", type=int, default=60000)
     ap.add_argument("--skip-reference", action="store_true")
+    ap.add_argument("--repeat", type=int, default=1, help="run every loop this many times (run-to-run spread of the PSNR)")
+    ap.add_argument("--fused-fp32", action="store_true", help="also the fused step on fp32 planes")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     scene = make_scene(dev)
     batches = batches_of(scene[0], args.steps, args.rays)
-    fused = run_fused(args.workload, dev, args.steps, args.rays, scene, batches)
-    fused.pop("_model")
-    torch.cuda.empty_cache()
-    rep = {"fused": fused}
-    if not args.skip_reference:
-        ref = run_reference_loop(args.workload, dev, args.steps, args.rays, scene, batches)
-        ref.pop("_model")
-        rep["reference_loop"] = ref
-        rep["psnr_difference_db"] = round(fused["held_out_psnr_db"] - ref["held_out_psnr_db"], 4)
+    rep = {"psnr_runs": {"fused_fp16": [], "fused_fp32_planes": [], "reference_loop": []}}
+    for _ in range(args.repeat):
+        fused = run_fused(args.workload, dev, args.steps, args.rays, scene, batches)
+        fused.pop("_model")
+        torch.cuda.empty_cache()
+        rep["fused"] = fused
+        rep["psnr_runs"]["fused_fp16"].append(fused["held_out_psnr_db"])
+        if args.fused_fp32:
+            f32 = run_fused(args.workload, dev, args.steps, args.rays, scene, batches, plane_dtype=torch.float32)
+            f32.pop("_model")
+            torch.cuda.empty_cache()
+            rep["psnr_runs"]["fused_fp32_planes"].append(f32["held_out_psnr_db"])
+        if not args.skip_reference:
+            ref = run_reference_loop(args.workload, dev, args.steps, args.rays, scene, batches)
+            ref.pop("_model")
+            torch.cuda.empty_cache()
+            rep["reference_loop"] = ref
+            rep["psnr_runs"]["reference_loop"].append(ref["held_out_psnr_db"])
+            rep["psnr_difference_db"] = round(fused["held_out_psnr_db"] - ref["held_out_psnr_db"], 4)
+        print({k: v for k, v in rep["psnr_runs"].items() if v}, file=sys.stderr)
     s = json.dumps(rep, indent=1)
     print(s)
     if args.out:
