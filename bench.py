@@ -229,26 +229,30 @@ def variant_ms(workload, device, bitfield_np_unused, batches, mean_count, steps,
 
 def inference_figure(model, device, max_steps=4096, images=3):
     """BASELINE config 5's `--test` render: 800 x 800 rays of one pose through run_cuda's inference branch at
-    max_steps = 4096 (renderer.py:324-374), the trained-state planes of the benchmark model.  SURVEY.md 8(d)
-    "Inference unit": bytes = samples * (12*C*e + 48) + sum over iterations of n_alive * (4 + 4 + 20*2)."""
+    max_steps = 4096 (renderer.py:324-374), the trained-state planes of the benchmark model.  Three forms: the
+    one-kernel render (csrc/render.hip, the default of the eval branch), the device-driven alive-ray loop with the
+    reference's schedule, and that loop with 8-sample iterations.  SURVEY.md 8(d) "Inference unit":
+    bytes = samples * (12*C*e + 48) + sum over iterations of n_alive * (4 + 4 + 20*2) for the loop; the one-kernel
+    render moves the gathers only (samples * 12*C*e) plus 52 B per ray."""
     from trinerflet_amd import synthetic
     import trinerflet_amd.raymarching as rm
     poses = synthetic.hemisphere_poses(images, seed=3)
     model.eval()
     model.encoder.reset_cahce()
-    times, wide = [], []
+    modes = {"kernel": {}, "loop": {"device_loop": True}, "loop_wide": {"infer_min_step": 8}}
+    times = {k: [] for k in modes}
     sched = []
     with torch.no_grad():
         for k in range(images + 1):
             pix = np.stack([np.full(640000, k % images, np.int64), np.arange(640000)], -1)
             o, d = synthetic.get_rays(poses, pix)
             o, d = torch.from_numpy(o).to(device)[None], torch.from_numpy(d).to(device)[None]
-            for min_step, acc in ((1, times), (8, wide)):
+            for name, kw in modes.items():
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                model.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, infer_min_step=min_step)
+                model.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, **kw)
                 torch.cuda.synchronize()
-                acc.append(time.perf_counter() - t0)
+                times[name].append(time.perf_counter() - t0)
             if k == images:
                 # the schedule of that image (iterations, survivors, samples): the host-driven loop runs the same
                 # iterations (bit-identical image, tests/test_renderer_gpu.py) and passes them through march_rays
@@ -259,34 +263,39 @@ def inference_figure(model, device, max_steps=4096, images=3):
                     return real(n_alive, n_step, *a, **kw)
                 rm.march_rays = logging_march
                 try:
-                    model.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, device_loop=False)
+                    out = model.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, device_loop=False)
                 finally:
                     rm.march_rays = real
     model.train()
-    t, tw = float(np.mean(times[1:])), float(np.mean(wide[1:]))
+    t = {k: float(np.mean(v[1:])) for k, v in times.items()}
     C = model.encoder.number_of_features
     e = 2 if model.encoder.plane_dtype == torch.float16 else 4
-    samples = float(sum(a * b for a, b in sched))
+    slots = float(sum(a * b for a, b in sched))          # sample rows the loop evaluates (padding of dead rays included)
     alive = float(sum(a for a, _ in sched))
-    nbytes = samples * (12 * C * e + 48) + alive * 48.0
+    loop_bytes = slots * (12 * C * e + 48) + alive * 48.0
     H = model.hidden_dim
     mac = 3 * C * H + 16 * H + 31 * H + H * H + 3 * H
-    return {"image": "800x800", "max_steps": max_steps, "ms_per_image": round(t * 1e3, 2), "rays_per_s": 640000 / t,
-            "iterations": len(sched), "samples_per_image": samples, "samples_per_s": samples / t,
-            "sum_n_alive_over_iterations": alive,
-            "algorithmic_bytes": nbytes, "GB/s": round(nbytes / t / 1e9, 1), "frac_of_8_TB/s": round(nbytes / t / 8e12, 4),
-            "mlp_TFLOP/s": round(2.0 * mac * samples / t / 1e12, 1),
-            "bound_note": "SURVEY.md 8(d) inference unit: samples * (12*C*e + 48) + sum_iterations n_alive * 48 bytes over the "
-                          "image time; the loop is bound by its iteration count (each iteration = plan + march + field + "
-                          "composite + compaction launches over a shrinking ray set), not by bytes -- see wide_iterations",
-            "wide_iterations": {"ms_per_image": round(tw * 1e3, 2), "rays_per_s": 640000 / tw,
-                                "GB/s": round(nbytes / tw / 1e9, 1), "frac_of_8_TB/s": round(nbytes / tw / 8e12, 4),
-                                "note": "render(..., infer_min_step=8): the same per-ray sample sequences in an eighth of "
-                                        "the iterations; identical pixels for rays that end before the max_steps cap "
-                                        "(tests/test_renderer_gpu.py)"},
-            "note": "run_cuda eval branch (device-driven alive-ray loop, the reference's schedule), solid-sphere "
-                    "occupancy, the benchmark's field after its training steps; mean of 3 images after one warm-up; "
-                    "rocprofv3 summary: profiles/r03_infer_kernel_stats.csv"}
+
+    def fig(seconds, nbytes, samples):
+        return {"ms_per_image": round(seconds * 1e3, 2), "rays_per_s": 640000 / seconds, "samples_per_s": samples / seconds,
+                "algorithmic_bytes": nbytes, "GB/s": round(nbytes / seconds / 1e9, 1),
+                "frac_of_8_TB/s": round(nbytes / seconds / 8e12, 4),
+                "mlp_TFLOP/s": round(2.0 * mac * samples / seconds / 1e12, 1)}
+    kernel_bytes = slots * 12 * C * e + 640000 * 52.0
+    res = {"image": "800x800", "max_steps": max_steps, **fig(t["kernel"], kernel_bytes, slots),
+           "form": "one persistent kernel (tnl_render_rays): march + fused field + compositing per ray, rays from a queue, "
+                   "no sample buffers; bytes = the texel gathers (samples * 12*C*e) + 52 B per ray",
+           "loop": {**fig(t["loop"], loop_bytes, slots), "iterations": len(sched), "sum_n_alive_over_iterations": alive,
+                    "note": "the device-driven alive-ray loop with the reference's schedule (render(..., device_loop=True)); "
+                            "bytes = SURVEY.md 8(d) inference unit"},
+           "loop_wide_iterations": {**fig(t["loop_wide"], loop_bytes, slots),
+                                    "note": "render(..., infer_min_step=8): the same per-ray sample sequences in an eighth "
+                                            "of the iterations"},
+           "samples_per_image": slots,
+           "note": "run_cuda eval branch, solid-sphere occupancy, the benchmark's field after its training steps (a "
+                   "transparent random field: few rays end by transmittance); mean of 3 images after one warm-up; "
+                   "rocprofv3 summaries: profiles/r03c_infer_kernel_stats.csv"}
+    return res
 
 
 def trajectory_figure(workload, device, steps=512):

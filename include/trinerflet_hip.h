@@ -408,6 +408,24 @@ TNL_API int tnl_ray_batch(const float *poses, const float *intrinsics_host, uint
                           void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The inference render as one persistent kernel (csrc/render.hip; replaces the alive-ray loop of
+ * reconstruction/nerf/renderer.py:338-372 and its march_rays / forward / composite_rays launches): every ray is marched
+ * (the loop kernels' state machine), evaluated (the fused field on 32-sample tiles of 32 different rays) and composited
+ * (raymarching.cu:853-904) inside the kernel; rays are taken from a queue.  rays_o / rays_d [N,3], nears / fars [N]
+ * (fars may be clipped to the occupied box, tnl_clip_fars), noises [N] or NULL (the first iteration's perturbation),
+ * queue: one int32 of device scratch.  Outputs as tnl_composite_rays leaves them: weights_sum [N], depth [N] (sum of
+ * weight * t), image [N,3], every element written.  planes_tm / packed / C / R / Hd as tnl_field_forward.
+ * A ray ends when it leaves [near, far) without a sample, after the sample at which its transmittance falls below
+ * T_thresh, or after max_steps samples.
+ * ------------------------------------------------------------------------------------------- */
+TNL_API int tnl_render_rays(const void *planes_tm, int half_in, uint32_t C, uint32_t R, uint32_t Hd, uint32_t Hc,
+                            const void *packed, const float *rays_o, const float *rays_d, const float *nears,
+                            const float *fars, uint32_t N, const uint8_t *grid, float bound, float dt_gamma,
+                            uint32_t max_steps, uint32_t cascades, uint32_t H, float T_thresh, float density_scale,
+                            const float *noises, int32_t *queue, float *weights_sum, float *depth, float *image,
+                            void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Inference loop with its state on the device (reference loop: reconstruction/nerf/renderer.py:338-372, which reads
  * the survivor count back every iteration).  state = device int32[4] {n_alive, n_step, step, rows}; the caller
  * initialises {N, 0, 0, 0}.  One iteration = plan -> march -> (field forward over `rows` = state[3], passed as its

@@ -261,7 +261,9 @@ def test_test_render_4096_steps_large_geometry_vs_oracle_loop(cuda, rays60k):
     bg = 1.0
     with torch.no_grad():
         out = m.render(t(o)[None], t(d)[None], staged=True, bg_color=bg, perturb=False, dt_gamma=0, max_steps=4096,
-                       T_thresh=1e-4)
+                       T_thresh=1e-4, device_loop=True)
+        one = m.render(t(o)[None], t(d)[None], staged=True, bg_color=bg, perturb=False, dt_gamma=0, max_steps=4096,
+                       T_thresh=1e-4)                     # the default: one persistent kernel (csrc/render.hip)
     aabb = np.array([-BOUND] * 3 + [BOUND] * 3, np.float32)
     nears, fars = cref.near_far_from_aabb(o, d, aabb, 0.2)
 
@@ -282,6 +284,8 @@ def test_test_render_4096_steps_large_geometry_vs_oracle_loop(cuda, rays60k):
     assert ended_by_T > 50, stats                           # transmittance-terminated rays exist
     got = out["image"][0].cpu().numpy()
     np.testing.assert_allclose(got, image, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(one["image"][0].cpu().numpy(), image, rtol=0, atol=2e-5)        # ... and the one-kernel render
+    np.testing.assert_allclose(one["weights_sum"].reshape(-1).cpu().numpy(), ws, rtol=0, atol=2e-5)
     np.testing.assert_allclose(out["weights_sum"].reshape(-1).cpu().numpy(), ws, rtol=0, atol=2e-5)
     hit = np.isfinite(depth)
     np.testing.assert_allclose(out["depth"][0].cpu().numpy()[hit], depth[hit], rtol=0, atol=2e-5)
@@ -335,12 +339,17 @@ def test_test_render_800x800_device_loop_equals_host_loop_large_geometry(cuda):
     o, d = synthetic.get_rays(poses, pix)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
     with torch.no_grad():
-        dev = m.render(t(o)[None], t(d)[None], staged=True, bg_color=1.0, perturb=False, max_steps=4096, T_thresh=1e-4)
+        dev = m.render(t(o)[None], t(d)[None], staged=True, bg_color=1.0, perturb=False, max_steps=4096, T_thresh=1e-4,
+                       device_loop=True)
+        one = m.render(t(o)[None], t(d)[None], staged=True, bg_color=1.0, perturb=False, max_steps=4096, T_thresh=1e-4)
         host = m.render(t(o)[None], t(d)[None], staged=True, bg_color=1.0, perturb=False, max_steps=4096, T_thresh=1e-4,
                         device_loop=False)
     assert torch.equal(dev["image"], host["image"])
     assert torch.equal(dev["weights_sum"], host["weights_sum"])
     assert torch.equal(torch.nan_to_num(dev["depth"]), torch.nan_to_num(host["depth"]))
+    # the one-kernel render (the default): the same image to fp32 rounding, most pixels to the bit
+    assert float((one["image"] - dev["image"]).abs().max()) < 5e-6
+    assert float((one["weights_sum"] == dev["weights_sum"]).float().mean()) > 0.95
     ws = dev["weights_sum"].reshape(-1)
     assert 0.1 < float((ws > 0.5).float().mean()) < 0.4                # the ball covers about a quarter of the image
 

@@ -167,7 +167,7 @@ def test_device_driven_inference_loop_equals_host_driven(cuda):
     assert float(outs[1]["weights_sum"].max()) > 0.5 and not torch.equal(outs[0]["image"], outs[1]["image"])
     # wider iterations (infer_min_step=8): with a cap no ray reaches (4096) the images are identical bit for bit
     with torch.no_grad():
-        ref = m.render(o, d, staged=True, bg_color=0.5, perturb=False, max_steps=4096)
+        ref = m.render(o, d, staged=True, bg_color=0.5, perturb=False, max_steps=4096, device_loop=True)
         wide = m.render(o, d, staged=True, bg_color=0.5, perturb=False, max_steps=4096, infer_min_step=8)
     for k in ("image", "depth", "weights_sum"):
         assert torch.equal(torch.nan_to_num(ref[k], nan=-1.0), torch.nan_to_num(wide[k], nan=-1.0)), k

@@ -1,5 +1,5 @@
 """Time one 800x800 image through NeRFRenderer.run_cuda's inference branch (base planes, solid-sphere occupancy):
-host-driven alive-ray loop vs the device-driven one.  usage (GPU box): PYTHONPATH=. python tools/bench_infer.py"""
+host-driven alive-ray loop, the device-driven one, and the one-kernel render.  usage (GPU box): PYTHONPATH=. python tools/bench_infer.py"""
 import time
 import numpy as np
 import torch
@@ -19,13 +19,13 @@ o, d = synthetic.get_rays(poses, pix)
 o, d = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
 with torch.no_grad():
     for max_steps in (1024, 4096):
-        for dev_loop, min_step in ((False, 1), (True, 1), (True, 8)):
+        for tag, kw in (("host-driven loop", dict(device_loop=False)), ("device-driven loop", dict(device_loop=True)),
+                        ("device-driven loop, 8-sample iterations", dict(infer_min_step=8)),
+                        ("one persistent kernel (default)", dict())):
             for rep in range(3):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                out = m.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, device_loop=dev_loop,
-                               infer_min_step=min_step)
+                out = m.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, **kw)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
-            print(f"max_steps {max_steps} device_loop {dev_loop} min_step {min_step}: {dt * 1e3:.1f} ms / image  "
-                  f"({640000 / dt / 1e6:.1f} M rays/s)")
+            print(f"max_steps {max_steps} {tag}: {dt * 1e3:.1f} ms / image  ({640000 / dt / 1e6:.1f} M rays/s)")

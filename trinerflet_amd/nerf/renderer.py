@@ -182,6 +182,19 @@ class NeRFRenderer(nn.Module):
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             results['weights_sum'] = weights_sum
+        elif kwargs.get("fused_render", "device_loop" not in kwargs and "infer_min_step" not in kwargs) \
+                and getattr(self, "_fused_ok", lambda: False)() and not torch.is_grad_enabled():
+            # one persistent kernel instead of the alive-ray loop (csrc/render.hip): the default of the eval branch unless
+            # the caller asks for the loop (fused_render=False, or one of the loop's own knobs device_loop / infer_min_step).
+            # Same samples per ray, same order, same arithmetic; a ray still alive after max_steps samples stops exactly
+            # there (the loop's cap depends on its schedule: max_steps ... max_steps + 7).
+            weights_sum, depth, image = self._infer_render_kernel(rays_o, rays_d, nears, fars, dt_gamma, perturb,
+                                                                  max_steps, T_thresh)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars_aabb - nears)
+            image = image.view(*prefix, 3)
+            depth = depth.view(*prefix)
+            weights_sum = weights_sum.view(*prefix)
         elif kwargs.get("device_loop", True) and getattr(self, "_fused_ok", lambda: False)() \
                 and not torch.is_grad_enabled():
             weights_sum, depth, image = self._infer_device_loop(rays_o, rays_d, nears, fars, dt_gamma, perturb,
@@ -226,6 +239,29 @@ class NeRFRenderer(nn.Module):
         results['image'] = image
         results['weights_sum'] = weights_sum
         return results
+
+    def _infer_render_kernel(self, rays_o, rays_d, nears, fars, dt_gamma, perturb, max_steps, T_thresh):
+        """renderer.py:324-374 as ONE launch (tnl_render_rays): march, fused field and compositing per ray inside a
+        persistent kernel, no sample buffers.  Same samples, same order and same arithmetic per ray as the loop."""
+        lib = L.lib()
+        N, dev = rays_o.shape[0], rays_o.device
+        weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        if N == 0:
+            return weights_sum, depth, image
+        enc = self.encoder
+        tm = enc.get_planes_texel_major()
+        packed = self.packed_weights()
+        noises = torch.rand(N, dtype=torch.float32, device=dev) if perturb else None
+        queue = torch.empty(1, dtype=torch.int32, device=dev)
+        L.check(lib.tnl_render_rays(
+            L.ptr(tm), L.i32(int(tm.dtype == torch.float16)), L.u32(enc.number_of_features), L.u32(enc.plane_resolution),
+            L.u32(self.hidden_dim), L.u32(self.hidden_dim), L.ptr(packed), L.ptr(rays_o), L.ptr(rays_d), L.ptr(nears),
+            L.ptr(fars), L.u32(N), L.ptr(self.density_bitfield), L.f32(self.bound), L.f32(dt_gamma), L.u32(max_steps),
+            L.u32(self.cascade), L.u32(self.grid_size), L.f32(T_thresh), L.f32(float(self.density_scale)), L.ptr(noises),
+            L.ptr(queue), L.ptr(weights_sum), L.ptr(depth), L.ptr(image), L.stream()), "render_rays")
+        return weights_sum, depth, image
 
     def _infer_device_loop(self, rays_o, rays_d, nears, fars, dt_gamma, perturb, max_steps, T_thresh, poll=4,
                            min_step=1):

@@ -76,7 +76,7 @@ class Trainer:
         self.max_steps, self.dt_gamma, self.T_thresh = max_steps, dt_gamma, T_thresh
         self.max_keep_ckpt, self.eval_interval, self.fast_training = max_keep_ckpt, eval_interval, fast_training
         self.seed, self.mute = seed, mute
-        self.infer_min_step = infer_min_step   # 8: wider inference iterations (NeRFRenderer._infer_device_loop)
+        self.infer_min_step = infer_min_step   # != 1: the alive-ray loop with wider iterations instead of the one-kernel render
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -210,7 +210,8 @@ class Trainer:
         data = pool.image_rays(index, bg_color=self.background_color)
         out = model.render(data["rays_o"].unsqueeze(0), data["rays_d"].unsqueeze(0), staged=True,
                            bg_color=self.background_color, perturb=perturb, dt_gamma=self.dt_gamma,
-                           max_steps=max_steps or self.max_steps, infer_min_step=self.infer_min_step)
+                           max_steps=max_steps or self.max_steps,
+                           **({"infer_min_step": self.infer_min_step} if self.infer_min_step != 1 else {}))
         H, W = pool.H, pool.W
         pred = out["image"].reshape(H, W, 3)
         depth = out["depth"].reshape(H, W)
