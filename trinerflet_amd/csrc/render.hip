@@ -29,10 +29,17 @@
 
 namespace {
 
-constexpr int RT = 256;   // threads per workgroup: four waves = 128 ray slots
+// threads per workgroup: four waves = 128 ray slots.  Hidden 128 (92 KB of fragments: one workgroup per CU, 295 registers)
+// with eight waves (two per SIMD, 256 registers + 54 spilled): 800 x 800 at max_steps 1024 18.1 -> 15.3 ms, at 4096
+// 56.3 -> 57.9 ms -- the BASELINE render is the 4096 one, so four.
+#ifndef TNL_RENDER_RT128
+#define TNL_RENDER_RT128 256
+#endif
+template <int H>
+constexpr int render_threads() { return H > 64 ? TNL_RENDER_RT128 : 256; }
 
 template <int C, int H, bool HALFP, bool WIDE>
-__global__ void __launch_bounds__(RT)
+__global__ void __launch_bounds__(render_threads<H>())
 k_render_rays(const void* __restrict__ planes, int R, const half8* __restrict__ packed,
               const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ nears,
               const float* __restrict__ fars, uint32_t N, const uint8_t* __restrict__ grid, float bound, float dt_gamma,
@@ -40,6 +47,7 @@ k_render_rays(const void* __restrict__ planes, int R, const half8* __restrict__ 
               const float* __restrict__ noises, int* __restrict__ queue, float* __restrict__ weights_sum,
               float* __restrict__ depth, float* __restrict__ image) {
   using G = FieldGeom<C, H>;
+  constexpr int RT = render_threads<H>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half8* w = reinterpret_cast<half8*>(smem);
   for (int i = threadIdx.x; i < G::NF * 64; i += RT) w[i] = packed[i];
@@ -169,7 +177,8 @@ int launch_render(const void* planes, int half_in, uint32_t R, const void* packe
   using G = FieldGeom<C, H>;
   const size_t lds = (size_t)G::NF * 1024;
   // persistent workgroups: a few per CU; the queue balances the load
-  uint32_t blocks = (N + 127) / 128;
+  constexpr int RT = render_threads<H>();
+  uint32_t blocks = (N + RT / 2 - 1) / (RT / 2);
   if (blocks > 1024) blocks = 1024;
   const half8* pk = reinterpret_cast<const half8*>(packed);
   const bool wide = (reinterpret_cast<uintptr_t>(grid) & 7u) == 0 && ((size_t)Cas * Hg * Hg * Hg) % 64 == 0;
