@@ -68,6 +68,8 @@ def build(workload, device, dist_mode, plane_dtype=None, **ts_kwargs):
     ts = TrainStep(model, lr=1e-2, wavelet_regularization=lam, iters=40000, warmup_steps=0, fp16=True,
                    background_color=0.0, dist_mode=dist_mode, **ts_kwargs)
     ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", ts.prefetch_at)   # "auto" | "bwd" | "adam" (experiments)
+    if os.environ.get("TNL_LIVE_BANDS"):      # A/B: 0 = whole live rectangles
+        ts.live_bands = os.environ["TNL_LIVE_BANDS"] != "0"
     if os.environ.get("TNL_LIVE_ALIGN"):      # experiments: column granule of the live rectangles
         ts.live_col_align = int(os.environ["TNL_LIVE_ALIGN"])
     if os.environ.get("TNL_SPLIT_P2"):        # experiments: where phase 2 of the split side work starts
@@ -472,11 +474,31 @@ def main():
     # with the live / deferred split (TrainStep.defer_adam) a level's per-step launch covers only its live rectangle;
     # the coefficients outside it are replayed by k_adam_l1_catchup once per flush (24 B each, reported separately)
     live = ts.last_live if (ts.defer_adam and rects is not None and ts.last_live is not None) else [None] * ts.J
+    tables = ts.last_live_bands if (ts.last_live_bands is not None and live[0] is ts.last_live[0]) else [None] * ts.J
     adam_bytes, n_launch, deferred_coefs = 0.0, 0, 0.0
+    band_share = [None] * ts.J
+
+    def band_counts(lv, tbl, r):
+        """Coefficients per (slice, band) of a level's band pieces, and how many of them lie inside the stored-gradient
+        rectangle r (mean over the planes)."""
+        nb = lv[7] // 8
+        w = 4 * tbl[nb + 1:2 * nb + 1].astype(np.int64)
+        dom, ins = float(8 * w.sum()), 0.0
+        for pl in range(3):
+            x0 = tbl[2 * nb + 1 + pl * nb:2 * nb + 1 + (pl + 1) * nb].astype(np.int64)
+            cols = np.clip(np.minimum(x0 + w, r[pl] + r[6]) - np.maximum(x0, r[pl]), 0, None)
+            y0 = lv[3 + pl] + 8 * np.arange(nb)
+            rows = np.clip(np.minimum(y0 + 8, r[3 + pl] + r[7]) - np.maximum(y0, r[3 + pl]), 0, None)
+            ins += float((cols * rows).sum()) / 3
+        return dom, ins
     for lvl in range(ts.J):
         n_l = ts.coef.params[lvl].shape[-1]
         inside = rects[lvl][6] * rects[lvl][7] if rects is not None else n_l * n_l
         domain = live[lvl][6] * live[lvl][7] if live[lvl] is not None else n_l * n_l
+        if live[lvl] is not None and tables[lvl] is not None:
+            rect_area = domain
+            domain, inside = band_counts(live[lvl], tables[lvl][2], rects[lvl])
+            band_share[lvl] = round(domain / rect_area, 4)
         adam_bytes += S_own * 3 * (24.0 * domain + 4.0 * inside)
         deferred_coefs += S_own * 3 * float(n_l * n_l - domain)
         n_launch += 1
@@ -493,14 +515,16 @@ def main():
             "live_rectangles": [None if lv is None else {"level_size": ts.coef.params[k].shape[-1], "origin_x": lv[0:3],
                                                          "origin_y": lv[3:6], "width": lv[6], "height": lv[7]}
                                 for k, lv in enumerate(live)],
+            "band_pieces_share_of_rectangle": band_share,
             "deferred_share_of_coefficients": round(deferred_coefs / all_coefs, 4),
             "steps_deferred_in_timed_region": timed_deferred, "flushes_in_timed_region": timed_flushes,
             "catchup": None if cu_ms != cu_ms else {
                 "ms": round(cu_ms, 4), "records": ts.last_flush_records, "bytes": 24.0 * deferred_coefs,
                 "GB/s": round(24.0 * deferred_coefs / (cu_ms * 1e-3) / 1e9, 1)},
             "note": "coefficients outside a level's live rectangle (what the windowed plane rebuild reads + where the "
-                    "windowed adjoint writes) are neither read nor reached by a data gradient until the occupancy window "
-                    "changes; their Adam(+L1) steps are replayed in registers by k_adam_l1_catchup, all pending steps "
+                    "windowed adjoint writes; where band_pieces_share_of_rectangle is given, only that share of it: per 8 "
+                    "rows the columns the occupied cells' projection reaches, level by level) are neither read for a "
+                    "sampled texel nor reached by a data gradient until the occupancy window changes; their Adam(+L1) steps are replayed in registers by k_adam_l1_catchup, all pending steps "
                     "in one 24-B/coefficient pass (bit-identical p, m, v).  Every replay the timed steps caused runs "
                     "inside the timed region (the ring holds 16 steps; a flush also precedes the clock's stop)."}
 

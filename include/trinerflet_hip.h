@@ -61,6 +61,13 @@ TNL_API int tnl_packbits_dev(const float *grid, uint32_t N, float density_thresh
  * refresh (renderer.py:448-542 changes the bitfield there); no reference counterpart. */
 TNL_API int tnl_occupancy_bounds(const uint8_t *bitfield, uint32_t bytes_per_cascade, uint32_t cascades,
                                  int32_t *bounds, void *stream);
+/* Per plane p and 8-texel row group g of the R x R feature planes: the column extent ext[(p * R/8 + g) * 2 + {0,1}] =
+ * [lo, end) of the bilinear footprints of all positions inside occupied cells (int32, preset by the caller to
+ * {INT_MAX, -1}; untouched = no sample can read that row group).  TrainStep derives from it, level by level, which
+ * coefficients of a level's live rectangle can receive a gradient or reach a sampled texel at all (the "bands" of
+ * tnl_adam_l1_step_live_bands); no reference counterpart. */
+TNL_API int tnl_occupancy_row_extents(const uint8_t *bitfield, uint32_t bytes_per_cascade, uint32_t cascades, uint32_t H,
+                                      float bound, uint32_t R, int32_t *ext, void *stream);
 
 /* No sample can lie outside the box of the occupied cells, and `far` only enters the march's loop conditions: marching
  * with min(far, the ray's exit from that box) gives the same samples to the bit, without the probe chain through the
@@ -485,6 +492,25 @@ TNL_API int tnl_idwt_level_backward_win(const float *dout, uint32_t S, uint32_t 
  * before launching work.  The kernel choice depends on n only, so windowed and whole-plane calls of one level always
  * take the same kernel (their results are bit-identical). */
 TNL_API int tnl_idwt_set_walk_min_n(uint32_t walk_min_n);
+/* The windowed level calls restricted to the pieces anything reads.  `spans`: device int32 [3][n / 8][2] on the level's
+ * own n x n (coarse) grid -- for plane pl and coarse rows 8g .. 8g+7 the coarse columns [lo, end) -- or, for the
+ * layout change, [3][R / 8][2] on the R x R plane grid (what tnl_occupancy_row_extents writes); NULL = no restriction.
+ *   forward   results outside the pieces are not produced (the output keeps what it held); half_out / win / strided
+ *             as tnl_idwt_level_forward_half_roi (1, roi, 0) and tnl_idwt_level_forward_win (0, win, 1)
+ *   backward  arguments of tnl_idwt_level_backward_win; the band gradients outside the pieces are not produced, the
+ *             LL gradient dx is written as zero there (which it is, exactly, when the pieces hold every coefficient
+ *             a data gradient can reach)
+ * Levels that run the tile kernels (n < walk_min_n) ignore the spans.  TrainStep builds the tables level by level from
+ * the occupied cells' projection; no reference counterpart. */
+TNL_API int tnl_idwt_level_forward_spans(const float *x, const float *yh, uint32_t S, uint32_t n, int wave, void *out,
+                                         int half_out, const int32_t *win, int strided, const int32_t *spans,
+                                         void *stream);
+TNL_API int tnl_idwt_level_backward_spans(const float *dout, uint32_t S, uint32_t n, int wave, float *dx, float *dyh,
+                                          const int32_t *win, int strided, int32_t *out_rect, const int32_t *spans,
+                                          void *stream);
+TNL_API int tnl_planes_half_to_texel_major_spans(const void *planes_roi_half, uint32_t C, uint32_t R,
+                                                 void *planes_tm_half, const int32_t *roi, const int32_t *spans,
+                                                 void *stream);
 /* Launch-shape knobs of the walk kernels, for A/B measurements (tools/bench_idwt.py); results do not depend on them.
  * key 1: coarse rows per phase of the forward kernel (4 or 8); key 2: XCD-aware block order (0 / 1);
  * key 3: coarse rows per workgroup (multiple of 8; 0 = automatic). */
@@ -522,6 +548,24 @@ TNL_API int tnl_adam_record_step(float *ring, int32_t slot, float lr, const floa
 TNL_API int tnl_adam_l1_catchup(float *p, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n, uint32_t spp,
                                 uint32_t s0, const int32_t *live, const float *ring, int32_t count, float beta1,
                                 float beta2, float eps, float l1_coef, float *abs_sums, void *stream);
+/* The same two passes over a live SET finer than the rectangle: the rectangle's rows in groups of 8 ("bands",
+ * nb = live h / 8 <= 128), each with its own column piece.  A band table is device int32[5 nb + 1]:
+ *   [0 .. nb]              prefix sums of the bands' float4 counts 8 * w_b / 4   ([nb] = float4s per slice = band_quads)
+ *   [nb + 1 + b]           w_b / 4 (0 = nothing live in the band)
+ *   [2 nb + 1 + pl nb + b] first column of band b on plane pl (multiple of 4, piece inside the rectangle)
+ * band_tables[k] / band_table NULL = the whole rectangle (the functions above).  TrainStep builds the tables from
+ * tnl_occupancy_row_extents, halving and growing by the filter reach level by level. */
+TNL_API int tnl_adam_l1_step_live_bands(float *p, float *grad, float *m, float *v, uint32_t S, uint32_t spp, uint32_t s0,
+                                        uint32_t n_levels, const uint64_t *offsets, const uint32_t *sizes,
+                                        const uint32_t *bands, const int32_t *live, const int32_t *grad_rect,
+                                        const int32_t *const *band_tables, const uint32_t *band_quads,
+                                        const float *l1_coefs, float lr, const float *opt_step_dev, const float *step_rec,
+                                        float beta1, float beta2, float eps, float inv_scale, const float *inv_scale_dev,
+                                        const float *found_inf, float *abs_sum, void *stream);
+TNL_API int tnl_adam_l1_catchup_bands(float *p, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n, uint32_t spp,
+                                      uint32_t s0, const int32_t *live, const int32_t *band_table, const float *ring,
+                                      int32_t count, float beta1, float beta2, float eps, float l1_coef, float *abs_sums,
+                                      void *stream);
 /* Dynamic LDS (bytes, <= 64 KB) reserved by every workgroup of the FOLLOWING tnl_adam_l1_* launches of this process:
  * limits the pass to 160 KB / bytes workgroups per CU so that kernels of another stream (the next batch's march and
  * tile sort) find wave slots underneath it.  0 (default) = no limit.  Host-side state, not thread-safe. */

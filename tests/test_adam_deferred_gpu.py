@@ -164,7 +164,8 @@ def test_windowed_step_reads_nothing_outside_the_live_rectangles(cuda, geom):
     from trinerflet_amd.train import TrainStep
     o, d, gt, noise, base, bf = _setup(cuda, **geom)
     m = copy.deepcopy(base)
-    ts = TrainStep(m, update_extra_interval=16, use_roi=True, defer_adam=True)
+    # live_bands=False: the statement about the rectangles (the whole window is rebuilt); the band pieces have their own
+    ts = TrainStep(m, update_extra_interval=16, use_roi=True, defer_adam=True, live_bands=False)
     ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf)
     m.mean_count = 0
     ts.step(o, d, gt, noises=noise)
@@ -196,3 +197,198 @@ def test_windowed_step_reads_nothing_outside_the_live_rectangles(cuda, geom):
         for p in range(3):
             assert lv[p] <= r[p] and r[p] + r[6] <= lv[p] + lv[6] and lv[3 + p] <= r[3 + p] and \
                 r[3 + p] + r[7] <= lv[3 + p] + lv[7]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# band tables: the live set cut down, per 8 rows of the rectangle, to the columns the occupied cells' projection reaches
+def _live_mask(lv, bt, n, dev):
+    """[3, n, n] bool: the live set of a level -- the rectangle, or its band pieces where a table exists."""
+    mask = torch.zeros(3, n, n, dtype=torch.bool, device=dev)
+    for p in range(3):
+        if bt is None:
+            mask[p, lv[3 + p]:lv[3 + p] + lv[7], lv[p]:lv[p] + lv[6]] = True
+            continue
+        tbl, nb = bt[2], lv[7] // 8
+        for b in range(nb):
+            w, x0 = 4 * int(tbl[nb + 1 + b]), int(tbl[2 * nb + 1 + p * nb + b])
+            assert lv[p] <= x0 and x0 + w <= lv[p] + lv[6] and x0 % 4 == 0
+            mask[p, lv[3 + p] + 8 * b:lv[3 + p] + 8 * b + 8, x0:x0 + w] = True
+    return mask
+
+
+def test_banded_live_plus_catchup_equals_per_step_pass_bit_for_bit(cuda):
+    """The kernel-level statement of the first test for a live set given as a band table (a band of zero width, pieces
+    that differ from plane to plane, a workgroup count that makes the chunks start inside bands)."""
+    import trinerflet_amd._lib as L
+    lib = L.lib()
+    S, bands, n, spp, K, l1 = 6, 3, 64, 2, 5, 3e-9
+    g = torch.Generator(device="cpu").manual_seed(9)
+    numel = S * bands * n * n
+    p0 = torch.randn(numel, generator=g).to(cuda) * 0.1
+    m0 = torch.randn(numel, generator=g).to(cuda) * 1e-3
+    v0 = torch.rand(numel, generator=g).to(cuda) * 1e-6
+    live = [16, 0, 32, 8, 16, 0, 32, 40]
+    grect = [16, 0, 32, 8, 16, 0, 32, 40]
+    w = np.array([8, 20, 32, 0, 12])
+    x0 = np.array([[16, 20, 16, 16, 36], [0, 12, 0, 4, 0], [56, 32, 32, 32, 40]])
+    tbl = np.concatenate([[0], np.cumsum(2 * w), w // 4, x0.reshape(-1)]).astype(np.int32)
+    quads = int(2 * w.sum())
+    bt = (torch.from_numpy(tbl).to(cuda), quads, tbl)
+    mask = _live_mask(live, bt, n, cuda)                              # [3, n, n]
+    full = mask.repeat_interleave(spp, 0)[:, None].expand(S, bands, n, n).reshape(-1)
+    assert 0 < int(full.sum()) == S * bands * quads * 4
+    grads = [torch.randn(numel, generator=g).to(cuda) * 64.0 * full for _ in range(K)]   # no gradient outside the pieces
+    inv_scale = torch.full((1,), 1.0 / 64.0, device=cuda)
+    b1, b2, eps, lr = 0.9, 0.99, 1e-15, 1e-2
+
+    def run(deferred):
+        p, m, v = p0.clone(), m0.clone(), v0.clone()
+        opt = torch.zeros(1, device=cuda)
+        ring = torch.zeros(64, device=cuda)
+        sums = torch.zeros(16, device=cuda)
+        per_step = []
+        for k in range(K):
+            fi = torch.zeros(1, device=cuda)
+            ab = torch.zeros(1, device=cuda)
+            if deferred:
+                L.check(lib.tnl_adam_record_step(L.ptr(ring), L.i32(k), L.f32(lr), L.ptr(opt), L.f32(b1), L.f32(b2),
+                                                 L.ptr(fi), L.stream()), "record")
+                L.check(lib.tnl_adam_l1_step_live_bands(
+                    L.ptr(p), L.ptr(grads[k]), L.ptr(m), L.ptr(v), L.u32(S), L.u32(spp), L.u32(0), L.u32(1),
+                    (C_.c_uint64 * 1)(0), (C_.c_uint32 * 1)(n), (C_.c_uint32 * 1)(bands), _rect(*live), _rect(*grect),
+                    (C_.c_void_p * 1)(bt[0].data_ptr()), (C_.c_uint32 * 1)(quads),
+                    (C_.c_float * 1)(l1), L.f32(lr), L.ptr(opt), L.ptr(ring[4 * k:]), L.f32(b1),
+                    L.f32(b2), L.f32(eps), L.f32(1.0), L.ptr(inv_scale), L.ptr(fi), L.ptr(ab), L.stream()), "live")
+                if k == 0:                                           # the live pass touched the pieces and nothing else
+                    torch.cuda.synchronize()
+                    assert torch.equal(p[~full], p0[~full]) and not torch.equal(p[full], p0[full])
+                    assert int((p != p0).sum()) > 0.99 * int(full.sum())
+            else:
+                L.check(lib.tnl_adam_l1_step_rect(L.ptr(p), L.ptr(grads[k]), L.ptr(m), L.ptr(v), L.u32(S), L.u32(bands),
+                                                  L.u32(n), L.u32(spp), L.u32(0), _rect(*grect), L.f32(lr), L.ptr(opt),
+                                                  L.f32(b1), L.f32(b2), L.f32(eps), L.f32(1.0), L.ptr(inv_scale),
+                                                  L.f32(l1), L.ptr(fi), L.ptr(ab), L.stream()), "rect")
+            opt += 1.0
+            per_step.append(ab)
+        if deferred:
+            L.check(lib.tnl_adam_l1_catchup_bands(L.ptr(p), L.ptr(m), L.ptr(v), L.u32(S), L.u32(bands), L.u32(n),
+                                                  L.u32(spp), L.u32(0), _rect(*live), L.ptr(bt[0]), L.ptr(ring), L.i32(K),
+                                                  L.f32(b1), L.f32(b2), L.f32(eps), L.f32(l1), L.ptr(sums), L.stream()),
+                    "catchup")
+            per_step = [a + sums[k] for k, a in enumerate(per_step)]
+        torch.cuda.synchronize()
+        return p, m, v, torch.cat(per_step)
+
+    ref, dfr = run(False), run(True)
+    for a, b, name in zip(ref[:3], dfr[:3], "pmv"):
+        ne = a != b
+        assert torch.equal(a, b), (name, int(ne.sum()), "inside the pieces:", int((ne & full).sum()))
+    np.testing.assert_allclose(dfr[3].cpu().numpy(), ref[3].cpu().numpy(), rtol=2e-5)
+    # rejected tables
+    bad = lib.tnl_adam_l1_step_live_bands(
+        L.ptr(p0), L.ptr(grads[0]), L.ptr(m0), L.ptr(v0), L.u32(S), L.u32(spp), L.u32(0), L.u32(1),
+        (C_.c_uint64 * 1)(0), (C_.c_uint32 * 1)(n), (C_.c_uint32 * 1)(bands), _rect(*live), _rect(*grect),
+        (C_.c_void_p * 1)(bt[0].data_ptr()), (C_.c_uint32 * 1)(0), (C_.c_float * 1)(l1), L.f32(lr), L.ptr(None),
+        L.ptr(torch.zeros(4, device=cuda)), L.f32(b1), L.f32(b2), L.f32(eps), L.f32(1.0), L.ptr(inv_scale), L.ptr(None),
+        L.ptr(None), L.stream())
+    assert bad != 0
+
+
+def _reachable_texels(R, H, bound, radius):
+    """[3, R, R] bool, computed on the host from the analytic occupancy alone: texels a bilinear lookup of a position
+    inside an occupied cell can read (plane p: x <- axis (0, 0, 1)[p], y <- axis (2, 1, 2)[p])."""
+    c = ((np.arange(H) + 0.5) / H * 2 - 1) * bound
+    occ = np.sqrt(c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2) <= radius
+    edge = (np.arange(H + 1) / H * 2 - 1) * bound
+    f = (np.clip(edge / bound, -1, 1) + 1) / 2 * (R - 1)
+    t0, t1 = np.floor(f[:-1]).astype(int), np.minimum(np.floor(f[1:]).astype(int) + 1, R - 1)
+    out = np.zeros((3, R, R), bool)
+    for p, (xa, ya) in enumerate(((0, 2), (0, 1), (1, 2))):
+        third = ({0, 1, 2} - {xa, ya}).pop()
+        proj = occ.any(axis=third)                                   # remaining axes in increasing order
+        if xa > ya:
+            proj = proj.T
+        for i, j in zip(*np.nonzero(proj)):                          # i along xa, j along ya
+            out[p, t0[j]:t1[j] + 1, t0[i]:t1[i] + 1] = True
+    return out
+
+
+@pytest.mark.parametrize("geom", [dict(C=16, R=512, scale=8), dict(C=16, R=1024, scale=16)])
+def test_band_pieces_hold_everything_the_samples_can_reach(cuda, geom):
+    """NaN in every coefficient outside the band pieces: every plane texel a sample can read keeps its bits, and the
+    coefficient gradient of a step is exactly zero outside the pieces (so replaying those coefficients with g = 0 IS
+    the per-step update)."""
+    from trinerflet_amd.train import TrainStep
+    radius, bound = 0.3, 1.0
+    o, d, gt, noise, base, bf = _setup(cuda, radius=radius, bound=bound, **geom)
+    m = copy.deepcopy(base)
+    ts = TrainStep(m, update_extra_interval=16, use_roi=True, defer_adam=True)
+    ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf)
+    m.mean_count = 0
+    ts.step(o, d, gt, noises=noise)
+    ts.step(o, d, gt, noises=noise)
+    lives = [None if lv is None else list(lv) for lv in ts._live]
+    tables = list(ts._live_bands)
+    assert sum(t is not None for t in tables) >= 1, "no level got a band table: the test would be vacuous"
+    R = geom["R"]
+    reach = torch.from_numpy(_reachable_texels(R, 128, bound, radius)).to(cuda)
+    # the gradient of the last step, inside its rectangles, against the pieces
+    for lvl, (lv, bt) in enumerate(zip(lives, tables)):
+        if bt is None:
+            continue
+        n = ts.coef.params[lvl].shape[-1]
+        live = _live_mask(lv, bt, n, cuda)
+        assert float(live.float().mean()) < 0.92 * lv[6] * lv[7] / (n * n)
+        r = ts._rects[lvl]
+        stored = _live_mask(r, None, n, cuda)
+        g = ts.coef.grad_view(lvl).view(3, -1, 3, n, n)
+        sel = (stored & ~live)[:, None, None].expand_as(g)
+        assert int(sel.sum()) > 0 and float(g[sel].abs().max()) == 0.0, lvl
+        assert float(g[(stored & live)[:, None, None].expand_as(g)].abs().max()) > 0
+    ts.flush_deferred()
+    ts.rebuild_planes(roi=True)
+    want = ts._tm_full.clone()
+    with torch.no_grad():
+        for lvl, (lv, bt) in enumerate(zip(lives, tables)):
+            if lv is None:
+                continue
+            cf = ts.coef.params[lvl]
+            n = cf.shape[-1]
+            dead = ~_live_mask(lv, bt, n, cuda)
+            cf[dead[:, None, None].expand_as(cf)] = float("nan")
+    ts.rebuild_planes(roi=True)
+    got = ts._tm_full
+    assert not torch.isfinite(got.float()).all()                     # the poison did reach unread texels
+    assert torch.isfinite(got[reach].float()).all()
+    assert torch.equal(got[reach], want[reach])
+
+
+def test_training_with_band_pieces_equals_per_step_pass(cuda):
+    """The statement of test_training_with_deferred_pass_equals_per_step_pass for the band pieces: every coefficient
+    outside them (inside or outside the rectangle) ends bit-identical to the run that steps every coefficient."""
+    from trinerflet_amd.train import TrainStep
+    o, d, gt, noise, base, bf = _setup(cuda)
+    res = []
+    for kw in (dict(defer_adam=False), dict(defer_adam=True, live_bands=True), dict(defer_adam=True, live_bands=False)):
+        m = copy.deepcopy(base)
+        ts = TrainStep(m, update_extra_interval=4, use_roi=True, **kw)
+        ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf)
+        m.mean_count = 0
+        lives = tables = None
+        for it in range(7):
+            ts.step(o, d, gt, noises=noise)
+            if ts.defer_adam:
+                lives, tables = [None if lv is None else list(lv) for lv in ts._live], list(ts._live_bands)
+        ts.flush_deferred()
+        res.append(([p.detach().clone() for p in ts.coef.params], ts.coef.m.clone(), ts.coef.v.clone(), lives, tables))
+    assert all(t is None for t in res[2][4]) and sum(t is not None for t in res[1][4]) >= 1
+    assert res[1][3] == res[2][3]
+    for lvl, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+        lv, bt = res[1][3][lvl], res[1][4][lvl]
+        if lv is None:
+            continue
+        n = a.shape[-1]
+        dead = (~_live_mask(lv, bt, n, cuda))[:, None, None].expand_as(a)
+        assert torch.equal(a[dead], b[dead]), lvl
+        if bt is not None:
+            assert int(dead.sum()) > int((~_live_mask(lv, None, n, cuda)).sum()) * a.shape[1] * a.shape[2]

@@ -239,7 +239,7 @@ def test_windowed_rebuild_equals_full_rebuild_inside_the_window(cuda):
         for p in m.encoder.planes_features_wavelet_coefs:
             p.normal_(0, 0.05)
     m.density_bitfield.copy_(torch.from_numpy(synthetic.sphere_bitfield(128, 1, 1.0, 0.12, 0.0)).to(cuda))
-    ts = TrainStep(m, update_extra_interval=0)
+    ts = TrainStep(m, update_extra_interval=0, live_bands=False)   # the whole window (pieces: tests/test_spans_gpu.py)
     full = ts.rebuild_planes().clone()                      # whole planes, sets the persistent array
     ts._roi, ts._roi_valid = ts._compute_roi(), True
     roi = ts._roi

@@ -222,11 +222,18 @@ __device__ __forceinline__ int rect_plane(const AdamRect& rc, uint32_t sb) {
 // scalars come from the record k_adam_record wrote (same double-precision expressions, evaluated once per step
 // instead of by every workgroup).
 constexpr int ADAM_MAX_SEGS = 8;
+// Band table of a live rectangle (device, int32): the rectangle's rows in groups of 8 ("bands", nb = rh / 8), each with its
+// own column piece -- bt[0 .. nb] prefix sums of the bands' float4 counts (8 * w_b / 4; bt[nb] = float4s per slice),
+// bt[nb + 1 + b] = w_b / 4, bt[2 nb + 1 + pl * nb + b] = first column of band b on plane pl.  The live set is then the
+// union of the pieces (what the occupied cells' projection can reach, level by level) instead of the whole rectangle.
+constexpr int ADAM_MAX_BANDS = 128;
 struct LiveSeg {
   AdamRect live, gr;
   uint64_t off;            // element offset of the level in the flat arrays
   uint32_t rows, blocks0;  // S * bands * live.rh ; first workgroup of the segment
   float l1_coef;
+  const int* bt;           // band table or nullptr (the whole rectangle)
+  uint32_t nb, quads;      // bands ; bt[nb] as the host knows it
 };
 struct LiveSegs {
   LiveSeg s[ADAM_MAX_SEGS];
@@ -264,8 +271,9 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
   a.l1_coef = sg.l1_coef;
   const uint32_t nblk = (si + 1 < segs.n ? segs.s[si + 1].blocks0 : gridDim.x) - sg.blocks0;
   float acc = 0.f;
+  __shared__ int s_bt[5 * ADAM_MAX_BANDS + 1];
   const uint32_t w4 = (uint32_t)live.rw / 4;
-  const uint32_t total = sg.rows * w4;
+  const uint32_t total = sg.bt == nullptr ? sg.rows * w4 : sg.rows / (uint32_t)live.rh * sg.quads;
   const uint32_t chunk = (total + nblk - 1) / nblk;
   const uint32_t c0 = (blockIdx.x - sg.blocks0) * chunk, c1 = min(c0 + chunk, total);
   float* pb = p + sg.off;
@@ -273,11 +281,7 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
   float* mb = m + sg.off;
   float* vb = v + sg.off;
   struct Quad { float4 pp, gg, mm, vv; uint64_t e; };
-  auto load = [&](uint32_t i, Quad& q) {
-    const uint32_t row = i / w4, c4 = i - row * w4;
-    const uint32_t sb = row / (uint32_t)live.rh, r = row - sb * (uint32_t)live.rh;
-    const int pl = rect_plane(live, sb);
-    const int x = live.rx[pl] + 4 * (int)c4, y = live.ry[pl] + (int)r;
+  auto fetch = [&](uint32_t sb, int pl, int x, int y, Quad& q) {
     q.e = ((uint64_t)sb << (2 * live.log2n)) + ((uint64_t)y << live.log2n) + (uint64_t)x;
     q.pp = ld_nt(reinterpret_cast<const float4*>(pb + q.e));
     q.gg = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -301,13 +305,58 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
       acc += fabsf(q.pp.x) + fabsf(q.pp.y) + fabsf(q.pp.z) + fabsf(q.pp.w);
     }
   };
-  uint32_t i = c0 + threadIdx.x;
-  for (; i + 256 < c1; i += 512) {
-    Quad q0, q1;
-    load(i, q0); load(i + 256, q1);
-    finish(q0); finish(q1);
+  auto load = [&](uint32_t i, Quad& q) {
+    const uint32_t row = i / w4, c4 = i - row * w4;
+    const uint32_t sb = row / (uint32_t)live.rh, r = row - sb * (uint32_t)live.rh;
+    const int pl = rect_plane(live, sb);
+    fetch(sb, pl, live.rx[pl] + 4 * (int)c4, live.ry[pl] + (int)r, q);
+  };
+  if (sg.bt == nullptr) {
+    uint32_t i = c0 + threadIdx.x;
+    for (; i + 256 < c1; i += 512) {
+      Quad q0, q1;
+      load(i, q0); load(i + 256, q1);
+      finish(q0); finish(q1);
+    }
+    for (; i < c1; i += 256) { Quad q; load(i, q); finish(q); }
+  } else {
+    // banded: a thread's float4s advance by 256 along (slice, band, row, column), so it keeps a cursor (slice, offset
+    // in the slice, band) and only the first position is searched for
+    const int nb = (int)sg.nb;
+    const uint32_t Q = sg.quads;
+    for (int k = threadIdx.x; k < 5 * nb + 1; k += 256) s_bt[k] = sg.bt[k];
+    __syncthreads();
+    const int* s_w4 = s_bt + nb + 1;
+    const int* s_x0 = s_bt + 2 * nb + 1;
+    struct Cur { uint32_t sb, rem; int b; };
+    auto advance = [&](Cur& c, uint32_t d) {
+      c.rem += d;
+      while (c.rem >= Q) { c.rem -= Q; c.sb++; c.b = 0; }
+      while (c.rem >= (uint32_t)s_bt[c.b + 1]) c.b++;
+    };
+    auto load_at = [&](const Cur& c, Quad& q) {
+      const uint32_t off = c.rem - (uint32_t)s_bt[c.b], bw4 = (uint32_t)s_w4[c.b];
+      const uint32_t r = off / bw4, c4 = off - r * bw4;
+      const int pl = rect_plane(live, c.sb);
+      fetch(c.sb, pl, s_x0[pl * nb + c.b] + 4 * (int)c4, live.ry[pl] + 8 * c.b + (int)r, q);
+    };
+    uint32_t i = c0 + threadIdx.x;
+    Cur c;
+    c.sb = i / Q; c.rem = i - c.sb * Q;
+    int lo = 0, hi = nb;                                     // s_bt[lo] <= rem < s_bt[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((uint32_t)s_bt[mid] <= c.rem) lo = mid; else hi = mid; }
+    c.b = lo;
+    for (; i + 256 < c1; i += 512) {
+      Quad q0, q1;
+      Cur d = c;
+      advance(d, 256);
+      load_at(c, q0); load_at(d, q1);
+      finish(q0); finish(q1);
+      c = d;
+      advance(c, 256);
+    }
+    for (; i < c1; i += 256) { Quad q; load_at(c, q); finish(q); advance(c, 256); }
   }
-  for (; i < c1; i += 256) { Quad q; load(i, q); finish(q); }
   if (abs_sum != nullptr) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
@@ -324,8 +373,14 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
 // is a real loop (one scalar load per record and 8 coefficients), the per-record |p| sums live in per-thread LDS slots.
 __global__ void __launch_bounds__(256)
 k_adam_l1_catchup(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, uint64_t n, AdamArgs a,
-                  const AdamStepRec* __restrict__ ring, int count, float* __restrict__ abs_sums, AdamRect live) {
+                  const AdamStepRec* __restrict__ ring, int count, float* __restrict__ abs_sums, AdamRect live,
+                  const int* __restrict__ bt, int nb) {
   __shared__ float s_acc[ADAM_REPLAY_MAX][256];
+  __shared__ int s_bt[5 * ADAM_MAX_BANDS + 1];
+  if (bt != nullptr) {
+    for (int k = threadIdx.x; k < 5 * nb + 1; k += 256) s_bt[k] = bt[k];
+    __syncthreads();
+  }
   const bool sums = abs_sums != nullptr;
   if (sums)
     for (int r = 0; r < ADAM_REPLAY_MAX; r++) s_acc[r][threadIdx.x] = 0.f;
@@ -340,7 +395,10 @@ k_adam_l1_catchup(float* __restrict__ p, float* __restrict__ m, float* __restric
     const uint64_t e = i * 4;
     const int c = (int)(e & nm), r0 = (int)((e >> live.log2n) & nm);
     const int pl = rect_plane(live, (uint32_t)(e >> (2 * live.log2n)));
-    return !(c >= live.rx[pl] && c < live.rx[pl] + live.rw && r0 >= live.ry[pl] && r0 < live.ry[pl] + live.rh);
+    if (!(c >= live.rx[pl] && c < live.rx[pl] + live.rw && r0 >= live.ry[pl] && r0 < live.ry[pl] + live.rh)) return true;
+    if (bt == nullptr) return false;
+    const int b = (r0 - live.ry[pl]) >> 3, x0 = s_bt[2 * nb + 1 + pl * nb + b];
+    return !(c >= x0 && c < x0 + 4 * s_bt[nb + 1 + b]);
   };
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   for (uint64_t i = c0 + threadIdx.x; i < c1; i += 512) {
@@ -488,12 +546,13 @@ extern "C" int tnl_adam_record_step(float* ring, int32_t slot, float lr, const f
   return (int)hipGetLastError();
 }
 
-extern "C" int tnl_adam_l1_step_live(float* p, float* grad, float* m, float* v, uint32_t S, uint32_t spp, uint32_t s0,
-                                     uint32_t n_levels, const uint64_t* offsets, const uint32_t* sizes,
-                                     const uint32_t* bands, const int32_t* live_host, const int32_t* grad_rect_host,
-                                     const float* l1_coefs, float lr, const float* opt_step_dev, const float* step_rec,
-                                     float beta1, float beta2, float eps, float inv_scale, const float* inv_scale_dev,
-                                     const float* found_inf, float* abs_sum, void* stream) {
+extern "C" int tnl_adam_l1_step_live_bands(float* p, float* grad, float* m, float* v, uint32_t S, uint32_t spp, uint32_t s0,
+                                           uint32_t n_levels, const uint64_t* offsets, const uint32_t* sizes,
+                                           const uint32_t* bands, const int32_t* live_host, const int32_t* grad_rect_host,
+                                           const int32_t* const* band_tables, const uint32_t* band_quads,
+                                           const float* l1_coefs, float lr, const float* opt_step_dev, const float* step_rec,
+                                           float beta1, float beta2, float eps, float inv_scale, const float* inv_scale_dev,
+                                           const float* found_inf, float* abs_sum, void* stream) {
   if ((opt_step_dev == nullptr && step_rec == nullptr) || live_host == nullptr || grad_rect_host == nullptr ||
       offsets == nullptr || sizes == nullptr || bands == nullptr || l1_coefs == nullptr || n_levels == 0 ||
       n_levels > ADAM_MAX_SEGS || spp == 0 || S == 0)
@@ -512,7 +571,16 @@ extern "C" int tnl_adam_l1_step_live(float* p, float* grad, float* m, float* v, 
         fill_rect(sg.gr, grad_rect_host + 8 * k, n, bands[k], spp, s0))
       return (int)hipErrorInvalidValue;
     const uint64_t rows = (uint64_t)S * bands[k] * sg.live.rh;
-    items[k] = rows * (sg.live.rw / 4);
+    sg.bt = band_tables != nullptr ? band_tables[k] : nullptr;
+    sg.nb = 0; sg.quads = 0;
+    if (sg.bt != nullptr) {
+      if (band_quads == nullptr || band_quads[k] == 0 || sg.live.rh % 8 != 0 || sg.live.rh / 8 > ADAM_MAX_BANDS ||
+          band_quads[k] > (uint32_t)(sg.live.rh * (sg.live.rw / 4)))
+        return (int)hipErrorInvalidValue;
+      sg.nb = (uint32_t)sg.live.rh / 8;
+      sg.quads = band_quads[k];
+    }
+    items[k] = sg.bt != nullptr ? (uint64_t)S * bands[k] * sg.quads : rows * (sg.live.rw / 4);
     if (items[k] >= (1ull << 32)) return (int)hipErrorInvalidValue;
     sg.off = offsets[k];
     sg.rows = (uint32_t)rows;
@@ -520,8 +588,10 @@ extern "C" int tnl_adam_l1_step_live(float* p, float* grad, float* m, float* v, 
     all += items[k];
   }
   // workgroups dealt in proportion to the levels' float4 counts (512 per workgroup and trip), at least one each
+  static const uint64_t max_blocks = getenv("TNL_ADAM_LIVE_BLOCKS") ? strtoull(getenv("TNL_ADAM_LIVE_BLOCKS"), nullptr, 10)
+                                                                    : TNL_ADAM_BLOCKS;
   uint64_t want = (all + 511) / 512;
-  if (want > TNL_ADAM_BLOCKS) want = TNL_ADAM_BLOCKS;
+  if (want > max_blocks) want = max_blocks;
   if (want < n_levels) want = n_levels;
   uint32_t next = 0;
   for (uint32_t k = 0; k < n_levels; k++) {
@@ -536,9 +606,21 @@ extern "C" int tnl_adam_l1_step_live(float* p, float* grad, float* m, float* v, 
   return (int)hipGetLastError();
 }
 
-extern "C" int tnl_adam_l1_catchup(float* p, float* m, float* v, uint32_t S, uint32_t bands, uint32_t n, uint32_t spp,
-                                   uint32_t s0, const int32_t* live_host, const float* ring, int32_t count, float beta1,
-                                   float beta2, float eps, float l1_coef, float* abs_sums, void* stream) {
+extern "C" int tnl_adam_l1_step_live(float* p, float* grad, float* m, float* v, uint32_t S, uint32_t spp, uint32_t s0,
+                                     uint32_t n_levels, const uint64_t* offsets, const uint32_t* sizes,
+                                     const uint32_t* bands, const int32_t* live_host, const int32_t* grad_rect_host,
+                                     const float* l1_coefs, float lr, const float* opt_step_dev, const float* step_rec,
+                                     float beta1, float beta2, float eps, float inv_scale, const float* inv_scale_dev,
+                                     const float* found_inf, float* abs_sum, void* stream) {
+  return tnl_adam_l1_step_live_bands(p, grad, m, v, S, spp, s0, n_levels, offsets, sizes, bands, live_host, grad_rect_host,
+                                     nullptr, nullptr, l1_coefs, lr, opt_step_dev, step_rec, beta1, beta2, eps, inv_scale,
+                                     inv_scale_dev, found_inf, abs_sum, stream);
+}
+
+extern "C" int tnl_adam_l1_catchup_bands(float* p, float* m, float* v, uint32_t S, uint32_t bands, uint32_t n, uint32_t spp,
+                                         uint32_t s0, const int32_t* live_host, const int32_t* band_table,
+                                         const float* ring, int32_t count, float beta1, float beta2, float eps,
+                                         float l1_coef, float* abs_sums, void* stream) {
   if (count == 0) return 0;
   if (ring == nullptr || live_host == nullptr || count < 0 || count > ADAM_REPLAY_MAX || n == 0 || (n & (n - 1)) != 0 ||
       n % 4 != 0 || bands == 0 || spp == 0 || S == 0)
@@ -547,11 +629,20 @@ extern "C" int tnl_adam_l1_catchup(float* p, float* m, float* v, uint32_t S, uin
     return (int)hipErrorInvalidValue;
   AdamRect live;
   if (fill_rect(live, live_host, n, bands, spp, s0)) return (int)hipErrorInvalidValue;
+  if (band_table != nullptr && (live.rh % 8 != 0 || live.rh / 8 > ADAM_MAX_BANDS)) return (int)hipErrorInvalidValue;
   const uint64_t total = (uint64_t)S * bands * n * n;
   AdamArgs a = make_adam_args(0.f, 1.0f, beta1, beta2, eps, 1.0f, l1_coef);
   uint64_t blocks = (total / 4 + 255) / 256;
   if (blocks > 4 * TNL_ADAM_BLOCKS) blocks = 4 * TNL_ADAM_BLOCKS;
   hipLaunchKernelGGL(k_adam_l1_catchup, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, m, v, total, a,
-                     reinterpret_cast<const AdamStepRec*>(ring), (int)count, abs_sums, live);
+                     reinterpret_cast<const AdamStepRec*>(ring), (int)count, abs_sums, live, band_table,
+                     band_table != nullptr ? live.rh / 8 : 0);
   return (int)hipGetLastError();
+}
+
+extern "C" int tnl_adam_l1_catchup(float* p, float* m, float* v, uint32_t S, uint32_t bands, uint32_t n, uint32_t spp,
+                                   uint32_t s0, const int32_t* live_host, const float* ring, int32_t count, float beta1,
+                                   float beta2, float eps, float l1_coef, float* abs_sums, void* stream) {
+  return tnl_adam_l1_catchup_bands(p, m, v, S, bands, n, spp, s0, live_host, nullptr, ring, count, beta1, beta2, eps,
+                                   l1_coef, abs_sums, stream);
 }

@@ -113,6 +113,54 @@ k_occupancy_bounds(const uint8_t* __restrict__ bitfield, uint32_t bytes_per_casc
 }
 
 
+// Per plane and 8-texel row group of the R x R planes: the column extent [lo, end) of the bilinear footprints of every
+// position inside an occupied cell (any cascade) -- a finer description of where samples can fall than the bounding
+// window (a ball fills 78 % of its window).  Same texel mapping as TrainStep._compute_roi: floor of the cell's low /
+// high corner, -1 / +3 texels of slack.  ext[(p * G + g) * 2 + {0, 1}], preset by the caller to {INT_MAX, -1}.
+// Plane p samples (axis xa[p] -> texel x, axis ya[p] -> texel y) with xa = (0, 0, 1), ya = (2, 1, 2).
+__global__ void __launch_bounds__(256)
+k_occupancy_rows(const uint8_t* __restrict__ bitfield, uint32_t bytes_per_cascade, uint32_t cascades, int H, float bound,
+                 int R, int G, int* __restrict__ ext) {
+  extern __shared__ int srow[];                 // [3][G][2]
+  for (int i = threadIdx.x; i < 3 * G * 2; i += 256) srow[i] = (i & 1) ? -1 : 0x7fffffff;
+  __syncthreads();
+  const uint32_t c = blockIdx.y;
+  const float sc = fminf((float)(1u << c), bound);
+  for (uint32_t n = blockIdx.x * 256 + threadIdx.x; n < bytes_per_cascade; n += gridDim.x * 256) {
+    uint32_t b = bitfield[(size_t)c * bytes_per_cascade + n];
+    while (b) {
+      const uint32_t j = __builtin_ctz(b);
+      b &= b - 1;
+      const uint32_t cell = 8 * n + j;
+      const int cc[3] = {(int)morton3D_invert_(cell), (int)morton3D_invert_(cell >> 1), (int)morton3D_invert_(cell >> 2)};
+      int t0[3], t1[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const float w0 = ((float)cc[a] / (float)H * 2.f - 1.f) * sc, w1 = ((float)(cc[a] + 1) / (float)H * 2.f - 1.f) * sc;
+        const float f0 = (fminf(fmaxf(w0 / bound, -1.f), 1.f) + 1.f) * 0.5f * (float)(R - 1);
+        const float f1 = (fminf(fmaxf(w1 / bound, -1.f), 1.f) + 1.f) * 0.5f * (float)(R - 1);
+        t0[a] = max((int)floorf(f0) - 1, 0);
+        t1[a] = min((int)floorf(f1) + 3, R);          // exclusive
+      }
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+        const int xa = p == 2 ? 1 : 0, ya = p == 1 ? 1 : 2;
+        for (int g = t0[ya] >> 3; g <= (t1[ya] - 1) >> 3; g++) {
+          atomicMin(&srow[(p * G + g) * 2], t0[xa]);
+          atomicMax(&srow[(p * G + g) * 2 + 1], t1[xa]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * G; i += 256) {
+    if (srow[2 * i + 1] >= 0) {
+      atomicMin(&ext[2 * i], srow[2 * i]);
+      atomicMax(&ext[2 * i + 1], srow[2 * i + 1]);
+    }
+  }
+}
+
 // One thread packs 4 output bytes from 32 floats read as 8 x float4 (coalesced 128 B per lane).
 __global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thresh,
                            uint8_t* __restrict__ bitfield, const float* __restrict__ thresh_dev) {
@@ -947,6 +995,17 @@ int tnl_occupancy_bounds(const uint8_t* bitfield, uint32_t bytes_per_cascade, ui
   if (bytes_per_cascade == 0 || cascades == 0) return 0;
   hipLaunchKernelGGL(k_occupancy_bounds, dim3(min(cdiv(bytes_per_cascade, 256u), 256u), cascades), dim3(256), 0,
                      (hipStream_t)stream, bitfield, bytes_per_cascade, cascades, bounds);
+  return (int)hipGetLastError();
+}
+
+int tnl_occupancy_row_extents(const uint8_t* bitfield, uint32_t bytes_per_cascade, uint32_t cascades, uint32_t H,
+                              float bound, uint32_t R, int32_t* ext, void* stream) {
+  if (bytes_per_cascade == 0 || cascades == 0) return 0;
+  if (R % 8 != 0 || ext == nullptr || H == 0) return (int)hipErrorInvalidValue;
+  const int G = (int)(R / 8);
+  hipLaunchKernelGGL(k_occupancy_rows, dim3(min(cdiv(bytes_per_cascade, 256u), 128u), cascades), dim3(256),
+                     (size_t)3 * G * 2 * sizeof(int), (hipStream_t)stream, bitfield, bytes_per_cascade, cascades, (int)H,
+                     bound, (int)R, G, ext);
   return (int)hipGetLastError();
 }
 

@@ -669,10 +669,31 @@ __device__ __forceinline__ bool logical_block(const LGrid& lg, int& bx, int& by,
   return true;
 }
 
+// Needed-column table of a level ("spans"; device int32 [3][n / 8][2], nullptr = everything): for plane pl and coarse rows
+// 8g .. 8g+7 the coarse columns [lo, end) whose results anything reads.  A walk workgroup (columns [vx0, vx1), rows
+// [ry0, ry1), both multiples of 8 at the low end) narrows its rows to the row groups whose piece meets its columns;
+// false: none does.  TrainStep builds the tables from the occupied cells' projection (tnl_occupancy_row_extents).
+__device__ __forceinline__ bool narrow_rows(const int* __restrict__ spans, int n, int pl, int vx0, int vx1, int& ry0,
+                                            int& ry1, int* s_span) {
+  if (threadIdx.x == 0) { s_span[0] = 0x7fffffff; s_span[1] = -1; }
+  __syncthreads();
+  const int g0 = ry0 >> 3, g1 = (ry1 - 1) >> 3;
+  for (int g = g0 + (int)threadIdx.x; g <= g1; g += (int)blockDim.x) {
+    const int lo = spans[(pl * (n >> 3) + g) * 2], hi = spans[(pl * (n >> 3) + g) * 2 + 1];
+    if (lo < vx1 && hi > vx0) { atomicMin(&s_span[0], g); atomicMax(&s_span[1], g); }
+  }
+  __syncthreads();
+  const int first = s_span[0], last = s_span[1];
+  if (last < 0) return false;
+  ry0 = max(ry0, 8 * first);
+  ry1 = min(ry1, 8 * last + 8);
+  return true;
+}
+
 template <int W, bool HALF_OUT, int FB>
 __global__ void __launch_bounds__(WT)
 k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n, void* __restrict__ out, Roi roi,
-                int seg, LGrid lg) {
+                int seg, LGrid lg, const int* __restrict__ spans) {
   // FB = coarse rows per phase (4 or 8): the rolling window holds FB + 8 rows of the four bands, FB more are in flight
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2, HW = L / 4;
@@ -692,8 +713,10 @@ k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n
   const int sox = compact ? fox : 0, soy = compact ? foy : 0;
   const int cx0 = fox / 2, cy0 = foy / 2, cw = roi.rw ? roi.rw / 2 : n, ch = roi.rw ? roi.rh / 2 : n;
   const int vx0 = cx0 + bx * WV, vx1 = min(vx0 + WV, cx0 + cw);        // coarse columns this tile produces
-  const int ry0 = cy0 + by * seg, ry1 = min(ry0 + seg, cy0 + ch);      // coarse rows of this segment
+  int ry0 = cy0 + by * seg, ry1 = min(ry0 + seg, cy0 + ch);            // coarse rows of this segment
   if (vx0 >= vx1 || ry0 >= ry1) return;
+  __shared__ int s_span[2];
+  if (spans != nullptr && !narrow_rows(spans, n, pl, vx0, vx1, ry0, ry1, s_span)) return;   // nothing here is read
   const int c = vx0 - 4 + tid;                                                 // this thread's coarse column
   const bool col_ok = c >= 0 && c < n && c < vx1 + 4;
   const size_t nn = (size_t)n * n;
@@ -802,7 +825,7 @@ k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n
 template <int W>
 __global__ void __launch_bounds__(AT)
 k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh, Roi roi,
-                Roi orect, int seg, LGrid lg) {
+                Roi orect, int seg, LGrid lg, const int* __restrict__ spans) {
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2;
   constexpr int KA = (K + 3) / 4 * 4, SH = KA - K;       // staged left halo (fine samples), 16-byte aligned
@@ -823,8 +846,23 @@ k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, f
   const int ox0 = has_or ? orect.ox[pl] : 0, oy0 = has_or ? orect.oy[pl] : 0;
   const int ow = has_or ? orect.rw : n, oh = has_or ? orect.rh : n;
   const int vx0 = ox0 + bx * AVC, vx1 = min(vx0 + AVC, ox0 + ow);      // coarse columns this tile produces
-  const int ry0 = oy0 + by * seg, ry1 = min(ry0 + seg, oy0 + oh);      // coarse rows of this segment
+  int ry0 = oy0 + by * seg, ry1 = min(ry0 + seg, oy0 + oh);            // coarse rows of this segment
   if (vx0 >= vx1 || ry0 >= ry1) return;
+  if (spans != nullptr) {
+    // outside the spans the band gradients are read by nobody and stay unwritten; the LL gradient is the next level's
+    // input, which reads the whole rectangle: it gets its (exact) zeros
+    __shared__ int s_span[2];
+    const int fy0 = ry0, fy1 = ry1;
+    const bool any = narrow_rows(spans, n, pl, vx0, vx1, ry0, ry1, s_span);
+    if (!any) ry0 = ry1 = fy1;
+    float* zl = dx + (size_t)s * n * n;
+    const int zj = tid >> 5, zc = vx0 + 4 * (tid & 31);
+    if ((tid & 31) < AVC / 4 && zc < vx1) {
+      for (int r = fy0 + zj; r < ry0; r += AT / 32) *reinterpret_cast<v4f*>(zl + (size_t)r * n + zc) = v4f{0.f, 0.f, 0.f, 0.f};
+      for (int r = ry1 + zj; r < fy1; r += AT / 32) *reinterpret_cast<v4f*>(zl + (size_t)r * n + zc) = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    if (!any) return;
+  }
   const int fc = 2 * vx0 - KA + tid;                                            // this thread's fine column
   const bool col_ok = fc - fox >= 0 && fc - fox < fw && fc < 2 * vx1 + L;       // inside the input window
   const float* colp = src + (col_ok ? (fc - sox) : 0);
@@ -905,7 +943,8 @@ k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, f
 
 // fp16 (3,C,R,R) -> fp16 [3,R,R,C]: 16-byte loads along x, 16-byte stores along the channels
 __global__ void __launch_bounds__(NT)
-k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __restrict__ tm, Roi roi) {
+k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __restrict__ tm, Roi roi,
+                   const int* __restrict__ spans) {
   extern __shared__ __attribute__((aligned(16))) _Float16 tileh[];  // [C][TX + 8] + 8 halfs of shift per 8 channels
   constexpr int LD = TX + 8;
   // row of channel c starts at c*LD + (c/8)*8: the extra 16 bytes per channel group put the four groups that one
@@ -917,6 +956,10 @@ k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __re
   const int sw = roi.rw ? roi.rw : R, shh = roi.rw ? roi.rh : R;
   const int ys = blockIdx.y, xs0 = blockIdx.x * TX;                  // source coordinates
   const int y = ys + (roi.rw ? roi.oy[p] : 0), x0 = xs0 + (roi.rw ? roi.ox[p] : 0);
+  if (spans != nullptr) {     // [3][R / 8][2]: texel columns of this row group any sample can read
+    const int lo = spans[(p * (R >> 3) + (y >> 3)) * 2], hi = spans[(p * (R >> 3) + (y >> 3)) * 2 + 1];
+    if (!(lo < x0 + TX && hi > x0)) return;
+  }
   for (int idx = threadIdx.x; idx < C * (TX / 8); idx += NT) {
     const int c = idx / (TX / 8), x8 = (idx - c * (TX / 8)) * 8;
     h8 v;
@@ -1018,7 +1061,8 @@ inline int pick_seg(uint32_t tiles, uint32_t rows, uint32_t S) {
 
 template <int W>
 int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, void* out, int half_out, hipStream_t st,
-               Roi roi = Roi{}) {
+               Roi roi = Roi{}, const int* spans = nullptr) {
+  if (spans != nullptr && !(roi.rw && n % 8 == 0 && (int)n >= g_walk_min_n)) spans = nullptr;   // walk kernels only
   if (n % 8 == 0 && (int)n >= g_walk_min_n) {
     const uint32_t cw = roi.rw ? roi.rw / 2 : n, ch = roi.rw ? roi.rh / 2 : n;
     const uint32_t tiles = cdiv(cw, WV);
@@ -1027,7 +1071,7 @@ int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, void* ou
     LGrid lg;
     walk_grid(tiles, cdiv(ch, seg), S, grid, lg);
 #define TNL_FWD_WALK(HALF, FB) \
-  hipLaunchKernelGGL((k_idwt_fwd_walk<W, HALF, FB>), grid, dim3(WT), 0, st, x, yh, (int)n, out, roi, seg, lg)
+  hipLaunchKernelGGL((k_idwt_fwd_walk<W, HALF, FB>), grid, dim3(WT), 0, st, x, yh, (int)n, out, roi, seg, lg, spans)
     if (half_out) { if (g_fwd_fb == 4) TNL_FWD_WALK(true, 4); else TNL_FWD_WALK(true, 8); }
     else { if (g_fwd_fb == 4) TNL_FWD_WALK(false, 4); else TNL_FWD_WALK(false, 8); }
 #undef TNL_FWD_WALK
@@ -1049,7 +1093,7 @@ int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, void* ou
 }
 template <int W>
 int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh, hipStream_t st, Roi roi = Roi{},
-               int32_t* out_rect = nullptr) {
+               int32_t* out_rect = nullptr, const int* spans = nullptr) {
   Roi orect{};
   if (out_rect != nullptr) {
     // Tiles of coarse outputs the input window reaches (same test as the tile kernel's hits()), per plane, then grown
@@ -1097,7 +1141,8 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
     dim3 grid;
     LGrid lg;
     walk_grid(tiles, cdiv(oh, seg), S, grid, lg);
-    hipLaunchKernelGGL(k_idwt_bwd_walk<W>, grid, dim3(AT), 0, st, dout, (int)n, dx, dyh, roi, orect, seg, lg);
+    if (spans != nullptr && (out_rect == nullptr || dx == nullptr)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_idwt_bwd_walk<W>, grid, dim3(AT), 0, st, dout, (int)n, dx, dyh, roi, orect, seg, lg, spans);
   } else if (n % 2 == 0) {
     const int tpw = pick_tpw(cdiv(n, TI), cdiv(n, TI), S);
     hipLaunchKernelGGL((k_idwt_bwd_pipe<W, false>), dim3(cdiv(cdiv(n, TI), tpw), cdiv(n, TI), S), dim3(NT), 0, st, dout,
@@ -1128,7 +1173,8 @@ int tnl_idwt_set_tuning(int key, int value) {
 }
 
 static int idwt_forward_any(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, void* out,
-                            int half_out, void* stream, const int32_t* roi_host = nullptr, int strided = 0) {
+                            int half_out, void* stream, const int32_t* roi_host = nullptr, int strided = 0,
+                            const int32_t* spans = nullptr) {
   Roi roi;
   if (!make_roi(roi_host, S, 2 * n, roi)) return (int)hipErrorInvalidValue;
   roi.strided = (roi.rw && strided) ? 1 : 0;
@@ -1136,11 +1182,11 @@ static int idwt_forward_any(const float* x, const float* yh, uint32_t S, uint32_
   if (S > 65535) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   switch (wave) {
-    case 0: return launch_fwd<0>(x, yh, S, n, out, half_out, st, roi);
-    case 1: return launch_fwd<1>(x, yh, S, n, out, half_out, st, roi);
-    case 2: return launch_fwd<2>(x, yh, S, n, out, half_out, st, roi);
-    case 3: return launch_fwd<3>(x, yh, S, n, out, half_out, st, roi);
-    case 4: return launch_fwd<4>(x, yh, S, n, out, half_out, st, roi);
+    case 0: return launch_fwd<0>(x, yh, S, n, out, half_out, st, roi, spans);
+    case 1: return launch_fwd<1>(x, yh, S, n, out, half_out, st, roi, spans);
+    case 2: return launch_fwd<2>(x, yh, S, n, out, half_out, st, roi, spans);
+    case 3: return launch_fwd<3>(x, yh, S, n, out, half_out, st, roi, spans);
+    case 4: return launch_fwd<4>(x, yh, S, n, out, half_out, st, roi, spans);
     default: return (int)hipErrorInvalidValue;
   }
 }
@@ -1169,7 +1215,23 @@ int tnl_idwt_level_forward_win(const float* x, const float* yh, uint32_t S, uint
 }
 
 static int planes_half_to_tm(const void* planes_cm_half, uint32_t C, uint32_t R, void* planes_tm_half,
-                             const int32_t* roi_host, void* stream);
+                             const int32_t* roi_host, void* stream, const int32_t* spans = nullptr);
+
+// The three windowed calls above restricted to the pieces anything reads (`spans`: device tables as described at
+// narrow_rows, on the level's own n x n grid; for the layout change on the R x R plane grid; NULL = no restriction).
+// Forward: results outside the pieces are not produced (the output keeps what it held).  Adjoint: the band gradients
+// outside the pieces are not produced, the LL gradient is zero there (it is exactly zero when the pieces hold every
+// coefficient a data gradient can reach).  Levels that run the tile kernels (n < walk_min_n) ignore the spans.
+int tnl_idwt_level_forward_spans(const float* x, const float* yh, uint32_t S, uint32_t n, int wave, void* out,
+                                 int half_out, const int32_t* win, int strided, const int32_t* spans, void* stream) {
+  if (n % 4 != 0 || win == nullptr) return (int)hipErrorInvalidValue;
+  return idwt_forward_any(x, yh, S, n, wave, out, half_out, stream, win, strided, spans);
+}
+
+int tnl_planes_half_to_texel_major_spans(const void* planes_roi_half, uint32_t C, uint32_t R, void* planes_tm_half,
+                                         const int32_t* roi, const int32_t* spans, void* stream) {
+  return planes_half_to_tm(planes_roi_half, C, R, planes_tm_half, roi, stream, spans);
+}
 
 int tnl_planes_half_to_texel_major_roi(const void* planes_roi_half, uint32_t C, uint32_t R, void* planes_tm_half,
                                        const int32_t* roi, void* stream) {
@@ -1182,7 +1244,7 @@ int tnl_planes_half_to_texel_major(const void* planes_cm_half, uint32_t C, uint3
 }
 
 static int planes_half_to_tm(const void* planes_cm_half, uint32_t C, uint32_t R, void* planes_tm_half,
-                             const int32_t* roi_host, void* stream) {
+                             const int32_t* roi_host, void* stream, const int32_t* spans) {
   if (C == 0 || R == 0) return 0;
   if (C % 8 != 0 || R % 8 != 0) return (int)hipErrorInvalidValue;
   Roi roi;
@@ -1192,12 +1254,21 @@ static int planes_half_to_tm(const void* planes_cm_half, uint32_t C, uint32_t R,
   const size_t lds = ((size_t)C * (TX + 8) + (C / 8) * 8) * sizeof(_Float16);
   hipLaunchKernelGGL(k_to_texel_major_h, grid, dim3(NT), lds, (hipStream_t)stream,
                      reinterpret_cast<const _Float16*>(planes_cm_half), (int)C, (int)R,
-                     reinterpret_cast<_Float16*>(planes_tm_half), roi);
+                     reinterpret_cast<_Float16*>(planes_tm_half), roi, roi.rw ? spans : nullptr);
   return (int)hipGetLastError();
 }
 
 static int idwt_backward_any(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
-                             const int32_t* roi_host, void* stream, int strided = 0, int32_t* out_rect = nullptr);
+                             const int32_t* roi_host, void* stream, int strided = 0, int32_t* out_rect = nullptr,
+                             const int32_t* spans = nullptr);
+
+int tnl_idwt_level_backward_spans(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
+                                  const int32_t* win, int strided, int32_t* out_rect, const int32_t* spans,
+                                  void* stream) {
+  if (win == nullptr) return (int)hipErrorInvalidValue;
+  if (!(n % 8 == 0 && (int)n >= g_walk_min_n)) spans = nullptr;       // tile kernels: everything is produced
+  return idwt_backward_any(dout, S, n, wave, dx, dyh, win, stream, strided, out_rect, spans);
+}
 
 int tnl_idwt_level_backward(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
                             void* stream) {
@@ -1215,7 +1286,8 @@ int tnl_idwt_level_backward_win(const float* dout, uint32_t S, uint32_t n, int w
 }
 
 static int idwt_backward_any(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, float* dyh,
-                             const int32_t* roi_host, void* stream, int strided, int32_t* out_rect) {
+                             const int32_t* roi_host, void* stream, int strided, int32_t* out_rect,
+                             const int32_t* spans) {
   if (S == 0 || n == 0) return 0;
   if (S > 65535) return (int)hipErrorInvalidValue;
   Roi roi;
@@ -1224,11 +1296,11 @@ static int idwt_backward_any(const float* dout, uint32_t S, uint32_t n, int wave
   if (out_rect != nullptr && roi_host == nullptr) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   switch (wave) {
-    case 0: return launch_bwd<0>(dout, S, n, dx, dyh, st, roi, out_rect);
-    case 1: return launch_bwd<1>(dout, S, n, dx, dyh, st, roi, out_rect);
-    case 2: return launch_bwd<2>(dout, S, n, dx, dyh, st, roi, out_rect);
-    case 3: return launch_bwd<3>(dout, S, n, dx, dyh, st, roi, out_rect);
-    case 4: return launch_bwd<4>(dout, S, n, dx, dyh, st, roi, out_rect);
+    case 0: return launch_bwd<0>(dout, S, n, dx, dyh, st, roi, out_rect, spans);
+    case 1: return launch_bwd<1>(dout, S, n, dx, dyh, st, roi, out_rect, spans);
+    case 2: return launch_bwd<2>(dout, S, n, dx, dyh, st, roi, out_rect, spans);
+    case 3: return launch_bwd<3>(dout, S, n, dx, dyh, st, roi, out_rect, spans);
+    case 4: return launch_bwd<4>(dout, S, n, dx, dyh, st, roi, out_rect, spans);
     default: return (int)hipErrorInvalidValue;
   }
 }

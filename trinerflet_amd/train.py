@@ -30,6 +30,8 @@ Multi-GPU: rays are sharded across ranks, planes and MLP weight
 import ctypes as C_
 import math
 
+import numpy as np
+
 import torch
 import torch.distributed as dist
 
@@ -151,7 +153,7 @@ class TrainStep:
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
                  dist_mode=None, process_group=None, binned=True, fuse_adam=False, use_roi=True, tune_placement=None,
-                 defer_adam=None, deterministic=False):
+                 defer_adam=None, deterministic=False, live_bands=True):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
@@ -219,6 +221,11 @@ class TrainStep:
         self._ring_sums = torch.zeros(16, dtype=torch.float32, device=dev)
         self._pending = 0          # recorded steps not yet applied outside the live rectangles
         self._live = None          # per level the live rectangle (8 ints) or None; fixed while steps are pending
+        self._live_bands = None    # per level None or the rectangle's band table (see _band_tables)
+        self.last_live_bands = None
+        self._band_cache = {}
+        self._row_ext = None
+        self._rects_roi = None     # the occupancy window self._rects were computed under
         self.last_live = None
         self._defer_ctx = None     # (s0, s1, l1) of the pending steps
         self.deferred_reg = torch.zeros((), dtype=torch.float32, device=dev)   # replayed steps' L1 value, summed
@@ -257,6 +264,7 @@ class TrainStep:
         self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
         self.prefetch_at = "auto"   # "start" | "fwd" | "bwd" | "adam" | "auto": where step(next_rays=...) starts the next batch's march
         self.live_col_align = 32    # column granule of the live rectangles (see _live_rects)
+        self.live_bands = live_bands
         self.split_phase2_at = "pg"  # prefetch_at = "split": phase 2 after the field backward ("bwd") or after the tile reduction ("pg")
         self.adam_reserve = False   # experiments: limit the Adam pass's residency (LDS reservation) whenever side work may run beside it
         self._side = None
@@ -323,6 +331,16 @@ class TrainStep:
         bounds = torch.tensor([[Hg + 1] * 3 + [-1] * 3] * casc, dtype=torch.int32, device=self.dev)
         L.check(L.lib().tnl_occupancy_bounds(L.ptr(bits), L.u32(bits.shape[1]), L.u32(casc), L.ptr(bounds), L.stream()),
                 "occupancy_bounds")
+        self._band_cache = {}
+        self._row_ext = None
+        if self.live_bands and R % 8 == 0:
+            # per plane and 8-texel row group the columns a sample can touch (see _level_needs); read back with the box
+            ext = torch.tensor([0x7fffffff, -1], dtype=torch.int32, device=self.dev).repeat(3 * (R // 8))
+            L.check(L.lib().tnl_occupancy_row_extents(L.ptr(bits), L.u32(bits.shape[1]), L.u32(casc), L.u32(Hg),
+                                                      L.f32(float(model.bound)), L.u32(R), L.ptr(ext), L.stream()),
+                    "occupancy_row_extents")
+            ext = ext.cpu()
+            self._row_ext = ext.numpy().reshape(3, R // 8, 2).astype(np.int64)
         vals = [float("inf")] * 3 + [float("-inf")] * 3            # world-space box over the cascades
         for k, bk in enumerate(bounds.tolist()):                    # the one read-back
             if bk[3] < 0:
@@ -376,16 +394,45 @@ class TrainStep:
             wins[lvl] = [min(l, m - rw) for l in lo_x] + [min(l, m - rh) for l in lo_y] + [rw, rh]
         return wins
 
-    def _idwt_level_win(self, x, yh, win, s0=0):
+    def _idwt_level_win(self, x, yh, win, s0=0, spans=None):
         """One non-finest level restricted to the window of its output (fp32, full-size array, rest undefined)."""
         x = x.detach().contiguous()
         yh = yh.detach().contiguous()
         P, Cc, n = x.shape[0], x.shape[1], x.shape[-1]
         out = torch.empty(P, Cc, 2 * n, 2 * n, dtype=torch.float32, device=x.device)
-        L.check(L.lib().tnl_idwt_level_forward_win(L.ptr(x), L.ptr(yh), L.u32(P * Cc), L.u32(n),
-                                                   L.i32(self.enc.wave_id), L.ptr(out),
-                                                   L.roi_array(list(win) + [self.C, s0]), L.stream()),
-                "idwt_level_forward_win")
+        L.check(L.lib().tnl_idwt_level_forward_spans(L.ptr(x), L.ptr(yh), L.u32(P * Cc), L.u32(n),
+                                                     L.i32(self.enc.wave_id), L.ptr(out), L.i32(0),
+                                                     L.roi_array(list(win) + [self.C, s0]), L.i32(1), L.ptr(spans),
+                                                     L.stream()),
+                "idwt_level_forward_spans")
+        return out
+
+    def _forward_spans(self):
+        """(per level the device table of the coarse pieces whose results something reads, the plane grid's own table):
+        level lvl produces the grid the next level's needed coefficients (_level_needs) live on -- the finest one the
+        texels tnl_occupancy_row_extents reports -- so a coarse row group needs the union of the two output row groups
+        it produces, halved.  (None, ...) where there is nothing to gain or the geometry is not the plain one."""
+        if "fwd" in self._band_cache:
+            return self._band_cache["fwd"]
+        out = ([None] * self.J, None)
+        needs = self._level_needs() if self.live_bands else None
+        if needs is not None:
+            big = np.int64(0x7fffffff)
+            tabs = []
+            for lvl in range(self.J):
+                src = self._row_ext if lvl == self.J - 1 else needs[lvl + 1]
+                G = self.coef.params[lvl].shape[-1] // 8
+                pair = src.reshape(3, G, 2, 2)
+                lo, hi = pair[..., 0].min(2), pair[..., 1].max(2)
+                has = hi > lo
+                tabs.append(np.stack([np.where(has, lo // 2, big), np.where(has, (hi + 1) // 2, -1)], axis=-1))
+            tabs.append(self._row_ext)
+            flat = np.concatenate([t.reshape(-1) for t in tabs]).astype(np.int32)
+            dev = torch.from_numpy(flat).to(self.dev)
+            offs = np.cumsum([0] + [t.size for t in tabs])
+            parts = [dev[offs[k]:offs[k + 1]] for k in range(len(tabs))]
+            out = (parts[:-1], parts[-1])
+        self._band_cache["fwd"] = out
         return out
 
     def _cropped(self, lvl):
@@ -409,17 +456,18 @@ class TrainStep:
             self.flush_deferred()     # whole planes read every coefficient
         with torch.no_grad():
             wins = self._forward_windows() if roi else [None] * self.J
+            spans, plane_spans = self._forward_spans() if roi else ([None] * self.J, None)
             if self.dist_mode == "sharded":
-                planes = self._rebuild_sharded(roi, wins)
+                planes = self._rebuild_sharded(roi, wins, spans)
             else:
                 x = enc.planes_features
                 for lvl in range(self.J):
                     yh = enc.planes_features_wavelet_coefs[lvl]
                     if fast and lvl == self.J - 1:  # finest level written as fp16: the fp32 planes never exist
-                        x = idwt_level_half_roi(x, yh, enc.wave_id, self._roi10()) if roi else \
+                        x = idwt_level_half_roi(x, yh, enc.wave_id, self._roi10(), spans[lvl]) if roi else \
                             idwt_level_half(x, yh, enc.wave_id)
                     elif wins[lvl] is not None:
-                        x = self._idwt_level_win(x, yh, wins[lvl])
+                        x = self._idwt_level_win(x, yh, wins[lvl], spans=spans[lvl])
                     else:
                         x = _IDWTLevel.apply(x, yh, enc.wave_id)
                     x = self._crop(x, lvl)
@@ -427,7 +475,7 @@ class TrainStep:
             if roi:
                 enc.last_used_planes = None
                 enc._planes_tm = None
-                return half_roi_into_texel_major(planes, self._tm_full, self._roi10())
+                return half_roi_into_texel_major(planes, self._tm_full, self._roi10(), plane_spans)
             if planes.dtype == torch.float16:
                 # the (3,C,R,R) fp32 planes never exist on this path: only the sampler's copy is installed in the
                 # encoder's cache (get_planes() rebuilds on demand; get_planes_texel_major() serves this copy)
@@ -442,10 +490,11 @@ class TrainStep:
     def _slice_range(self):
         return D.slice_range(3 * self.C, self.world, self.rank)
 
-    def _rebuild_sharded(self, roi=False, wins=None):
+    def _rebuild_sharded(self, roi=False, wins=None, spans=None):
         """IDWT of this rank's (plane, channel) slices, then all-gather of the rebuilt slices -- in fp16 when the
         sampler's planes are fp16 (half the bytes on the wire); with roi only the occupancy window travels."""
         enc = self.enc
+        spans = spans if spans is not None else [None] * self.J
         s0, s1 = self._slice_range()
         n0 = enc.planes_features.shape[-1]
         x = enc.planes_features.reshape(3 * self.C, n0, n0)[s0:s1].unsqueeze(0).contiguous()
@@ -454,10 +503,10 @@ class TrainStep:
             n = x.shape[-1]
             yh = enc.planes_features_wavelet_coefs[lvl].reshape(3 * self.C, 3, n, n)[s0:s1].unsqueeze(0).contiguous()
             if fast and lvl == self.J - 1:
-                x = idwt_level_half_roi(x, yh, enc.wave_id, self._roi10(s0)) if roi else \
+                x = idwt_level_half_roi(x, yh, enc.wave_id, self._roi10(s0), spans[lvl]) if roi else \
                     idwt_level_half(x, yh, enc.wave_id)
             elif wins is not None and wins[lvl] is not None:
-                x = self._idwt_level_win(x, yh, wins[lvl], s0)
+                x = self._idwt_level_win(x, yh, wins[lvl], s0, spans[lvl])
             else:
                 x = _IDWTLevel.apply(x, yh, enc.wave_id)
             x = self._crop(x, lvl)
@@ -527,6 +576,7 @@ class TrainStep:
         if fuse is not None:
             lr_t, l1, found_inf, inv_scale = fuse
             step_size, bias2_sqrt = self._adam_scalars(lr_t)
+        adj_spans = self._adjoint_spans() if (roi is not None and fuse is None) else [None] * self.J
         for lvl in reversed(range(self.J)):
             if self._cropped(lvl):       # the level's output was cropped by k per side: its gradient is zero there
                 g = torch.nn.functional.pad(g, (self.crop_k,) * 4)
@@ -555,10 +605,13 @@ class TrainStep:
                     # Adam pass of this level takes g = 0 outside (self._rects[lvl])
                     win = list(roi) if lvl == self.J - 1 else list(self._rects[lvl + 1])
                     rect = (C_.c_int32 * 8)()
-                    L.check(lib.tnl_idwt_level_backward_win(
+                    L.check(lib.tnl_idwt_level_backward_spans(
                         L.ptr(g), L.u32(ns), L.u32(n), L.i32(self.enc.wave_id), L.ptr(dx), L.ptr(dyh),
-                        L.roi_array(win + [C, s0]), L.i32(0 if lvl == self.J - 1 else 1), rect, L.stream()),
-                        "idwt_level_backward_win")
+                        L.roi_array(win + [C, s0]), L.i32(0 if lvl == self.J - 1 else 1), rect,
+                        L.ptr(adj_spans[lvl] if lvl > 0 else None), L.stream()),
+                        "idwt_level_backward_spans")
+                    if adj_spans[lvl] is not None and list(rect) != self._rects[lvl]:
+                        raise RuntimeError("the adjoint's rectangle changed under an unchanged occupancy window")
                     self._rects[lvl] = list(rect)
                 else:
                     lvl_roi = L.roi_array(list(roi) + [C, s0]) if (roi is not None and lvl == self.J - 1) else None
@@ -566,7 +619,19 @@ class TrainStep:
                                                             L.ptr(dx), L.ptr(dyh), lvl_roi, L.stream()),
                             "idwt_level_backward")
             g = dx
+        self._rects_roi = self._roi if roi is not None else None
         return s0, s1
+
+    def _adjoint_spans(self):
+        """Per level the device table of the pieces whose band gradients the optimiser pass will read (its band pieces),
+        or None: known once an adjoint has run under the current occupancy window (the live rectangles derive from the
+        rectangles it returns, which depend on the window alone)."""
+        none = [None] * self.J
+        if not (self.defer_adam and self.live_bands and self._rect_ok and self._roi is not None and
+                self._rects_roi is self._roi):
+            return none
+        tables = self._live_bands if self._pending else self._band_tables(self._live_rects(self._rects))
+        return [None if t is None else t[3] for t in tables]
 
     def _adam_levels(self, lr_t, l1, found_inf, inv_scale, s0, s1, rects):
         """Adam(+L1) over this rank's slices [s0, s1) of every wavelet level and of LL.  rects: per level the
@@ -1100,6 +1165,101 @@ class TrainStep:
             live[lvl] = [min(l, n - rw) for l, _ in xs] + [min(l, n - rh) for l, _ in ys] + [rw, rh]
         return live
 
+    def _level_needs(self):
+        """Per level [3, n/8, 2] int arrays: for plane p and rows 8b .. 8b+7 of the level's n x n grid the column piece
+        [lo, end) that can reach a sampled texel (and that a gradient can reach) -- the planes' own piece
+        (tnl_occupancy_row_extents) halved and grown by 6 per level, exactly like the rectangles of _live_rects; rows
+        8b .. 8b+7 are within 6 of the halves of rows 16b-12 .. 16b+27 of the next finer grid = its row groups
+        2b-2 .. 2b+3.  Empty pieces are (big, -1).  None when the geometry is not the plain dyadic one."""
+        if "needs" in self._band_cache:
+            return self._band_cache["needs"]
+        needs = None
+        if self._row_ext is not None and not self.base_res:
+            big = np.int64(0x7fffffff)
+            cur, nf = self._row_ext, self.R
+            needs = [None] * self.J
+            for lvl in reversed(range(self.J)):
+                n = self.coef.params[lvl].shape[-1]
+                if 2 * n != nf or n % 8 != 0:
+                    needs = None
+                    break
+                G, Gf = n // 8, cur.shape[1]
+                lo = np.full((3, G), big)
+                hi = np.full((3, G), -1, dtype=np.int64)
+                for b in range(G):
+                    seg = cur[:, max(2 * b - 2, 0):min(2 * b + 3, Gf - 1) + 1]
+                    lo[:, b], hi[:, b] = seg[:, :, 0].min(1), seg[:, :, 1].max(1)
+                has = hi > lo
+                lo = np.where(has, np.maximum(lo // 2 - 6, 0), big)
+                hi = np.where(has, np.minimum((hi + 1) // 2 + 6, n), -1)
+                needs[lvl] = cur = np.stack([lo, hi], axis=-1)
+                nf = n
+        self._band_cache["needs"] = needs
+        return needs
+
+    def _band_tables(self, live):
+        """Per level None or (device int32 band table, float4s per slice, host table, device span table of the same
+        pieces for the adjoint) for tnl_adam_l1_step_live_bands:
+        the live rectangle's 8-row bands cut down to the columns _level_needs allows (aligned outward to the column
+        granule, one width per band over the three planes).  None where that saves less than 8 % of the rectangle."""
+        key = tuple(None if lv is None else tuple(lv) for lv in live)
+        if key in self._band_cache:
+            return self._band_cache[key]
+        needs = self._level_needs()
+        out = [None] * self.J
+        host = []
+        al = getattr(self, "live_col_align", 32)
+        for lvl, lv in enumerate(live):
+            if lv is None or needs is None or lv[7] % 8 != 0 or lv[7] // 8 > 128 or any(o % 8 for o in lv[3:6]):
+                continue
+            rw, rh = lv[6], lv[7]
+            nb = rh // 8
+            E = needs[lvl]
+            w = np.zeros(nb, dtype=np.int64)
+            x0 = np.zeros((3, nb), dtype=np.int64)
+            los, his = [], []
+            for p in range(3):
+                e = E[p, lv[3 + p] // 8: lv[3 + p] // 8 + nb]
+                lo = np.clip(e[:, 0], lv[p], lv[p] + rw) // al * al
+                hi = np.clip((np.clip(e[:, 1], lv[p], lv[p] + rw) + al - 1) // al * al, lv[p], lv[p] + rw)
+                empty = e[:, 1] <= e[:, 0]
+                lo = np.where(empty, lv[p], lo)
+                hi = np.where(empty, lv[p], np.maximum(hi, lo))
+                los.append(lo)
+                his.append(hi)
+                w = np.maximum(w, hi - lo)
+            for p in range(3):
+                x0[p] = np.clip(np.minimum(los[p], lv[p] + rw - w), lv[p], None)
+            quads = int(2 * w.sum())
+            if quads == 0 or quads > 0.92 * rh * (rw // 4) or (al % 4) != 0:
+                continue
+            pref = np.concatenate([[0], np.cumsum(2 * w)])
+            tbl = np.concatenate([pref, w // 4, x0.reshape(-1)]).astype(np.int32)
+            # the same pieces as a span table of the level's grid (tnl_idwt_level_backward_spans)
+            n = self.coef.params[lvl].shape[-1]
+            sp = np.empty((3, n // 8, 2), dtype=np.int32)
+            sp[..., 0], sp[..., 1] = 0x7fffffff, -1
+            for p in range(3):
+                g0 = lv[3 + p] // 8
+                sp[p, g0:g0 + nb, 0] = np.where(w > 0, x0[p], 0x7fffffff)
+                sp[p, g0:g0 + nb, 1] = np.where(w > 0, x0[p] + w, -1)
+            host.append((lvl, np.concatenate([tbl, np.zeros(-tbl.size % 4, np.int32), sp.reshape(-1)]), quads, tbl.size,
+                         (tbl.size + 3) // 4 * 4))
+        if host:
+            # one upload for all levels (each table 16-byte aligned inside it)
+            offs, tot = [], 0
+            for h in host:
+                offs.append(tot)
+                tot += (h[1].size + 3) // 4 * 4
+            flat = np.zeros(tot, dtype=np.int32)
+            for o, h in zip(offs, host):
+                flat[o:o + h[1].size] = h[1]
+            dev = torch.from_numpy(flat).to(self.dev)
+            for o, (lvl, both, quads, nt, so) in zip(offs, host):
+                out[lvl] = (dev[o:o + nt], quads, both[:nt], dev[o + so:o + both.size])
+        self._band_cache[key] = out
+        return out
+
     def _adam_levels_live(self, lr_t, l1, found_inf, inv_scale, s0, s1, rects):
         """_adam_levels over the live rectangles only; the step's scalars are recorded for the replay."""
         lib = L.lib()
@@ -1108,7 +1268,9 @@ class TrainStep:
             self.flush_deferred()                  # the regulariser's weight (or the slice range) changed: new period
         if self._pending == 0:
             self._live = self._live_rects(rects)
+            self._live_bands = self._band_tables(self._live) if self.live_bands else [None] * self.J
             self.last_live = self._live            # kept after the flush, for reports
+            self.last_live_bands = self._live_bands
             self._defer_ctx = (s0, s1, l1)
         slot = self._pending
         L.check(lib.tnl_adam_record_step(L.ptr(self._ring), L.i32(slot), L.f32(lr_t), L.ptr(self.opt_steps),
@@ -1120,12 +1282,15 @@ class TrainStep:
         offs = [cf.offsets[lvl] + s0 * 3 * sizes[lvl] ** 2 for lvl in range(J)]
         live = [lv if lv is not None else [0, 0, 0, 0, 0, 0, sizes[k], sizes[k]] for k, lv in enumerate(self._live)]
         flat = lambda rs: (C_.c_int32 * (8 * J))(*[x for r in rs for x in r[:8]])
-        L.check(lib.tnl_adam_l1_step_live(
+        bt = self._live_bands
+        L.check(lib.tnl_adam_l1_step_live_bands(
             L.ptr(cf.data), L.ptr(cf.grad), L.ptr(cf.m), L.ptr(cf.v), L.u32(ns), L.u32(self.C), L.u32(s0), L.u32(J),
             (C_.c_uint64 * J)(*offs), (C_.c_uint32 * J)(*sizes), (C_.c_uint32 * J)(*([3] * J)), flat(live), flat(rects),
+            (C_.c_void_p * J)(*[None if b is None else b[0].data_ptr() for b in bt]),
+            (C_.c_uint32 * J)(*[0 if b is None else b[1] for b in bt]),
             (C_.c_float * J)(*([l1] * J)), L.f32(lr_t), L.ptr(self.opt_steps), L.ptr(self._ring[4 * slot:]),
             L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0), L.ptr(inv_scale), L.ptr(found_inf),
-            L.ptr(self.abs_sum), L.stream()), "adam_l1_step_live")
+            L.ptr(self.abs_sum), L.stream()), "adam_l1_step_live_bands")
         n0 = self.ll.params[0].shape[-1]
         ll = self.ll
         off = s0 * n0 * n0
@@ -1154,11 +1319,13 @@ class TrainStep:
             n = self.coef.params[lvl].shape[-1]
             base = self.coef.offsets[lvl] + s0 * 3 * n * n
             cf = self.coef
-            L.check(lib.tnl_adam_l1_catchup(
+            bt = self._live_bands[lvl]
+            L.check(lib.tnl_adam_l1_catchup_bands(
                 L.ptr(cf.data[base:]), L.ptr(cf.m[base:]), L.ptr(cf.v[base:]), L.u32(ns), L.u32(3), L.u32(n),
-                L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*self._live[lvl]), L.ptr(self._ring), L.i32(self._pending),
+                L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*self._live[lvl]), L.ptr(None if bt is None else bt[0]),
+                L.ptr(self._ring), L.i32(self._pending),
                 L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(l1), L.ptr(self._ring_sums if l1 > 0 else None),
-                L.stream()), "adam_l1_catchup")
+                L.stream()), "adam_l1_catchup_bands")
         if l1 > 0:
             self.deferred_reg += l1 * self._ring_sums[:self._pending].sum()
         self.last_flush_records = self._pending

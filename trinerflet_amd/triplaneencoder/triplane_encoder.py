@@ -101,25 +101,28 @@ def idwt_level_half(x, yh, wave_id):
     return out
 
 
-def idwt_level_half_roi(x, yh, wave_id, roi):
+def idwt_level_half_roi(x, yh, wave_id, roi, spans=None):
     """Finest level over the ROI window only: -> compact fp16 (P*C, rh, rw).  roi = 8 ints, see
-    include/trinerflet_hip.h (window of the 2n x 2n grid, multiples of 64)."""
+    include/trinerflet_hip.h (window of the 2n x 2n grid, multiples of 64).  spans: device table of the pieces of the
+    window anything reads (tnl_idwt_level_forward_spans); the rest of the result is then undefined."""
     x = x.detach().to(torch.float32).contiguous()
     yh = yh.detach().to(torch.float32).contiguous()
     P, C, n = x.shape[0], x.shape[1], x.shape[-1]
     out = torch.empty(P * C, roi[7], roi[6], dtype=torch.float16, device=x.device)
-    L.check(L.lib().tnl_idwt_level_forward_half_roi(L.ptr(x), L.ptr(yh), L.u32(P * C), L.u32(n), L.i32(wave_id),
-                                                    L.ptr(out), L.roi_array(roi), L.stream()),
-            "idwt_level_forward_half_roi")
+    L.check(L.lib().tnl_idwt_level_forward_spans(L.ptr(x), L.ptr(yh), L.u32(P * C), L.u32(n), L.i32(wave_id),
+                                                 L.ptr(out), L.i32(1), L.roi_array(roi), L.i32(0), L.ptr(spans),
+                                                 L.stream()),
+            "idwt_level_forward_spans")
     return out
 
 
-def half_roi_into_texel_major(planes_roi_half, tm, roi):
-    """Compact fp16 window (3C, rh, rw) -> the same window of the full fp16 [3,R,R,C] array `tm`, in place."""
+def half_roi_into_texel_major(planes_roi_half, tm, roi, spans=None):
+    """Compact fp16 window (3C, rh, rw) -> the same window of the full fp16 [3,R,R,C] array `tm`, in place (spans: only
+    the 64-texel row pieces that meet the table's pieces of the plane grid)."""
     _, R, _, C = tm.shape
-    L.check(L.lib().tnl_planes_half_to_texel_major_roi(L.ptr(planes_roi_half), L.u32(C), L.u32(R), L.ptr(tm),
-                                                       L.roi_array(roi), L.stream()),
-            "planes_half_to_texel_major_roi")
+    L.check(L.lib().tnl_planes_half_to_texel_major_spans(L.ptr(planes_roi_half), L.u32(C), L.u32(R), L.ptr(tm),
+                                                         L.roi_array(roi), L.ptr(spans), L.stream()),
+            "planes_half_to_texel_major_spans")
     return tm
 
 
