@@ -31,8 +31,10 @@
 #endif
 #ifndef TNL_BWD_MODE
 #define TNL_BWD_MODE 0   // hidden-64 binned backward: 0 shared stages (NW waves in lock step), 1 per-wave weight gradients,
-#endif                   // 2 two staggered 4-wave teams -- see BwdGeom.  Round-3 measurements at base, kernel alone (ms):
+#endif                   // 2 two staggered 4-wave teams, 3 roles (4 chain waves + 4 weight-gradient waves) -- see BwdGeom.
+                         // Round-3 measurements at base, kernel alone (ms):
                          // mode 0 0.77-0.78 | mode 1 0.83 | mode 2 stagger 0: 0.75, stagger 3 / 5 / 7: 0.94 / 0.91 / 0.93
+                         // | mode 3 0.93-0.94
 #ifndef TNL_BWD_STAGGER
 #define TNL_BWD_STAGGER 0   // MODE 2: barriers by which the second team trails the first (10 per super-tile)
 #endif
@@ -63,16 +65,25 @@ namespace {
 // MEASURED: the stagger LOSES (0.91-0.94 ms against 0.75 without it): with workgroup-wide barriers every interval lasts
 // as long as the LONGER of the two phases that share it, and the sum of those maxima exceeds the sum of the phases.
 // Without a stagger the team form is 3 % faster than mode 0 alone (4 tiles per wave, 128-sample stages), equal in the step.
+//
+// MODE 3 ("roles", round 3): the 8 waves split by WORK instead of by samples.  Waves 0-3 (one per SIMD) run the chain
+// for 32 samples each (128-sample super-tiles): recompute, data gradients, staging; waves 4-7 (the other wave of each
+// SIMD) hold all 16 weight-gradient tiles (4 each, K = 128) and do nothing else, one layer behind the chain waves: two
+// stage sets used alternately, ONE workgroup barrier per layer, and the two waves of a SIMD are never in the same phase
+// -- an MFMA-only wave beside a convert / stage / wait wave.  184 registers, no spill, results identical.
+// MEASURED: 0.93 ms against mode 0's 0.76: a chain wave needs ~15.7 k cycles per 32 samples with or without the weight
+// gradients (mode 0: two chain-and-gradient waves per SIMD deliver 64 samples per 25.7 k); what bounds the kernel is
+// the serial latency of ONE wave's layer chain, and only a second chain wave on the SIMD -- not a helper -- hides it.
 template <int C, int H, int NW, bool ATOMIC, int PART = 0, int MODE = 0>
 struct BwdGeom {
   using G = FieldGeom<C, H>;
-  static constexpr bool PW = MODE == 1, TM = MODE == 2;
+  static constexpr bool PW = MODE == 1, TM = MODE == 2, RL = MODE == 3;
   static constexpr bool PWv = PW;
   static constexpr int BW_WAVES = NW;
   static constexpr int BW_THREADS = 64 * NW;
-  static constexpr int ST = 32 * NW;      // samples per super-tile (of the workgroup)
+  static constexpr int ST = RL ? 16 * NW : 32 * NW;      // samples per super-tile (of the workgroup; RL: half the waves carry samples)
   static constexpr int SS = PW ? 32 : (TM ? ST / 2 : ST); // samples per stage image (PW: the wave's own 32, TM: the team's)
-  static constexpr int COPIES = PW ? NW : (TM ? 2 : 1);
+  static constexpr int COPIES = PW ? NW : ((TM || RL) ? 2 : 1);   // RL: two stage sets used alternately, layer by layer
   // A stage image holds fp16 [32-feature block][sample][32 features]: 64-byte rows whose eight 8-byte chunks are
   // XOR-swizzled with the row (img_off), so that a lane stores four consecutive features of its sample with one
   // ds_write_b64 and the weight-gradient MFMA reads both operands (8 samples of one feature per lane) with the
@@ -98,7 +109,7 @@ struct BwdGeom {
   // Double-buffered X / Y stages (layers alternate between the two pairs): the barrier that protected a stage from
   // the next layer's writes disappears, one barrier per layer remains.  Only where it fits next to the weights.
   // (hidden 64 split by layer: single-buffered, so that TWO workgroups fit a CU -- independent barriers, 2 waves per SIMD)
-  static constexpr bool DB = !PW && !TM && !(H == 64 && PART != 0) && EARLY_F && 2 * (XS_BYTES + YS_BYTES) + FS_BYTES + W_BYTES <= 160 * 1024;
+  static constexpr bool DB = !PW && !TM && !RL && !(H == 64 && PART != 0) && EARLY_F && 2 * (XS_BYTES + YS_BYTES) + FS_BYTES + W_BYTES <= 160 * 1024;
   static constexpr size_t COPY_BYTES = (DB ? 2 : 1) * (XS_BYTES + YS_BYTES) + FS_BYTES;   // one stage set (PW: one per wave)
   static constexpr size_t BASE_BYTES = COPIES * COPY_BYTES + STAGE_BYTES;
   static constexpr bool LDSW = BASE_BYTES + W_BYTES <= 160 * 1024;  // weights cached in LDS when they fit
@@ -113,9 +124,9 @@ struct BwdGeom {
 #ifndef TNL_BWD_GT_MIN
 #define TNL_BWD_GT_MIN 8
 #endif
-  static constexpr bool GT = NW >= TNL_BWD_GT_MIN || PW || TM;
+  static constexpr bool GT = NW >= TNL_BWD_GT_MIN || PW || TM || RL;
   static constexpr int NTILES = NT0 + NT1 + NT2 + NT3 + NT4;
-  static constexpr int TW = PW ? 1 : (TM ? NW / 2 : NW);   // waves the tiles are dealt over (PW: every wave holds them all)
+  static constexpr int TW = PW ? 1 : ((TM || RL) ? NW / 2 : NW);   // waves the tiles are dealt over (PW: every wave holds them all)
   static constexpr int NSLOT = (NTILES + TW - 1) / TW;
   static constexpr int B4 = 0, B3 = NT4, B2 = B3 + NT3, B1 = B2 + NT2, B0 = B1 + NT1;   // first tile id of each layer
 };
@@ -223,7 +234,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
             const int32_t* __restrict__ m_actual, _Float16* __restrict__ dfeat, _Float16* __restrict__ dO) {
   using G = FieldGeom<C, H>;
   using B = BwdGeom<C, H, NW, ATOMIC, PART, MODE>;
-  constexpr bool PW = B::PW, TM = B::TM;
+  constexpr bool PW = B::PW, TM = B::TM, RL = B::RL;
   static_assert(PART == 0 || !ATOMIC, "the split launch exists for the binned mode only");
   static_assert(MODE == 0 || (PART == 0 && !ATOMIC), "per-wave / team weight gradients: single-launch binned mode");
   constexpr bool DO_COL = PART != 2, DO_SIG = PART != 1;
@@ -233,10 +244,17 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr size_t XY = B::XS_BYTES + B::YS_BYTES;
-  const int team = TM ? wv / B::TW : 0;
-  char* const sbase = smem + (PW ? (size_t)wv : (size_t)team) * B::COPY_BYTES;   // PW / TM: the wave's / team's own stage set
-  char* const Xb[2] = {sbase, sbase + (B::DB ? XY : 0)};
-  char* const Yb[2] = {sbase + B::XS_BYTES, sbase + (B::DB ? XY : 0) + B::XS_BYTES};
+  const int team = (TM || RL) ? wv / B::TW : 0;
+  char* const sbase = smem + (PW ? (size_t)wv : (TM ? (size_t)team : 0)) * B::COPY_BYTES;   // PW / TM: the wave's / team's own stage set
+  char* const Xb[2] = {sbase, sbase + (B::DB ? XY : (RL ? B::COPY_BYTES : 0))};
+  char* const Yb[2] = {sbase + B::XS_BYTES, sbase + (B::DB ? XY : (RL ? B::COPY_BYTES : 0)) + B::XS_BYTES};
+  // RL ("roles"): team 0 (waves 0 .. NW/2-1, one per SIMD) runs the chain -- recompute, data gradients, staging -- and
+  // never touches a weight-gradient tile; team 1 (the other wave of each SIMD) does nothing but the weight-gradient
+  // MFMAs, one layer BEHIND: at the workgroup barrier that publishes layer k's stage it has just finished layer k-1's,
+  // whose stage set (the other of the two) the chain waves then overwrite with layer k+1.  One barrier per layer, and
+  // the two waves of a SIMD are never in the same phase.  `kk` counts published layers (5 per super-tile: the parity
+  // alternates across super-tiles too).
+  int kk = 0;
   float* stage_all = reinterpret_cast<float*>(smem + (B::DB ? 2 : 1) * XY);
   char* Fs = PW ? sbase + XY : smem + (B::DB ? 2 : 1) * XY + B::STAGE_BYTES;
   // stage published -> stage read.  PW: writer and reader are the same wave, whose LDS operations execute in order:
@@ -245,7 +263,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     if (PW) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     else __syncthreads();
   };
-  auto sync_stage = [&]() { if (!B::DB && !PW) __syncthreads(); };   // stage reuse barrier (shared stages, single-buffered)
+  auto sync_stage = [&]() { if (!B::DB && !PW && !RL) __syncthreads(); };   // stage reuse barrier (shared stages, single-buffered)
   const half8* w = packed;    // forward fragments (and, outside PART 2, all of them)
   const half8* wH = packed;   // layers 3, 4 forward and 4, 3, 2 transposed
   const half8* wT = packed;   // transposed fragments of layers 1 and 0
@@ -269,7 +287,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int col = 32 * wv + r;             // this lane's sample within the workgroup's super-tile
   constexpr int TW = B::TW;                // waves the weight-gradient tiles are dealt over
-  const int tw = PW ? 0 : (TM ? wv % TW : wv);
+  const int tw = PW ? 0 : ((TM || RL) ? wv % TW : wv);
   const int scol = PW ? r : (TM ? 32 * tw + r : col);   // ... and its row in the stage images
   // transposed-read offsets of the weight-gradient operands: lane 4q + p of a 16-lane group addresses sample row q of
   // the block, chunk p of the group's 16 features
@@ -337,6 +355,36 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
   };
   constexpr bool PREFETCH = PART != 1;   // the colour half of hidden 128 is register-bound: its 44 B of inputs are read in place
+  if (RL && team == 1) {
+    for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
+      __syncthreads();
+      dw_layer<SS, BLK, TW, B::NSLOT, B::B4, B::NT4, B::NT4>(dwg, tw, smem + (size_t)(kk & 1) * B::COPY_BYTES + B::XS_BYTES, smem + (size_t)(kk & 1) * B::COPY_BYTES, t0, t1);
+      kk++;
+      __syncthreads();
+      dw_layer<SS, BLK, TW, B::NSLOT, B::B3, B::NT3, G::OB>(dwg, tw, smem + (size_t)(kk & 1) * B::COPY_BYTES + B::XS_BYTES, smem + (size_t)(kk & 1) * B::COPY_BYTES, t0, t1);
+      kk++;
+      __syncthreads();
+      dw_layer<SS, BLK, TW, B::NSLOT, B::B2, B::NT2, 1>(dwg, tw, smem + (size_t)(kk & 1) * B::COPY_BYTES + B::XS_BYTES, smem + (size_t)(kk & 1) * B::COPY_BYTES, t0, t1);
+      kk++;
+      __syncthreads();
+      dw_layer<SS, BLK, TW, B::NSLOT, B::B1, B::NT1, B::NT1>(dwg, tw, smem + (size_t)(kk & 1) * B::COPY_BYTES + B::XS_BYTES, smem + (size_t)(kk & 1) * B::COPY_BYTES, t0, t1);
+      kk++;
+      __syncthreads();
+      dw_layer<SS, BLK, TW, B::NSLOT, B::B0, B::NT0, G::IB0>(dwg, tw, smem + (size_t)(kk & 1) * B::COPY_BYTES + B::XS_BYTES, smem + (size_t)(kk & 1) * B::COPY_BYTES, t0, t1);
+      kk++;
+    }
+    float* slab = slabs + (size_t)blockIdx.x * G::NW;
+#pragma unroll
+    for (int sl = 0; sl < B::NSLOT; sl++) {
+      const int T = tw + TW * sl;
+      if (T < B::B3) slab_tile(slab, G::OFF4, 3, H, 0, T - B::B4, dwg[sl], r, h);
+      else if (T < B::B2) slab_tile(slab, G::OFF3, H, H, (T - B::B3) / G::OB, (T - B::B3) % G::OB, dwg[sl], r, h);
+      else if (T < B::B1) slab_tile<2>(slab, G::OFF2, H, 31, T - B::B2, 0, dwg[sl], r, h);
+      else if (T < B::B0) slab_tile<1>(slab, G::OFF1, 16, H, 0, T - B::B1, dwg[sl], r, h);
+      else if (T < B::NTILES) slab_tile(slab, G::OFF0, H, G::F, (T - B::B0) / G::IB0, (T - B::B0) % G::IB0, dwg[sl], r, h);
+    }
+    return;
+  }
   Inputs nxt;
   if (PREFETCH && blockIdx.x < nst) load_inputs(blockIdx.x, nxt);
   if (TM && team == 1) {      // the second team trails by TNL_BWD_STAGGER barriers (made up by the first team after the loop)
@@ -404,7 +452,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       dz4[2] = g_c2 * c2 * (1.f - c2);
     }
     const half8 dz4f = acc_to_frag<false>(dz4, 0);
-    Xs = Xb[0]; Ys = Yb[0];
+    Xs = RL ? smem + (size_t)(kk & 1) * B::COPY_BYTES : Xb[0]; Ys = RL ? Xs + B::XS_BYTES : Yb[0]; kk++;
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h4[ks], h, scol);
     put_acc<1>(Ys, dz4, h, scol);   // rows 0..7 (rgb logits' gradient in rows 0..2); the rest of the block is never used
@@ -412,9 +460,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     // (Every wave accumulates A_l tiles per layer without a branch: behind `if (tile < NT_l)` the accumulators of that
     // block live in VGPRs and are copied into AGPRs and back around the MFMAs, 32 moves per tile and super-tile.  The
     // duplicates cost idle waves a few MFMAs and are dropped when the slabs are written.)
-    if (B::GT) {
+    if (B::GT && !RL) {
       dw_layer<SS, BLK, TW, B::NSLOT, B::B4, B::NT4, B::NT4>(dwg, tw, Ys, Xs, t0, t1);
-    } else {
+    } else if (!B::GT) {
 #pragma unroll
     for (int k = 0; k < B::A4; k++) {
       const int t = (wv + NW * k) % B::NT4;   // a wave without a tile of its own repeats another's
@@ -433,15 +481,15 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     sync_stage();
 
     // ---- layer 3
-    Xs = Xb[1]; Ys = Yb[1];
+    Xs = RL ? smem + (size_t)(kk & 1) * B::COPY_BYTES : Xb[1]; Ys = RL ? Xs + B::XS_BYTES : Yb[1]; kk++;
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h3[ks], h, scol);
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d4f[ks], h, scol);
     stage_ready();
-    if (B::GT) {
+    if (B::GT && !RL) {
       dw_layer<SS, BLK, TW, B::NSLOT, B::B3, B::NT3, G::OB>(dwg, tw, Ys, Xs, t0, t1);
-    } else {
+    } else if (!B::GT) {
 #pragma unroll
     for (int k = 0; k < B::A3; k++) {
       const int t = (wv + NW * k) % B::NT3;   // a wave without a tile of its own repeats another's
@@ -464,7 +512,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 
     // ---- layer 2: X = z, staged as [SH(16) | the 16 chain slots of the sigma net's outputs] (slot 0 = the logit, which
     // is no input of the colour net: slab_tile<2> drops that column and shifts the geo features back by one)
-    Xs = Xb[0]; Ys = Yb[0];
+    Xs = RL ? smem + (size_t)(kk & 1) * B::COPY_BYTES : Xb[0]; Ys = RL ? Xs + B::XS_BYTES : Yb[0]; kk++;
     {
       half8 geo = in.geo;
       if (PART != 1) {
@@ -477,9 +525,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d3f[ks], h, scol);
     stage_ready();
-    if (B::GT) {
+    if (B::GT && !RL) {
       dw_layer<SS, BLK, TW, B::NSLOT, B::B2, B::NT2, 1>(dwg, tw, Ys, Xs, t0, t1);
-    } else {
+    } else if (!B::GT) {
 #pragma unroll
     for (int k = 0; k < B::A2; k++) {
       const int t = (wv + NW * k) % B::NT2;   // a wave without a tile of its own repeats another's
@@ -508,14 +556,14 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     if (DO_SIG) {
 
     // ---- layer 1: X = H1, dY = dO in chain-slot order (slot 15 = the logit's gradient; slab_tile<1> maps the rows back)
-    Xs = Xb[1]; Ys = Yb[1];
+    Xs = RL ? smem + (size_t)(kk & 1) * B::COPY_BYTES : Xb[1]; Ys = RL ? Xs + B::XS_BYTES : Yb[1]; kk++;
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h1[ks], h, scol);
     put_frag<BLK>(Ys, 0, dof, h, scol);   // features 0..15 of the block; 16..31 are never used
     stage_ready();
-    if (B::GT) {
+    if (B::GT && !RL) {
       dw_layer<SS, BLK, TW, B::NSLOT, B::B1, B::NT1, B::NT1>(dwg, tw, Ys, Xs, t0, t1);
-    } else {
+    } else if (!B::GT) {
 #pragma unroll
     for (int k = 0; k < B::A1; k++) {
       const int t = (wv + NW * k) % B::NT1;   // a wave without a tile of its own repeats another's
@@ -532,7 +580,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     sync_stage();
 
     // ---- layer 0: X = F (natural k order) from the feature stage written at the top of the super-tile
-    Xs = Xb[0]; Ys = Yb[0];
+    Xs = RL ? smem + (size_t)(kk & 1) * B::COPY_BYTES : Xb[0]; Ys = RL ? Xs + B::XS_BYTES : Yb[0]; kk++;
     if (!B::EARLY_F) {   // into Xs: re-read (L2-hot) in atomic mode, from registers in PART 2
       const uint32_t il = valid ? i : M - 1;
 #pragma unroll
@@ -549,9 +597,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d1f[ks], h, scol);
     stage_ready();
-    if (B::GT) {
+    if (B::GT && !RL) {
       dw_layer<SS, BLK, TW, B::NSLOT, B::B0, B::NT0, G::IB0>(dwg, tw, Ys, B::EARLY_F ? Fs : Xs, t0, t1);
-    } else {
+    } else if (!B::GT) {
 #pragma unroll
     for (int k = 0; k < B::A0; k++) {
       const int t = (wv + NW * k) % B::NT0;   // a wave without a tile of its own repeats another's
@@ -643,8 +691,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     }
     }  // DO_SIG
-    if (!PW) __syncthreads();  // Xs/Ys are rewritten by the next super-tile (PW: by the same wave, in order)
+    if (!PW && !RL) __syncthreads();  // Xs/Ys are rewritten by the next super-tile (PW: by the same wave, in order)
   }
+  if (RL) return;   // the chain waves hold no weight gradients
 
   if (TM && team == 0) {
     for (int k = 0; k < TNL_BWD_STAGGER; k++) __syncthreads();
@@ -751,7 +800,7 @@ int launch_bwd_impl(const float* gsig, const float* grgb, const float* sigma, co
                     void* workspace, const int32_t* m_actual, void* dfeat, hipStream_t st) {
   using G = FieldGeom<C, H>;
   // persistent workgroups: one per CU, two where two fit (hidden 64 split by layer)
-  const uint32_t blocks = bwd_blocks(M, 32 * NW, (H == 64 && split_launch<C, H, ATOMIC>()) ? 512 : 256);
+  const uint32_t blocks = bwd_blocks(M, MODE == 3 ? 16 * NW : 32 * NW, (H == 64 && split_launch<C, H, ATOMIC>()) ? 512 : 256);
   float* slabs = reinterpret_cast<float*>(workspace);
   int e;
   if constexpr (split_launch<C, H, ATOMIC>()) {
@@ -782,6 +831,9 @@ int launch_bwd(const float* gsig, const float* grgb, const float* sigma, const v
                                                 workspace, m_actual, dfeat, st);
     else if constexpr (TNL_BWD_MODE == 1 && H == 64)   // per-wave weight gradients: 4 waves per workgroup, one per SIMD, no barriers
       return launch_bwd_impl<C, H, 4, false, 1>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW,
+                                                workspace, m_actual, dfeat, st);
+    else if constexpr (TNL_BWD_MODE == 3 && H == 64)   // roles: four chain waves + four weight-gradient waves
+      return launch_bwd_impl<C, H, 8, false, 3>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW,
                                                 workspace, m_actual, dfeat, st);
     else if constexpr (TNL_BWD_MODE == 2 && H == 64)   // two staggered teams of four waves
       return launch_bwd_impl<C, H, 8, false, 2>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW,
