@@ -297,19 +297,21 @@ class TrainStep:
             ev.record()  # torch's current stream = the stream every kernel of the step is launched on
             self.section_events.append((name, ev, self._mark_seq))
 
-    def section_times(self):
-        """Mean milliseconds per stage over the recorded steps (requires a prior torch.cuda.synchronize())."""
+    def section_times(self, stat="mean"):
+        """Milliseconds per stage over the recorded steps: the mean, or with stat="median" the median over the steps
+        (one step that allocates or waits does not move it).  Requires a prior torch.cuda.synchronize()."""
         if not self.section_events:
             return {}
-        tot, cnt = {}, {}
+        vals = {}
         prev = None
         for name, ev, seq in self.section_events:
             # a section is timed only when the boundary before it was recorded too (consecutive _mark calls)
             if name != "begin" and prev is not None and prev[1] == seq - 1:
-                tot[name] = tot.get(name, 0.0) + prev[0].elapsed_time(ev)
-                cnt[name] = cnt.get(name, 0) + 1
+                vals.setdefault(name, []).append(prev[0].elapsed_time(ev))
             prev = (ev, seq)
-        return {k: tot[k] / cnt[k] for k in tot}
+        if stat == "median":
+            return {k: float(np.median(v)) for k, v in vals.items()}
+        return {k: sum(v) / len(v) for k, v in vals.items()}
 
     def invalidate_roi(self):
         """Call after changing model.density_bitfield by hand (update_extra_state inside step() is tracked): the
