@@ -76,6 +76,8 @@ def build(workload, device, dist_mode, plane_dtype=None, **ts_kwargs):
         ts.split_phase2_at = os.environ["TNL_SPLIT_P2"]
     if os.environ.get("TNL_ADAM_RESERVE"):    # experiments: Adam pass with reduced residency beside the side work
         ts.adam_reserve = True
+    if os.environ.get("TNL_SIDE_PRIORITY"):   # experiments: priority of the side stream (-1 = high)
+        ts.side_priority = int(os.environ["TNL_SIDE_PRIORITY"])
     if os.environ.get("TNL_SIDE_CUS"):        # experiments: CUs the side stream may use
         ts.side_cus = int(os.environ["TNL_SIDE_CUS"])
     if os.environ.get("TNL_NO_OVERLAP"):      # experiments: march + tile sort in order on the launch stream (kernels alone)
@@ -350,6 +352,8 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if os.environ.get("TNL_MAIN_PRIORITY"):   # experiments: the step's own stream at a priority above the side stream's
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["TNL_MAIN_PRIORITY"])))
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1022,7 +1022,7 @@ class TrainStep:
         evenly over the device (tnl_stream_create_cu_mask), else an ordinary stream."""
         n = int(self.side_cus)
         if n <= 0:
-            return torch.cuda.Stream()
+            return torch.cuda.Stream(priority=int(getattr(self, "side_priority", 0)))
         total = torch.cuda.get_device_properties(self.dev).multi_processor_count
         n = min(n, total)
         words = (total + 31) // 32
