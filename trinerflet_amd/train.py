@@ -330,21 +330,31 @@ class TrainStep:
         model, R = self.model, self.R
         Hg, casc = model.grid_size, model.cascade
         bits = model.density_bitfield.view(casc, -1)                                       # [casc, H^3/8] uint8
-        bounds = torch.tensor([[Hg + 1] * 3 + [-1] * 3] * casc, dtype=torch.int32, device=self.dev)
+        # one device buffer for both results, initialised by two device fills, ONE read-back:
+        #   [casc][6] bounding boxes {H+1, H+1, H+1, -1, -1, -1} | [3][R/8][2] row pieces {INT_MAX, -1}
+        rows = self.live_bands and R % 8 == 0
+        nb, ne = casc * 6, (3 * (R // 8) * 2 if rows else 0)
+        buf = torch.empty(nb + ne, dtype=torch.int32, device=self.dev)
+        buf[:nb].view(casc, 2, 3)[:, 0].fill_(Hg + 1)
+        buf[:nb].view(casc, 2, 3)[:, 1].fill_(-1)
+        bounds = buf[:nb].view(casc, 6)
         L.check(L.lib().tnl_occupancy_bounds(L.ptr(bits), L.u32(bits.shape[1]), L.u32(casc), L.ptr(bounds), L.stream()),
                 "occupancy_bounds")
         self._band_cache = {}
         self._row_ext = None
-        if self.live_bands and R % 8 == 0:
-            # per plane and 8-texel row group the columns a sample can touch (see _level_needs); read back with the box
-            ext = torch.tensor([0x7fffffff, -1], dtype=torch.int32, device=self.dev).repeat(3 * (R // 8))
+        if rows:
+            # per plane and 8-texel row group the columns a sample can touch (see _level_needs)
+            ext = buf[nb:].view(-1, 2)
+            ext[:, 0].fill_(0x7fffffff)
+            ext[:, 1].fill_(-1)
             L.check(L.lib().tnl_occupancy_row_extents(L.ptr(bits), L.u32(bits.shape[1]), L.u32(casc), L.u32(Hg),
                                                       L.f32(float(model.bound)), L.u32(R), L.ptr(ext), L.stream()),
                     "occupancy_row_extents")
-            ext = ext.cpu()
-            self._row_ext = ext.numpy().reshape(3, R // 8, 2).astype(np.int64)
+        host = buf.cpu().numpy()                                    # the one read-back
+        if rows:
+            self._row_ext = host[nb:].reshape(3, R // 8, 2).astype(np.int64)
         vals = [float("inf")] * 3 + [float("-inf")] * 3            # world-space box over the cascades
-        for k, bk in enumerate(bounds.tolist()):                    # the one read-back
+        for k, bk in enumerate(host[:nb].reshape(casc, 6).tolist()):
             if bk[3] < 0:
                 continue                                            # no occupied cell in this cascade
             sk = min(2.0 ** k, float(model.bound))
