@@ -28,6 +28,9 @@ def _traj():
 
 
 def test_base_geometry_fused_fp16_vs_reference_loop_fp32_psnr(cuda):
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()        # what earlier tests left in this process's caching allocator is not "in use"
     free, _ = torch.cuda.mem_get_info()
     if free < 96 * 2 ** 30:
         pytest.skip(f"needs 96 GB of free device memory, {free / 2 ** 30:.0f} GB available")
