@@ -558,8 +558,8 @@ def main():
                                   "recompute + dX + dW = 6*MAC flops"},
         "adam_coef": {"bytes": adam_bytes, "flops": 0.0,
                       "per_unit": "per live coefficient: 28 B inside the gradient rectangle, 24 B outside it; nothing outside a live rectangle"},
-        "plane_grad_binned": {"bytes": Ms * 3 * (2 * Cc + 12 + 4.4) + 3 * Cc * win_area(ts.J - 1, Rr) * 4, "flops": 0.0,
-                              "per_unit": "per sample and plane: 2*C B dF + 12 B position + 4.4 B list entries; + 4 B per window texel and channel stored"},
+        "plane_grad_binned": {"bytes": Ms * 3 * (2 * Cc + 1.13 * 12) + 3 * Cc * win_area(ts.J - 1, Rr) * 4, "flops": 0.0,
+                              "per_unit": "per sample and plane: 2*C B dF + 1.13 list entries of 12 B (sample id + its texel coordinates on the plane); + 4 B per window texel and channel stored"},
         "idwt_fwd": {"bytes": fwd_bytes, "flops": 0.0,
                      "per_unit": "per computed output texel and slice: 4 B of input bands + e (finest) or 4 B out, + 2*e for the texel-major layout pass"},
         "idwt_adjoint": {"bytes": adj_bytes, "flops": 0.0,

@@ -295,10 +295,13 @@ TNL_API int tnl_plane_grad_binned(const void *dfeat_half, const float *xyz, floa
  * _reduce consumes the sorted workspace together with dfeat.  Same workspace size and contents contract. */
 /* Layout of the tile lists inside a tnl_plane_grad_binned_workspace, in int32 units: out[0] = bins (sub-bins
  * included), out[1] = index of offsets[0] (out[0] + 1 entries; a tile's list spans offsets[tile * out[3]] ..
- * offsets[(tile + 1) * out[3]]), out[2] = index of the first list entry (sample ids), out[3] = sub-bins per tile.
- * A caller may reorder the entries INSIDE a tile's span between tnl_plane_grad_sort* and tnl_plane_grad_reduce
- * (trinerflet_amd.nerf.field.order_tile_lists sorts them by sample id: a reproducible summation order). */
-TNL_API int tnl_plane_grad_sort_layout(uint32_t R, int64_t *out);
+ * offsets[(tile + 1) * out[3]]), out[2] = index of the first list entry (sample ids), out[3] = sub-bins per tile,
+ * out[4] = index of the entries' positions (two floats per list entry, parallel to the ids: the sample's clipped
+ * texel coordinates on the list's plane, which the reduction reads instead of gathering xyz[id]); M as given to
+ * tnl_plane_grad_binned_workspace.  A caller may reorder the entries (ids AND positions alike) INSIDE a tile's span
+ * between tnl_plane_grad_sort* and tnl_plane_grad_reduce (trinerflet_amd.nerf.field.order_tile_lists sorts them by
+ * sample id: a reproducible summation order). */
+TNL_API int tnl_plane_grad_sort_layout(uint32_t M, uint32_t R, int64_t *out);
 TNL_API int tnl_plane_grad_sort(const float *xyz, float bound, uint32_t M, const int32_t *m_actual, uint32_t R,
                                 void *workspace, void *stream);
 /* _sort with the first pass (per-bin counts) already done by tnl_march_rays_train_binned: scan + fill only. */

@@ -43,13 +43,15 @@ __device__ __forceinline__ Foot footprint(const TexelTap& t) {
 template <bool FILL>
 __device__ __forceinline__ void bin_sample(float x, float y, float z, bool live, uint32_t i, float bound, int R, int TNX,
                                            int TNY, int* __restrict__ counts_or_cursor, uint32_t* __restrict__ entries,
-                                           int lane) {
+                                           int lane, float2* __restrict__ epos = nullptr) {
   int slot_r[3][4], lead_r[3][4], rank_r[3][4];
   bool act_r[3][4];
+  float fxs[3], fys[3];
 #pragma unroll
   for (int p = 0; p < 3; p++) {
     TexelTap t;
-    triplane_tap(x, y, z, bound, R, p, t);
+    triplane_texel(x, y, z, bound, R, p, fxs[p], fys[p]);
+    tap_from_texel(fxs[p], fys[p], R, t);
     const Foot f = footprint(t);
     const int base = p * TNX * TNY;
     // primary tile, run-aggregated
@@ -104,7 +106,12 @@ __device__ __forceinline__ void bin_sample(float x, float y, float z, bool live,
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int slot = __shfl(slot_r[p][k], lead_r[p][k]);
-        if (act_r[p][k]) entries[slot + rank_r[p][k]] = i;
+        if (act_r[p][k]) {
+          entries[slot + rank_r[p][k]] = i;
+          // the sample's clipped texel coordinates on this plane ride along: the reduction reads them in list order
+          // instead of gathering xyz[i] (a 12-byte read that costs a whole sector, as many requests as the dF row)
+          if (epos != nullptr) epos[slot + rank_r[p][k]] = make_float2(fxs[p], fys[p]);
+        }
       }
     }
   }

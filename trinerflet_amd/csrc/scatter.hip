@@ -11,8 +11,11 @@
 //   3. one workgroup per tile reduces its samples on the matrix cores (separable bilinear weights x dF, fp32
 //      accumulators in registers) and writes the finished tile with plain 16-byte stores -- every tile is
 //      written exactly once, so the 4*P-byte zero fill of the gradient disappears too.
-// HBM traffic per sample: 12 B xyz x3 passes + ~3.4 list entries x 4 B x2 + 6*C B of dF, versus 48*C B
-// of atomics; per step additionally the 4*P-byte tile stores that replace the memset (only the ROI's with a ROI).
+// HBM traffic per sample: 12 B xyz (the fill pass) + ~3.4 list entries x 12 B x2 (written by the fill pass, read by the
+// reduction: sample id + its clipped texel coordinates on the list's plane -- round 3; before, the reduction gathered
+// xyz[id], a 12-byte read that costs a sector, i.e. as many requests as the dF row: 0.40 -> 0.35 ms at base) + 6*C B of
+// dF, versus 48*C B of atomics; per step additionally the 4*P-byte tile stores that replace the memset (only the ROI's
+// with a ROI).
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,13 +37,13 @@ __device__ __forceinline__ uint32_t eff_m(uint32_t M, const int32_t* m_actual) {
 template <bool FILL>
 __global__ void __launch_bounds__(NT)
 k_bin(const float* __restrict__ xyz, float bound, uint32_t M, const int32_t* __restrict__ m_actual, int R, int TNX,
-      int TNY, int* __restrict__ counts_or_cursor, uint32_t* __restrict__ entries) {
+      int TNY, int* __restrict__ counts_or_cursor, uint32_t* __restrict__ entries, float2* __restrict__ epos) {
   const uint32_t Me = eff_m(M, m_actual);
   const uint32_t i = blockIdx.x * NT + threadIdx.x;
   const bool live = i < Me;
   const uint32_t il = live ? i : 0;
   bin_sample<FILL>(xyz[(size_t)il * 3], xyz[(size_t)il * 3 + 1], xyz[(size_t)il * 3 + 2], live, i, bound, R, TNX, TNY,
-                   counts_or_cursor, entries, threadIdx.x & 63);
+                   counts_or_cursor, entries, threadIdx.x & 63, epos);
 }
 
 // exclusive scan of the bin counts; also leaves a copy as the fill cursors.  Two tiny launches: (1) each
@@ -139,7 +142,8 @@ __device__ __forceinline__ h4v tr4(const char* p) {
 template <int C>
 __global__ void __launch_bounds__(NT)
 k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float* __restrict__ xyz, float bound, int R, int TNX,
-                  int TNY, const int* __restrict__ offsets, const uint32_t* __restrict__ entries, float grad_scale,
+                  int TNY, const int* __restrict__ offsets, const uint32_t* __restrict__ entries,
+                  const float2* __restrict__ epos, float grad_scale,
                   float* __restrict__ grad_out, int channel_major, int* __restrict__ nonfinite_flag, Roi roi) {
   constexpr int NTEX = TSX * TSY;
   constexpr int TILE_F = NTEX * C;
@@ -225,8 +229,9 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
   }
   int prev_c0 = -100;   // first of the (up to) two cwT rows this thread's previous record wrote
 
-  // prefetch registers for one record
-  float px = 0.f, py = 0.f, pz = 0.f;
+  // prefetch registers for one record: its texel coordinates on this plane (from the list) and its dF row
+  float px = 0.f, py = 0.f;
+  float2 npos = make_float2(0.f, 0.f);
   h8v pg[C / 8];
   bool pv = false;
   // two levels ahead: the record id of chunk t+2 is requested while the data of chunk t+1 (addressed by the id
@@ -235,13 +240,13 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
   bool nv = false;
   auto fetch_id = [&](int base) {
     nv = base + (int)threadIdx.x < end;
-    if (nv) nid = entries[base + threadIdx.x];
+    if (nv) { nid = entries[base + threadIdx.x]; npos = epos[base + threadIdx.x]; }
   };
   auto prefetch = [&]() {   // data of the chunk whose ids are in (nid, nv)
     pv = nv;
     if (pv) {
       const uint32_t i = nid;
-      px = xyz[(size_t)i * 3]; py = xyz[(size_t)i * 3 + 1]; pz = xyz[(size_t)i * 3 + 2];
+      px = npos.x; py = npos.y;
       const h8v* src = reinterpret_cast<const h8v*>(dfeat + ((size_t)p * Mcap + i) * C);   // plane-major [3][M][C]
 #pragma unroll
       for (int k = 0; k < C / 8; k++) pg[k] = src[k];   // (non-temporal loads here: 0.80 -> 0.85 ms, not used)
@@ -263,7 +268,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
       float wy0 = 0.f, wy1 = 0.f;
       if (pv) {
         TexelTap t;
-        triplane_tap(px, py, pz, bound, R, p, t);
+        tap_from_texel(px, py, R, t);
         const float wx = t.w01 + t.w11, wy = t.w10 + t.w11;  // weights are (1-wx|wx) x (1-wy|wy)
         const int lx0 = t.x0 - x_lo, lx1 = t.x1 - x_lo;
         ly0 = t.y0 - y_lo; ly1 = (t.y1 != t.y0) ? t.y1 - y_lo : -1;
@@ -368,11 +373,11 @@ inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 extern "C" {
 
-// bytes of scratch: counts, offsets(+1), cursor: one int per (plane, tile) each; entries: 12 * M uint32
+// bytes of scratch: counts, offsets(+1), cursor: one int per (plane, tile) each; entries: 12 * M uint32 + 12 * M float2
 uint64_t tnl_plane_grad_binned_workspace(uint32_t M, uint32_t R) {
   if (R % TSX != 0) return 0;
   const uint64_t nb = 3ull * (R / TSX) * (R / TSY) * BIN_SUBS;
-  return (3 * nb + 8 + (nb + 1023) / 1024 + 8) * 4 + 12ull * M * 4;
+  return (3 * nb + 8 + (nb + 1023) / 1024 + 8 + 2) * 4 + 12ull * M * 4 + 12ull * M * 8;   // + (fx, fy) per list entry
 }
 
 int tnl_plane_grad_binned(const void* dfeat_half, const float* xyz, float bound, uint32_t M,
@@ -385,10 +390,11 @@ int tnl_plane_grad_binned(const void* dfeat_half, const float* xyz, float bound,
 struct SortWs {
   int *counts, *offsets, *cursor, *block_tot;
   uint32_t* entries;
+  float2* epos;       // per list entry the sample's clipped texel coordinates on the list's plane
   int nb, nblk;
 };
 
-static SortWs sort_ws(void* workspace, uint32_t R) {
+static SortWs sort_ws(void* workspace, uint32_t R, uint32_t M = 0) {
   SortWs w;
   const int TNX = R / TSX, TNY = R / TSY;
   w.nb = 3 * TNX * TNY * BIN_SUBS;   // counters: BIN_SUBS sub-bins per (plane, tile), see bin_common.h
@@ -398,6 +404,9 @@ static SortWs sort_ws(void* workspace, uint32_t R) {
   w.cursor = w.offsets + w.nb + 1;
   w.block_tot = w.cursor + w.nb + 1;  // nblk ints, inside the slack before the entry list (see workspace())
   w.entries = reinterpret_cast<uint32_t*>(w.cursor + w.nb + 2 + w.nblk + 8);
+  uint32_t* after = w.entries + 12ull * M;                      // 12 entries per sample at most (4 tiles x 3 planes)
+  after += (reinterpret_cast<uintptr_t>(after) & 7) ? 1 : 0;    // 8-byte aligned
+  w.epos = reinterpret_cast<float2*>(after);
   return w;
 }
 
@@ -406,13 +415,14 @@ static SortWs sort_ws(void* workspace, uint32_t R) {
 // callers that post-process the lists -- TrainStep(deterministic=True) orders every tile's list by sample id, so that
 // the reduction's summation order (and with it every bit of the plane gradient) no longer depends on the arrival order
 // of the fill pass's atomics.
-int tnl_plane_grad_sort_layout(uint32_t R, int64_t* out) {
+int tnl_plane_grad_sort_layout(uint32_t M, uint32_t R, int64_t* out) {
   if (R % TSX != 0 || out == nullptr) return (int)hipErrorInvalidValue;
-  const SortWs w = sort_ws(nullptr, R);
+  const SortWs w = sort_ws(nullptr, R, M);
   out[0] = w.nb;
   out[1] = w.offsets - w.counts;
   out[2] = reinterpret_cast<int*>(w.entries) - w.counts;
   out[3] = BIN_SUBS;
+  out[4] = reinterpret_cast<int*>(w.epos) - w.counts;     // (fx, fy) float pairs, one per list entry
   return 0;
 }
 
@@ -423,20 +433,20 @@ static int plane_grad_sort_impl(const float* xyz, float bound, uint32_t M, const
   if (R % TSX != 0) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int TNX = R / TSX, TNY = R / TSY;
-  const SortWs w = sort_ws(workspace, R);
+  const SortWs w = sort_ws(workspace, R, M);
   if (!counted) {
     hipError_t e = hipMemsetAsync(w.counts, 0, (size_t)(w.nb + 1) * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
     if (M > 0) {
       hipLaunchKernelGGL(k_bin<false>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
-                         w.counts, w.entries);
+                         w.counts, w.entries, w.epos);
     }
   }
   hipLaunchKernelGGL(k_scan_local, dim3(w.nblk), dim3(256), 0, st, w.counts, w.nb, w.offsets, w.block_tot);
   hipLaunchKernelGGL(k_scan_fix, dim3(w.nblk), dim3(256), 0, st, w.nb, w.nblk, w.block_tot, w.offsets, w.cursor);
   if (M > 0) {
     hipLaunchKernelGGL(k_bin<true>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
-                       w.cursor, w.entries);
+                       w.cursor, w.entries, w.epos);
   }
   return (int)hipGetLastError();
 }
@@ -463,20 +473,21 @@ int tnl_plane_grad_reduce(const void* dfeat_half, const float* xyz, float bound,
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int TNX = R / TSX, TNY = R / TSY;
-  const SortWs w = sort_ws(const_cast<void*>(workspace), R);
+  const SortWs w = sort_ws(const_cast<void*>(workspace), R, M);
   const int* offsets = w.offsets;
   const uint32_t* entries = w.entries;
+  const float2* epos = w.epos;
   const _Float16* df = reinterpret_cast<const _Float16*>(dfeat_half);
   const int ntiles = roi.rw ? 3 * (roi.rw / TSX) * (roi.rh / TSY) : w.nb / BIN_SUBS;
   if (C == 16)
     hipLaunchKernelGGL(k_tile_accumulate<16>, dim3(ntiles), dim3(NT), 0, st, df, M, xyz, bound, (int)R, TNX, TNY,
-                       offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
+                       offsets, entries, epos, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   else if (C == 32)
     hipLaunchKernelGGL(k_tile_accumulate<32>, dim3(ntiles), dim3(NT), 0, st, df, M, xyz, bound, (int)R, TNX, TNY,
-                       offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
+                       offsets, entries, epos, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   else
     hipLaunchKernelGGL(k_tile_accumulate<48>, dim3(ntiles), dim3(NT), 0, st, df, M, xyz, bound, (int)R, TNX, TNY,
-                       offsets, entries, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
+                       offsets, entries, epos, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   return (int)hipGetLastError();
 }
 

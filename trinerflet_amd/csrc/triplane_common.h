@@ -13,6 +13,34 @@ struct TexelTap {
   float w00, w01, w10, w11;  // (y0,x0) (y0,x1) (y1,x0) (y1,x1)
 };
 
+// The clipped texel coordinates of a position on one plane (the first half of triplane_tap) ...
+__device__ __forceinline__ void triplane_texel(float x, float y, float z, float bound, int R, int plane, float& fx,
+                                               float& fy) {
+  const float ux = x / bound, uy = y / bound, uz = z / bound;
+  const float gx = plane == 2 ? uy : ux;
+  const float gy = plane == 1 ? uy : uz;
+  const float rm1 = (float)(R - 1);
+  fx = ((gx + 1.f) / 2.f) * rm1;
+  fy = ((gy + 1.f) / 2.f) * rm1;
+  fx = fminf(rm1, fmaxf(fx, 0.f));
+  fy = fminf(rm1, fmaxf(fy, 0.f));
+}
+
+// ... and corners + weights from them (the second half): tap_from_texel(triplane_texel(...)) == triplane_tap(...), bit
+// for bit -- the tile lists of scatter.hip carry (fx, fy) so that the reduction does not gather the position again.
+__device__ __forceinline__ void tap_from_texel(float fx, float fy, int R, TexelTap& t) {
+  const float flx = floorf(fx), fly = floorf(fy);
+  t.x0 = (int)flx;
+  t.y0 = (int)fly;
+  t.x1 = min(t.x0 + 1, R - 1);
+  t.y1 = min(t.y0 + 1, R - 1);
+  const float wx = fx - flx, wy = fy - fly;
+  t.w00 = (1.f - wx) * (1.f - wy);
+  t.w01 = wx * (1.f - wy);
+  t.w10 = (1.f - wx) * wy;
+  t.w11 = wx * wy;
+}
+
 __device__ __forceinline__ void triplane_tap(float x, float y, float z, float bound, int R, int plane, TexelTap& t) {
   const float ux = x / bound, uy = y / bound, uz = z / bound;
   const float gx = plane == 2 ? uy : ux;

@@ -116,14 +116,14 @@ def plane_grad_sort(xyz, bound, R, m_actual=None):
     return ws
 
 
-def order_tile_lists(ws, R):
+def order_tile_lists(ws, R, M):
     """Sorts every tile's list of sample ids ascending, in place (the counting sort leaves them in the arrival order of
     its atomics, so the tile reduction's fp32 summation order -- hence the last bits of the plane gradient -- differs
     from run to run).  With this the plane gradient is a pure function of its inputs.  A test / debugging knob
     (TrainStep(deterministic=True)): a 64-bit torch.sort over all list entries, ~10 ms at the base workload."""
-    lay = (C.c_int64 * 4)()
-    L.check(L.lib().tnl_plane_grad_sort_layout(L.u32(R), lay), "plane_grad_sort_layout")
-    nb, off_idx, ent_idx, subs = (int(v) for v in lay)
+    lay = (C.c_int64 * 5)()
+    L.check(L.lib().tnl_plane_grad_sort_layout(L.u32(M), L.u32(R), lay), "plane_grad_sort_layout")
+    nb, off_idx, ent_idx, subs, pos_idx = (int(v) for v in lay)
     w32 = ws.view(torch.int32)
     offsets = w32[off_idx:off_idx + nb + 1]
     tile_off = offsets[::subs].long()                      # nb / subs + 1 boundaries (the last = total entries)
@@ -131,9 +131,12 @@ def order_tile_lists(ws, R):
     if total == 0:
         return
     entries = w32[ent_idx:ent_idx + total]
+    pos = w32[pos_idx:pos_idx + 2 * total].view(total, 2)  # the entries' (fx, fy), moved with their ids
     seg = torch.searchsorted(tile_off[1:].contiguous(), torch.arange(total, device=ws.device), right=True)
     key = (seg << 32) | (entries.long() & 0xFFFFFFFF)
-    entries.copy_((torch.sort(key).values & 0xFFFFFFFF).to(torch.int32))
+    skey, perm = torch.sort(key)
+    entries.copy_((skey & 0xFFFFFFFF).to(torch.int32))
+    pos.copy_(pos[perm])
 
 
 def plane_grad_sort_workspace(M, R, device):

@@ -940,7 +940,7 @@ class TrainStep:
             if side is not None or sort_beside:
                 torch.cuda.current_stream().wait_event(ev_sort)
             if self.deterministic:
-                F_.order_tile_lists(sort_ws, R)
+                F_.order_tile_lists(sort_ws, R, xyzs.shape[0])
             F_.plane_grad_reduce(sort_ws, dfeat, xyzs, float(model.bound), C, R, g_cm, channel_major=True,
                                  nonfinite_flag=self.nonfinite, roi=self._roi10() if roi is not None else None)
             self._mark("plane_grad_binned")
