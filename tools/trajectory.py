@@ -208,18 +208,25 @@ def main():
     ap.add_argument("--skip-reference", action="store_true")
     ap.add_argument("--repeat", type=int, default=1, help="run every loop this many times (run-to-run spread of the PSNR)")
     ap.add_argument("--fused-fp32", action="store_true", help="also the fused step on fp32 planes")
+    ap.add_argument("--no-pieces", action="store_true", help="also the fused step with whole windows / rectangles (live_bands=False)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     scene = make_scene(dev)
     batches = batches_of(scene[0], args.steps, args.rays)
-    rep = {"psnr_runs": {"fused_fp16": [], "fused_fp32_planes": [], "reference_loop": []}}
+    rep = {"psnr_runs": {"fused_fp16": [], "fused_fp16_no_pieces": [], "fused_fp32_planes": [], "reference_loop": []}}
     for _ in range(args.repeat):
         fused = run_fused(args.workload, dev, args.steps, args.rays, scene, batches)
         fused.pop("_model")
         torch.cuda.empty_cache()
         rep["fused"] = fused
         rep["psnr_runs"]["fused_fp16"].append(fused["held_out_psnr_db"])
+        if args.no_pieces:
+            npc = run_fused(args.workload, dev, args.steps, args.rays, scene, batches, ts_kwargs={"live_bands": False})
+            npc.pop("_model")
+            torch.cuda.empty_cache()
+            rep["psnr_runs"]["fused_fp16_no_pieces"].append(npc["held_out_psnr_db"])
+            rep["no_pieces_after_step_64_ms_per_step"] = npc.get("after_step_64_ms_per_step")
         if args.fused_fp32:
             f32 = run_fused(args.workload, dev, args.steps, args.rays, scene, batches, plane_dtype=torch.float32)
             f32.pop("_model")
