@@ -67,3 +67,36 @@ def test_base_geometry_fused_fp16_vs_reference_loop_fp32_psnr(cuda):
     # the trajectory really moved: the sample count fell by more than 3x from the untrained grid and a window formed
     assert fused["samples_per_step_first_last"][1] * 3 < fused["samples_per_step_first_last"][0], msg
     assert fused["window_first_last"][1] is not None and fused["deferred_steps"] > steps // 2, msg
+
+
+def test_real_trajectory_with_and_without_the_occupancy_pieces_is_the_same_training(cuda):
+    """Base geometry from an untrained grid, real density-grid refreshes (two cascades, a window that forms and moves),
+    ordered plane-gradient reduction: 192 steps with the occupancy pieces (TrainStep(live_bands=True)) and without -- every
+    step's rendered colours and sample count, and all parameters and the occupancy bitfield at the end, bit for bit.
+    (Stops before step 256: the partial refreshes that start there resolve cells drawn twice by a race, in the
+    reference's index_put_ as in this build's scatter, so two runs of the SAME variant part ways there.)"""
+    import gc
+    import importlib.util
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 64 * 2 ** 30:
+        pytest.skip(f"needs 64 GB of free device memory, {free / 2 ** 30:.0f} GB available")
+    spec = importlib.util.spec_from_file_location("tnl_check_pieces", os.path.join(ROOT, "tools", "check_pieces_trajectory.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    T = chk.T
+    steps = 192
+    scene = T.make_scene(cuda)
+    batches = T.batches_of(scene[0], steps, 60000)
+    a = chk.run("base", cuda, steps, scene, batches, False)
+    torch.cuda.empty_cache()
+    b = chk.run("base", cuda, steps, scene, batches, True)
+    assert b[4] >= 64 and sum(w is not None for w in b[1]) >= 80, (b[4], sum(w is not None for w in b[1]))
+    assert a[4] == 0
+    for k in range(steps):
+        assert a[0][k][:2] == b[0][k][:2], (k, a[0][k], b[0][k], a[1][k], b[1][k])
+    assert a[1] == b[1]
+    assert torch.equal(a[3], b[3])
+    for x, y in zip(a[2], b[2]):
+        assert torch.equal(x, y)
