@@ -71,10 +71,10 @@ def test_base_geometry_fused_fp16_vs_reference_loop_fp32_psnr(cuda):
 
 def test_real_trajectory_with_and_without_the_occupancy_pieces_is_the_same_training(cuda):
     """Base geometry from an untrained grid, real density-grid refreshes (two cascades, a window that forms and moves),
-    ordered plane-gradient reduction: 192 steps with the occupancy pieces (TrainStep(live_bands=True)) and without -- every
+    ordered plane-gradient reduction: 288 steps with the occupancy pieces (TrainStep(live_bands=True)) and without -- every
     step's rendered colours and sample count, and all parameters and the occupancy bitfield at the end, bit for bit.
-    (Stops before step 256: the partial refreshes that start there resolve cells drawn twice by a race, in the
-    reference's index_put_ as in this build's scatter, so two runs of the SAME variant part ways there.)"""
+    (The two partial refreshes at steps 256 and 272 are inside: a cell drawn twice keeps the larger candidate in this
+    build -- one of the outcomes of the reference's racing index assignment -- so the run is reproducible.)"""
     import gc
     import importlib.util
     gc.collect()
@@ -86,7 +86,7 @@ def test_real_trajectory_with_and_without_the_occupancy_pieces_is_the_same_train
     chk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(chk)
     T = chk.T
-    steps = 192
+    steps = 288
     scene = T.make_scene(cuda)
     batches = T.batches_of(scene[0], steps, 60000)
     a = chk.run("base", cuda, steps, scene, batches, False)

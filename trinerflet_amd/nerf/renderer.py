@@ -446,11 +446,14 @@ class NeRFRenderer(nn.Module):
                 xyzs = xyzs + (jitter(cas, xyzs) * 2 - 1) * half_grid_size
                 dens = sigma_of(xyzs).reshape(-1).detach().float() * self.density_scale
                 tmp_c = -torch.ones(H ** 3 + 1, dtype=tmp_grid.dtype, device=dev)   # + the spare slot of the picks above
+                # a cell drawn twice keeps the LARGER of its candidates: the reference's index assignment
+                # (renderer.py:513) keeps an arbitrary one -- a race, so two runs of one training part ways at the
+                # first partial refresh, and on several ranks each could keep a different one (the grids must stay
+                # bit-identical across ranks).  The maximum is one of the outcomes the reference can produce, and it is
+                # reproducible.
                 if world == 1:
-                    tmp_c[indices] = dens
+                    tmp_c.scatter_reduce_(0, indices, dens, reduce="amax", include_self=True)
                 else:
-                    # a cell drawn twice keeps the larger value (index assignment would keep an arbitrary one,
-                    # possibly a different one on each rank; the grids must stay bit-identical across ranks)
                     tmp_c.scatter_reduce_(0, gather(indices), gather(dens), reduce="amax", include_self=True)
                 tmp_grid[cas] = tmp_c[:H ** 3]
         # The same values as the reference's masked assignment / .item() / packbits / .item() sequence, with ONE host
