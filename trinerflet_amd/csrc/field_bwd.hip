@@ -74,6 +74,10 @@ namespace {
 // MEASURED: 0.93 ms against mode 0's 0.76: a chain wave needs ~15.7 k cycles per 32 samples with or without the weight
 // gradients (mode 0: two chain-and-gradient waves per SIMD deliver 64 samples per 25.7 k); what bounds the kernel is
 // the serial latency of ONE wave's layer chain, and only a second chain wave on the SIMD -- not a helper -- hides it.
+// (A THIRD chain wave per SIMD, -DTNL_BWD_NW=12, as the code stands: 384-sample stage images leave no room for the 50 KB
+//  of weight fragments in LDS, so they come from L2, and 168 registers spill 54 dwords: 1.49 ms.  It would take a form
+//  whose stages and weights fit together -- e.g. the forward layer-0 fragments read from L2 with the inputs' prefetch --
+//  and ~20 fewer live registers in the chain.)
 template <int C, int H, int NW, bool ATOMIC, int PART = 0, int MODE = 0>
 struct BwdGeom {
   using G = FieldGeom<C, H>;
