@@ -74,10 +74,11 @@ namespace {
 // MEASURED: 0.93 ms against mode 0's 0.76: a chain wave needs ~15.7 k cycles per 32 samples with or without the weight
 // gradients (mode 0: two chain-and-gradient waves per SIMD deliver 64 samples per 25.7 k); what bounds the kernel is
 // the serial latency of ONE wave's layer chain, and only a second chain wave on the SIMD -- not a helper -- hides it.
-// (A THIRD chain wave per SIMD, -DTNL_BWD_NW=12, as the code stands: 384-sample stage images leave no room for the 50 KB
-//  of weight fragments in LDS, so they come from L2, and 168 registers spill 54 dwords: 1.49 ms.  It would take a form
-//  whose stages and weights fit together -- e.g. the forward layer-0 fragments read from L2 with the inputs' prefetch --
-//  and ~20 fewer live registers in the chain.)
+// (A THIRD chain wave per SIMD, -DTNL_BWD_NW=12: 384-sample stage images leave no room for the 60 KB of weight
+//  fragments in LDS.  With all of them read from L2 and 54 dwords spilled at 168 registers: 1.49 ms.  With the two
+//  layer-0 sets alone in L2 (LDSW_PART: 36 KB of fragments beside 120 KB of stages), no input prefetch and 33 spilled
+//  dwords: 0.99 ms -- still behind the 8-wave form's 0.76: five 12-wave barriers per super-tile and the spills cost more
+//  than the third wave hides.)
 template <int C, int H, int NW, bool ATOMIC, int PART = 0, int MODE = 0>
 struct BwdGeom {
   using G = FieldGeom<C, H>;
@@ -117,7 +118,11 @@ struct BwdGeom {
   static constexpr size_t COPY_BYTES = (DB ? 2 : 1) * (XS_BYTES + YS_BYTES) + FS_BYTES;   // one stage set (PW: one per wave)
   static constexpr size_t BASE_BYTES = COPIES * COPY_BYTES + STAGE_BYTES;
   static constexpr bool LDSW = BASE_BYTES + W_BYTES <= 160 * 1024;  // weights cached in LDS when they fit
-  static constexpr size_t LDS_BYTES = BASE_BYTES + (LDSW ? W_BYTES : 0);
+  // ... or all but the two layer-0 sets (forward F0 .. F1, transposed T0 .. NTOT: each used once per super-tile, at its
+  // start and at its end), which then come from L2 -- what lets a 12-wave workgroup's 384-sample stages fit
+  static constexpr size_t WP_BYTES = (size_t)(G::T0 - G::F1) * 1024;
+  static constexpr bool LDSW_PART = !LDSW && PART == 0 && !ATOMIC && BASE_BYTES + WP_BYTES <= 160 * 1024;
+  static constexpr size_t LDS_BYTES = BASE_BYTES + (LDSW ? W_BYTES : (LDSW_PART ? WP_BYTES : 0));
   static constexpr int NT0 = G::OB * G::IB0, NT1 = G::OB, NT2 = G::OB, NT3 = G::OB * G::OB, NT4 = G::OB;
   static constexpr int A0 = (NT0 + NW - 1) / NW, A1 = (NT1 + NW - 1) / NW, A2 = (NT2 + NW - 1) / NW,
                        A3 = (NT3 + NW - 1) / NW, A4 = (NT4 + NW - 1) / NW;
@@ -271,6 +276,13 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   const half8* w = packed;    // forward fragments (and, outside PART 2, all of them)
   const half8* wH = packed;   // layers 3, 4 forward and 4, 3, 2 transposed
   const half8* wT = packed;   // transposed fragments of layers 1 and 0
+  const half8* w0f = packed;  // forward layer-0 fragments (w's range [F0, F1)) and
+  const half8* w0t = packed;  // transposed layer-0 fragments (wT's range [T0, NTOT)): where those two sets are read from
+  if (B::LDSW_PART) {
+    half8* wl = reinterpret_cast<half8*>(smem + B::BASE_BYTES);
+    for (int i = threadIdx.x; i < (G::T0 - G::F1) * 64; i += BW_THREADS) wl[i] = packed[G::F1 * 64 + i];
+    w = wT = wH = wl - G::F1 * 64;    // fragments F1 .. T0-1 from LDS; w0f / w0t stay in global memory (L2)
+  }
   if (B::LDSW) {
     half8* wl = reinterpret_cast<half8*>(smem + B::BASE_BYTES);
     if (PART == 1) {
@@ -286,6 +298,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     if (PART != 1) w = wl;
   }
+  if (!B::LDSW_PART) { w0f = w; w0t = wT; }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
@@ -358,7 +371,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       }
     }
   };
-  constexpr bool PREFETCH = PART != 1;   // the colour half of hidden 128 is register-bound: its 44 B of inputs are read in place
+  // the colour half of hidden 128 is register-bound: its 44 B of inputs are read in place; so is a 12-wave workgroup
+  // (168 registers per lane), whose three waves per SIMD cover the load instead
+  constexpr bool PREFETCH = PART != 1 && NW < 12;
   if (RL && team == 1) {
     for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
       __syncthreads();
@@ -395,7 +410,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     for (int k = 0; k < TNL_BWD_STAGGER; k++) __syncthreads();
   }
   for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
-    if (!B::LDSW || PART == 1) {
+    if ((!B::LDSW && !B::LDSW_PART) || PART == 1) {
       // Weight fragments read from global memory (L2) inside the loop: the 8 layer-2 fragments of PART 1, and all 180
       // of the one-launch hidden-128 kernel (atomic mode only, the drop-in autograd path).  Keep the compiler from
       // hoisting these loop-invariant loads out of the super-tile loop: it tried to hold them all in registers and
@@ -406,7 +421,11 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       // (27 / 47 ms), H1 / H3 / H4 kept in LDS stages instead of registers (16 ms), the weights streamed through a
       // 56-KB LDS window in four phases per super-tile (10.4 ms).
       asm volatile("" : "+s"(w));
-      if (!B::LDSW) wT = wH = w;
+      if (!B::LDSW && !B::LDSW_PART) wT = wH = w;
+    }
+    if (B::LDSW_PART) {   // the two layer-0 fragment sets are read from L2 inside the loop, not kept in registers across it
+      asm volatile("" : "+s"(w0f));
+      asm volatile("" : "+s"(w0t));
     }
     const uint32_t i = st * ST + col;
     const bool valid = i < M;
@@ -430,7 +449,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       for (int ks = 0; ks < G::KS0; ks++) {
 #pragma unroll
         for (int ob = 0; ob < G::OB; ob++)
-          acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], in.fk[ks], acc0[ob]);
+          acc0[ob] = MFMA32(w0f[(G::F0 + ob * G::KS0 + ks) * 64 + lane], in.fk[ks], acc0[ob]);
       }
     }
     Chain<C, H> ch;
@@ -619,7 +638,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       for (int ib = 0; ib < G::IB0; ib++) {
         f32x16 df = zero16();
 #pragma unroll
-        for (int ks = 0; ks < G::KH; ks++) df = MFMA32(wT[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
+        for (int ks = 0; ks < G::KH; ks++) df = MFMA32(w0t[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
         // Registers 4q..4q+3 hold features 32 ib + 8q + 4h .. +3 of sample r: a lane owns four 8-byte pieces of its
         // 64-byte row.  The two lanes of a sample trade two pieces each (v_permlane32_swap: lanes r and r + 32), after
         // which lane (r, h) holds features 32 ib + 16h .. +15 -- 32 contiguous bytes, two 16-byte stores instead of
@@ -663,7 +682,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     for (int ib = 0; ib < G::IB0; ib++) {
       f32x16 df = zero16();
 #pragma unroll
-      for (int ks = 0; ks < G::KH; ks++) df = MFMA32(wT[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
+      for (int ks = 0; ks < G::KH; ks++) df = MFMA32(w0t[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
 #pragma unroll
       for (int g = 0; g < 16; g++) {
         const int f = 32 * ib + acc_row(g, h);
