@@ -24,7 +24,7 @@ COMMON += os.environ.get("TNL_HIPCC_FLAGS", "").split()
 # VGPRs instead of AGPRs (saves the v_accvgpr_read per element; field backward 1.06 -> 1.01 ms at base)
 MFMA_VGPR = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 PER_FILE = {"raymarch.hip": ["-ffp-contract=off"], "rays.hip": ["-ffp-contract=off"],
-            "field_bwd.hip": MFMA_VGPR, "field.hip": MFMA_VGPR, "scatter.hip": MFMA_VGPR, "render.hip": MFMA_VGPR}
+            "field_bwd.hip": MFMA_VGPR, "field_bwd_rows.hip": MFMA_VGPR, "field.hip": MFMA_VGPR, "scatter.hip": MFMA_VGPR, "render.hip": MFMA_VGPR}
 
 
 def _newer(src, dst, extra=()):

@@ -23,7 +23,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/trinerflet_hip.h"
+#include "field_bwd_rows.h"
 #include "field_device.h"
 
 #ifndef TNL_BWD_NW
@@ -35,6 +38,9 @@
                          // Round-3 measurements at base, kernel alone (ms):
                          // mode 0 0.77-0.78 | mode 1 0.83 | mode 2 stagger 0: 0.75, stagger 3 / 5 / 7: 0.94 / 0.91 / 0.93
                          // | mode 3 0.93-0.94
+#ifndef TNL_BWD_ROWS
+#define TNL_BWD_ROWS 1   // hidden-64 binned backward: 1 = k_field_bwd_rows (register-only weight gradients), 0 = the shared-stage forms
+#endif
 #ifndef TNL_BWD_STAGGER
 #define TNL_BWD_STAGGER 0   // MODE 2: barriers by which the second team trails the first (10 per super-tile)
 #endif
@@ -849,7 +855,16 @@ int launch_bwd(const float* gsig, const float* grgb, const float* sigma, const v
                float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW, void* workspace,
                const int32_t* m_actual, void* dfeat, hipStream_t st) {
   if (dfeat != nullptr) {
-    if constexpr (TNL_SPLIT_H64 && H == 64)       // two launches split by layer, 4-wave workgroups, two per CU
+    if constexpr (TNL_BWD_ROWS && H == 64)        // round 4: no stage images, no barriers (k_field_bwd_rows)
+    {
+      uint32_t nslab = 0;
+      const int e = tnl_bwd_rows_launch(C, gsig, grgb, feats, dirs, M, packed, workspace, m_actual, dfeat, st, &nslab);
+      if (e != 0) return e;
+      hipLaunchKernelGGL(k_slab_reduce, dim3((FieldGeom<C, H>::NW + 15) / 16), dim3(256), 0, st,
+                         reinterpret_cast<const float*>(workspace), (int)nslab, (int)FieldGeom<C, H>::NW, gradW);
+      return (int)hipGetLastError();
+    }
+    else if constexpr (TNL_SPLIT_H64 && H == 64)       // two launches split by layer, 4-wave workgroups, two per CU
       return launch_bwd_impl<C, H, 4, false, 0>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW,
                                                 workspace, m_actual, dfeat, st);
     else if constexpr (TNL_BWD_MODE == 1 && H == 64)   // per-wave weight gradients: 4 waves per workgroup, one per SIMD, no barriers
