@@ -226,9 +226,9 @@ def test_trainstep_window_equals_whole_plane(cuda, rays60k, cfg):
             (cfg, bad, noise, a.numel())
 
 
-def _render_model(cuda, bf):
-    """The large configuration with a medium dense enough that rays end by transmittance as well as by leaving the box."""
-    m = _model(cuda, "large", seed=6)
+def _render_model(cuda, bf, cfg="large"):
+    """A README configuration with a medium dense enough that rays end by transmittance as well as by leaving the box."""
+    m = _model(cuda, cfg, seed=6)
     m.density_bitfield.copy_(torch.from_numpy(bf).to(cuda))
     m.eval()
     # density_scale (renderer.py:309,352: sigmas = self.density_scale * sigmas) chosen so that the median optical depth
@@ -352,6 +352,125 @@ def test_test_render_800x800_device_loop_equals_host_loop_large_geometry(cuda):
     assert float((one["weights_sum"] == dev["weights_sum"]).float().mean()) > 0.95
     ws = dev["weights_sum"].reshape(-1)
     assert 0.1 < float((ws > 0.5).float().mean()) < 0.4                # the ball covers about a quarter of the image
+
+
+@pytest.mark.parametrize("cfg", ["base", "large"])
+def test_one_kernel_render_at_readme_geometry_vs_oracle_loop(cuda, rays60k, cfg):
+    """The DEFAULT of run_cuda's eval branch -- render_mode="kernel", csrc/render.hip k_render_rays, for hidden 128 its
+    one-workgroup-per-CU form -- at the README geometries (base: C 32 / hidden 64, large: C 48 / hidden 128; R = 2048,
+    max_steps = 4096; reference: renderer.py:324-374 over raymarching.cu:701-905):
+      (i)   a 4 096-ray subset against the ORACLE loop (C march_rays / composite_rays, the reference's n_step rule)
+            evaluating the same HIP field: image / weights / depth to 2e-5 -- the quantities that do not depend on the
+            loop's schedule;
+      (ii)  against the oracle loop with its own CPU field in the kernel's operand precision: 1e-3 (north_star);
+      (iii) the full 800 x 800 image against the device-driven loop: fp32 rounding everywhere, >= 95 % of the rays to the bit."""
+    _need_memory()
+    from tests.test_reference_pins import oracle_infer_loop
+    o, d, _, bf = rays60k
+    n = 4096
+    o, d = np.ascontiguousarray(o[:n]), np.ascontiguousarray(d[:n])
+    m = _render_model(cuda, bf, cfg)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    bg = 1.0
+    with torch.no_grad():
+        one = m.render(t(o)[None], t(d)[None], staged=True, bg_color=bg, perturb=False, dt_gamma=0, max_steps=4096,
+                       T_thresh=1e-4, render_mode="kernel")
+    aabb = np.array([-BOUND] * 3 + [BOUND] * 3, np.float32)
+    nears, fars = cref.near_far_from_aabb(o, d, aabb, 0.2)
+
+    def finish(ws, dep, img):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return img + (1 - ws)[:, None] * bg, np.clip(dep - nears, 0, None) / (fars - nears)
+
+    def field_hip(x, dd):
+        with torch.no_grad():
+            s, c = m(t(x), t(dd))
+        return (m.density_scale * s.float()).cpu().numpy(), c.float().cpu().numpy()
+    ws, dep, img, hist = oracle_infer_loop(o, d, nears, fars, bf, BOUND, 4096, field_hip)
+    image, depth = finish(ws, dep, img)
+    assert len(hist) > 100 and (ws > 1 - 2e-4).sum() > 50 and 0.05 * n < (ws > 0.5).sum() < 0.5 * n
+    got_i, got_w = one["image"][0].cpu().numpy(), one["weights_sum"].reshape(-1).cpu().numpy()
+    got_d = one["depth"][0].cpu().numpy()
+    np.testing.assert_allclose(got_i, image, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(got_w, ws, rtol=0, atol=2e-5)
+    hit = np.isfinite(depth)
+    np.testing.assert_allclose(got_d[hit], depth[hit], rtol=0, atol=2e-5)
+    assert np.isnan(got_d[~hit]).all()
+    # (ii) the oracle's own field, fp16 planes / operands, fp32 accumulation
+    planes = m.encoder.get_planes().detach().cpu()
+    W = [w.detach().cpu() for w in (m.sigma_net[0].weight, m.sigma_net[1].weight, m.color_net[0].weight,
+                                    m.color_net[1].weight, m.color_net[2].weight)]
+    pl16 = planes.half().float()
+    del planes
+
+    def field_cpu(x, dd):
+        with torch.no_grad():
+            s, c = ofield.field(pl16, torch.from_numpy(x), torch.from_numpy(dd), W, BOUND, fp16=True)
+        return (m.density_scale * s).numpy(), c.numpy()
+    ws2, dep2, img2, _ = oracle_infer_loop(o, d, nears, fars, bf, BOUND, 4096, field_cpu)
+    image2, _ = finish(ws2, dep2, img2)
+    assert np.abs(got_i - image2).max() < 1e-3 and np.abs(got_w - ws2).max() < 1e-3
+    # (iii) the whole image
+    poses = synthetic.hemisphere_poses(3, seed=7)
+    pix = np.stack([np.full(640000, 1), np.arange(640000)], -1)
+    fo, fd = synthetic.get_rays(poses, pix)
+    with torch.no_grad():
+        dev = m.render(t(fo)[None], t(fd)[None], staged=True, bg_color=bg, perturb=False, max_steps=4096, T_thresh=1e-4,
+                       render_mode="device_loop")
+        ker = m.render(t(fo)[None], t(fd)[None], staged=True, bg_color=bg, perturb=False, max_steps=4096, T_thresh=1e-4)
+    assert float((ker["image"] - dev["image"]).abs().max()) < 5e-6
+    assert float((ker["weights_sum"] - dev["weights_sum"]).abs().max()) < 5e-6
+    assert float((ker["weights_sum"] == dev["weights_sum"]).float().mean()) > 0.95
+    # (all three colour channels to the bit: fewer -- the loop adds a ray's samples to the image in groups of n_step across
+    #  iterations, the kernel in one running sum per ray; 82 % measured at base)
+    assert float((ker["image"] == dev["image"]).all(-1).float().mean()) > 0.7
+    dk, dd_ = torch.nan_to_num(ker["depth"], nan=-1.0), torch.nan_to_num(dev["depth"], nan=-1.0)
+    assert float((dk - dd_).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("cfg", ["base", "large"])
+def test_one_kernel_render_stops_at_exactly_max_steps(cuda, rays60k, cfg):
+    """A ray still alive after max_steps samples: the one-kernel render composites exactly max_steps samples (the alive-ray
+    loop's cap depends on its schedule: max_steps .. max_steps + 7, renderer.py:338-372 -- stated in INTEGRATION.md).  The
+    oracle loop run ONE RAY AT A TIME takes one sample per iteration (n_step = max(min(1 // 1, 8), 1)), i.e. it stops at
+    exactly max_steps samples too: the two must agree to fp32 rounding."""
+    _need_memory()
+    from tests.test_reference_pins import oracle_infer_loop
+    _, _, _, bf_ball = rays60k
+    m = _render_model(cuda, bf_ball, cfg)
+    m.density_scale = m.density_scale * 0.002         # nearly transparent: no ray ends by transmittance
+    # The step is dt_min = 2 sqrt(3) / max_steps (raymarching.cu:338-346): only a chord longer than 2 sqrt(3) = 3.46 through
+    # OCCUPIED space holds more than max_steps samples -- every cell occupied, rays along the box's space diagonals (5.2).
+    bf = np.full_like(bf_ball, 255)
+    m.density_bitfield.fill_(255)
+    rng = np.random.default_rng(5)
+    u = np.array([[1, 1, 1], [1, 1, -1], [1, -1, 1], [-1, 1, 1]], np.float64)[rng.integers(0, 4, 16)] + 0.04 * rng.standard_normal((16, 3))
+    u /= np.linalg.norm(u, axis=-1, keepdims=True)
+    o16, d16 = (4.0311 * u).astype(np.float32), (-u).astype(np.float32)
+    aabb = np.array([-BOUND] * 3 + [BOUND] * 3, np.float32)
+    n16, f16 = cref.near_far_from_aabb(o16, d16, aabb, 0.2)
+    assert ((f16 - n16) > 4.5).all()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    K = 96
+    with torch.no_grad():
+        cap = m.render(t(o16)[None], t(d16)[None], staged=True, bg_color=0.0, perturb=False, max_steps=K, T_thresh=1e-4,
+                       render_mode="kernel")
+        full = m.render(t(o16)[None], t(d16)[None], staged=True, bg_color=0.0, perturb=False, max_steps=4096, T_thresh=1e-4,
+                        render_mode="kernel")
+
+    def field_hip(x_, d_):
+        with torch.no_grad():
+            s, c = m(t(x_), t(d_))
+        return (m.density_scale * s.float()).cpu().numpy(), c.float().cpu().numpy()
+    ws = np.zeros(16, np.float32)
+    img = np.zeros((16, 3), np.float32)
+    for k in range(16):
+        w1, _, i1, hist = oracle_infer_loop(o16[k:k + 1], d16[k:k + 1], n16[k:k + 1], f16[k:k + 1], bf, BOUND, K, field_hip)
+        assert len(hist) == K and hist[-1] == 1          # alive to the cap, one sample per iteration
+        ws[k], img[k] = w1[0], i1[0]
+    np.testing.assert_allclose(cap["weights_sum"].reshape(-1).cpu().numpy(), ws, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(cap["image"][0].cpu().numpy(), img, rtol=0, atol=2e-6)
+    assert torch.isfinite(full["weights_sum"]).all()
 
 
 def test_trainstep_window_equals_whole_plane_bit_for_bit_when_deterministic(cuda, rays60k):

@@ -27,7 +27,10 @@ def _traj():
     return mod
 
 
-def test_base_geometry_fused_fp16_vs_reference_loop_fp32_psnr(cuda):
+def _psnr_pairs(cuda, scene_name, k_fused=2, k_ref=3):
+    """k_fused runs of the fused fp16-plane TrainStep (the second and later ones with deterministic=True: the ordered
+    plane-gradient reduction) and k_ref runs of the reference-precision loop, all on the same batches / perturbation
+    noise / refresh draws; returns the report."""
     import gc
     gc.collect()
     torch.cuda.empty_cache()        # what earlier tests left in this process's caching allocator is not "in use"
@@ -36,37 +39,70 @@ def test_base_geometry_fused_fp16_vs_reference_loop_fp32_psnr(cuda):
         pytest.skip(f"needs 96 GB of free device memory, {free / 2 ** 30:.0f} GB available")
     T = _traj()
     steps = int(os.environ.get("TNL_TRAJ_STEPS", "512"))
-    scene = T.make_scene(cuda)
+    scene = T.make_scene(cuda, scene=scene_name)
     batches = T.batches_of(scene[0], steps, 60000)
-    fused = T.run_fused("base", cuda, steps, 60000, scene, batches)
-    fused.pop("_model")
-    torch.cuda.empty_cache()
-    ref = T.run_reference_loop("base", cuda, steps, 60000, scene, batches)
-    ref.pop("_model")
-    rep = {"fused": fused, "reference_loop": ref,
-           "psnr_difference_db": round(fused["held_out_psnr_db"] - ref["held_out_psnr_db"], 4)}
+    fused_runs, ref_runs = [], []
+    for k in range(k_fused):
+        fused = T.run_fused("base", cuda, steps, 60000, scene, batches, ts_kwargs={"deterministic": k > 0})
+        model = fused.pop("_model")
+        if k == 0:
+            energy = T.level_energy(model)
+        del model
+        fused_runs.append(fused)
+        torch.cuda.empty_cache()
+    for k in range(k_ref):
+        ref = T.run_reference_loop("base", cuda, steps, 60000, scene, batches)
+        ref.pop("_model")
+        ref_runs.append(ref)
+        torch.cuda.empty_cache()
+    pf = [r["held_out_psnr_db"] for r in fused_runs]
+    pr = [r["held_out_psnr_db"] for r in ref_runs]
+    rep = {"scene": scene_name, "fused": fused_runs[0], "reference_loop": ref_runs[0], "psnr_fused_db": pf,
+           "psnr_reference_loop_db": pr, "level_energy_fused": energy,
+           "psnr_mean_difference_db": round(sum(pf) / len(pf) - sum(pr) / len(pr), 4)}
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
-        with open(os.path.join(out, "trajectory_base.json"), "w") as f:
+        with open(os.path.join(out, f"trajectory_base_{scene_name}.json"), "w") as f:
             json.dump(rep, f, indent=1)
-    msg = (f"fused fp16 planes {fused['held_out_psnr_db']:.3f} dB vs reference loop fp32 planes "
-           f"{ref['held_out_psnr_db']:.3f} dB; fused {fused['wall_ms_per_step']:.2f} ms/step over the trajectory "
-           f"({fused['second_half_ms_per_step']:.2f} in its second half), reference loop {ref['wall_ms_per_step']:.1f} ms/step; "
-           f"window {fused['window_first_last']}, samples/step {fused['samples_per_step_first_last']}")
+    return rep
+
+
+def _check_psnr(rep, steps_floor_db):
+    fused, ref = rep["fused"], rep["reference_loop"]
+    msg = (f"[{rep['scene']}] fused fp16 planes {rep['psnr_fused_db']} dB vs reference loop fp32 planes "
+           f"{rep['psnr_reference_loop_db']} dB (means differ by {rep['psnr_mean_difference_db']:+.3f} dB); fused "
+           f"{fused['wall_ms_per_step']:.2f} ms/step over the trajectory ({fused['second_half_ms_per_step']:.2f} in its second "
+           f"half), reference loop {ref['wall_ms_per_step']:.1f} ms/step; window {fused['window_first_last']}, samples/step "
+           f"{fused['samples_per_step_first_last']}; level energy {rep['level_energy_fused']}")
     print(msg)
-    assert fused["held_out_psnr_db"] > 25.0 and ref["held_out_psnr_db"] > 25.0, msg
+    assert min(rep["psnr_fused_db"]) > steps_floor_db and min(rep["psnr_reference_loop_db"]) > steps_floor_db, msg
     # north_star: PSNR within 0.1 dB of the reference.  Both loops are chaotic in the last bits (float atomics in the
     # reference-precision backward, tile-list order in the fused one; Adam with eps 1e-15 amplifies either, and the
-    # occupancy grid they prune with follows): four runs each on one box (profiles/r03e_psnr_spread.json) gave
-    # 32.53-32.59 dB for the fused loop (mean 32.559), 32.46-32.59 dB for the reference-precision loop (mean 32.546):
-    # the MEANS agree to 0.013 dB, single runs scatter by 0.05 dB each, so a single pair differs by more than 0.1 dB in
-    # about one run in eight.  The bar on one pair is therefore 0.1 dB plus that scatter, one-sided (the fused
-    # fp16-plane loop may not be WORSE), and a two-sided sanity bound of 0.3 dB.
-    assert rep["psnr_difference_db"] > -0.2, msg
-    assert abs(rep["psnr_difference_db"]) < 0.3, msg
+    # occupancy grid they prune with follows): single runs scatter by ~0.05 dB (profiles/r03e_psnr_spread.json), so the
+    # bar is held on the MEANS of two fused runs (one of them with the ordered, reproducible reduction) and three
+    # reference-loop runs.
+    assert abs(rep["psnr_mean_difference_db"]) < 0.1, msg
+    return msg
+
+
+def test_base_geometry_fused_fp16_vs_reference_loop_fp32_psnr(cuda):
+    rep = _psnr_pairs(cuda, "sphere")
+    msg = _check_psnr(rep, 25.0)
+    fused = rep["fused"]
+    steps = fused["steps"]
     # the trajectory really moved: the sample count fell by more than 3x from the untrained grid and a window formed
     assert fused["samples_per_step_first_last"][1] * 3 < fused["samples_per_step_first_last"][0], msg
     assert fused["window_first_last"][1] is not None and fused["deferred_steps"] > steps // 2, msg
+
+
+def test_base_geometry_psnr_on_the_scene_with_fine_structure(cuda):
+    """The same bar on synthetic.detail_scene_rgba (checkered ball, striped box, thin plate, thin fin: albedo with
+    100-170 cycles across the bound, 8-texel-thick structures): here the two finest wavelet levels carry energy, so fp16
+    training planes are compared with fp32 ones where it could matter (VERDICT r03 'missing' 2)."""
+    rep = _psnr_pairs(cuda, "detail")
+    msg = _check_psnr(rep, 15.0)
+    fine = rep["level_energy_fused"][-2:]
+    assert all(lv["share_above_1e-3"] > 0.002 for lv in fine), msg       # the fine levels are in use on this scene
 
 
 def test_real_trajectory_with_and_without_the_occupancy_pieces_is_the_same_training(cuda):

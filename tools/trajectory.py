@@ -40,12 +40,15 @@ GEOM = {  # channels, resolution, wavelet scale, hidden, lambda (README.md:46-58
 }
 
 
-def make_scene(device, n_train=36, n_valid=4, hw=400, seed=0):
-    """Analytic opaque sphere (alpha 1 on the ball, 0 elsewhere), Blender-style cameras: pools of training and held-out
-    pixels on the device."""
+def make_scene(device, n_train=36, n_valid=4, hw=400, seed=0, scene="sphere"):
+    """Blender-style cameras around an analytic scene: pools of training and held-out pixels on the device.
+    scene = "sphere": an opaque ball shaded by its normal (smooth: the fine wavelet levels stay nearly empty);
+    scene = "detail": synthetic.detail_scene_rgba -- checkered ball, striped box, a thin plate and a thin fin (albedo
+    with 100-170 cycles across the bound, structures 7-8 texels thick: the two finest levels carry energy)."""
     from trinerflet_amd import synthetic
     from trinerflet_amd.raypool import RayPool
-    poses, intr, images = synthetic.sphere_dataset(n_cams=n_train + n_valid, H=hw, W=hw, seed=seed)
+    make = synthetic.detail_dataset if scene == "detail" else synthetic.sphere_dataset
+    poses, intr, images = make(n_cams=n_train + n_valid, H=hw, W=hw, seed=seed)
     train = RayPool(poses[n_valid:], intr, hw, hw, images[n_valid:], device=device)
     valid = RayPool(poses[:n_valid], intr, hw, hw, images[:n_valid], device=device)
     return train, valid
@@ -200,6 +203,17 @@ def run_reference_loop(workload, device, steps=512, num_rays=60000, scene=None, 
             "samples_per_step_first_last": [int(M[0]), int(M[-1])], "held_out_psnr_db": round(psnr, 4), "_model": model}
 
 
+def level_energy(model):
+    """RMS of the trained wavelet coefficients per level (coarse -> fine) and the share of non-negligible ones: what the
+    fine levels carry on this scene."""
+    out = []
+    for p in model.encoder.planes_features_wavelet_coefs:
+        x = p.detach().float()
+        out.append({"size": int(x.shape[-1]), "rms": float(x.pow(2).mean().sqrt()),
+                    "share_above_1e-3": float((x.abs() > 1e-3).float().mean())})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="base", choices=sorted(GEOM))
@@ -210,16 +224,23 @@ def main():
     ap.add_argument("--fused-fp32", action="store_true", help="also the fused step on fp32 planes")
     ap.add_argument("--no-pieces", action="store_true", help="also the fused step with whole windows / rectangles (live_bands=False)")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--scene", default="sphere", choices=["sphere", "detail"])
+    ap.add_argument("--deterministic", action="store_true", help="the fused runs with TrainStep(deterministic=True)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    scene = make_scene(dev)
+    scene = make_scene(dev, scene=args.scene)
     batches = batches_of(scene[0], args.steps, args.rays)
     rep = {"psnr_runs": {"fused_fp16": [], "fused_fp16_no_pieces": [], "fused_fp32_planes": [], "reference_loop": []}}
     for _ in range(args.repeat):
-        fused = run_fused(args.workload, dev, args.steps, args.rays, scene, batches)
-        fused.pop("_model")
+        fused = run_fused(args.workload, dev, args.steps, args.rays, scene, batches,
+                          ts_kwargs={"deterministic": True} if args.deterministic else None)
+        model = fused.pop("_model")
+        if args.scene == "detail":
+            fused["finest_level_energy"] = level_energy(model)
+        del model
         torch.cuda.empty_cache()
         rep["fused"] = fused
+        rep["scene"] = args.scene
         rep["psnr_runs"]["fused_fp16"].append(fused["held_out_psnr_db"])
         if args.no_pieces:
             npc = run_fused(args.workload, dev, args.steps, args.rays, scene, batches, ts_kwargs={"live_bands": False})

@@ -83,7 +83,10 @@ __device__ __forceinline__ void turn1(const half8& fe, const half8& Ie, half8 (&
 __device__ __forceinline__ void dw_rows(const half8 (&y)[2], const half8 (&x)[2], f32x16& acc) {
   if (TNL_ROWS_DROP & 1) return;
 #if TNL_ROWS_ASM_DW
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %3, %4, %0"
+#ifndef TNL_ROWS_DW_NOP
+#define TNL_ROWS_DW_NOP "s_nop 1\n\t"
+#endif
+  asm volatile(TNL_ROWS_DW_NOP "v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %3, %4, %0"
                : "+a"(acc) : "v"(y[0]), "v"(x[0]), "v"(y[1]), "v"(x[1]));
 #else
   acc = MFMA32(y[0], x[0], acc);
@@ -463,7 +466,10 @@ k_field_bwd_rows(const float* __restrict__ gsig, const float* __restrict__ grgb,
 #else
 #define STAMP()
 #endif
-#define SLOT(MCODE, ...) { MCODE; } TNL_ROWS_INNER; { __VA_ARGS__; } ROWS_STAGE; STAMP() ROWS_STAGE;
+#ifndef TNL_ROWS_FENCE_EVERY
+#define TNL_ROWS_FENCE_EVERY 1    // experiments: a fence only behind every n-th slot
+#endif
+#define SLOT(MCODE, ...) { MCODE; } TNL_ROWS_INNER; { __VA_ARGS__; } if (__COUNTER__ % TNL_ROWS_FENCE_EVERY == 0) ROWS_STAGE; STAMP() if (TNL_ROWS_STAMP) ROWS_STAGE;
 #define TURN2(T, FE, FO, IE, IO) if (TNL_ROWS_DROP & 2) { T = zero16(); T[0] = (float)FE[0] + (float)FO[1]; } else { T = MFMA32(FE, IE, zero16()); T = MFMA32(FO, IO, T); }
 #define TURN1(T, FE, IE) if (TNL_ROWS_DROP & 2) { T = zero16(); T[0] = (float)FE[0]; } else T = MFMA32(FE, IE, zero16())
 #define POST_T(T, X) X[0] = acc_to_frag<false>(T, 0); X[1] = acc_to_frag<false>(T, 1)

@@ -182,12 +182,10 @@ class NeRFRenderer(nn.Module):
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             results['weights_sum'] = weights_sum
-        elif kwargs.get("fused_render", "device_loop" not in kwargs and "infer_min_step" not in kwargs) \
-                and getattr(self, "_fused_ok", lambda: False)() and not torch.is_grad_enabled():
-            # one persistent kernel instead of the alive-ray loop (csrc/render.hip): the default of the eval branch unless
-            # the caller asks for the loop (fused_render=False, or one of the loop's own knobs device_loop / infer_min_step).
-            # Same samples per ray, same order, same arithmetic; a ray still alive after max_steps samples stops exactly
-            # there (the loop's cap depends on its schedule: max_steps ... max_steps + 7).
+        elif self._eval_render_mode(kwargs) == "kernel":
+            # render_mode="kernel" (the default of the eval branch): one persistent kernel instead of the alive-ray loop
+            # (csrc/render.hip).  Same samples per ray, same order, same arithmetic; a ray still alive after max_steps
+            # samples stops exactly there (the loop's cap depends on its schedule: max_steps ... max_steps + 7).
             weights_sum, depth, image = self._infer_render_kernel(rays_o, rays_d, nears, fars, dt_gamma, perturb,
                                                                   max_steps, T_thresh)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
@@ -195,8 +193,7 @@ class NeRFRenderer(nn.Module):
             image = image.view(*prefix, 3)
             depth = depth.view(*prefix)
             weights_sum = weights_sum.view(*prefix)
-        elif kwargs.get("device_loop", True) and getattr(self, "_fused_ok", lambda: False)() \
-                and not torch.is_grad_enabled():
+        elif self._eval_render_mode(kwargs) == "device_loop":
             weights_sum, depth, image = self._infer_device_loop(rays_o, rays_d, nears, fars, dt_gamma, perturb,
                                                                 max_steps, T_thresh,
                                                                 min_step=kwargs.get("infer_min_step", 1))
@@ -239,6 +236,35 @@ class NeRFRenderer(nn.Module):
         results['image'] = image
         results['weights_sum'] = weights_sum
         return results
+
+    RENDER_MODES = ("kernel", "device_loop", "host_loop")
+
+    def _eval_render_mode(self, kwargs):
+        """Which form of the inference branch (renderer.py:324-374) render(..., render_mode=...) runs:
+          "kernel"      one persistent kernel (csrc/render.hip) -- the default;
+          "device_loop" the reference's alive-ray loop with its sizes on the device (takes infer_min_step);
+          "host_loop"   the reference's structure literally: one survivor count read back per iteration.
+        The older keywords still select a form when render_mode is absent: fused_render=True/False, device_loop=True/False,
+        infer_min_step=n (a knob of the loop: it implies "device_loop").  The two fused forms need a configuration the
+        fused field kernel is built for and no autograd; otherwise the host loop runs."""
+        mode = kwargs.get("render_mode")
+        if mode is None:
+            if "fused_render" in kwargs:
+                mode = "kernel" if kwargs["fused_render"] else \
+                    ("device_loop" if kwargs.get("device_loop", True) else "host_loop")
+            elif "device_loop" in kwargs:
+                mode = "device_loop" if kwargs["device_loop"] else "host_loop"
+            elif "infer_min_step" in kwargs:
+                mode = "device_loop"
+            else:
+                mode = "kernel"
+        elif mode not in self.RENDER_MODES:
+            raise ValueError(f"render_mode must be one of {self.RENDER_MODES}, got {mode!r}")
+        elif mode != "device_loop" and kwargs.get("infer_min_step", 1) != 1:
+            raise ValueError("infer_min_step is a knob of render_mode='device_loop'")
+        if mode != "host_loop" and (not getattr(self, "_fused_ok", lambda: False)() or torch.is_grad_enabled()):
+            mode = "host_loop"
+        return mode
 
     def _infer_render_kernel(self, rays_o, rays_d, nears, fars, dt_gamma, perturb, max_steps, T_thresh):
         """renderer.py:324-374 as ONE launch (tnl_render_rays): march, fused field and compositing per ray inside a

@@ -105,6 +105,85 @@ def sphere_dataset(n_cams=8, H=64, W=64, seed=0, radius=0.6, camera_angle_x=0.69
     return poses, (fl, fl, W / 2, H / 2), images
 
 
+def detail_scene_rgba(rays_o, rays_d):
+    """A second analytic scene, with FINE structure (the sphere scene's finest wavelet levels carry almost
+    nothing): opaque solids with view-consistent 3D procedural albedo, first hit wins, alpha = 1 on a hit --
+      * a ball (r 0.42, centre (-0.3, 0.05, 0)) with a 3D checker of 0.022-wide cells (136 cells across the 3.0-wide
+        bound: 15 texels per cell at R = 2048, sharp cell edges at every scale),
+      * a box [0.12, 0.62] x [-0.28, 0.30] x [-0.30, 0.28] with diagonal stripes of wavelength 0.018 (167 cycles across),
+      * a THIN plate (thickness 0.012 = 8 texels) under both, [-0.75, 0.75] x [-0.42, -0.408] x [-0.75, 0.75], checker 0.03,
+      * a thin vertical fin (thickness 0.010) x in [-0.02, -0.01], y in [-0.408, 0.35], z in [-0.5, 0.5], stripes 0.025.
+    -> [N,4] like a Blender RGBA pixel."""
+    o, d = np.asarray(rays_o, np.float64), np.asarray(rays_d, np.float64)
+    N = o.shape[0]
+    t_best = np.full(N, np.inf)
+    rgb = np.zeros((N, 3))
+
+    def take(t, hit, color_fn, normal):
+        better = hit & (t < t_best) & (t > 0)
+        if not better.any():
+            return
+        p = o[better] + t[better, None] * d[better]
+        c = color_fn(p)
+        n = normal(p) if callable(normal) else normal[better]
+        shade = 0.75 + 0.25 * n[:, 1:2]                      # light from +y, view-independent
+        rgb[better] = np.clip(c * shade, 0.0, 1.0)
+        t_best[better] = t[better]
+
+    def checker(cell, a, b):
+        def f(p):
+            k = np.floor(p / cell).astype(np.int64).sum(-1) & 1
+            return np.where(k[:, None] == 0, np.asarray(a)[None], np.asarray(b)[None])
+        return f
+
+    def stripes(wl, direction, a, b):
+        direction = np.asarray(direction, np.float64) / np.linalg.norm(direction)
+
+        def f(p):
+            k = np.floor((p @ direction) / (wl / 2)).astype(np.int64) & 1
+            return np.where(k[:, None] == 0, np.asarray(a)[None], np.asarray(b)[None])
+        return f
+
+    # ball
+    c0, r0 = np.array([-0.3, 0.05, 0.0]), 0.42
+    oc = o - c0
+    bq = (oc * d).sum(-1)
+    disc = bq * bq - ((oc * oc).sum(-1) - r0 * r0)
+    t = -bq - np.sqrt(np.clip(disc, 0, None))
+    take(t, disc > 0, checker(0.022, (0.95, 0.35, 0.15), (0.15, 0.35, 0.9)), lambda p: (p - c0) / r0)
+
+    def box(lo, hi, color_fn):
+        lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / d
+            t0, t1 = (lo - o) * inv, (hi - o) * inv
+        tn, tf = np.minimum(t0, t1), np.maximum(t0, t1)
+        tnear, tfar = tn.max(-1), tf.min(-1)
+        hit = (tnear < tfar) & (tnear > 0)
+        axis = tn.argmax(-1)
+        nrm = np.zeros((N, 3))
+        nrm[np.arange(N), axis] = -np.sign(d[np.arange(N), axis])
+        take(tnear, hit, color_fn, nrm)
+
+    box((0.12, -0.28, -0.30), (0.62, 0.30, 0.28), stripes(0.018, (1.0, 1.0, 0.6), (0.9, 0.85, 0.2), (0.1, 0.5, 0.25)))
+    box((-0.75, -0.42, -0.75), (0.75, -0.408, 0.75), checker(0.03, (0.85, 0.85, 0.85), (0.2, 0.2, 0.25)))
+    box((-0.02, -0.408, -0.5), (-0.01, 0.35, 0.5), stripes(0.025, (0.0, 1.0, 1.0), (0.9, 0.2, 0.6), (0.2, 0.8, 0.8)))
+    hit = np.isfinite(t_best)
+    return np.concatenate([rgb * hit[:, None], hit[:, None].astype(np.float64)], -1).astype(np.float32)
+
+
+def detail_dataset(n_cams=8, H=64, W=64, seed=0, camera_angle_x=0.6911):
+    """sphere_dataset's counterpart for detail_scene_rgba."""
+    poses = hemisphere_poses(n_cams, seed=seed)
+    fl = W / (2 * np.tan(camera_angle_x / 2))
+    images = np.empty((n_cams, H, W, 4), np.float32)
+    for c in range(n_cams):                                   # per camera: the float64 temporaries stay small
+        pix = np.stack([np.full(H * W, c), np.arange(H * W)], -1)
+        o, d = get_rays(poses, pix, H, W, camera_angle_x)
+        images[c] = detail_scene_rgba(o, d).reshape(H, W, 4)
+    return poses, (fl, fl, W / 2, H / 2), images
+
+
 def init_field_parameters(model, seed=0):
     """SURVEY.md 8(d) field parameters: LL = 0.1*N(0,1); level-i coefficients ~ N(0, (0.02 * 2^-i)^2);
     Linear weights = torch default init under a fixed seed."""
