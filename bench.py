@@ -54,7 +54,7 @@ WORKLOADS = {
 }
 
 
-def build(workload, device, dist_mode, plane_dtype=None, **ts_kwargs):
+def build(workload, device, dist_mode, plane_dtype=None, shell=(0.8, 0.0), **ts_kwargs):
     from trinerflet_amd import synthetic
     from trinerflet_amd.nerf.network import NeRFNetwork
     from trinerflet_amd.train import TrainStep
@@ -67,22 +67,11 @@ def build(workload, device, dist_mode, plane_dtype=None, **ts_kwargs):
     synthetic.init_field_parameters(model, seed=0)
     ts = TrainStep(model, lr=1e-2, wavelet_regularization=lam, iters=40000, warmup_steps=0, fp16=True,
                    background_color=0.0, dist_mode=dist_mode, **ts_kwargs)
-    ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", ts.prefetch_at)   # "auto" | "bwd" | "adam" (experiments)
     if os.environ.get("TNL_LIVE_BANDS"):      # A/B: 0 = whole live rectangles
         ts.live_bands = os.environ["TNL_LIVE_BANDS"] != "0"
-    if os.environ.get("TNL_LIVE_ALIGN"):      # experiments: column granule of the live rectangles
-        ts.live_col_align = int(os.environ["TNL_LIVE_ALIGN"])
-    if os.environ.get("TNL_SPLIT_P2"):        # experiments: where phase 2 of the split side work starts
-        ts.split_phase2_at = os.environ["TNL_SPLIT_P2"]
-    if os.environ.get("TNL_ADAM_RESERVE"):    # experiments: Adam pass with reduced residency beside the side work
-        ts.adam_reserve = True
-    if os.environ.get("TNL_SIDE_PRIORITY"):   # experiments: priority of the side stream (-1 = high)
-        ts.side_priority = int(os.environ["TNL_SIDE_PRIORITY"])
-    if os.environ.get("TNL_SIDE_CUS"):        # experiments: CUs the side stream may use
-        ts.side_cus = int(os.environ["TNL_SIDE_CUS"])
     if os.environ.get("TNL_NO_OVERLAP"):      # experiments: march + tile sort in order on the launch stream (kernels alone)
         ts.overlap_march = False
-    bitfield = torch.from_numpy(synthetic.sphere_bitfield(128, model.cascade, 1.5, 0.8, 0.0)).to(device)
+    bitfield = torch.from_numpy(synthetic.sphere_bitfield(128, model.cascade, 1.5, shell[0], shell[1])).to(device)
     model.density_bitfield.copy_(bitfield)
     return model, ts, bitfield, N
 
@@ -231,6 +220,50 @@ def variant_ms(workload, device, bitfield_np_unused, batches, mean_count, steps,
     return t * 1e3
 
 
+def variant_report(workload, device, batches, steps=16, shell=(0.8, 0.0), **kw):
+    """A second configuration measured like the headline one, in short: its own dry run for the sample budget, a
+    17-step set-up (past the refresh at step 16), `steps` timed steps (one whole density-grid period at 16: its refresh and
+    the replay of the deferred pass inside), then an instrumented period for the sections -> ms per step, the longest
+    section and its roofline fraction (same algorithmic-byte table as the headline)."""
+    model, ts, bitfield, N = build(workload, device, None, shell=shell, **kw)
+    model.mean_count = 0
+    counts = []
+    for b in batches:
+        one_step(model, ts, bitfield, b, 0)
+        counts.append(int(ts.last["counter"][0].item()))
+    mean_count = int(max(counts) * 1.02)
+    model.mean_count = mean_count
+    t_ms = time_steps(model, ts, bitfield, batches, mean_count, steps, setup=17) * 1e3
+    ts.section_events, ts.section_names = [], None
+    nb = len(batches)
+    for i in range(16):
+        one_step(model, ts, bitfield, batches[i % nb], mean_count, batches[(i + 1) % nb])
+    torch.cuda.synchronize()
+    sec = ts.section_times("median")
+    ts.section_events = None
+    acct = adam_accounting(ts, 1)
+    spec, launches = section_specs(ts, model, float(np.mean(counts)), 1, acct)
+    dominant = max(SECTION_PREV, key=lambda k: sec.get(k, 0.0))
+    rf = roof(spec, dominant, sec.get(dominant, float("nan"))) or {}
+    C, R, scale, H = WORKLOADS[workload][:4]
+    out = {"ms_per_step": round(t_ms, 4), "rays_per_s": N / (t_ms * 1e-3), "samples_per_step": float(np.mean(counts)),
+           "config": f"3x{C}ch x {R}^2, scale {scale}, hidden {H}" + ("" if shell == (0.8, 0.0) else f", occupancy r in [{shell[1]}, {shell[0]}]"),
+           "sections_ms_median": {k: round(v, 4) for k, v in sec.items()},
+           "roofline": {"section": dominant, "kernels": SECTION_KERNELS[dominant], "bound": rf.get("bound"),
+                        "achieved": rf.get("achieved"), "peak": rf.get("peak"), "unit": rf.get("unit"), "frac": rf.get("frac"),
+                        "ms_per_step": rf.get("ms_per_step"), "launches_per_step": launches[dominant],
+                        "algorithmic_bytes": rf.get("algorithmic_bytes"), "algorithmic_flops": rf.get("algorithmic_flops"),
+                        "note": "the section with the largest median time over an instrumented density-grid period; "
+                                "traffic counters: profiles/r04_<workload>_* (tools/profile_round.sh --workload)"},
+           "sections_roofline": {k: (lambda r_: None if r_ is None else {"ms": r_["ms_per_step"], "bound": r_["bound"],
+                                                                         "frac": round(r_["frac"], 4)})(roof(spec, k, sec.get(k, float("nan"))))
+                                 for k in spec}}
+    del model, ts
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def inference_figure(model, device, max_steps=4096, images=3):
     """BASELINE config 5's `--test` render: 800 x 800 rays of one pose through run_cuda's inference branch at
     max_steps = 4096 (renderer.py:324-374), the trained-state planes of the benchmark model.  Three forms: the
@@ -302,6 +335,26 @@ def inference_figure(model, device, max_steps=4096, images=3):
     return res
 
 
+def dropin_figure(workload, device, batches, mean_count):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tnl_bench_dropin", os.path.join(ROOT, "tools", "bench_dropin.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    out = {}
+    for name, (opt, planes) in {"fused_adam_fp16_planes": ("fused", "fp16"), "fused_adam_fp32_planes": ("fused", "fp32"),
+                                "torch_adam_fp32_planes": ("adam", "fp32")}.items():
+        out[name] = round(D.dropin_ms_per_step(workload, device, batches, mean_count, 32, opt, planes), 3)
+    out["note"] = ("the loop of reconstruction/nerf/utils.py:1134-1175 (get_planes -> render -> MSE + wavelet L1 through "
+                   "autograd -> scaler.scale(loss).backward() -> scaler.step(optimizer)) on the drop-in modules, 32 steps = two "
+                   "density-grid periods, same rays / occupancy / sample budget as the headline.  torch_adam_fp32_planes: "
+                   "main_nerf.py unchanged (torch.optim.Adam, the reference's fp32 training planes); fused_adam_*: the one-line "
+                   "change at main_nerf.py:119 to trinerflet_amd.optim.FusedAdamL1 (INTEGRATION.md); fp16 planes = the "
+                   "encoder's default plane_dtype.  Round 3 measured 30.7 ms/step for this loop over a trajectory (24.5 "
+                   "steady state): since then the autograd backward goes through the tile-sorted reduction instead of "
+                   "global float atomics, the regulariser's |x|.mean() is one fused pass, Adam one pass per parameter")
+    return out
+
+
 def trajectory_figure(workload, device, steps=512):
     """config.trajectory: the fused step on a REAL trajectory (tools/trajectory.py): untrained grid -> real refreshes,
     occupancy window and sample budget as they evolve, held-out PSNR at the end."""
@@ -312,7 +365,18 @@ def trajectory_figure(workload, device, steps=512):
     if workload not in T.GEOM:
         return None
     rep = T.run_fused(workload, device, steps, WORKLOADS[workload][4])
-    rep.pop("_model")
+    model = rep.pop("_model")
+    # the `--test` render on the TRAINED field of this trajectory (opaque ball: rays end by transmittance, the regime
+    # renderer.py:324-374 sees), beside config.inference's figure on the benchmark's transparent random field
+    try:
+        inf = inference_figure(model, device)
+        rep["inference_trained"] = {k: inf[k] for k in ("image", "max_steps", "ms_per_image", "rays_per_s", "samples_per_s",
+                                                         "samples_per_image", "GB/s", "frac_of_8_TB/s", "mlp_TFLOP/s")}
+        rep["inference_trained"]["loop_ms_per_image"] = inf["loop"]["ms_per_image"]
+        rep["inference_trained"]["note"] = "800x800, max_steps 4096, the field trained by this trajectory (its own occupancy grid)"
+    except Exception as e:                                   # noqa: BLE001
+        rep["inference_trained"] = {"error": str(e)}
+    del model
     periods = rep.pop("periods")
     rep["per_16_steps"] = {"ms_per_step": [p["ms_per_step"] for p in periods],
                            "refresh_step_ms": [p["refresh_step_ms"] for p in periods],
@@ -321,6 +385,116 @@ def trajectory_figure(workload, device, steps=512):
     gc.collect()
     torch.cuda.empty_cache()
     return rep
+
+
+def adam_accounting(ts, world):
+    """Algorithmic bytes of the step's coefficient pass and what it leaves to the deferred replay."""
+    # algorithmic bytes of the step's Adam launches (one per wavelet level + LL): 16 B read (p, g, m, v) + 12 B
+    # written (p, m, v) per coefficient; with the gradient-support chain g is neither stored nor read outside each
+    # level's rectangle (24 B there).  TrainStep._rects holds the rectangles of the last non-refresh step.
+    S_own = (3 * ts.C) // (world if ts.dist_mode == "sharded" else 1)
+    rects = ts._rects if (ts._rect_ok and ts._roi is not None and all(r is not None for r in ts._rects)) else None
+    # with the live / deferred split (TrainStep.defer_adam) a level's per-step launch covers only its live rectangle;
+    # the coefficients outside it are replayed by k_adam_l1_catchup once per flush (24 B each, reported separately)
+    live = ts.last_live if (ts.defer_adam and rects is not None and ts.last_live is not None) else [None] * ts.J
+    tables = ts.last_live_bands if (ts.last_live_bands is not None and live[0] is ts.last_live[0]) else [None] * ts.J
+    adam_bytes, n_launch, deferred_coefs = 0.0, 0, 0.0
+    band_share = [None] * ts.J
+
+    def band_counts(lv, tbl, r):
+        """Coefficients per (slice, band) of a level's band pieces, and how many of them lie inside the stored-gradient
+        rectangle r (mean over the planes)."""
+        nb = lv[7] // 8
+        w = 4 * tbl[nb + 1:2 * nb + 1].astype(np.int64)
+        dom, ins = float(8 * w.sum()), 0.0
+        for pl in range(3):
+            x0 = tbl[2 * nb + 1 + pl * nb:2 * nb + 1 + (pl + 1) * nb].astype(np.int64)
+            cols = np.clip(np.minimum(x0 + w, r[pl] + r[6]) - np.maximum(x0, r[pl]), 0, None)
+            y0 = lv[3 + pl] + 8 * np.arange(nb)
+            rows = np.clip(np.minimum(y0 + 8, r[3 + pl] + r[7]) - np.maximum(y0, r[3 + pl]), 0, None)
+            ins += float((cols * rows).sum()) / 3
+        return dom, ins
+    for lvl in range(ts.J):
+        n_l = ts.coef.params[lvl].shape[-1]
+        inside = rects[lvl][6] * rects[lvl][7] if rects is not None else n_l * n_l
+        domain = live[lvl][6] * live[lvl][7] if live[lvl] is not None else n_l * n_l
+        if live[lvl] is not None and tables[lvl] is not None:
+            rect_area = domain
+            domain, inside = band_counts(live[lvl], tables[lvl][2], rects[lvl])
+            band_share[lvl] = round(domain / rect_area, 4)
+        adam_bytes += S_own * 3 * (24.0 * domain + 4.0 * inside)
+        deferred_coefs += S_own * 3 * float(n_l * n_l - domain)
+        n_launch += 1
+    n_ll = ts.ll.params[0].shape[-1]
+    adam_bytes += S_own * (24.0 * n_ll * n_ll + 4.0 * (rects[0][6] * rects[0][7] if rects is not None else n_ll * n_ll))
+    n_launch += 1
+    if ts.defer_adam and rects is not None:
+        n_launch = 2          # all wavelet levels in one k_adam_l1_live launch + the LL launch
+    return {"adam_bytes": adam_bytes, "n_launch": n_launch, "deferred_coefs": deferred_coefs, "band_share": band_share,
+            "live": live, "rects": rects, "S_own": S_own}
+
+
+def section_specs(ts, model, samples_per_step, world, acct):
+    """Algorithmic bytes / flops per section of one step and the launches of each section's main kernel."""
+    S_own, rects, adam_bytes = acct["S_own"], acct["rects"], acct["adam_bytes"]
+    # algorithmic bytes / flops per section (SURVEY.md 8(d)) for what each section moves
+    Cc, Rr, Hh = ts.C, ts.R, ts.H
+    Ms = samples_per_step
+    e_pl = 2 if model.encoder.plane_dtype == torch.float16 else 4
+    mac = 3 * Cc * Hh + 16 * Hh + 31 * Hh + Hh * Hh + 3 * Hh
+    wins = ts._forward_windows() if ts._roi is not None else [None] * ts.J
+
+    def win_area(lvl, m):           # texels of level lvl's output that are computed
+        w = wins[lvl]
+        return float(w[6] * w[7]) if w is not None else float(m * m)
+    fwd_bytes = adj_bytes = 0.0
+    for lvl in range(ts.J):
+        m = Rr >> (ts.J - 1 - lvl)
+        out_b = e_pl if lvl == ts.J - 1 else 4
+        fwd_bytes += S_own * win_area(lvl, m) * (4.0 + out_b)      # 4 input bands at a quarter of the area + output
+        rect = rects[lvl][6] * rects[lvl][7] if rects is not None else (m // 2) ** 2
+        adj_bytes += S_own * (win_area(lvl, m) * 4.0 + 4.0 * rect * 4.0)   # gradient window in, 4 bands out
+    fwd_bytes += (3 * Cc // (world if ts.dist_mode == "sharded" else 1)) * win_area(ts.J - 1, Rr) * 2 * e_pl  # layout
+    spec = {
+        "field_fwd": {"bytes": Ms * (12 * Cc * e_pl + 48 + 6 * Cc), "flops": 2.0 * mac * Ms,
+                      "per_unit": "per sample: gather 12*C*e + 48 B + 6*C B of saved features; 2*MAC flops (MAC = 13 440 at base)"},
+        "field_bwd": {"bytes": Ms * (6 * Cc + 6 * Cc + 40), "flops": 6.0 * mac * Ms,
+                      "per_unit": "per sample: 6*C B features in + 6*C B fp16 dF out + 40 B (xyz, dir, g_sigma, g_rgb); "
+                                  "recompute + dX + dW = 6*MAC flops"},
+        "adam_coef": {"bytes": adam_bytes, "flops": 0.0,
+                      "per_unit": "per live coefficient: 28 B inside the gradient rectangle, 24 B outside it; nothing outside a live rectangle"},
+        "plane_grad_binned": {"bytes": Ms * 3 * (2 * Cc + 1.13 * 12) + 3 * Cc * win_area(ts.J - 1, Rr) * 4, "flops": 0.0,
+                              "per_unit": "per sample and plane: 2*C B dF + 1.13 list entries of 12 B (sample id + its texel coordinates on the plane); + 4 B per window texel and channel stored"},
+        "idwt_fwd": {"bytes": fwd_bytes, "flops": 0.0,
+                     "per_unit": "per computed output texel and slice: 4 B of input bands + e (finest) or 4 B out, + 2*e for the texel-major layout pass"},
+        "idwt_adjoint": {"bytes": adj_bytes, "flops": 0.0,
+                         "per_unit": "per slice: 4 B per gradient-window texel in + 16 B per coefficient-rectangle position out"},
+    }
+    launches = {"field_fwd": 1, "field_bwd": 1 if Hh == 64 else 2, "adam_coef": acct["n_launch"], "plane_grad_binned": 1,
+                "idwt_fwd": ts.J + 1, "idwt_adjoint": ts.J}
+    return spec, launches
+
+
+def roof(spec, name, ms_):
+    """The binding roof of a section: the longer of bytes / HBM peak and flops / MFMA peak."""
+    sp = spec[name]
+    if not (ms_ == ms_ and ms_ > 0):
+        return None
+    t_hbm = sp["bytes"] / (HBM_PEAK_GBS * 1e9)
+    t_mfma = sp["flops"] / (MFMA_PEAK_TFLOPS * 1e12)
+    bound = "mfma" if t_mfma > t_hbm else "hbm"
+    gbs = sp["bytes"] / (ms_ * 1e-3) / 1e9
+    tfl = sp["flops"] / (ms_ * 1e-3) / 1e12
+    out = {"section": name, "kernels": SECTION_KERNELS[name], "ms_per_step": round(ms_, 4), "bound": bound,
+           "achieved": tfl if bound == "mfma" else gbs, "peak": MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
+           "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+           "frac": (tfl / MFMA_PEAK_TFLOPS) if bound == "mfma" else (gbs / HBM_PEAK_GBS),
+           "algorithmic_bytes": sp["bytes"], "algorithmic_flops": sp["flops"], "per_unit": sp["per_unit"],
+           "GB/s": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+    if sp["flops"] > 0:
+        out["mfma_TFLOP/s"] = round(tfl, 1)
+        out["frac_mfma"] = round(tfl / MFMA_PEAK_TFLOPS, 4)
+    return out
 
 
 def main():
@@ -352,8 +526,6 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if os.environ.get("TNL_MAIN_PRIORITY"):   # experiments: the step's own stream at a priority above the side stream's
-        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["TNL_MAIN_PRIORITY"])))
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -371,11 +543,9 @@ def main():
         if world > 1:
             dist.barrier()
 
-    if os.environ.get("TNL_MAIN_PRIO"):    # experiments: the step on a high-priority stream, side work on a normal one
-        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["TNL_MAIN_PRIO"])))
     model, ts, bitfield, N = build(args.workload, device, args.dist_mode if world > 1 else None)
-    if os.environ.get("TNL_CLIP_FAR") == "1":      # A/B: march only to the exit from the occupied box (TrainStep.clip_far)
-        ts.clip_far = True
+    if os.environ.get("TNL_CLIP_FAR"):      # A/B: the in-order march of refresh steps clipped to the occupied box (default on)
+        ts.clip_far_in_order = os.environ["TNL_CLIP_FAR"] != "0"
     n_global = N * world
     if args.scaling == "strong":       # the step's 60 000 rays split over the ranks (the dense work is what shards)
         n_global = N
@@ -469,48 +639,14 @@ def main():
     sec_alone = ts.section_times()
     ts.overlap_march = not os.environ.get("TNL_NO_OVERLAP")
     ts.section_events = None
+    # the driver's K = 20 timed steps hold one grid refresh (1 / 20) where a long run holds one per 16 steps: the same
+    # loop over 32 steps = two whole density-grid periods, refreshes and replays inside (after the timed region)
+    whole_periods_ms = time_steps(model, ts, bitfield, batches, mean_count, 32, setup=0) * 1e3
     samples_per_step = float(np.mean(counts))
-    # algorithmic bytes of the step's Adam launches (one per wavelet level + LL): 16 B read (p, g, m, v) + 12 B
-    # written (p, m, v) per coefficient; with the gradient-support chain g is neither stored nor read outside each
-    # level's rectangle (24 B there).  TrainStep._rects holds the rectangles of the last non-refresh step.
-    S_own = (3 * ts.C) // (world if ts.dist_mode == "sharded" else 1)
-    rects = ts._rects if (ts._rect_ok and ts._roi is not None and all(r is not None for r in ts._rects)) else None
-    # with the live / deferred split (TrainStep.defer_adam) a level's per-step launch covers only its live rectangle;
-    # the coefficients outside it are replayed by k_adam_l1_catchup once per flush (24 B each, reported separately)
-    live = ts.last_live if (ts.defer_adam and rects is not None and ts.last_live is not None) else [None] * ts.J
+    acct = adam_accounting(ts, world)
+    adam_bytes, n_launch, deferred_coefs, band_share = acct["adam_bytes"], acct["n_launch"], acct["deferred_coefs"], acct["band_share"]
+    live, rects, S_own = acct["live"], acct["rects"], acct["S_own"]
     tables = ts.last_live_bands if (ts.last_live_bands is not None and live[0] is ts.last_live[0]) else [None] * ts.J
-    adam_bytes, n_launch, deferred_coefs = 0.0, 0, 0.0
-    band_share = [None] * ts.J
-
-    def band_counts(lv, tbl, r):
-        """Coefficients per (slice, band) of a level's band pieces, and how many of them lie inside the stored-gradient
-        rectangle r (mean over the planes)."""
-        nb = lv[7] // 8
-        w = 4 * tbl[nb + 1:2 * nb + 1].astype(np.int64)
-        dom, ins = float(8 * w.sum()), 0.0
-        for pl in range(3):
-            x0 = tbl[2 * nb + 1 + pl * nb:2 * nb + 1 + (pl + 1) * nb].astype(np.int64)
-            cols = np.clip(np.minimum(x0 + w, r[pl] + r[6]) - np.maximum(x0, r[pl]), 0, None)
-            y0 = lv[3 + pl] + 8 * np.arange(nb)
-            rows = np.clip(np.minimum(y0 + 8, r[3 + pl] + r[7]) - np.maximum(y0, r[3 + pl]), 0, None)
-            ins += float((cols * rows).sum()) / 3
-        return dom, ins
-    for lvl in range(ts.J):
-        n_l = ts.coef.params[lvl].shape[-1]
-        inside = rects[lvl][6] * rects[lvl][7] if rects is not None else n_l * n_l
-        domain = live[lvl][6] * live[lvl][7] if live[lvl] is not None else n_l * n_l
-        if live[lvl] is not None and tables[lvl] is not None:
-            rect_area = domain
-            domain, inside = band_counts(live[lvl], tables[lvl][2], rects[lvl])
-            band_share[lvl] = round(domain / rect_area, 4)
-        adam_bytes += S_own * 3 * (24.0 * domain + 4.0 * inside)
-        deferred_coefs += S_own * 3 * float(n_l * n_l - domain)
-        n_launch += 1
-    n_ll = ts.ll.params[0].shape[-1]
-    adam_bytes += S_own * (24.0 * n_ll * n_ll + 4.0 * (rects[0][6] * rects[0][7] if rects is not None else n_ll * n_ll))
-    n_launch += 1
-    if ts.defer_adam and rects is not None:
-        n_launch = 2          # all wavelet levels in one k_adam_l1_live launch + the LL launch
     adam_deferred = None
     if any(lv is not None for lv in live):
         cu_ms = sec.get("adam_catchup", float("nan"))
@@ -532,67 +668,11 @@ def main():
                     "in one 24-B/coefficient pass (bit-identical p, m, v).  Every replay the timed steps caused runs "
                     "inside the timed region (the ring holds 16 steps; a flush also precedes the clock's stop)."}
 
-    # algorithmic bytes / flops per section for what each section moves
+    spec, launches = section_specs(ts, model, samples_per_step, world, acct)
     Cc, Rr, Hh = ts.C, ts.R, ts.H
-    Ms = samples_per_step
-    e_pl = 2 if model.encoder.plane_dtype == torch.float16 else 4
-    mac = 3 * Cc * Hh + 16 * Hh + 31 * Hh + Hh * Hh + 3 * Hh
-    wins = ts._forward_windows() if ts._roi is not None else [None] * ts.J
-
-    def win_area(lvl, m):           # texels of level lvl's output that are computed
-        w = wins[lvl]
-        return float(w[6] * w[7]) if w is not None else float(m * m)
-    fwd_bytes = adj_bytes = 0.0
-    for lvl in range(ts.J):
-        m = Rr >> (ts.J - 1 - lvl)
-        out_b = e_pl if lvl == ts.J - 1 else 4
-        fwd_bytes += S_own * win_area(lvl, m) * (4.0 + out_b)      # 4 input bands at a quarter of the area + output
-        rect = rects[lvl][6] * rects[lvl][7] if rects is not None else (m // 2) ** 2
-        adj_bytes += S_own * (win_area(lvl, m) * 4.0 + 4.0 * rect * 4.0)   # gradient window in, 4 bands out
-    fwd_bytes += (3 * Cc // (world if ts.dist_mode == "sharded" else 1)) * win_area(ts.J - 1, Rr) * 2 * e_pl  # layout
-    spec = {
-        "field_fwd": {"bytes": Ms * (12 * Cc * e_pl + 48 + 6 * Cc), "flops": 2.0 * mac * Ms,
-                      "per_unit": "per sample: gather 12*C*e + 48 B + 6*C B of saved features; 2*MAC flops (MAC = 13 440 at base)"},
-        "field_bwd": {"bytes": Ms * (6 * Cc + 6 * Cc + 40), "flops": 6.0 * mac * Ms,
-                      "per_unit": "per sample: 6*C B features in + 6*C B fp16 dF out + 40 B (xyz, dir, g_sigma, g_rgb); "
-                                  "recompute + dX + dW = 6*MAC flops"},
-        "adam_coef": {"bytes": adam_bytes, "flops": 0.0,
-                      "per_unit": "per live coefficient: 28 B inside the gradient rectangle, 24 B outside it; nothing outside a live rectangle"},
-        "plane_grad_binned": {"bytes": Ms * 3 * (2 * Cc + 1.13 * 12) + 3 * Cc * win_area(ts.J - 1, Rr) * 4, "flops": 0.0,
-                              "per_unit": "per sample and plane: 2*C B dF + 1.13 list entries of 12 B (sample id + its texel coordinates on the plane); + 4 B per window texel and channel stored"},
-        "idwt_fwd": {"bytes": fwd_bytes, "flops": 0.0,
-                     "per_unit": "per computed output texel and slice: 4 B of input bands + e (finest) or 4 B out, + 2*e for the texel-major layout pass"},
-        "idwt_adjoint": {"bytes": adj_bytes, "flops": 0.0,
-                         "per_unit": "per slice: 4 B per gradient-window texel in + 16 B per coefficient-rectangle position out"},
-    }
-    # launches of the section's main kernel(s) per step (small helper launches inside a section -- k_slab_reduce,
-    # k_adam_record -- are in its time but not counted as launches of the kernel)
-    launches = {"field_fwd": 1, "field_bwd": 1, "adam_coef": n_launch, "plane_grad_binned": 1,
-                "idwt_fwd": ts.J + 1, "idwt_adjoint": ts.J}
-
-    def roof(name, ms_):
-        """The binding roof of a section: the longer of bytes / HBM peak and flops / MFMA peak."""
-        sp = spec[name]
-        if not (ms_ == ms_ and ms_ > 0):
-            return None
-        t_hbm = sp["bytes"] / (HBM_PEAK_GBS * 1e9)
-        t_mfma = sp["flops"] / (MFMA_PEAK_TFLOPS * 1e12)
-        bound = "mfma" if t_mfma > t_hbm else "hbm"
-        gbs = sp["bytes"] / (ms_ * 1e-3) / 1e9
-        tfl = sp["flops"] / (ms_ * 1e-3) / 1e12
-        out = {"section": name, "kernels": SECTION_KERNELS[name], "ms_per_step": round(ms_, 4), "bound": bound,
-               "achieved": tfl if bound == "mfma" else gbs, "peak": MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
-               "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-               "frac": (tfl / MFMA_PEAK_TFLOPS) if bound == "mfma" else (gbs / HBM_PEAK_GBS),
-               "algorithmic_bytes": sp["bytes"], "algorithmic_flops": sp["flops"], "per_unit": sp["per_unit"],
-               "GB/s": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
-        if sp["flops"] > 0:
-            out["mfma_TFLOP/s"] = round(tfl, 1)
-            out["frac_mfma"] = round(tfl / MFMA_PEAK_TFLOPS, 4)
-        return out
-    kernels = {k: roof(k, sec.get(k, float("nan"))) for k in spec}
+    kernels = {k: roof(spec, k, sec.get(k, float("nan"))) for k in spec}
     for k in kernels:
-        a = roof(k, sec_alone.get(k, float("nan")))
+        a = roof(spec, k, sec_alone.get(k, float("nan")))
         if kernels[k] is not None and a is not None:
             kernels[k]["alone_ms"] = a["ms_per_step"]
             kernels[k]["alone_frac"] = round(a["frac"], 4)
@@ -624,10 +704,15 @@ def main():
         for wl in ("small", "large"):
             if wl == args.workload:
                 continue
-            t_ms = variant_ms(wl, device, None, batches, mean_count, 16)
-            others[wl] = {"ms_per_step": round(t_ms, 4), "rays_per_s": N / (t_ms * 1e-3),
-                          "config": "3x{}ch x {}^2, scale {}, hidden {}".format(*WORKLOADS[wl][:4])}
+            others[wl] = variant_report(wl, device, batches)
         extras["other_workloads"] = others
+        # SURVEY.md 8(d)'s second occupancy: a thin shell r in [0.7, 0.8] (stresses the skipping; its own sample budget)
+        shell = variant_report(args.workload, device, batches, shell=(0.8, 0.7))
+        extras["thin_shell_ms_per_step"] = shell["ms_per_step"]
+        extras["thin_shell"] = shell
+        # what a main_nerf.py user gets WITHOUT swapping the loop for TrainStep: the reference's own loop
+        # (utils.py:1134-1175) on the drop-in modules, through autograd (tools/bench_dropin.py)
+        extras["dropin_autograd_ms_per_step"] = dropin_figure(args.workload, device, batches, mean_count)
         extras["variants_note"] = ("no_roi: every step rebuilds / differentiates whole planes (no occupancy window, no "
                                    "gradient-support rectangles); fp32_planes: the sampler reads fp32 planes as the "
                                    "reference's training does (SURVEY F9; implies whole planes); same rays, budget, "
@@ -704,6 +789,10 @@ def main():
                        "collectives": None if world == 1 else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                                                "bytes_on_the_wire": wire},
                        "samples_per_sec": samples_per_step * world * args.steps / elapsed,
+                       "ms_per_step_over_whole_periods": round(whole_periods_ms, 4),
+                       "whole_periods_note": "32 steps = two whole density-grid periods (2 refreshes + their replays of the "
+                                             "deferred pass), measured after the timed region: what a long run averages, "
+                                             "where the timed K steps hold K / 16 refreshes only on average",
                        # SURVEY.md 8(d)'s byte count of the REFERENCE's step (every coefficient rebuilt, differentiated and
                        # updated every step: (44 + e) P + M (12 C e + 48 C + 64) + 64 N) over this step's time
                        "survey_step": {"bytes": survey_bytes, "TB/s_equivalent": round(survey_bytes / (ms * 1e-3) / 1e12, 3),

@@ -112,16 +112,6 @@ TNL_API int tnl_march_rays_train_binned(const float *rays_o, const float *rays_d
                                  const float *fars, float *xyzs, float *dirs, float *deltas,
                                  int32_t *rays, int32_t *counter, const float *noises,
                                  int32_t *workspace, uint32_t workspace_words, uint32_t R, void *sort_workspace, void *stream);
-/* The same in two calls (no reference counterpart): phase 1 = the count pass only (the serial per-ray walk that records
- * every sample's t), phase 2 = ray records, sample emission with the tile counts, counter -- from what phase 1 left in
- * `workspace`.  Identical arguments to both calls; record-path workspace (tnl_march_rays_train_workspace_rec) required.
- * Lets a caller run the latency-bound walk and the wide passes at different points of its schedule. */
-TNL_API int tnl_march_rays_train_binned_phase(const float *rays_o, const float *rays_d, const uint8_t *grid, float bound,
-                                              float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
-                                              uint32_t M, const float *nears, const float *fars, float *xyzs, float *dirs,
-                                              float *deltas, int32_t *rays, int32_t *counter, const float *noises,
-                                              int32_t *workspace, uint32_t workspace_words, uint32_t R,
-                                              void *sort_workspace, int phase, void *stream);
 
 /* raymarching.h:14 composite_rays_train_forward ; kernel raymarching.cu:501-577.
  * One 64-lane wavefront per ray; transmittance by a wavefront product scan. */
@@ -281,7 +271,10 @@ TNL_API int tnl_field_backward(const float *grad_sigma, const float *grad_rgb, c
  * then counting-sorts the samples by 32x8-texel tile per plane and lets one workgroup per tile reduce its
  * samples on the matrix cores and store the tile.  EVERY tile of the gradient is written (no zero fill needed): texel-major
  * [3,R,R,C] if channel_major == 0, the reference's (3,C,R,R) otherwise (the adjoint IDWT reads that directly,
- * so the layout-change pass disappears).  grad_scale multiplies dfeat.  R % 32 == 0, C in {16,32,48}.
+ * so the layout-change pass disappears).  channel_major | 2: the caller has zero-filled grad_out (one contiguous fill) and
+ * untouched tiles are skipped instead of being zeroed tile by tile -- the faster form for WHOLE planes, of which a scene
+ * touches a third (the drop-in autograd path; TrainStep's windowed call keeps the in-kernel zeroes).
+ * grad_scale multiplies dfeat.  R % 32 == 0, C in {16,32,48}.
  * nonfinite_flag (device int32, may be NULL) is set to 1 if any stored value is inf/nan (GradScaler probe).
  * Replaces torch grid_sampler_2d_backward + the autograd zero fill. */
 TNL_API uint64_t tnl_plane_grad_binned_workspace(uint32_t M, uint32_t R);
@@ -372,6 +365,15 @@ TNL_API int tnl_adam_l1_step_dev(float *p, float *grad, float *m, float *v, uint
 TNL_API int tnl_mse_loss(const float *image, const float *weights_sum, const float *gt_rgb, float bg_color,
                          const float *bg_rays, uint32_t N, float inv_norm, const float *scale_dev, float *pred,
                          float *grad_pred, float *grad_weights_sum, float *mse_accum, void *stream);
+
+/* mean |x| of a coefficient tensor and its gradient (the wavelet L1 regulariser's term, nerf/utils.py:639-655
+ * `val.abs().mean()`), for the drop-in autograd path: forward = one read pass (fixed partition of x over <= 2048
+ * workgroups, partial sums in double: reproducible), backward grad_x = sign(x) * grad_out[0] / n (sign(0) = 0) = one read
+ * and one write pass -- instead of torch's abs, mean, sign, mul kernels.  x, grad_x 16-byte aligned; workspace of
+ * tnl_abs_mean_workspace() bytes; out / grad_out device floats. */
+TNL_API uint64_t tnl_abs_mean_workspace(void);
+TNL_API int tnl_abs_mean_forward(const float *x, uint64_t n, void *workspace, float *out, void *stream);
+TNL_API int tnl_abs_mean_backward(const float *x, uint64_t n, const float *grad_out, float *grad_x, void *stream);
 
 /* Measurement aid (bench.py): streaming copy of `bytes` (a multiple of 16) from src to dst, 16 bytes per lane,
  * non-temporal -- what this box's memory system gives a plain copy, printed beside the 8 TB/s HBM3E spec.  No
@@ -569,17 +571,6 @@ TNL_API int tnl_adam_l1_catchup_bands(float *p, float *m, float *v, uint32_t S, 
                                       uint32_t s0, const int32_t *live, const int32_t *band_table, const float *ring,
                                       int32_t count, float beta1, float beta2, float eps, float l1_coef, float *abs_sums,
                                       void *stream);
-/* Dynamic LDS (bytes, <= 64 KB) reserved by every workgroup of the FOLLOWING tnl_adam_l1_* launches of this process:
- * limits the pass to 160 KB / bytes workgroups per CU so that kernels of another stream (the next batch's march and
- * tile sort) find wave slots underneath it.  0 (default) = no limit.  Host-side state, not thread-safe. */
-TNL_API int tnl_adam_set_lds_reservation(uint32_t bytes);
-
-/* A HIP stream restricted to the compute units set in `mask` (hipExtStreamCreateWithCUMask; bit i of the n_words
- * 32-bit words = CU i).  TrainStep runs the next batch's march + tile sort on such a stream (a fraction of the CUs)
- * so that this latency-bound side work does not take one wave slot of every SIMD of the chip.  No reference
- * counterpart (the reference launches everything on the default stream). */
-TNL_API int tnl_stream_create_cu_mask(const uint32_t *mask, uint32_t n_words, void **stream);
-TNL_API int tnl_stream_destroy(void *stream);
 
 #ifdef __cplusplus
 }

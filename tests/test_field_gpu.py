@@ -164,3 +164,18 @@ def test_binned_plane_gradient_equals_atomic(cuda, C, H, R, M):
     ((so * a[:n]).sum() + (co * b[:n]).sum()).backward()
     ref = pl.grad.permute(0, 2, 3, 1).numpy().astype(np.float64)
     assert _relerr(g_bin.cpu().numpy(), ref) < 5e-3
+
+
+def test_tile_reduction_refuses_a_workspace_sorted_with_another_capacity(cuda):
+    """The tile lists' positions lie behind 12 * M entry slots: sort and reduce must be given the same capacity M
+    (ADVICE r03).  The library notes what a workspace was sorted with and refuses a mismatch."""
+    from trinerflet_amd.nerf import field as gfield
+    C, R, M = 16, 64, 2000
+    g = torch.Generator().manual_seed(0)
+    xyz = ((torch.rand(M, 3, generator=g) * 2 - 1) * 1.4).to(cuda)
+    dfeat = torch.zeros(3, M, C, dtype=torch.float16, device=cuda)
+    ws = gfield.plane_grad_sort(xyz, 1.5, R)
+    out = torch.empty(3, R, R, C, device=cuda)
+    gfield.plane_grad_reduce(ws, dfeat, xyz, 1.5, C, R, out)
+    with pytest.raises(RuntimeError):
+        gfield.plane_grad_reduce(ws, dfeat[:, :M - 128].contiguous(), xyz[:M - 128], 1.5, C, R, out)

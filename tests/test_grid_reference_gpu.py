@@ -141,3 +141,38 @@ def test_grid_refresh_queries_an_overriding_density(cuda):
     ga, gb = a.density_grid, b.density_grid
     assert float(ga.max()) > 0
     torch.testing.assert_close(gb, 2 * ga, rtol=1e-6, atol=0)
+
+
+def test_partial_refresh_duplicate_picks_keep_the_larger_density(cuda):
+    """A cell drawn more than once in one partial refresh (renderer.py:494-513: the reference's index assignment keeps an
+    arbitrary candidate) keeps the LARGER candidate here -- deterministic, one of the reference's possible outcomes
+    (INTEGRATION.md A.2); a NaN candidate propagates (amax) instead of being dropped by chance."""
+    H = 32
+    m = _model(cuda, H, 10.0)
+    m.iter_density = 16                                            # partial refreshes from here on
+    m.density_grid.fill_(0.0)
+    m.density_grid[:, 100] = 1.0                                   # one occupied cell per cascade: every occupied pick hits it
+    N = H ** 3 // 4
+    coords = torch.zeros(N, 3, dtype=torch.int32)
+    coords[:, 0] = 5                                               # every uniform pick is the cell (5, 0, 0)
+    noise = torch.rand(2 * N, 3, generator=torch.Generator().manual_seed(0))
+    draws = {"coords": [coords] * m.cascade, "occ_k": [torch.zeros(N, dtype=torch.int64)] * m.cascade,
+             "noise": [noise] * m.cascade}
+    seen = []
+
+    def density(x):
+        v = (x[:, 1] + 4.0).float()                                # positive, varies with the jitter: the candidates of a cell differ
+        seen.append(v.clone())
+        return {"sigma": v, "geo_feat": None}
+    m.density = density
+    m.update_extra_state(decay=1.0, draws=draws)
+    from trinerflet_amd import raymarching
+    cell = int(raymarching.morton3D(coords[:1].to(cuda))[0])
+    for cas in range(m.cascade):
+        cand = seen[cas] * m.density_scale
+        assert float(m.density_grid[cas, cell]) == float(cand[:N].max())
+        assert float(m.density_grid[cas, 100]) == max(1.0, float(cand[N:].max()))
+    # every other cell untouched
+    mask = torch.ones(H ** 3, dtype=torch.bool, device=cuda)
+    mask[cell] = mask[100] = False
+    assert float(m.density_grid[:, mask].abs().max()) == 0.0

@@ -1,0 +1,148 @@
+"""trinerflet_amd.optim.FusedAdamL1 against torch.optim.Adam (reconstruction/main_nerf.py:119: Adam(betas=(0.9, 0.99),
+eps=1e-15)) driven the way the reference's loop drives it (utils.py:1166-1173: scaler.scale(loss).backward();
+scaler.step(optimizer); scaler.update()), including a skipped step, a weight-decay group, the checkpoint layout in both
+directions, and the L1 term folded into the pass."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(3, 8, 3, 64, 64), (3, 8, 16, 16), (64, 24), (1001,), (7,)]
+    return [torch.nn.Parameter((torch.randn(s, generator=g) * 0.1).to(dev)) for s in shapes]
+
+
+def _groups(ps, wd=0.0):
+    return [{"params": ps[:2], "lr": 1e-2}, {"params": ps[2:], "lr": 3e-3, **({"weight_decay": wd} if wd else {})}]
+
+
+def _loss(ps, k):
+    return sum(((p * (1.0 + 0.1 * k)) ** 2).sum() * (0.5 + i) + (p.sin() * (k + 1)).sum() for i, p in enumerate(ps))
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-2])
+def test_fused_adam_follows_torch_adam_under_gradscaler(cuda, wd):
+    from trinerflet_amd.optim import FusedAdamL1
+    pa, pb = _params(cuda), _params(cuda)
+    oa = torch.optim.Adam(_groups(pa, wd), betas=(0.9, 0.99), eps=1e-15)
+    ob = FusedAdamL1(_groups(pb, wd), betas=(0.9, 0.99), eps=1e-15)
+    sa, sb = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=4), torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=4)
+    for k in range(12):
+        for ps, opt, sc in ((pa, oa, sa), (pb, ob, sb)):
+            opt.zero_grad(set_to_none=True)
+            loss = _loss(ps, k)
+            if k == 5:
+                loss = loss + ps[3][0] * float("inf")       # a non-finite gradient: the step must be skipped, the scale halved
+            sc.scale(loss).backward()
+            sc.step(opt)
+            sc.update()
+        assert float(sa.get_scale()) == float(sb.get_scale()), k
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=2e-7)
+    for a, b in zip(pa, pb):
+        sta, stb = oa.state[a], ob.state[b]
+        assert float(sta["step"]) == float(stb["step"]) == 11.0          # one of the twelve was skipped
+        np.testing.assert_allclose(stb["exp_avg"].cpu().numpy(), sta["exp_avg"].cpu().numpy(), rtol=2e-5, atol=1e-9)
+        np.testing.assert_allclose(stb["exp_avg_sq"].cpu().numpy(), sta["exp_avg_sq"].cpu().numpy(), rtol=2e-5, atol=1e-12)
+
+
+def test_state_dict_is_torch_adams_in_both_directions(cuda):
+    from trinerflet_amd.optim import FusedAdamL1
+    pa, pb = _params(cuda, 1), _params(cuda, 1)
+    oa = torch.optim.Adam(_groups(pa), betas=(0.9, 0.99), eps=1e-15)
+    ob = FusedAdamL1(_groups(pb), betas=(0.9, 0.99), eps=1e-15)
+    for k in range(3):
+        for ps, opt in ((pa, oa), (pb, ob)):
+            opt.zero_grad()
+            _loss(ps, k).backward()
+            opt.step()
+    sda, sdb = oa.state_dict(), ob.state_dict()
+    assert set(sda["state"][0]) == set(sdb["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert set(sda["param_groups"][0]) <= set(sdb["param_groups"][0])
+    # torch -> fused and fused -> torch, then three more steps each: all four trajectories agree
+    oa2 = torch.optim.Adam(_groups(pc := [torch.nn.Parameter(p.detach().clone()) for p in pb]), betas=(0.9, 0.99), eps=1e-15)
+    oa2.load_state_dict(copy.deepcopy(sdb))
+    ob2 = FusedAdamL1(_groups(pd := [torch.nn.Parameter(p.detach().clone()) for p in pa]), betas=(0.9, 0.99), eps=1e-15)
+    ob2.load_state_dict(copy.deepcopy(sda))
+    for k in range(3, 6):
+        for ps, opt in ((pa, oa), (pb, ob), (pc, oa2), (pd, ob2)):
+            opt.zero_grad()
+            _loss(ps, k).backward()
+            opt.step()
+    for a, b, c, d in zip(pa, pb, pc, pd):
+        for other in (b, c, d):
+            np.testing.assert_allclose(other.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-5, atol=2e-7)
+    assert float(ob2.state[pd[0]]["step"]) == 6.0
+
+
+def test_l1_inside_the_pass_equals_the_regulariser_through_autograd(cuda):
+    """utils.py:639-655: loss += lam * mean |coef| -- its gradient lam / n * sign(coef) added inside the Adam pass."""
+    from trinerflet_amd.optim import FusedAdamL1
+    pa, pb = _params(cuda, 2)[:1], _params(cuda, 2)[:1]
+    lam = 0.4
+    oa = torch.optim.Adam(pa, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    ob = FusedAdamL1(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, l1=lam / pb[0].numel())
+    for k in range(5):
+        oa.zero_grad()
+        (_loss(pa, k) + lam * pa[0].abs().mean()).backward()
+        oa.step()
+        ob.zero_grad()
+        _loss(pb, k).backward()
+        ob.step()
+    np.testing.assert_allclose(pb[0].detach().cpu().numpy(), pa[0].detach().cpu().numpy(), rtol=2e-5, atol=2e-7)
+
+
+def test_rejects_what_it_does_not_implement(cuda):
+    from trinerflet_amd.optim import FusedAdamL1
+    with pytest.raises(ValueError):
+        FusedAdamL1(_params(cuda), amsgrad=True)
+    p = [torch.nn.Parameter(torch.zeros(8, dtype=torch.float64, device=cuda))]
+    opt = FusedAdamL1(p)
+    p[0].grad = torch.ones_like(p[0])
+    with pytest.raises(ValueError):
+        opt.step()
+
+
+def test_wavelet_feature_views_fuse_abs_mean_and_behave_like_the_parameters(cuda):
+    """get_wavelet_features() hands out views of the coefficient parameters whose `.abs().mean()` (utils.py:639-655) is
+    one fused pass: same value, same gradient in the PARAMETER's .grad; every other use behaves like the plain tensor."""
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, hidden_dim=64, hidden_dim_color=64,
+                    triplane_channels=16, triplane_resolution=256, triplane_wavelet_levels=4).to(cuda)
+    enc = m.encoder
+    g = torch.Generator(device=cuda).manual_seed(0)
+    with torch.no_grad():
+        for p in enc.planes_features_wavelet_coefs:
+            p.copy_(torch.randn(p.shape, generator=g, device=cuda) * 0.05)
+            p.view(-1)[::7] = 0.0                         # exact zeros: sign(0) = 0
+    views = enc.get_wavelet_features()
+    assert len(views) == len(enc.planes_features_wavelet_coefs) == 2 and all(v.numel() == p.numel() and v.shape == p.shape
+                                                                           for v, p in zip(views, enc.planes_features_wavelet_coefs))
+    tot = sum(v.numel() for v in views)
+    reg = sum(v.abs().mean() * (v.numel() / tot) for v in views) / len(views)            # the reference's expression
+    (reg * 1024.0).backward()
+    got = [p.grad.clone() for p in enc.planes_features_wavelet_coefs]
+    enc.zero_grad()
+    enc.fused_l1_views = False
+    plain = enc.get_wavelet_features()
+    assert all(type(v) is torch.nn.Parameter for v in plain)
+    reg2 = sum(v.abs().mean() * (v.numel() / tot) for v in plain) / len(plain)
+    (reg2 * 1024.0).backward()
+    assert abs(float(reg) - float(reg2)) < 1e-6 * float(reg2)
+    for a, p in zip(got, enc.planes_features_wavelet_coefs):
+        np.testing.assert_allclose(a.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-6, atol=0)
+        assert float(a.view(-1)[::7].abs().max()) == 0.0
+    enc.zero_grad()
+    enc.fused_l1_views = True
+    v, p = enc.get_wavelet_features()[0], enc.planes_features_wavelet_coefs[0]
+    for f in (lambda t: (t * 2).sum(), lambda t: torch.abs(t).sum(), lambda t: t.abs().mean(dim=0).sum(),
+              lambda t: (t.abs() * 3 + 1).max(), lambda t: torch.mean(t.abs()), lambda t: t.abs().sum() / t.numel(),
+              lambda t: (t ** 2).mean(), lambda t: t.abs()[0, 1].sum()):
+        assert abs(float(f(v)) - float(f(p))) <= 1e-5 * abs(float(f(p))) + 1e-9
+    with torch.no_grad():
+        assert all(type(t) is torch.nn.Parameter for t in enc.get_wavelet_features())

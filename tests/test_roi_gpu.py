@@ -313,9 +313,10 @@ def test_occupancy_bounds_kernel(cuda):
         assert bounds[c].tolist() == want
 
 
-def test_side_work_start_positions_agree(cuda):
-    """TrainStep.prefetch_at only moves where the next batch's march + tile sort are launched (top of the step, before
-    the field forward, after the field backward, together with the Adam pass): the training run must not change."""
+def test_side_work_beside_the_step_does_not_change_the_training(cuda):
+    """The next batch's march + tile sort run on a side stream underneath the step's gradient / optimiser kernels
+    (step(next_rays=...)), or in order on the launch stream (overlap_march = False, no next_rays): the training run must
+    not change.  Also the far clip of the in-order march of refresh steps (clip_far_in_order: the same samples)."""
     from trinerflet_amd.train import TrainStep
     N, bound = 2048, 1.0
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
@@ -328,25 +329,28 @@ def test_side_work_start_positions_agree(cuda):
     bf = t(synthetic.sphere_bitfield(128, 1, bound, 0.4, 0.0))
     base.density_bitfield.copy_(bf)
     res = {}
-    for pf in ("bwd", "start", "fwd", "adam", "bwd2"):   # bwd2: the same position again, the yardstick of run-to-run noise
+    for pf in ("side", "in_order", "no_clip", "side2"):   # side2: the same configuration again, the yardstick of run-to-run noise
         m = copy.deepcopy(base)
         ts = TrainStep(m, update_extra_interval=4)
-        ts.prefetch_at = pf[:3] if pf == "bwd2" else pf
+        ts.overlap_march = pf != "in_order"
+        ts.clip_far_in_order = pf != "no_clip"
         ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf)
         m.mean_count = 0
-        losses = []
+        losses, counts = [], []
         for it in range(7):
             o, d, gt, nz = batches[it % 2]
             no, nd, _, nnz = batches[(it + 1) % 2]
-            losses.append(float(ts.step(o, d, gt, noises=nz, next_rays=(no, nd, nnz))))
+            losses.append(float(ts.step(o, d, gt, noises=nz, next_rays=None if pf == "in_order" else (no, nd, nnz))))
+            counts.append(int(ts.last["counter"][0]))
         torch.cuda.synchronize()
-        res[pf] = (losses, [p.detach().clone() for p in m.parameters()])
-    for pf in ("start", "fwd", "adam"):
-        np.testing.assert_allclose(res["bwd"][0], res[pf][0], rtol=2e-4, err_msg=pf)
-        for a, b, c in zip(res["bwd"][1], res[pf][1], res["bwd2"][1]):
+        res[pf] = (losses, [p.detach().clone() for p in m.parameters()], counts)
+    for pf in ("in_order", "no_clip"):
+        assert res[pf][2] == res["side"][2], pf                     # the same samples
+        np.testing.assert_allclose(res["side"][0], res[pf][0], rtol=2e-4, err_msg=pf)
+        for a, b, c in zip(res["side"][1], res[pf][1], res["side2"][1]):
             # see test_training_with_window_equals_whole_plane_training: Adam turns a gradient at the tile
             # reduction's noise level (its summation order follows the sort's atomics) into +-lr steps; two runs of
-            # the SAME position differ that way too, and that is the measure
+            # the SAME configuration differ that way too, and that is the measure
             far = lambda x, y: int(((x - y).abs() > 2e-3 + 1e-3 * y.abs()).sum())
             assert far(b, a) <= 10 * far(c, a) + max(8, int(2e-4 * a.numel())), (pf, far(b, a), far(c, a))   # the count scatters
             assert float((a - b).abs().max()) < 2 * 7 * 1e-2, pf

@@ -1,0 +1,100 @@
+"""The loop the REFERENCE's Trainer runs (reconstruction/nerf/utils.py:1134-1175: get_planes -> train_step ->
+scaler.scale(loss).backward() -> optimizer.step(), optimizer / scheduler of main_nerf.py:119,129) on the drop-in modules --
+what a main_nerf.py user gets after install_dropin() WITHOUT swapping the loop for TrainStep.  Steady state at a README
+geometry on bench.py's synthetic inputs (solid-sphere occupancy re-imposed after each refresh, fixed sample budget).
+
+    python tools/bench_dropin.py [--workload base] [--steps 32] [--optimizer adam|fused] [--planes fp32|fp16]
+
+bench.py imports dropin_ms_per_step() for config.dropin_autograd_ms_per_step."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def dropin_ms_per_step(workload, device, batches, mean_count, steps=32, optimizer="fused", planes="fp32", setup=18):
+    """ms per step over `steps` steps (whole density-grid periods when steps % 16 == 0) after `setup` untimed ones."""
+    import bench as B
+    from trinerflet_amd import synthetic
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    from trinerflet_amd.train import lr_factor
+    C, R, scale, H, N, lam = B.WORKLOADS[workload]
+    model = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, density_scale=1, min_near=0.2,
+                        density_thresh=10, bg_radius=-1, hidden_dim=H, hidden_dim_color=H, triplane_channels=C,
+                        triplane_resolution=R, triplane_wavelet_levels=scale, wavelet_type="bior6.8",
+                        plane_dtype=torch.float32 if planes == "fp32" else torch.float16).to(device)
+    synthetic.init_field_parameters(model, seed=0)
+    bitfield = torch.from_numpy(synthetic.sphere_bitfield(128, model.cascade, 1.5, 0.8, 0.0)).to(device)
+    model.density_bitfield.copy_(bitfield)
+    model.mean_count = mean_count
+    model.train()
+    if optimizer == "fused":
+        from trinerflet_amd.optim import FusedAdamL1
+        opt = FusedAdamL1(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    else:
+        opt = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)            # main_nerf.py:119
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: lr_factor(k, 40000, 0))             # main_nerf.py:129
+    scaler = torch.amp.GradScaler("cuda")
+    enc = model.encoder
+    nb = len(batches)
+
+    def one(k):
+        o, d, gt, nz = batches[k % nb]
+        enc.reset_cahce()
+        enc.get_planes()                                                                     # utils.py:1138-1140
+        if k % 16 == 0:
+            model.update_extra_state()                                                       # utils.py:1144-1146
+            model.density_bitfield.copy_(bitfield)          # bench.py's convention: analytic occupancy, fixed budget
+            model.mean_count = mean_count
+        opt.zero_grad(set_to_none=True)
+        out = model.render(o[None], d[None], staged=False, bg_color=0.0, perturb=True, force_all_rays=False, noises=nz,
+                           dt_gamma=0, max_steps=1024)
+        loss = ((out["image"][0] - gt) ** 2).mean()                                         # utils.py:595 (MSE mean)
+        wf = enc.get_wavelet_features()                                                      # utils.py:639-655
+        tot = sum(v.numel() for v in wf)
+        loss = loss + lam * sum(v.abs().mean() * (v.numel() / tot) for v in wf) / len(wf)
+        enc.reset_cahce()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        sched.step()
+    for k in range(setup):
+        one(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(setup, setup + steps):
+        one(k)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    del model, opt
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return ms
+
+
+def main():
+    import bench as B
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="base")
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--optimizer", default="fused", choices=["adam", "fused"])
+    ap.add_argument("--planes", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--mean-count", type=int, default=4_750_000)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    batches = B.make_batches(4, B.WORKLOADS[args.workload][4], 0, dev)
+    ms = dropin_ms_per_step(args.workload, dev, batches, args.mean_count, args.steps, args.optimizer, args.planes)
+    print(json.dumps({"workload": args.workload, "optimizer": args.optimizer, "planes": args.planes, "steps": args.steps,
+                      "ms_per_step": round(ms, 3)}))
+
+
+if __name__ == "__main__":
+    main()

@@ -105,7 +105,6 @@ def run_fused(workload, device, steps=512, num_rays=60000, scene=None, batches=N
     model, lam = make_model(workload, device, plane_dtype=plane_dtype, seed=seed)
     ts = TrainStep(model, lr=1e-2, wavelet_regularization=lam, iters=steps, warmup_steps=0, fp16=True,
                    background_color=0.0, **(ts_kwargs or {}))
-    ts.prefetch_at = os.environ.get("TNL_PREFETCH_AT", ts.prefetch_at)      # experiments
     model.mark_untrained_grid(train.poses, train.intrinsics)
     ts.invalidate_roi()
     if batches is None:

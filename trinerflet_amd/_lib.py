@@ -32,7 +32,7 @@ def lib():
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_uint32
         for name in ("tnl_plane_grad_binned_workspace", "tnl_permute_index", "tnl_field_backward_workspace",
-                     "tnl_field_feats_save_bytes"):
+                     "tnl_field_feats_save_bytes", "tnl_abs_mean_workspace"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_uint64
     return _lib

@@ -442,17 +442,6 @@ k_adam_l1_catchup(float* __restrict__ p, float* __restrict__ m, float* __restric
 
 }  // namespace
 
-// Dynamic LDS reserved (not used) by every workgroup of the following Adam launches: caps how many of them a CU holds
-// at once (160 KB / bytes), which leaves wave slots for kernels of another stream to run underneath this HBM-bound
-// pass.  TrainStep sets 40 KB (4 workgroups = 16 waves per CU; costs the pass ~2 %) on the steps whose next-batch march
-// and tile sort it starts together with the Adam pass, 0 otherwise.
-static unsigned g_lds_reservation = 0;
-extern "C" int tnl_adam_set_lds_reservation(uint32_t bytes) {
-  if (bytes > 64 * 1024) return (int)hipErrorInvalidValue;
-  g_lds_reservation = bytes;
-  return 0;
-}
-
 static int adam_launch(float* p, float* grad, float* m, float* v, uint64_t n, float step_size, float bias2_sqrt,
                        float beta1, float beta2, float eps, float inv_scale, const float* inv_scale_dev,
                        float l1_coef, const float* found_inf, float* abs_sum, int zero_grad,
@@ -468,12 +457,11 @@ static int adam_launch(float* p, float* grad, float* m, float* v, uint64_t n, fl
   // Non-temporal loads/stores: every byte is touched exactly once per step and the arrays are ~40x the Infinity Cache;
   // measured 1.99 -> 1.85 ms per step at base (A/B in one session).  TNL_ADAM_TEMPORAL=1 restores default caching.
   static const bool use_nt = getenv("TNL_ADAM_TEMPORAL") == nullptr;
-  const unsigned lds_throttle = g_lds_reservation;
   if (rect == nullptr && use_nt)
-    hipLaunchKernelGGL((k_adam_l1<false, true>), dim3((unsigned)blocks), dim3(256), lds_throttle, (hipStream_t)stream, p, grad, m, v,
+    hipLaunchKernelGGL((k_adam_l1<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v,
                        n, a, inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, AdamRect{});
   else if (rect != nullptr && use_nt)
-    hipLaunchKernelGGL((k_adam_l1<true, true>), dim3((unsigned)blocks), dim3(256), lds_throttle, (hipStream_t)stream, p, grad, m, v, n,
+    hipLaunchKernelGGL((k_adam_l1<true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n,
                        a, inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, *rect);
   else if (rect != nullptr)
     hipLaunchKernelGGL(k_adam_l1<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n, a,
@@ -601,7 +589,7 @@ extern "C" int tnl_adam_l1_step_live_bands(float* p, float* grad, float* m, floa
     next += (uint32_t)b;
   }
   AdamArgs a = make_adam_args(lr, 1.0f, beta1, beta2, eps, inv_scale, 0.f);
-  hipLaunchKernelGGL(k_adam_l1_live, dim3(next), dim3(256), g_lds_reservation, (hipStream_t)stream, p, grad, m, v, a,
+  hipLaunchKernelGGL(k_adam_l1_live, dim3(next), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, a,
                      inv_scale_dev, found_inf, abs_sum, opt_step_dev, reinterpret_cast<const AdamStepRec*>(step_rec), segs);
   return (int)hipGetLastError();
 }

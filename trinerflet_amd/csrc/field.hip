@@ -187,7 +187,7 @@ uint32_t tnl_field_packed_bytes(uint32_t C, uint32_t Hd, uint32_t Hc) {
 uint64_t tnl_field_feats_save_bytes(uint32_t M, uint32_t C, uint32_t Hd) {
   // [ceil(M/32)*32][3C] blocked by 32-sample tiles (field_common.h feat_slot) + [M][16] sigma-net outputs at hidden 128;
   // 5 GB at the 26 M samples of an untrained grid: 64-bit
-  return ((uint64_t)((M + 31) / 32) * 32 * 3 * C + (uint64_t)M * ((Hd > 64 || TNL_SPLIT_H64) ? 16 : 0)) * 2;
+  return ((uint64_t)((M + 31) / 32) * 32 * 3 * C + (uint64_t)M * (Hd > 64 ? 16 : 0)) * 2;
 }
 
 int tnl_field_pack(const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, uint32_t C,

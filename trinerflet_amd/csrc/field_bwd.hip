@@ -29,72 +29,22 @@
 #include "field_bwd_rows.h"
 #include "field_device.h"
 
-#ifndef TNL_BWD_NW
-#define TNL_BWD_NW 8   // waves per workgroup of the hidden-64 binned backward (4: one wave per SIMD, 8: two)
-#endif
-#ifndef TNL_BWD_MODE
-#define TNL_BWD_MODE 0   // hidden-64 binned backward: 0 shared stages (NW waves in lock step), 1 per-wave weight gradients,
-#endif                   // 2 two staggered 4-wave teams, 3 roles (4 chain waves + 4 weight-gradient waves) -- see BwdGeom.
-                         // Round-3 measurements at base, kernel alone (ms):
-                         // mode 0 0.77-0.78 | mode 1 0.83 | mode 2 stagger 0: 0.75, stagger 3 / 5 / 7: 0.94 / 0.91 / 0.93
-                         // | mode 3 0.93-0.94
-#ifndef TNL_BWD_ROWS
-#define TNL_BWD_ROWS 1   // hidden-64 binned backward: 1 = k_field_bwd_rows (register-only weight gradients), 0 = the shared-stage forms
-#endif
-#ifndef TNL_BWD_STAGGER
-#define TNL_BWD_STAGGER 0   // MODE 2: barriers by which the second team trails the first (10 per super-tile)
-#endif
-
 namespace {
 
-// NW waves per workgroup, 32 samples per wave.  The kernel needs ~320 registers per lane (dW accumulators + the
-// recomputed chain), i.e. one wave per SIMD; its waves wait 42 % of the time (SQ_WAIT_ANY) and issue 36 %.  An 8-wave
-// variant capped at 256 registers (two waves per SIMD) still spills ~120 dwords per lane to scratch -- the first one,
-// when the kernel needed 480 registers, ran 1.9x SLOWER (2.72 vs 1.46 ms) -- so NW = 4.
-//
-// PW ("per wave", round 3): every wave accumulates ALL weight-gradient tiles of the network for ITS OWN 32 samples
-// (K = 32 per tile: two MFMAs), through a private stage image in LDS.  No wave ever reads what another wave staged,
-// so the sample loop contains no workgroup barrier at all -- the five-to-ten s_barrier per 256-sample super-tile of the
-// shared-stage forms (54 % of the wave cycles parked, profiles/r02f_pmc_sq1.txt) disappear; LDS operations of one wave
-// execute in order, so staging and transposed read-back need no synchronisation.  Price: 16 accumulator tiles = 256
-// registers per lane (AGPR half of the unified file), i.e. one wave per SIMD, four waves per workgroup sharing the
-// fragment table in LDS.  MEASURED: 0.83 ms against mode 0's 0.77 -- 1 205 instructions and 86 s_waitcnt per 32-sample
-// tile with nothing else on the SIMD to cover a single wait: the kernel is bound by the latency of its dependent chain
-// (layer -> convert -> stage -> transposed read -> MFMA), not by its barriers.
-//
-// MODE 2 ("teams", round 3): the 8 waves form two teams of 4 (waves 4t .. 4t+3 = one per SIMD), each with its own stage
-// set, its own 128-sample half of the super-tile and its own complete set of weight-gradient tiles (4 per wave, 254
-// registers: still two waves per SIMD).  The teams run the same code with the same number of barriers per super-tile,
-// the second one TNL_BWD_STAGGER barriers behind the first: every s_barrier stays a workgroup barrier (stronger than
-// the team needs), but the two waves that share a SIMD are now in DIFFERENT phases of the layer sequence -- one in an
-// MFMA chain while the other converts / stages / waits on LDS -- instead of both stalling in the same place.
-// MEASURED: the stagger LOSES (0.91-0.94 ms against 0.75 without it): with workgroup-wide barriers every interval lasts
-// as long as the LONGER of the two phases that share it, and the sum of those maxima exceeds the sum of the phases.
-// Without a stagger the team form is 3 % faster than mode 0 alone (4 tiles per wave, 128-sample stages), equal in the step.
-//
-// MODE 3 ("roles", round 3): the 8 waves split by WORK instead of by samples.  Waves 0-3 (one per SIMD) run the chain
-// for 32 samples each (128-sample super-tiles): recompute, data gradients, staging; waves 4-7 (the other wave of each
-// SIMD) hold all 16 weight-gradient tiles (4 each, K = 128) and do nothing else, one layer behind the chain waves: two
-// stage sets used alternately, ONE workgroup barrier per layer, and the two waves of a SIMD are never in the same phase
-// -- an MFMA-only wave beside a convert / stage / wait wave.  184 registers, no spill, results identical.
-// MEASURED: 0.93 ms against mode 0's 0.76: a chain wave needs ~15.7 k cycles per 32 samples with or without the weight
-// gradients (mode 0: two chain-and-gradient waves per SIMD deliver 64 samples per 25.7 k); what bounds the kernel is
-// the serial latency of ONE wave's layer chain, and only a second chain wave on the SIMD -- not a helper -- hides it.
-// (A THIRD chain wave per SIMD, -DTNL_BWD_NW=12: 384-sample stage images leave no room for the 60 KB of weight
-//  fragments in LDS.  With all of them read from L2 and 54 dwords spilled at 168 registers: 1.49 ms.  With the two
-//  layer-0 sets alone in L2 (LDSW_PART: 36 KB of fragments beside 120 KB of stages), no input prefetch and 33 spilled
-//  dwords: 0.99 ms -- still behind the 8-wave form's 0.76: five 12-wave barriers per super-tile and the spills cost more
-//  than the third wave hides.)
-template <int C, int H, int NW, bool ATOMIC, int PART = 0, int MODE = 0>
+// Shared-stage form: NW = 4 waves per workgroup (one per SIMD, ~320-390 registers), 32 samples per wave, the weight
+// gradients through fp16 stage images in LDS (see the header).  It serves the atomic mode of every configuration (the
+// general fallback of the autograd path: plane sizes that are not a multiple of 32) and the two launches of the
+// hidden-128 binned backward (PART 1 / 2 below).  The hidden-64 binned backward is k_field_bwd_rows
+// (field_bwd_rows.hip: register-only weight gradients, 0.76 -> 0.59 ms at base); the forms it replaced -- 8 and 12 waves
+// per workgroup, per-wave weight gradients, staggered teams, roles, hidden 64 split by layer -- are in git history
+// (commit 407d188^) with their measurements in docs/EXPERIMENTS.md.
+template <int C, int H, int NW, bool ATOMIC, int PART = 0>
 struct BwdGeom {
   using G = FieldGeom<C, H>;
-  static constexpr bool PW = MODE == 1, TM = MODE == 2, RL = MODE == 3;
-  static constexpr bool PWv = PW;
   static constexpr int BW_WAVES = NW;
   static constexpr int BW_THREADS = 64 * NW;
-  static constexpr int ST = RL ? 16 * NW : 32 * NW;      // samples per super-tile (of the workgroup; RL: half the waves carry samples)
-  static constexpr int SS = PW ? 32 : (TM ? ST / 2 : ST); // samples per stage image (PW: the wave's own 32, TM: the team's)
-  static constexpr int COPIES = PW ? NW : ((TM || RL) ? 2 : 1);   // RL: two stage sets used alternately, layer by layer
+  static constexpr int ST = 32 * NW;      // samples per super-tile of the workgroup
+  static constexpr int SS = ST;           // samples per stage image
   // A stage image holds fp16 [32-feature block][sample][32 features]: 64-byte rows whose eight 8-byte chunks are
   // XOR-swizzled with the row (img_off), so that a lane stores four consecutive features of its sample with one
   // ds_write_b64 and the weight-gradient MFMA reads both operands (8 samples of one feature per lane) with the
@@ -103,7 +53,7 @@ struct BwdGeom {
   // features staged once per super-tile in their own LDS region (binned mode).  PART 2 (sigma half of the split launch)
   // instead keeps them in registers and stages them into the X region for layer 0, which leaves room for its 80
   // weight fragments in LDS.
-  static constexpr bool EARLY_F = !ATOMIC && PART != 2 && NW <= 4;
+  static constexpr bool EARLY_F = !ATOMIC && PART != 2;
   static constexpr int XBLKS = EARLY_F ? G::OB : (G::IB0 > G::OB ? G::IB0 : G::OB);
   static constexpr int STAGE_LD = G::F + 1;                       // floats per staged sample row
   static constexpr size_t XS_BYTES = (size_t)XBLKS * BLK;
@@ -119,31 +69,14 @@ struct BwdGeom {
   static constexpr size_t FS_BYTES = EARLY_F && PART != 1 ? (size_t)G::IB0 * BLK : 0;
   // Double-buffered X / Y stages (layers alternate between the two pairs): the barrier that protected a stage from
   // the next layer's writes disappears, one barrier per layer remains.  Only where it fits next to the weights.
-  // (hidden 64 split by layer: single-buffered, so that TWO workgroups fit a CU -- independent barriers, 2 waves per SIMD)
-  static constexpr bool DB = !PW && !TM && !RL && !(H == 64 && PART != 0) && EARLY_F && 2 * (XS_BYTES + YS_BYTES) + FS_BYTES + W_BYTES <= 160 * 1024;
-  static constexpr size_t COPY_BYTES = (DB ? 2 : 1) * (XS_BYTES + YS_BYTES) + FS_BYTES;   // one stage set (PW: one per wave)
-  static constexpr size_t BASE_BYTES = COPIES * COPY_BYTES + STAGE_BYTES;
+  static constexpr bool DB = EARLY_F && 2 * (XS_BYTES + YS_BYTES) + FS_BYTES + W_BYTES <= 160 * 1024;
+  static constexpr size_t COPY_BYTES = (DB ? 2 : 1) * (XS_BYTES + YS_BYTES) + FS_BYTES;
+  static constexpr size_t BASE_BYTES = COPY_BYTES + STAGE_BYTES;
   static constexpr bool LDSW = BASE_BYTES + W_BYTES <= 160 * 1024;  // weights cached in LDS when they fit
-  // ... or all but the two layer-0 sets (forward F0 .. F1, transposed T0 .. NTOT: each used once per super-tile, at its
-  // start and at its end), which then come from L2 -- what lets a 12-wave workgroup's 384-sample stages fit
-  static constexpr size_t WP_BYTES = (size_t)(G::T0 - G::F1) * 1024;
-  static constexpr bool LDSW_PART = !LDSW && PART == 0 && !ATOMIC && BASE_BYTES + WP_BYTES <= 160 * 1024;
-  static constexpr size_t LDS_BYTES = BASE_BYTES + (LDSW ? W_BYTES : (LDSW_PART ? WP_BYTES : 0));
+  static constexpr size_t LDS_BYTES = BASE_BYTES + (LDSW ? W_BYTES : 0);
   static constexpr int NT0 = G::OB * G::IB0, NT1 = G::OB, NT2 = G::OB, NT3 = G::OB * G::OB, NT4 = G::OB;
   static constexpr int A0 = (NT0 + NW - 1) / NW, A1 = (NT1 + NW - 1) / NW, A2 = (NT2 + NW - 1) / NW,
                        A3 = (NT3 + NW - 1) / NW, A4 = (NT4 + NW - 1) / NW;
-  // GT (8-wave workgroups): the weight-gradient tiles of ALL layers are dealt out together, tile T to wave T % NW
-  // (in the order layer 4, 3, 2, 1, 0), so that a wave holds NSLOT = 2 accumulator tiles (32 registers) instead of one
-  // or two per layer (80-96): with that the kernel fits 256 registers per lane, i.e. two waves per SIMD, which is what
-  // covers the barrier / LDS-latency stalls that made up more than half of the one-wave-per-SIMD kernel's time.
-#ifndef TNL_BWD_GT_MIN
-#define TNL_BWD_GT_MIN 8
-#endif
-  static constexpr bool GT = NW >= TNL_BWD_GT_MIN || PW || TM || RL;
-  static constexpr int NTILES = NT0 + NT1 + NT2 + NT3 + NT4;
-  static constexpr int TW = PW ? 1 : ((TM || RL) ? NW / 2 : NW);   // waves the tiles are dealt over (PW: every wave holds them all)
-  static constexpr int NSLOT = (NTILES + TW - 1) / TW;
-  static constexpr int B4 = 0, B3 = NT4, B2 = B3 + NT3, B1 = B2 + NT2, B0 = B1 + NT1;   // first tile id of each layer
 };
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -175,17 +108,6 @@ __device__ __forceinline__ f32x16 dw_tile(const char* yb, const char* xb, int t0
     acc = MFMA32(a, b, acc);
   }
   return acc;
-}
-
-// GT (global tile ownership): the tiles [BASE, BASE + NT) of one layer, laid out [y block][x block] with NX x blocks;
-// wave wv accumulates those of its slots (tile ids wv, wv + NW, ...) that belong to this layer.  Wave-uniform branches.
-template <int ST, int BLK, int NW, int NSLOT, int BASE, int NT, int NX>
-__device__ __forceinline__ void dw_layer(f32x16 (&dwg)[NSLOT], int wv, const char* Y, const char* X, int t0, int t1) {
-#pragma unroll
-  for (int sl = 0; sl < NSLOT; sl++) {
-    const int t = wv + NW * sl - BASE;
-    if (t >= 0 && t < NT) dwg[sl] = dw_tile<ST>(Y + (t / NX) * BLK, X + (t % NX) * BLK, t0, t1, dwg[sl]);
-  }
 }
 
 // publish an accumulator-layout tile (registers 4q..4q+3 = features 8q + 4h .. + 3 of the lane's sample) into a block
@@ -240,18 +162,16 @@ __device__ __forceinline__ void slab_tile(float* slab, int off, int out_dim, int
 //            and hand the gradient of the 16 sigma-net outputs (dO, 32 B per sample) to
 //   PART 2 = sigma net: recompute layer 0 only, backward through layers 1, 0, weight gradients of W0, W1, dF.
 // Each part holds 6 weight-gradient tiles per wave and half the chain; PART 0 = everything in one launch (hidden 64).
-template <int C, int H, int NW, bool ATOMIC, int PART, int MODE>
-__global__ void __launch_bounds__(64 * NW, (H == 64 && PART != 0) ? 2 : 1)
+template <int C, int H, int NW, bool ATOMIC, int PART>
+__global__ void __launch_bounds__(64 * NW, 1)
 k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, const float* __restrict__ sigma,
             const _Float16* __restrict__ feats,
             const float* __restrict__ xyz, const float* __restrict__ dirs, float bound, uint32_t M, int R,
             const half8* __restrict__ packed, float* __restrict__ grad_tm, float* __restrict__ slabs,
             const int32_t* __restrict__ m_actual, _Float16* __restrict__ dfeat, _Float16* __restrict__ dO) {
   using G = FieldGeom<C, H>;
-  using B = BwdGeom<C, H, NW, ATOMIC, PART, MODE>;
-  constexpr bool PW = B::PW, TM = B::TM, RL = B::RL;
+  using B = BwdGeom<C, H, NW, ATOMIC, PART>;
   static_assert(PART == 0 || !ATOMIC, "the split launch exists for the binned mode only");
-  static_assert(MODE == 0 || (PART == 0 && !ATOMIC), "per-wave / team weight gradients: single-launch binned mode");
   constexpr bool DO_COL = PART != 2, DO_SIG = PART != 1;
   constexpr int BW_THREADS = B::BW_THREADS, ST = B::ST, BLK = B::BLK, SS = B::SS;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: tile ownership tests become scalar branches
@@ -259,36 +179,15 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   if (m_actual != nullptr) M = min(M, (uint32_t)max(*m_actual, 0));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr size_t XY = B::XS_BYTES + B::YS_BYTES;
-  const int team = (TM || RL) ? wv / B::TW : 0;
-  char* const sbase = smem + (PW ? (size_t)wv : (TM ? (size_t)team : 0)) * B::COPY_BYTES;   // PW / TM: the wave's / team's own stage set
-  char* const Xb[2] = {sbase, sbase + (B::DB ? XY : (RL ? B::COPY_BYTES : 0))};
-  char* const Yb[2] = {sbase + B::XS_BYTES, sbase + (B::DB ? XY : (RL ? B::COPY_BYTES : 0)) + B::XS_BYTES};
-  // RL ("roles"): team 0 (waves 0 .. NW/2-1, one per SIMD) runs the chain -- recompute, data gradients, staging -- and
-  // never touches a weight-gradient tile; team 1 (the other wave of each SIMD) does nothing but the weight-gradient
-  // MFMAs, one layer BEHIND: at the workgroup barrier that publishes layer k's stage it has just finished layer k-1's,
-  // whose stage set (the other of the two) the chain waves then overwrite with layer k+1.  One barrier per layer, and
-  // the two waves of a SIMD are never in the same phase.  `kk` counts published layers (5 per super-tile: the parity
-  // alternates across super-tiles too).
-  int kk = 0;
+  char* const Xb[2] = {smem, smem + (B::DB ? XY : 0)};
+  char* const Yb[2] = {smem + B::XS_BYTES, smem + (B::DB ? XY : 0) + B::XS_BYTES};
   float* stage_all = reinterpret_cast<float*>(smem + (B::DB ? 2 : 1) * XY);
-  char* Fs = PW ? sbase + XY : smem + (B::DB ? 2 : 1) * XY + B::STAGE_BYTES;
-  // stage published -> stage read.  PW: writer and reader are the same wave, whose LDS operations execute in order:
-  // only the compiler has to keep them in order (a wavefront-scope fence emits no instruction).
-  auto stage_ready = [&]() {
-    if (PW) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-    else __syncthreads();
-  };
-  auto sync_stage = [&]() { if (!B::DB && !PW && !RL) __syncthreads(); };   // stage reuse barrier (shared stages, single-buffered)
+  char* Fs = smem + (B::DB ? 2 : 1) * XY + B::STAGE_BYTES;
+  auto stage_ready = [&]() { __syncthreads(); };                        // stage published -> stage read
+  auto sync_stage = [&]() { if (!B::DB) __syncthreads(); };             // stage reuse barrier (single-buffered stages)
   const half8* w = packed;    // forward fragments (and, outside PART 2, all of them)
   const half8* wH = packed;   // layers 3, 4 forward and 4, 3, 2 transposed
   const half8* wT = packed;   // transposed fragments of layers 1 and 0
-  const half8* w0f = packed;  // forward layer-0 fragments (w's range [F0, F1)) and
-  const half8* w0t = packed;  // transposed layer-0 fragments (wT's range [T0, NTOT)): where those two sets are read from
-  if (B::LDSW_PART) {
-    half8* wl = reinterpret_cast<half8*>(smem + B::BASE_BYTES);
-    for (int i = threadIdx.x; i < (G::T0 - G::F1) * 64; i += BW_THREADS) wl[i] = packed[G::F1 * 64 + i];
-    w = wT = wH = wl - G::F1 * 64;    // fragments F1 .. T0-1 from LDS; w0f / w0t stay in global memory (L2)
-  }
   if (B::LDSW) {
     half8* wl = reinterpret_cast<half8*>(smem + B::BASE_BYTES);
     if (PART == 1) {
@@ -304,14 +203,11 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     if (PART != 1) w = wl;
   }
-  if (!B::LDSW_PART) { w0f = w; w0t = wT; }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int col = 32 * wv + r;             // this lane's sample within the workgroup's super-tile
-  constexpr int TW = B::TW;                // waves the weight-gradient tiles are dealt over
-  const int tw = PW ? 0 : ((TM || RL) ? wv % TW : wv);
-  const int scol = PW ? r : (TM ? 32 * tw + r : col);   // ... and its row in the stage images
+  const int scol = col;                    // ... and its row in the stage images
   // transposed-read offsets of the weight-gradient operands: lane 4q + p of a 16-lane group addresses sample row q of
   // the block, chunk p of the group's 16 features
   const int tq = (lane & 15) >> 2, tc = 4 * ((lane >> 4) & 1) + (lane & 3);
@@ -319,9 +215,6 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   float* stage = stage_all + (size_t)(ATOMIC ? wv : 0) * 32 * B::STAGE_LD;
 
   f32x16 dw0[B::A0], dw1[B::A1], dw2[B::A2], dw3[B::A3], dw4[B::A4];
-  f32x16 dwg[B::NSLOT];      // GT: this wave's tiles wv, wv + NW, ... of the whole network
-#pragma unroll
-  for (int k = 0; k < B::NSLOT; k++) dwg[k] = zero16();
 #pragma unroll
   for (int k = 0; k < B::A0; k++) dw0[k] = zero16();
 #pragma unroll
@@ -377,46 +270,12 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       }
     }
   };
-  // the colour half of hidden 128 is register-bound: its 44 B of inputs are read in place; so is a 12-wave workgroup
-  // (168 registers per lane), whose three waves per SIMD cover the load instead
-  constexpr bool PREFETCH = PART != 1 && NW < 12;
-  if (RL && team == 1) {
-    for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
-      __syncthreads();
-      dw_layer<SS, BLK, TW, B::NSLOT, B::B4, B::NT4, B::NT4>(dwg, tw, smem + (size_t)(kk & 1) * B::COPY_BYTES + B::XS_BYTES, smem + (size_t)(kk & 1) * B::COPY_BYTES, t0, t1);
-      kk++;
-      __syncthreads();
-      dw_layer<SS, BLK, TW, B::NSLOT, B::B3, B::NT3, G::OB>(dwg, tw, smem + (size_t)(kk & 1) * B::COPY_BYTES + B::XS_BYTES, smem + (size_t)(kk & 1) * B::COPY_BYTES, t0, t1);
-      kk++;
-      __syncthreads();
-      dw_layer<SS, BLK, TW, B::NSLOT, B::B2, B::NT2, 1>(dwg, tw, smem + (size_t)(kk & 1) * B::COPY_BYTES + B::XS_BYTES, smem + (size_t)(kk & 1) * B::COPY_BYTES, t0, t1);
-      kk++;
-      __syncthreads();
-      dw_layer<SS, BLK, TW, B::NSLOT, B::B1, B::NT1, B::NT1>(dwg, tw, smem + (size_t)(kk & 1) * B::COPY_BYTES + B::XS_BYTES, smem + (size_t)(kk & 1) * B::COPY_BYTES, t0, t1);
-      kk++;
-      __syncthreads();
-      dw_layer<SS, BLK, TW, B::NSLOT, B::B0, B::NT0, G::IB0>(dwg, tw, smem + (size_t)(kk & 1) * B::COPY_BYTES + B::XS_BYTES, smem + (size_t)(kk & 1) * B::COPY_BYTES, t0, t1);
-      kk++;
-    }
-    float* slab = slabs + (size_t)blockIdx.x * G::NW;
-#pragma unroll
-    for (int sl = 0; sl < B::NSLOT; sl++) {
-      const int T = tw + TW * sl;
-      if (T < B::B3) slab_tile(slab, G::OFF4, 3, H, 0, T - B::B4, dwg[sl], r, h);
-      else if (T < B::B2) slab_tile(slab, G::OFF3, H, H, (T - B::B3) / G::OB, (T - B::B3) % G::OB, dwg[sl], r, h);
-      else if (T < B::B1) slab_tile<2>(slab, G::OFF2, H, 31, T - B::B2, 0, dwg[sl], r, h);
-      else if (T < B::B0) slab_tile<1>(slab, G::OFF1, 16, H, 0, T - B::B1, dwg[sl], r, h);
-      else if (T < B::NTILES) slab_tile(slab, G::OFF0, H, G::F, (T - B::B0) / G::IB0, (T - B::B0) % G::IB0, dwg[sl], r, h);
-    }
-    return;
-  }
+  // the colour half of hidden 128 is register-bound: its 44 B of inputs are read in place
+  constexpr bool PREFETCH = PART != 1;
   Inputs nxt;
   if (PREFETCH && blockIdx.x < nst) load_inputs(blockIdx.x, nxt);
-  if (TM && team == 1) {      // the second team trails by TNL_BWD_STAGGER barriers (made up by the first team after the loop)
-    for (int k = 0; k < TNL_BWD_STAGGER; k++) __syncthreads();
-  }
   for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
-    if ((!B::LDSW && !B::LDSW_PART) || PART == 1) {
+    if (!B::LDSW || PART == 1) {
       // Weight fragments read from global memory (L2) inside the loop: the 8 layer-2 fragments of PART 1, and all 180
       // of the one-launch hidden-128 kernel (atomic mode only, the drop-in autograd path).  Keep the compiler from
       // hoisting these loop-invariant loads out of the super-tile loop: it tried to hold them all in registers and
@@ -427,11 +286,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       // (27 / 47 ms), H1 / H3 / H4 kept in LDS stages instead of registers (16 ms), the weights streamed through a
       // 56-KB LDS window in four phases per super-tile (10.4 ms).
       asm volatile("" : "+s"(w));
-      if (!B::LDSW && !B::LDSW_PART) wT = wH = w;
-    }
-    if (B::LDSW_PART) {   // the two layer-0 fragment sets are read from L2 inside the loop, not kept in registers across it
-      asm volatile("" : "+s"(w0f));
-      asm volatile("" : "+s"(w0t));
+      if (!B::LDSW) wT = wH = w;
     }
     const uint32_t i = st * ST + col;
     const bool valid = i < M;
@@ -455,7 +310,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       for (int ks = 0; ks < G::KS0; ks++) {
 #pragma unroll
         for (int ob = 0; ob < G::OB; ob++)
-          acc0[ob] = MFMA32(w0f[(G::F0 + ob * G::KS0 + ks) * 64 + lane], in.fk[ks], acc0[ob]);
+          acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], in.fk[ks], acc0[ob]);
       }
     }
     Chain<C, H> ch;
@@ -481,7 +336,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       dz4[2] = g_c2 * c2 * (1.f - c2);
     }
     const half8 dz4f = acc_to_frag<false>(dz4, 0);
-    Xs = RL ? smem + (size_t)(kk & 1) * B::COPY_BYTES : Xb[0]; Ys = RL ? Xs + B::XS_BYTES : Yb[0]; kk++;
+    Xs = Xb[0]; Ys = Yb[0];
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h4[ks], h, scol);
     put_acc<1>(Ys, dz4, h, scol);   // rows 0..7 (rgb logits' gradient in rows 0..2); the rest of the block is never used
@@ -489,14 +344,10 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     // (Every wave accumulates A_l tiles per layer without a branch: behind `if (tile < NT_l)` the accumulators of that
     // block live in VGPRs and are copied into AGPRs and back around the MFMAs, 32 moves per tile and super-tile.  The
     // duplicates cost idle waves a few MFMAs and are dropped when the slabs are written.)
-    if (B::GT && !RL) {
-      dw_layer<SS, BLK, TW, B::NSLOT, B::B4, B::NT4, B::NT4>(dwg, tw, Ys, Xs, t0, t1);
-    } else if (!B::GT) {
 #pragma unroll
     for (int k = 0; k < B::A4; k++) {
       const int t = (wv + NW * k) % B::NT4;   // a wave without a tile of its own repeats another's
       dw4[k] = dw_tile<SS>(Ys, Xs + t * BLK, t0, t1, dw4[k]);
-    }
     }
     // (a gradient tile leaves the registers as soon as it is masked and converted: its two fp16 fragments feed the next
     // layer's MFMAs AND are what the stage receives -- put_frag of fragments 2ib, 2ib+1 writes exactly put_acc's chunks)
@@ -510,20 +361,16 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     sync_stage();
 
     // ---- layer 3
-    Xs = RL ? smem + (size_t)(kk & 1) * B::COPY_BYTES : Xb[1]; Ys = RL ? Xs + B::XS_BYTES : Yb[1]; kk++;
+    Xs = Xb[1]; Ys = Yb[1];
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h3[ks], h, scol);
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d4f[ks], h, scol);
     stage_ready();
-    if (B::GT && !RL) {
-      dw_layer<SS, BLK, TW, B::NSLOT, B::B3, B::NT3, G::OB>(dwg, tw, Ys, Xs, t0, t1);
-    } else if (!B::GT) {
 #pragma unroll
     for (int k = 0; k < B::A3; k++) {
       const int t = (wv + NW * k) % B::NT3;   // a wave without a tile of its own repeats another's
       dw3[k] = dw_tile<SS>(Ys + (t / G::OB) * BLK, Xs + (t % G::OB) * BLK, t0, t1, dw3[k]);
-    }
     }
     half8 d3f[G::KH];
 #pragma unroll
@@ -541,7 +388,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 
     // ---- layer 2: X = z, staged as [SH(16) | the 16 chain slots of the sigma net's outputs] (slot 0 = the logit, which
     // is no input of the colour net: slab_tile<2> drops that column and shifts the geo features back by one)
-    Xs = RL ? smem + (size_t)(kk & 1) * B::COPY_BYTES : Xb[0]; Ys = RL ? Xs + B::XS_BYTES : Yb[0]; kk++;
+    Xs = Xb[0]; Ys = Yb[0];
     {
       half8 geo = in.geo;
       if (PART != 1) {
@@ -554,14 +401,10 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d3f[ks], h, scol);
     stage_ready();
-    if (B::GT && !RL) {
-      dw_layer<SS, BLK, TW, B::NSLOT, B::B2, B::NT2, 1>(dwg, tw, Ys, Xs, t0, t1);
-    } else if (!B::GT) {
 #pragma unroll
     for (int k = 0; k < B::A2; k++) {
       const int t = (wv + NW * k) % B::NT2;   // a wave without a tile of its own repeats another's
       dw2[k] = dw_tile<SS>(Ys + t * BLK, Xs, t0, t1, dw2[k]);
-    }
     }
     f32x16 dzz = zero16();
 #pragma unroll
@@ -585,19 +428,15 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     if (DO_SIG) {
 
     // ---- layer 1: X = H1, dY = dO in chain-slot order (slot 15 = the logit's gradient; slab_tile<1> maps the rows back)
-    Xs = RL ? smem + (size_t)(kk & 1) * B::COPY_BYTES : Xb[1]; Ys = RL ? Xs + B::XS_BYTES : Yb[1]; kk++;
+    Xs = Xb[1]; Ys = Yb[1];
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h1[ks], h, scol);
     put_frag<BLK>(Ys, 0, dof, h, scol);   // features 0..15 of the block; 16..31 are never used
     stage_ready();
-    if (B::GT && !RL) {
-      dw_layer<SS, BLK, TW, B::NSLOT, B::B1, B::NT1, B::NT1>(dwg, tw, Ys, Xs, t0, t1);
-    } else if (!B::GT) {
 #pragma unroll
     for (int k = 0; k < B::A1; k++) {
       const int t = (wv + NW * k) % B::NT1;   // a wave without a tile of its own repeats another's
       dw1[k] = dw_tile<SS>(Ys, Xs + t * BLK, t0, t1, dw1[k]);
-    }
     }
     half8 d1f[G::KH];
 #pragma unroll
@@ -609,7 +448,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     sync_stage();
 
     // ---- layer 0: X = F (natural k order) from the feature stage written at the top of the super-tile
-    Xs = RL ? smem + (size_t)(kk & 1) * B::COPY_BYTES : Xb[0]; Ys = RL ? Xs + B::XS_BYTES : Yb[0]; kk++;
+    Xs = Xb[0]; Ys = Yb[0];
     if (!B::EARLY_F) {   // into Xs: re-read (L2-hot) in atomic mode, from registers in PART 2
       const uint32_t il = valid ? i : M - 1;
 #pragma unroll
@@ -626,14 +465,10 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d1f[ks], h, scol);
     stage_ready();
-    if (B::GT && !RL) {
-      dw_layer<SS, BLK, TW, B::NSLOT, B::B0, B::NT0, G::IB0>(dwg, tw, Ys, B::EARLY_F ? Fs : Xs, t0, t1);
-    } else if (!B::GT) {
 #pragma unroll
     for (int k = 0; k < B::A0; k++) {
       const int t = (wv + NW * k) % B::NT0;   // a wave without a tile of its own repeats another's
       dw0[k] = dw_tile<SS>(Ys + (t / G::IB0) * BLK, (B::EARLY_F ? Fs : Xs) + (t % G::IB0) * BLK, t0, t1, dw0[k]);
-    }
     }
     // feature gradient dF^T = W0^T dH1^T
     if (!ATOMIC) {
@@ -644,7 +479,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       for (int ib = 0; ib < G::IB0; ib++) {
         f32x16 df = zero16();
 #pragma unroll
-        for (int ks = 0; ks < G::KH; ks++) df = MFMA32(w0t[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
+        for (int ks = 0; ks < G::KH; ks++) df = MFMA32(wT[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
         // Registers 4q..4q+3 hold features 32 ib + 8q + 4h .. +3 of sample r: a lane owns four 8-byte pieces of its
         // 64-byte row.  The two lanes of a sample trade two pieces each (v_permlane32_swap: lanes r and r + 32), after
         // which lane (r, h) holds features 32 ib + 16h .. +15 -- 32 contiguous bytes, two 16-byte stores instead of
@@ -688,7 +523,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     for (int ib = 0; ib < G::IB0; ib++) {
       f32x16 df = zero16();
 #pragma unroll
-      for (int ks = 0; ks < G::KH; ks++) df = MFMA32(w0t[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
+      for (int ks = 0; ks < G::KH; ks++) df = MFMA32(wT[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
 #pragma unroll
       for (int g = 0; g < 16; g++) {
         const int f = 32 * ib + acc_row(g, h);
@@ -720,27 +555,10 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     }
     }  // DO_SIG
-    if (!PW && !RL) __syncthreads();  // Xs/Ys are rewritten by the next super-tile (PW: by the same wave, in order)
-  }
-  if (RL) return;   // the chain waves hold no weight gradients
-
-  if (TM && team == 0) {
-    for (int k = 0; k < TNL_BWD_STAGGER; k++) __syncthreads();
+    __syncthreads();  // Xs/Ys are rewritten by the next super-tile
   }
   // ---- epilogue: this workgroup's weight-gradient slab
-  float* slab = slabs + (size_t)(PW ? blockIdx.x * NW + wv : (TM ? blockIdx.x * 2 + team : blockIdx.x)) * G::NW;   // one per wave / team
-  if (B::GT) {
-#pragma unroll
-    for (int sl = 0; sl < B::NSLOT; sl++) {
-      const int T = tw + TW * sl;
-      if (T < B::B3) slab_tile(slab, G::OFF4, 3, H, 0, T - B::B4, dwg[sl], r, h);
-      else if (T < B::B2) slab_tile(slab, G::OFF3, H, H, (T - B::B3) / G::OB, (T - B::B3) % G::OB, dwg[sl], r, h);
-      else if (T < B::B1) slab_tile<2>(slab, G::OFF2, H, 31, T - B::B2, 0, dwg[sl], r, h);
-      else if (T < B::B0) slab_tile<1>(slab, G::OFF1, 16, H, 0, T - B::B1, dwg[sl], r, h);
-      else if (T < B::NTILES) slab_tile(slab, G::OFF0, H, G::F, (T - B::B0) / G::IB0, (T - B::B0) % G::IB0, dwg[sl], r, h);
-    }
-    return;
-  }
+  float* slab = slabs + (size_t)blockIdx.x * G::NW;
 #pragma unroll
   for (int k = 0; k < B::A0; k++) {
     const int t = wv + NW * k;
@@ -804,32 +622,27 @@ inline uint32_t bwd_blocks(uint32_t M, uint32_t st = 128, uint32_t cap = 256) {
 template <int C, int H, bool ATOMIC>
 constexpr bool split_launch() { return split_backward<H>() && !ATOMIC; }
 
-template <int C, int H, int NW, bool ATOMIC, int PART, int MODE = 0>
+template <int C, int H, int NW, bool ATOMIC, int PART>
 int launch_bwd_part(const float* gsig, const float* grgb, const float* sigma, const void* feats, const float* xyz, const float* dirs,
                     float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* slabs,
                     const int32_t* m_actual, void* dfeat, _Float16* dO, uint32_t blocks, hipStream_t st) {
-  using B = BwdGeom<C, H, NW, ATOMIC, PART, MODE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd<C, H, NW, ATOMIC, PART, MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)B::LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((k_field_bwd<C, H, NW, ATOMIC, PART, MODE>), dim3(blocks), dim3(B::BW_THREADS), B::LDS_BYTES, st, gsig,
+  using B = BwdGeom<C, H, NW, ATOMIC, PART>;
+  static bool attr_set[64] = {};
+  const hipError_t ea = ensure_dynamic_lds(&k_field_bwd<C, H, NW, ATOMIC, PART>, (int)B::LDS_BYTES, attr_set);
+  if (ea != hipSuccess) return (int)ea;
+  hipLaunchKernelGGL((k_field_bwd<C, H, NW, ATOMIC, PART>), dim3(blocks), dim3(B::BW_THREADS), B::LDS_BYTES, st, gsig,
                      grgb, sigma, reinterpret_cast<const _Float16*>(feats), xyz, dirs, bound, M, (int)R,
                      reinterpret_cast<const half8*>(packed), grad_tm, slabs, m_actual,
                      reinterpret_cast<_Float16*>(dfeat), dO);
   return 0;
 }
 
-template <int C, int H, int NW, bool ATOMIC, int MODE = 0>
+template <int C, int H, int NW, bool ATOMIC>
 int launch_bwd_impl(const float* gsig, const float* grgb, const float* sigma, const void* feats, const float* xyz, const float* dirs,
                     float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW,
                     void* workspace, const int32_t* m_actual, void* dfeat, hipStream_t st) {
   using G = FieldGeom<C, H>;
-  // persistent workgroups: one per CU, two where two fit (hidden 64 split by layer)
-  const uint32_t blocks = bwd_blocks(M, MODE == 3 ? 16 * NW : 32 * NW, (H == 64 && split_launch<C, H, ATOMIC>()) ? 512 : 256);
+  const uint32_t blocks = bwd_blocks(M, 32 * NW, 256);     // persistent workgroups: one per CU
   float* slabs = reinterpret_cast<float*>(workspace);
   int e;
   if constexpr (split_launch<C, H, ATOMIC>()) {
@@ -841,44 +654,31 @@ int launch_bwd_impl(const float* gsig, const float* grgb, const float* sigma, co
     e = launch_bwd_part<C, H, NW, ATOMIC, 2>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, slabs, m_actual,
                                              dfeat, dO, blocks, st);
   } else {
-    e = launch_bwd_part<C, H, NW, ATOMIC, 0, MODE>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, slabs, m_actual,
+    e = launch_bwd_part<C, H, NW, ATOMIC, 0>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, slabs, m_actual,
                                                  dfeat, nullptr, blocks, st);
   }
   if (e != 0) return e;
-  hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 15) / 16), dim3(256), 0, st, slabs, (int)(MODE == 1 ? blocks * NW : (MODE == 2 ? blocks * 2 : blocks)),
+  hipLaunchKernelGGL(k_slab_reduce, dim3((G::NW + 15) / 16), dim3(256), 0, st, slabs, (int)blocks,
                      (int)G::NW, gradW);
   return (int)hipGetLastError();
 }
 
-template <int C, int H, int NWB>
+template <int C, int H>
 int launch_bwd(const float* gsig, const float* grgb, const float* sigma, const void* feats, const float* xyz, const float* dirs,
                float bound, uint32_t M, uint32_t R, const void* packed, float* grad_tm, float* gradW, void* workspace,
                const int32_t* m_actual, void* dfeat, hipStream_t st) {
   if (dfeat != nullptr) {
-    if constexpr (TNL_BWD_ROWS && H == 64)        // round 4: no stage images, no barriers (k_field_bwd_rows)
-    {
+    if constexpr (H == 64) {     // binned mode, hidden 64: k_field_bwd_rows (field_bwd_rows.hip)
       uint32_t nslab = 0;
       const int e = tnl_bwd_rows_launch(C, gsig, grgb, feats, dirs, M, packed, workspace, m_actual, dfeat, st, &nslab);
       if (e != 0) return e;
       hipLaunchKernelGGL(k_slab_reduce, dim3((FieldGeom<C, H>::NW + 15) / 16), dim3(256), 0, st,
                          reinterpret_cast<const float*>(workspace), (int)nslab, (int)FieldGeom<C, H>::NW, gradW);
       return (int)hipGetLastError();
+    } else {                     // hidden 128: two launches split by layer
+      return launch_bwd_impl<C, H, 4, false>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
+                                             m_actual, dfeat, st);
     }
-    else if constexpr (TNL_SPLIT_H64 && H == 64)       // two launches split by layer, 4-wave workgroups, two per CU
-      return launch_bwd_impl<C, H, 4, false, 0>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW,
-                                                workspace, m_actual, dfeat, st);
-    else if constexpr (TNL_BWD_MODE == 1 && H == 64)   // per-wave weight gradients: 4 waves per workgroup, one per SIMD, no barriers
-      return launch_bwd_impl<C, H, 4, false, 1>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW,
-                                                workspace, m_actual, dfeat, st);
-    else if constexpr (TNL_BWD_MODE == 3 && H == 64)   // roles: four chain waves + four weight-gradient waves
-      return launch_bwd_impl<C, H, 8, false, 3>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW,
-                                                workspace, m_actual, dfeat, st);
-    else if constexpr (TNL_BWD_MODE == 2 && H == 64)   // two staggered teams of four waves
-      return launch_bwd_impl<C, H, 8, false, 2>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW,
-                                                workspace, m_actual, dfeat, st);
-    else
-      return launch_bwd_impl<C, H, NWB, false>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
-                                               m_actual, dfeat, st);
   }
   return launch_bwd_impl<C, H, 4, true>(gsig, grgb, sigma, feats, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace,
                                         m_actual, dfeat, st);
@@ -891,8 +691,8 @@ extern "C" {
 uint64_t tnl_field_backward_workspace(uint32_t M, uint32_t C, uint32_t Hd, uint32_t Hc) {
   if (Hd != Hc || M == 0) return 0;
   const uint32_t blocks = bwd_blocks(M);
-  if (C == 16 && Hd == 64) return (uint64_t)blocks * FieldGeom<16, 64>::NW * 4 * 4 + (uint64_t)M * 32;   // x4: one slab per wave (PW); + dO (split)
-  if (C == 32 && Hd == 64) return (uint64_t)blocks * FieldGeom<32, 64>::NW * 4 * 4 + (uint64_t)M * 32;
+  if (C == 16 && Hd == 64) return (uint64_t)blocks * FieldGeom<16, 64>::NW * 4;       // one fp32 slab per workgroup
+  if (C == 32 && Hd == 64) return (uint64_t)blocks * FieldGeom<32, 64>::NW * 4;
   if (C == 48 && Hd == 128) return (uint64_t)blocks * FieldGeom<48, 128>::NW * 4 + (uint64_t)M * 32;   // + the dO hand-over (split launch)
   return 0;
 }
@@ -907,11 +707,11 @@ int tnl_field_backward(const float* grad_sigma, const float* grad_rgb, const flo
   if (Hd != Hc) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   if (C == 16 && Hd == 64)
-    return launch_bwd<16, 64, TNL_BWD_NW>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
+    return launch_bwd<16, 64>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   if (C == 32 && Hd == 64)
-    return launch_bwd<32, 64, TNL_BWD_NW>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
+    return launch_bwd<32, 64>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   if (C == 48 && Hd == 128)
-    return launch_bwd<48, 128, 4>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
+    return launch_bwd<48, 128>(grad_sigma, grad_rgb, sigma, feats_save, xyz, dirs, bound, M, R, packed, grad_tm, gradW, workspace, m_actual, dfeat_half, st);
   return (int)hipErrorInvalidValue;
 }
 

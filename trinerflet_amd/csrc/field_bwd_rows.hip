@@ -55,43 +55,15 @@ __device__ __forceinline__ IdFrags make_identity(int r, int h) {
   return I;
 }
 
-// two k-steps of chain fragments (the 32 features of one block) -> that block with features on the lanes: two operand
-// fragments of the weight-gradient MFMA (k-steps of 16 samples each)
-__device__ __forceinline__ void turn2(const half8& fe, const half8& fo, const half8& Ie, const half8& Io, half8 (&out)[2]) {
-  f32x16 t = MFMA32(fe, Ie, zero16());
-  t = MFMA32(fo, Io, t);
-  out[0] = acc_to_frag<false>(t, 0);
-  out[1] = acc_to_frag<false>(t, 1);
-}
-__device__ __forceinline__ void turn1(const half8& fe, const half8& Ie, half8 (&out)[2]) {
-  const f32x16 t = MFMA32(fe, Ie, zero16());
-  out[0] = acc_to_frag<false>(t, 0);
-  out[1] = acc_to_frag<false>(t, 1);
-}
 // One weight-gradient tile += dY'^T X' over the tile's 32 samples (two k-steps).  Written as inline assembly with the
 // accumulator constrained to AGPRs: the 16 tiles (256 registers) are read by nothing but these MFMAs until the kernel's
 // epilogue, and with them pinned to the accumulator half of the register file the 256 architectural VGPRs are left to the
 // chain (the file's other MFMAs are built in VGPR form, -amdgpu-mfma-vgpr-form=1, so that the VALU converts their results
 // without v_accvgpr_read).  The compiler's hazard recogniser does not look inside inline assembly: the s_nop in front
 // covers the VALU-write -> MFMA-read distance of the operands, the one between the two MFMAs the dependent accumulate.
-#ifndef TNL_ROWS_DROP
-#define TNL_ROWS_DROP 0   // timing experiments only (wrong results): 1 no weight-gradient MFMAs, 2 no turning MFMAs, 4 no dF stores
-#endif
-#ifndef TNL_ROWS_ASM_DW
-#define TNL_ROWS_ASM_DW 1
-#endif
 __device__ __forceinline__ void dw_rows(const half8 (&y)[2], const half8 (&x)[2], f32x16& acc) {
-  if (TNL_ROWS_DROP & 1) return;
-#if TNL_ROWS_ASM_DW
-#ifndef TNL_ROWS_DW_NOP
-#define TNL_ROWS_DW_NOP "s_nop 1\n\t"
-#endif
-  asm volatile(TNL_ROWS_DW_NOP "v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %3, %4, %0"
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %3, %4, %0"
                : "+a"(acc) : "v"(y[0]), "v"(x[0]), "v"(y[1]), "v"(x[1]));
-#else
-  acc = MFMA32(y[0], x[0], acc);
-  acc = MFMA32(y[1], x[1], acc);
-#endif
 }
 
 // slab_tile into / through the workgroup's LDS reduction buffer: OP 0 store, 1 add in place, 2 global = LDS + tile
@@ -120,9 +92,6 @@ __device__ __forceinline__ void red_tile(float* lds, float* slab, int off, int o
   }
 }
 
-#ifndef TNL_ROWS_FENCE
-#define TNL_ROWS_FENCE __builtin_amdgcn_sched_barrier(0)   // layer boundaries: keep the scheduler from pulling a later layer's loads across
-#endif
 template <int C>
 struct RowsGeom {
   static constexpr int H = 64;
@@ -170,24 +139,6 @@ k_field_bwd_rows(const float* __restrict__ gsig, const float* __restrict__ grgb,
     float dx, dy, dz, g_s, g_c0, g_c1, g_c2;
     half8 fk[G::KS0];
   };
-  auto load_inputs = [&](uint32_t st_, Inputs& in) {
-    const uint32_t i_ = st_ * ST + col;
-    const bool v_ = i_ < M;
-    const uint32_t il_ = v_ ? i_ : M - 1;
-    in.dx = dirs[(size_t)il_ * 3]; in.dy = dirs[(size_t)il_ * 3 + 1]; in.dz = dirs[(size_t)il_ * 3 + 2];
-    in.g_s = v_ ? gsig[i_] : 0.f;
-    in.g_c0 = v_ ? grgb[(size_t)i_ * 3] : 0.f; in.g_c1 = v_ ? grgb[(size_t)i_ * 3 + 1] : 0.f;
-    in.g_c2 = v_ ? grgb[(size_t)i_ * 3 + 2] : 0.f;
-#pragma unroll
-    for (int ks = 0; ks < G::KS0; ks++) {
-      in.fk[ks] = *reinterpret_cast<const half8*>(feats + feat_slot<G::KS0>(il_, ks, h));
-      if (!v_) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) in.fk[ks][j] = (_Float16)0.f;
-      }
-    }
-  };
-
   // Weight fragments come from LDS (ds_read_b128, ~100+ cycles).  With one wave per SIMD nothing hides that latency, and
   // left to itself the compiler issues each read right in front of the MFMA that takes it (read, wait, MFMA: ~100 cycles
   // per 32-cycle MFMA, measured 0.86 ms against the shared-stage kernel's 0.76).  So the loop is written as stages: the
@@ -200,13 +151,9 @@ k_field_bwd_rows(const float* __restrict__ gsig, const float* __restrict__ grgb,
       if (k < n) dst[k] = w[(base + k) * 64 + lane];
   };
 #define ROWS_STAGE __builtin_amdgcn_sched_barrier(0)
-#ifndef TNL_ROWS_INNER
-#define TNL_ROWS_INNER   // (a fence here pins "all MFMAs of the batch, then the previous batch's post"; without it the compiler may interleave them)
-#endif
   constexpr int OB = G::OB, KH = G::KH, KS0 = G::KS0, IB0 = G::IB0;
   const uint32_t nst = M == 0 ? 0 : (M + ST - 1) / ST;
   Inputs nxt;
-#if TNL_ROWS_PIPE
   if (blockIdx.x < nst) {
     const uint32_t i_ = blockIdx.x * ST + col, il_ = i_ < M ? i_ : M - 1;
     nxt.dx = dirs[(size_t)il_ * 3]; nxt.dy = dirs[(size_t)il_ * 3 + 1]; nxt.dz = dirs[(size_t)il_ * 3 + 2];
@@ -214,245 +161,9 @@ k_field_bwd_rows(const float* __restrict__ gsig, const float* __restrict__ grgb,
     nxt.g_c0 = i_ < M ? grgb[(size_t)i_ * 3] : 0.f; nxt.g_c1 = i_ < M ? grgb[(size_t)i_ * 3 + 1] : 0.f;
     nxt.g_c2 = i_ < M ? grgb[(size_t)i_ * 3 + 2] : 0.f;
   }
-#else
-  if (blockIdx.x < nst) load_inputs(blockIdx.x, nxt);
-#endif
   half8 wA[OB * KS0];                     // layer 0 forward, [ob][ks]
   ldw(wA, G::F0, OB * KS0);
-#ifndef TNL_ROWS_PIPE
-#define TNL_ROWS_PIPE 1
-#endif
-#if !TNL_ROWS_PIPE
-  for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
-    const uint32_t i = st * ST + col;
-    const bool valid = i < M;
-    const Inputs in = nxt;
-    if (st + gridDim.x < nst) load_inputs(st + gridDim.x, nxt);
-    const float dx = in.dx, dy = in.dy, dz = in.dz;
-    Chain<C, H> ch;
-
-    // ---- stage 1: layer 0 (recompute from the saved fp16 features)
-    half8 wB[KH + 2 * OB];                // layers 1 and 2 forward
-    ldw(wB, G::F1, KH + 2 * OB);
-    ROWS_STAGE;
-    {
-      f32x16 acc0[OB];
-#pragma unroll
-      for (int ob = 0; ob < OB; ob++) acc0[ob] = zero16();
-#pragma unroll
-      for (int ks = 0; ks < KS0; ks++) {
-#pragma unroll
-        for (int ob = 0; ob < OB; ob++) acc0[ob] = MFMA32(wA[ob * KS0 + ks], in.fk[ks], acc0[ob]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < KH; ks++)
-        ch.h1[ks] = (ks & 1) ? acc_to_frag<true>(acc0[ks >> 1], 1) : acc_to_frag<true>(acc0[ks >> 1], 0);
-    }
-    ROWS_STAGE;
-
-    // ---- stage 2: layers 1 and 2
-    half8 wC[OB * KH];                    // layer 3 forward, [ob][ks]
-    ldw(wC, G::F3, OB * KH);
-    ROWS_STAGE;
-    half8 geo;
-    const half8 shf = sh_frag(dx, dy, dz, h);
-    {
-      f32x16 o = zero16();
-#pragma unroll
-      for (int ks = 0; ks < KH; ks++) o = MFMA32(wB[ks], ch.h1[ks], o);
-#pragma unroll
-      for (int g = 0; g < 8; g++) ch.o8[g] = o[g];
-      geo = acc_to_frag<false>(o, 0);
-      f32x16 acc2[OB];
-#pragma unroll
-      for (int ob = 0; ob < OB; ob++) {
-        acc2[ob] = MFMA32(wB[KH + 2 * ob], shf, zero16());
-        acc2[ob] = MFMA32(wB[KH + 2 * ob + 1], geo, acc2[ob]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < KH; ks++)
-        ch.h3[ks] = (ks & 1) ? acc_to_frag<true>(acc2[ks >> 1], 1) : acc_to_frag<true>(acc2[ks >> 1], 0);
-    }
-    ROWS_STAGE;
-
-    // ---- stage 3: layer 3
-    half8 wD[KH + OB];                    // layer 4 forward + layer 4 transposed
-    ldw(wD, G::F4, KH + OB);              // F4 .. NF = T4 .. T4 + OB: contiguous
-    static_assert(G::NF == G::T4 && G::T4 + OB == G::T3 && G::T2 + KH == G::T1 && G::T1 + OB == G::T0, "fragment table order");
-    ROWS_STAGE;
-    {
-      f32x16 acc3[OB];
-#pragma unroll
-      for (int ob = 0; ob < OB; ob++) {
-        acc3[ob] = zero16();
-#pragma unroll
-        for (int ks = 0; ks < KH; ks++) acc3[ob] = MFMA32(wC[ob * KH + ks], ch.h3[ks], acc3[ob]);
-      }
-#pragma unroll
-      for (int ks = 0; ks < KH; ks++)
-        ch.h4[ks] = (ks & 1) ? acc_to_frag<true>(acc3[ks >> 1], 1) : acc_to_frag<true>(acc3[ks >> 1], 0);
-    }
-    ROWS_STAGE;
-
-    // ---- stage 4: layer 4 forward, dZ4 = drgb * rgb * (1 - rgb) on rows 0..2 (lanes h == 0), layer 4 backward
-    half8 wE[OB * KH];                    // layer 3 transposed, [ib][ks]
-    ldw(wE, G::T3, OB * KH);
-    ROWS_STAGE;
-    half8 d4f[KH];
-    {
-      f32x16 out = zero16();
-#pragma unroll
-      for (int ks = 0; ks < KH; ks++) out = MFMA32(wD[ks], ch.h4[ks], out);
-      half8 xR[OB][2];      // h4 turned (independent of the logits: fills the wait for them)
-#pragma unroll
-      for (int ib = 0; ib < OB; ib++) turn2(ch.h4[2 * ib], ch.h4[2 * ib + 1], I.pe, I.po, xR[ib]);
-      f32x16 dz4 = zero16();
-      if (h == 0) {
-        const float c0 = 1.f / (1.f + expf(-out[0])), c1 = 1.f / (1.f + expf(-out[1])), c2 = 1.f / (1.f + expf(-out[2]));
-        dz4[0] = in.g_c0 * c0 * (1.f - c0);
-        dz4[1] = in.g_c1 * c1 * (1.f - c1);
-        dz4[2] = in.g_c2 * c2 * (1.f - c2);
-      }
-      const half8 dz4f = acc_to_frag<false>(dz4, 0);
-#pragma unroll
-      for (int ib = 0; ib < OB; ib++) {
-        f32x16 t = MFMA32(wD[KH + ib], dz4f, zero16());
-        d4f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h4[2 * ib]);
-        d4f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h4[2 * ib + 1]);
-      }
-      half8 yR[2];
-      turn1(dz4f, I.po, yR);
-#pragma unroll
-      for (int ib = 0; ib < OB; ib++) dw_rows(yR, xR[ib], dw[B::B4 + ib]);
-    }
-    ROWS_STAGE;
-
-    // ---- stage 5: layer 3 backward
-    half8 wF[KH + OB];                    // layer 2 transposed + layer 1 transposed
-    ldw(wF, G::T2, KH + OB);
-    ROWS_STAGE;
-    half8 d3f[KH];
-    {
-#pragma unroll
-      for (int ib = 0; ib < OB; ib++) {
-        f32x16 t = zero16();
-#pragma unroll
-        for (int ks = 0; ks < KH; ks++) t = MFMA32(wE[ib * KH + ks], d4f[ks], t);
-        d3f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h3[2 * ib]);
-        d3f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h3[2 * ib + 1]);
-      }
-      half8 yR[OB][2], xR[2];
-#pragma unroll
-      for (int ob = 0; ob < OB; ob++) turn2(d4f[2 * ob], d4f[2 * ob + 1], I.pe, I.po, yR[ob]);
-#pragma unroll
-      for (int ib = 0; ib < OB; ib++) {
-        turn2(ch.h3[2 * ib], ch.h3[2 * ib + 1], I.pe, I.po, xR);
-#pragma unroll
-        for (int ob = 0; ob < OB; ob++) dw_rows(yR[ob], xR, dw[B::B3 + ob * OB + ib]);
-      }
-    }
-    ROWS_STAGE;
-
-    // ---- stage 6: layers 2 and 1 backward.  Layer 2: X = [SH(16), natural order | the 16 chain slots of the sigma net's
-    // outputs] (slot 0 = the logit, no input of the colour net: red_tile<2> drops that column and shifts the geo features
-    // back by one); layer 1: X = H1, dY = dO in chain-slot order (slot 15 = the logit's gradient; red_tile<1> maps the rows)
-    half8 wG[IB0 * KH];                   // layer 0 transposed, [ib][ks]
-    ldw(wG, G::T0, IB0 * KH);
-    ROWS_STAGE;
-    half8 d1f[KH];
-    {
-      f32x16 dzz = zero16();
-#pragma unroll
-      for (int ks = 0; ks < KH; ks++) dzz = MFMA32(wF[ks], d3f[ks], dzz);
-      {
-        half8 xR[2], yR[2];
-        turn2(shf, geo, I.ne, I.po, xR);
-#pragma unroll
-        for (int ob = 0; ob < OB; ob++) {
-          turn2(d3f[2 * ob], d3f[2 * ob + 1], I.pe, I.po, yR);
-          dw_rows(yR, xR, dw[B::B2 + ob]);
-        }
-      }
-      // dO fragment: slots rho = 0..14 <- d geo (rows 16..30 of dz = regs 8..15); slot rho = 15 <- d logit
-      // trunc_exp backward (activation.py:14-17): g * exp(clamp(logit, -15, 15))
-      half8 dof = acc_to_frag<false>(dzz, 1);
-      {
-        const float logit = __shfl(ch.o8[0], r);  // row 0 lives in lanes h == 0
-        const float dlogit = in.g_s * expf(fminf(fmaxf(logit, -15.f), 15.f));
-        if (h == 1) dof[7] = (_Float16)dlogit;
-      }
-#pragma unroll
-      for (int ib = 0; ib < OB; ib++) {
-        f32x16 t = MFMA32(wF[KH + ib], dof, zero16());
-        d1f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h1[2 * ib]);
-        d1f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h1[2 * ib + 1]);
-      }
-      half8 yR[2], xR[2];
-      turn1(dof, I.pe, yR);
-#pragma unroll
-      for (int ib = 0; ib < OB; ib++) {
-        turn2(ch.h1[2 * ib], ch.h1[2 * ib + 1], I.pe, I.po, xR);
-        dw_rows(yR, xR, dw[B::B1 + ib]);
-      }
-    }
-    ROWS_STAGE;
-
-    // ---- stage 7: layer 0 backward: weight gradient with X = F (natural slot order), and the feature gradient
-    ldw(wA, G::F0, OB * KS0);             // the next tile's first stage
-    ROWS_STAGE;
-    {
-      half8 yR[OB][2], xR[2];
-#pragma unroll
-      for (int ob = 0; ob < OB; ob++) turn2(d1f[2 * ob], d1f[2 * ob + 1], I.pe, I.po, yR[ob]);
-#pragma unroll
-      for (int ib = 0; ib < IB0; ib++) {
-        constexpr int KL = KS0 - 1;
-        if (2 * ib + 1 < KS0) turn2(in.fk[2 * ib], in.fk[2 * ib + 1 < KL ? 2 * ib + 1 : KL], I.ne, I.no, xR);
-        else turn1(in.fk[2 * ib], I.ne, xR);
-#pragma unroll
-        for (int ob = 0; ob < OB; ob++) dw_rows(yR[ob], xR, dw[B::B0 + ob * IB0 + ib]);
-      }
-    }
-    // ---- feature gradient dF^T = W0^T dH1^T: fp16, plane-major [3][M][C] (see the shared-stage kernel above)
-    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int ib = 0; ib < G::IB0; ib++) {
-      f32x16 df = zero16();
-#pragma unroll
-      for (int ks = 0; ks < G::KH; ks++) df = MFMA32(wG[ib * KH + ks], d1f[ks], df);
-      typedef unsigned u2 __attribute__((ext_vector_type(2)));
-      u2 pc[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        half4 v;
-        v[0] = (_Float16)df[4 * q]; v[1] = (_Float16)df[4 * q + 1];
-        v[2] = (_Float16)df[4 * q + 2]; v[3] = (_Float16)df[4 * q + 3];
-        pc[q] = __builtin_bit_cast(u2, v);
-      }
-#pragma unroll
-      for (int k = 0; k < 2; k++) {     // lower lane: pc[k + 2] <- partner's pc[k]; upper lane: pc[k] <- partner's pc[k + 2]
-#pragma unroll
-        for (int d = 0; d < 2; d++) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(pc[k][d], pc[k + 2][d], false, false);
-          pc[k][d] = sw[0];
-          pc[k + 2][d] = sw[1];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        const int f0 = 32 * ib + 16 * h + 8 * k;
-        if (f0 < G::F && valid) {
-          typedef unsigned u4 __attribute__((ext_vector_type(4)));
-          const u4 v = {pc[k][0], pc[k][1], pc[k + 2][0], pc[k + 2][1]};
-          const int pl = f0 / C, fc = f0 - pl * C;   // 8 consecutive features never straddle planes (C % 8 == 0)
-          *reinterpret_cast<u4*>(dfeat + ((size_t)pl * Mcap + i) * C + fc) = v;
-        }
-      }
-    }
-  }
-
-#else
-  // The pipelined form (TNL_ROWS_PIPE, default).  One wave per SIMD issues in order, so an MFMA batch followed by the
+  // One wave per SIMD issues in order, so an MFMA batch followed by the
   // conversion of its own result leaves the matrix pipe idle during the conversion and the vector ALU idle during the
   // MFMAs (the staged form above: 0.89 ms).  Here the tile's work is a fixed list of BATCHES -- a few MFMAs into one or
   // two accumulator tiles, then a POST part on the vector ALU (convert / ReLU / mask / store) -- issued as
@@ -466,12 +177,10 @@ k_field_bwd_rows(const float* __restrict__ gsig, const float* __restrict__ grgb,
 #else
 #define STAMP()
 #endif
-#ifndef TNL_ROWS_FENCE_EVERY
-#define TNL_ROWS_FENCE_EVERY 1    // experiments: a fence only behind every n-th slot
-#endif
-#define SLOT(MCODE, ...) { MCODE; } TNL_ROWS_INNER; { __VA_ARGS__; } if (__COUNTER__ % TNL_ROWS_FENCE_EVERY == 0) ROWS_STAGE; STAMP() if (TNL_ROWS_STAMP) ROWS_STAGE;
-#define TURN2(T, FE, FO, IE, IO) if (TNL_ROWS_DROP & 2) { T = zero16(); T[0] = (float)FE[0] + (float)FO[1]; } else { T = MFMA32(FE, IE, zero16()); T = MFMA32(FO, IO, T); }
-#define TURN1(T, FE, IE) if (TNL_ROWS_DROP & 2) { T = zero16(); T[0] = (float)FE[0]; } else T = MFMA32(FE, IE, zero16())
+// (no fence between a slot's two parts: the compiler may place the previous batch's post between this batch's MFMAs)
+#define SLOT(MCODE, ...) { MCODE; } { __VA_ARGS__; } ROWS_STAGE; STAMP() if (TNL_ROWS_STAMP) ROWS_STAGE;
+#define TURN2(T, FE, FO, IE, IO) T = MFMA32(FE, IE, zero16()); T = MFMA32(FO, IO, T)
+#define TURN1(T, FE, IE) T = MFMA32(FE, IE, zero16())
 #define POST_T(T, X) X[0] = acc_to_frag<false>(T, 0); X[1] = acc_to_frag<false>(T, 1)
 #define POST_RELU(T, F0_, F1_) F0_ = acc_to_frag<true>(T, 0); F1_ = acc_to_frag<true>(T, 1)
 #define POST_MASK(T, F0_, F1_, H0_, H1_) F0_ = relu_mask_frag(acc_to_frag<false>(T, 0), H0_); F1_ = relu_mask_frag(acc_to_frag<false>(T, 1), H1_)
@@ -563,7 +272,7 @@ k_field_bwd_rows(const float* __restrict__ gsig, const float* __restrict__ grgb,
 #pragma unroll
       for (int k = 0; k < 2; k++) {
         const int f0 = 32 * ib + 16 * h + 8 * k;
-        if (f0 < G::F && valid && (!(TNL_ROWS_DROP & 4) || pc[k][0] == 0x12345678u)) {
+        if (f0 < G::F && valid) {
           const u4 v = {pc[k][0], pc[k][1], pc[k + 2][0], pc[k + 2][1]};
           const int pl = f0 / C, fc = f0 - pl * C;   // 8 consecutive features never straddle planes (C % 8 == 0)
           *reinterpret_cast<u4*>(dfeat + ((size_t)pl * Mcap + i) * C + fc) = v;
@@ -673,7 +382,6 @@ k_field_bwd_rows(const float* __restrict__ gsig, const float* __restrict__ grgb,
     if (stamp_on) { g_rows_stamps[63 * 64 + stamp_t] = __builtin_amdgcn_s_memrealtime(); stamp_t++; }
 #endif
   }
-#endif
   // ---- epilogue: the four waves' tiles summed through LDS (over the fragment table, no longer needed) into the slab
   float* red = reinterpret_cast<float*>(smem);
   float* slab = slabs + (size_t)blockIdx.x * G::NW;
@@ -703,13 +411,9 @@ int launch_rows(const float* gsig, const float* grgb, const void* feats, const f
   using B = RowsGeom<C>;
   const uint32_t nst = (M + B::ST - 1) / B::ST;
   const uint32_t blocks = nst < 256 ? nst : 256;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_field_bwd_rows<C>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)B::LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static bool attr_set[64] = {};
+  const hipError_t ea = ensure_dynamic_lds(&k_field_bwd_rows<C>, (int)B::LDS_BYTES, attr_set);
+  if (ea != hipSuccess) return (int)ea;
   float* slabs = reinterpret_cast<float*>(workspace);
   hipLaunchKernelGGL((k_field_bwd_rows<C>), dim3(blocks), dim3(256), B::LDS_BYTES, st, gsig, grgb,
                      reinterpret_cast<const _Float16*>(feats), dirs, M, reinterpret_cast<const half8*>(packed), slabs,

@@ -14,16 +14,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// The backward of the hidden-128 network runs as two launches split by layer (field_bwd.hip PART); TNL_SPLIT_H64 = 1
-// builds the hidden-64 networks the same way (4-wave workgroups of <= 214 registers, TWO per CU with independent
-// barriers; the forward then saves the 16 sigma-net outputs per sample behind the features for them as well).
-// Measured at base (round 3, A/B of two builds on one box): backward 0.76 ms as two launches against 0.80 ms as one,
-// forward +0.035 ms for the extra 32 B per sample -- a wash, so the default stays the single launch.
-#ifndef TNL_SPLIT_H64
-#define TNL_SPLIT_H64 0
-#endif
+// The binned backward of the hidden-128 network runs as two launches split by layer (field_bwd.hip PART); the forward
+// then saves the 16 sigma-net outputs per sample behind the features for the colour half.
 template <int H>
-constexpr bool split_backward() { return H > 64 || TNL_SPLIT_H64; }
+constexpr bool split_backward() { return H > 64; }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

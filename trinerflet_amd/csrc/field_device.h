@@ -13,6 +13,18 @@ namespace {
 
 constexpr int FWD_THREADS = 256;
 
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device): `done` is the call site's own static table (one
+// per template instantiation); the attribute belongs to the device's code object, not to the process
+template <typename K>
+inline hipError_t ensure_dynamic_lds(K kernel, int bytes, bool (&done)[64]) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+  return e;
+}
+
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
 #pragma unroll

@@ -42,7 +42,83 @@ k_mse_loss(const float* __restrict__ image, const float* __restrict__ ws, const 
   if (threadIdx.x == 0) atomicAdd(mse, (part[0] + part[1] + part[2] + part[3]) * inv_norm);
 }
 
+// ---- mean |x| and its gradient: the wavelet L1 regulariser's term for one coefficient tensor (nerf/utils.py:639-655:
+// val.abs().mean()) as one read pass forward and one read + one write pass backward, instead of torch's abs, mean, sign,
+// mul (3.3 ms per step at the base configuration's 403 M coefficients through autograd).
+constexpr int ABS_BLOCKS = 2048;
+
+__global__ void __launch_bounds__(256)
+k_abs_sum(const float* __restrict__ x, uint64_t n, double* __restrict__ partial) {
+  const uint64_t n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float acc = 0.f;
+  // a contiguous chunk per workgroup (fixed partition: the result does not depend on scheduling)
+  const uint64_t chunk = (n4 + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < n4 ? lo + chunk : n4;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const float4 v = x4[i];
+    acc += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x < (n & 3)) acc += fabsf(x[n4 * 4 + threadIdx.x]);
+  double d = (double)acc;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ void __launch_bounds__(256)
+k_abs_mean_finish(const double* __restrict__ partial, int nb, double inv_n, float* __restrict__ out) {
+  double d = 0.0;
+  for (int i = threadIdx.x; i < nb; i += 256) d += partial[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) d += __shfl_xor(d, off);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)(((part[0] + part[1]) + (part[2] + part[3])) * inv_n);
+}
+
+__global__ void __launch_bounds__(256)
+k_abs_mean_bwd(const float* __restrict__ x, uint64_t n, const float* __restrict__ g, float inv_n, float* __restrict__ grad) {
+  const float s = g[0] * inv_n;
+  const uint64_t n4 = n / 4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* o4 = reinterpret_cast<float4*>(grad);
+  auto sg = [s](float v) { return v > 0.f ? s : (v < 0.f ? -s : (v == 0.f ? 0.f : v)); };   // torch.sign: sign(0) = 0, NaN stays NaN
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) {
+    const float4 v = x4[i];
+    o4[i] = make_float4(sg(v.x), sg(v.y), sg(v.z), sg(v.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) grad[n4 * 4 + threadIdx.x] = sg(x[n4 * 4 + threadIdx.x]);
+}
+
 }  // namespace
+
+extern "C" uint64_t tnl_abs_mean_workspace(void) { return (uint64_t)ABS_BLOCKS * sizeof(double); }
+
+extern "C" int tnl_abs_mean_forward(const float* x, uint64_t n, void* workspace, float* out, void* stream) {
+  if (n == 0 || ((uintptr_t)x & 15) != 0) return (int)hipErrorInvalidValue;
+  const uint64_t n4 = n / 4;
+  int nb = (int)((n4 + 1023) / 1024);
+  nb = nb < 1 ? 1 : (nb > ABS_BLOCKS ? ABS_BLOCKS : nb);
+  hipLaunchKernelGGL(k_abs_sum, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, reinterpret_cast<double*>(workspace));
+  hipLaunchKernelGGL(k_abs_mean_finish, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const double*>(workspace), nb, 1.0 / (double)n, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tnl_abs_mean_backward(const float* x, uint64_t n, const float* grad_out, float* grad_x, void* stream) {
+  if (n == 0 || ((uintptr_t)x & 15) != 0 || ((uintptr_t)grad_x & 15) != 0) return (int)hipErrorInvalidValue;
+  const uint64_t n4 = n / 4;
+  int nb = (int)((n4 + 255) / 256);
+  nb = nb < 1 ? 1 : (nb > 8192 ? 8192 : nb);
+  hipLaunchKernelGGL(k_abs_mean_bwd, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, n, grad_out, (float)(1.0 / (double)n),
+                     grad_x);
+  return (int)hipGetLastError();
+}
 
 extern "C" int tnl_mse_loss(const float* image, const float* weights_sum, const float* gt_rgb, float bg_color,
                             const float* bg_rays, uint32_t N, float inv_norm, const float* scale_dev, float* pred,

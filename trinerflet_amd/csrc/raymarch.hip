@@ -1122,12 +1122,8 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
                                  float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                  const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                                  int32_t* rays, int32_t* counter, const float* noises, int32_t* workspace,
-                                 uint32_t workspace_words, uint32_t binR, void* sort_workspace, void* stream,
-                                 int phase = 0) {
-  // phase 0: everything; 1: the count pass only (the serial per-ray walk: few waves, pure latency); 2: the rest (ray
-  // records, sample emission + tile counts, counter) from phase 1's scratch -- record path only
-  const bool do1 = phase != 2, do2 = phase != 1;
-  if (do1 && sort_workspace != nullptr) {   // the tile sort's bin counts (first nb + 1 ints of its workspace) start from zero
+                                 uint32_t workspace_words, uint32_t binR, void* sort_workspace, void* stream) {
+  if (sort_workspace != nullptr) {   // the tile sort's bin counts (first nb + 1 ints of its workspace) start from zero
     if (binR == 0 || binR % TSX != 0) return (int)hipErrorInvalidValue;
     const size_t nbins = 3ull * (binR / TSX) * (binR / TSY) * BIN_SUBS;
     hipError_t e = hipMemsetAsync(sort_workspace, 0, (nbins + 1) * sizeof(int), (hipStream_t)stream);
@@ -1142,24 +1138,18 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
   if (need_rec != 0 && workspace_words >= need_rec) {
     // one march: the count pass records each sample's t, the samples are written from the record
     float* tbuf = reinterpret_cast<float*>(workspace + ((tnl_march_rays_train_workspace(N) + 3) & ~3u));
-    if (do1) {
-      if (wide_bitfield(grid, C, H))
-        hipLaunchKernelGGL((k_march_train_count<true, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid,
-                           bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf);
-      else
-        hipLaunchKernelGGL((k_march_train_count<false, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid,
-                           bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf);
-    }
-    if (do2) {
-      hipLaunchKernelGGL((k_march_train_write<true, false>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
-                         dt_gamma, max_steps, N, C, H, M, nears, fars, noises, num_steps, block_sums, counter, xyzs,
-                         dirs, deltas, rays);
-      hipLaunchKernelGGL(k_march_train_emit, dim3(cdiv(N, MARCH_BLOCK / WAVE)), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d,
-                         bound, dt_gamma, max_steps, N, C, H, M, nears, noises, counter, tbuf, rays, xyzs, dirs, deltas,
-                         (int)binR, reinterpret_cast<int*>(sort_workspace));
-    }
-  } else if (phase != 0) {
-    return (int)hipErrorInvalidValue;   // the two-phase form exists for the record path only
+    if (wide_bitfield(grid, C, H))
+      hipLaunchKernelGGL((k_march_train_count<true, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid,
+                         bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf);
+    else
+      hipLaunchKernelGGL((k_march_train_count<false, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid,
+                         bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf);
+    hipLaunchKernelGGL((k_march_train_write<true, false>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
+                       dt_gamma, max_steps, N, C, H, M, nears, fars, noises, num_steps, block_sums, counter, xyzs,
+                       dirs, deltas, rays);
+    hipLaunchKernelGGL(k_march_train_emit, dim3(cdiv(N, MARCH_BLOCK / WAVE)), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d,
+                       bound, dt_gamma, max_steps, N, C, H, M, nears, noises, counter, tbuf, rays, xyzs, dirs, deltas,
+                       (int)binR, reinterpret_cast<int*>(sort_workspace));
   } else if (sort_workspace != nullptr) {
     return (int)hipErrorInvalidValue;   // the fused count needs the record path (workspace_rec words of scratch)
   } else if (wide_bitfield(grid, C, H)) {
@@ -1175,25 +1165,8 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
                        dt_gamma, max_steps, N, C, H, M, nears, fars, noises, num_steps, block_sums, counter, xyzs,
                        dirs, deltas, rays);
   }
-  if (do2) hipLaunchKernelGGL(k_march_train_finalize, dim3(1), dim3(MARCH_BLOCK), 0, st, block_sums, nb, N, counter);
+  hipLaunchKernelGGL(k_march_train_finalize, dim3(1), dim3(MARCH_BLOCK), 0, st, block_sums, nb, N, counter);
   return launch_status();
-}
-
-// tnl_march_rays_train_binned in two calls: phase 1 = the count pass (one lane per ray walks the occupancy grid and records
-// its samples' t: ~940 long-lived waves of pure latency, which co-reside with the register-heavy field kernels at little
-// cost), phase 2 = everything wide (ray records, sample emission with the tile counts, counter).  Same arguments to both
-// calls; phase 2 reads what phase 1 left in `workspace`.  Needs the record-path workspace
-// (tnl_march_rays_train_workspace_rec words).  TrainStep starts phase 1 of the NEXT batch before the field forward and
-// phase 2 after the field backward.
-int tnl_march_rays_train_binned_phase(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
-                                      float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                                      const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
-                                      int32_t* rays, int32_t* counter, const float* noises, int32_t* workspace,
-                                      uint32_t workspace_words, uint32_t R, void* sort_workspace, int phase,
-                                      void* stream) {
-  if (sort_workspace == nullptr || (phase != 1 && phase != 2)) return (int)hipErrorInvalidValue;
-  return march_rays_train_impl(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
-                               deltas, rays, counter, noises, workspace, workspace_words, R, sort_workspace, stream, phase);
 }
 
 int tnl_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,

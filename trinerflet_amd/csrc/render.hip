@@ -56,7 +56,7 @@ k_render_rays(const void* __restrict__ planes, int R, const half8* __restrict__ 
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   // ray state, identical in lanes r and r + 32
   int idx = -1;
-  MarchCtx m;
+  MarchCtx m = {};     // a slot the queue never filled still rides through the MFMA chain: defined (zero) operands
   float t = 0.f, last_t = 0.f, far = 0.f, tc = 0.f;
   uint32_t cblk = 0xffffffffu;
   unsigned long long cbits = 0ull;
@@ -184,12 +184,14 @@ int launch_render(const void* planes, int half_in, uint32_t R, const void* packe
   const bool wide = (reinterpret_cast<uintptr_t>(grid) & 7u) == 0 && ((size_t)Cas * Hg * Hg * Hg) % 64 == 0;
 #define TNL_RENDER(HP, WD)                                                                                               \
   do {                                                                                                                   \
-    static bool attr_set = false;                                                                                        \
-    if (!attr_set) {                                                                                                     \
+    static bool attr_set[64] = {};          /* per device: the attribute belongs to the device's code object */          \
+    int dev_ = 0;                                                                                                        \
+    (void)hipGetDevice(&dev_);                                                                                           \
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {                                                                     \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_rays<C, H, HP, WD>),                    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
       if (e != hipSuccess) return (int)e;                                                                                \
-      attr_set = true;                                                                                                   \
+      if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;                                                                 \
     }                                                                                                                    \
     hipLaunchKernelGGL((k_render_rays<C, H, HP, WD>), dim3(blocks), dim3(RT), lds, st, planes, (int)R, pk, rays_o, rays_d, \
                        nears, fars, N, grid, bound, dt_gamma, max_steps, Cas, Hg, T_thresh, density_scale, noises, queue,  \

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/trinerflet_hip.h"
 #include "roi_common.h"
 #include "bin_common.h"
@@ -144,7 +146,10 @@ __global__ void __launch_bounds__(NT)
 k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float* __restrict__ xyz, float bound, int R, int TNX,
                   int TNY, const int* __restrict__ offsets, const uint32_t* __restrict__ entries,
                   const float2* __restrict__ epos, float grad_scale,
-                  float* __restrict__ grad_out, int channel_major, int* __restrict__ nonfinite_flag, Roi roi) {
+                  float* __restrict__ grad_out, int layout, int* __restrict__ nonfinite_flag, Roi roi) {
+  // layout: bit 0 = channel-major (3,C,R,R) output; bit 1 = the caller zero-filled the output (one contiguous fill):
+  // untouched tiles are then skipped instead of being zeroed here in 128-byte row pieces
+  const int channel_major = layout & 1;
   constexpr int NTEX = TSX * TSY;
   constexpr int TILE_F = NTEX * C;
     constexpr int NB = (C + 31) / 32;          // 32-channel column blocks
@@ -184,6 +189,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
   const int ow = roi.rw ? roi.rw : R, oh = roi.rw ? roi.rh : R;
   const int x_out = x_lo - (roi.rw ? roi.ox[p] : 0), y_out = y_lo - (roi.rw ? roi.oy[p] : 0);
   if (beg == end) {  // untouched tile: this store replaces the zero fill of the gradient
+    if (layout & 2) return;
     if (!channel_major) {
       float* dst = grad_out + (((size_t)p * R + y_lo) * R + x_lo) * C;
       constexpr int ROW_F4 = TSX * C / 4;
@@ -426,14 +432,38 @@ int tnl_plane_grad_sort_layout(uint32_t M, uint32_t R, int64_t* out) {
   return 0;
 }
 
+// The positions of the list entries lie behind the 12 * M entry slots, so sort, reduce and tnl_plane_grad_sort_layout must
+// be given the SAME capacity M (and an 8-byte aligned workspace: the layout call computes the padding from a null base).
+// A host-side note of what each workspace was last sorted with lets the reduce refuse a mismatch instead of reading
+// positions from the wrong place (no device read-back; a small ring, newest first).
+struct SortNote { const void* ws; uint32_t M, R; };
+static SortNote g_sort_notes[32];
+static unsigned g_sort_note_next = 0;
+static std::mutex g_sort_note_mutex;
+
+static void note_sort(const void* ws, uint32_t M, uint32_t R) {
+  std::lock_guard<std::mutex> lock(g_sort_note_mutex);
+  for (auto& n : g_sort_notes)
+    if (n.ws == ws) { n.M = M; n.R = R; return; }
+  g_sort_notes[g_sort_note_next++ % 32] = SortNote{ws, M, R};
+}
+// false only if the workspace is known and was sorted with another capacity / plane size
+static bool sort_matches(const void* ws, uint32_t M, uint32_t R) {
+  std::lock_guard<std::mutex> lock(g_sort_note_mutex);
+  for (const auto& n : g_sort_notes)
+    if (n.ws == ws) return n.M == M && n.R == R;
+  return true;
+}
+
 // Part 1 (needs only the sample positions): counting sort of the samples by (plane, tile).  TrainStep runs it on
 // the march's side stream, so it is off the critical path of the step.
 static int plane_grad_sort_impl(const float* xyz, float bound, uint32_t M, const int32_t* m_actual, uint32_t R,
                                 void* workspace, bool counted, void* stream) {
-  if (R % TSX != 0) return (int)hipErrorInvalidValue;
+  if (R % TSX != 0 || (reinterpret_cast<uintptr_t>(workspace) & 7) != 0) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int TNX = R / TSX, TNY = R / TSY;
   const SortWs w = sort_ws(workspace, R, M);
+  note_sort(workspace, M, R);
   if (!counted) {
     hipError_t e = hipMemsetAsync(w.counts, 0, (size_t)(w.nb + 1) * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
@@ -468,8 +498,9 @@ int tnl_plane_grad_reduce(const void* dfeat_half, const float* xyz, float bound,
                           float grad_scale, float* grad_out, int channel_major, int32_t* nonfinite_flag,
                           const int32_t* roi_host, const void* workspace, void* stream) {
   if (R % TSX != 0 || (C != 16 && C != 32 && C != 48)) return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 7) != 0 || !sort_matches(workspace, M, R)) return (int)hipErrorInvalidValue;
   Roi roi;
-  if (!make_roi(roi_host, 3 * C, R, roi) || (roi.rw && (!channel_major || roi.spp != (int)C || roi.s0 != 0)))
+  if (!make_roi(roi_host, 3 * C, R, roi) || (roi.rw && (!(channel_major & 1) || roi.spp != (int)C || roi.s0 != 0)))
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int TNX = R / TSX, TNY = R / TSY;

@@ -111,22 +111,6 @@ int tnl_step_epilogue(const float* found_inf, float* opt_steps, float* scale, in
 
 }  // extern "C"
 
-// A stream whose kernels may only run on the compute units selected by `mask` (bit i of word i / 32 = CU i of the
-// device's enumeration; n_words 32-bit words).  TrainStep puts the next batch's march + tile sort -- latency-bound
-// work of ~1000 waves that otherwise spreads one wave onto every SIMD of the chip and slows whatever runs there -- on
-// a stream confined to a fraction of the CUs, where its waves share SIMDs with each other instead.
-extern "C" int tnl_stream_create_cu_mask(const uint32_t* mask, uint32_t n_words, void** stream) {
-  if (mask == nullptr || stream == nullptr || n_words == 0) return (int)hipErrorInvalidValue;
-  hipStream_t st = nullptr;
-  const hipError_t e = hipExtStreamCreateWithCUMask(&st, n_words, mask);
-  *stream = (void*)st;
-  return (int)e;
-}
-
-extern "C" int tnl_stream_destroy(void* stream) {
-  return stream == nullptr ? 0 : (int)hipStreamDestroy((hipStream_t)stream);
-}
-
 extern "C" int tnl_copy_probe(const void* src, void* dst, uint64_t bytes, void* stream) {
   const uint64_t n4 = bytes / 16;
   if (n4 == 0) return 0;

@@ -67,8 +67,13 @@ def field_backward(grad_sigma, grad_rgb, sigma, rgb, feats, xyz, dirs, packed, b
 
 
 class _FusedField(Function):
+    binned_backward = True     # False: the plane gradient by global float atomics (tests compare the two)
+
     @staticmethod
-    def forward(ctx, planes_tm, xyz, dirs, W0, W1, W2, W3, W4, bound):
+    def forward(ctx, planes_tm, xyz, dirs, W0, W1, W2, W3, W4, bound, planes_cm=None):
+        """planes_cm (optional): the (3,C,R,R) planes the texel-major copy `planes_tm` was made from.  When given, the
+        planes' gradient is returned for IT, already in its layout (the tile reduction writes channel-major directly),
+        and planes_tm is read as plain data -- the layout pass back to (3,C,R,R) (0.74 ms at base) disappears."""
         L.require_cuda(planes_tm, xyz, dirs, W0)
         _, R, _, C = planes_tm.shape
         H = W0.shape[0]
@@ -79,6 +84,9 @@ class _FusedField(Function):
         sigma, rgb, feats = field_forward(planes_tm, xyz, dirs, packed, float(bound), C, R, H, save_feats=need_grad)
         ctx.save_for_backward(xyz, dirs, packed, sigma, rgb, feats)
         ctx.dims = (C, R, H, float(bound), [tuple(w.shape) for w in (W0, W1, W2, W3, W4)])
+        ctx.cm = planes_cm is not None and R % 32 == 0 and _FusedField.binned_backward
+        if planes_cm is not None and not ctx.cm:
+            raise NotImplementedError("fused_field(planes_cm=...) needs plane_resolution % 32 == 0 (the tile reduction)")
         return sigma, rgb
 
     @staticmethod
@@ -88,15 +96,33 @@ class _FusedField(Function):
         dev = xyz.device
         g_sigma = g_sigma.to(torch.float32).contiguous()
         g_rgb = g_rgb.to(torch.float32).contiguous()
-        grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=dev)
         nw = sum(a * b for a, b in shapes)
         gradW = torch.zeros(nw, dtype=torch.float32, device=dev)
-        field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW)
+        if ctx.cm:
+            grad_cm = torch.zeros(3, C, R, R, dtype=torch.float32, device=dev)
+            if xyz.shape[0] > 0:
+                dfeat = torch.empty(3, xyz.shape[0], C, dtype=torch.float16, device=dev)
+                field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_cm, gradW, dfeat=dfeat)
+                plane_grad_binned(dfeat, xyz, bound, C, R, grad_cm, channel_major=True, prezeroed=True)
+            grad_tm = None
+        elif R % 32 == 0 and xyz.shape[0] > 0 and _FusedField.binned_backward:
+            # no global float atomics (round 4; before: 6.8 ms of a 24.5-ms step of the reference's loop at base, bound by
+            # the memory-side atomic rate): dF leaves the field kernel as fp16, plane-major, and a tile-sorted matrix-core
+            # reduction (csrc/scatter.hip) writes every texel of the plane gradient once -- what TrainStep does, here
+            # with the counting sort in line.  Under GradScaler an overflow of the fp16 dF shows up as inf in the
+            # gradient, which is what makes scaler.step() skip and back off.
+            grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=dev)
+            dfeat = torch.empty(3, xyz.shape[0], C, dtype=torch.float16, device=dev)
+            field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW, dfeat=dfeat)
+            plane_grad_binned(dfeat, xyz, bound, C, R, grad_tm, prezeroed=True)
+        else:
+            grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=dev)
+            field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW)
         gws, off = [], 0
         for a, b in shapes:
             gws.append(gradW[off:off + a * b].view(a, b))
             off += a * b
-        return (grad_tm, None, None, *gws, None)
+        return (grad_tm, None, None, *gws, None, grad_cm if ctx.cm else None)
 
 
 fused_field = _FusedField.apply
@@ -165,11 +191,12 @@ def plane_grad_reduce(ws, dfeat, xyz, bound, C, R, grad_out, grad_scale=1.0, cha
 
 
 def plane_grad_binned(dfeat, xyz, bound, C, R, grad_out, m_actual=None, grad_scale=1.0, channel_major=False,
-                      nonfinite_flag=None, roi=None):
+                      nonfinite_flag=None, roi=None, prezeroed=False):
     """fp16 feature gradients (plane-major [3,M,C], as field_backward(dfeat=...) writes them) -> plane gradient fp32
     by tile-sorted matrix-core reduction
     (csrc/scatter.hip): [3,R,R,C], or (3,C,R,R) with channel_major=True; writes every tile of grad_out.
-    roi (8 ints): only the window's tiles, grad_out compact (3C, rh, rw), channel_major required."""
+    roi (8 ints): only the window's tiles, grad_out compact (3C, rh, rw), channel_major required.
+    prezeroed: grad_out was zero-filled by the caller; untouched tiles are skipped (whole planes: 1.39 -> 0.7 ms at base)."""
     lib = L.lib()
     M = xyz.shape[0]
     nbytes = lib.tnl_plane_grad_binned_workspace(L.u32(M), L.u32(R))
@@ -178,6 +205,6 @@ def plane_grad_binned(dfeat, xyz, bound, C, R, grad_out, m_actual=None, grad_sca
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
     L.check(lib.tnl_plane_grad_binned_roi(L.ptr(dfeat), L.ptr(xyz), L.f32(bound), L.u32(M), L.ptr(m_actual),
                                           L.u32(C), L.u32(R), L.f32(grad_scale), L.ptr(grad_out),
-                                          L.i32(int(channel_major)), L.ptr(nonfinite_flag), L.roi_array(roi),
+                                          L.i32(int(channel_major) | (2 if prezeroed else 0)), L.ptr(nonfinite_flag), L.roi_array(roi),
                                           L.ptr(ws), L.stream()),
             "plane_grad_binned")

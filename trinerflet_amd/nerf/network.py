@@ -108,10 +108,19 @@ class NeRFNetwork(NeRFRenderer):
     def forward(self, x, d):
         # x: [N, 3] in [-bound, bound], d: [N, 3] unit directions -> sigma [N], color [N, 3]  (network.py:118-147)
         if self._fused_ok():
-            tm = self.encoder.get_planes_texel_major()
-            return _field.fused_field(tm, x, d, self.sigma_net[0].weight, self.sigma_net[1].weight,
-                                      self.color_net[0].weight, self.color_net[1].weight, self.color_net[2].weight,
-                                      self.bound)
+            enc = self.encoder
+            Ws = (self.sigma_net[0].weight, self.sigma_net[1].weight, self.color_net[0].weight, self.color_net[1].weight,
+                  self.color_net[2].weight)
+            if torch.is_grad_enabled() and enc.planes_features.requires_grad and enc.plane_resolution % 32 == 0:
+                # training through autograd (the reference's own loop): the graph runs through the (3,C,R,R) planes of
+                # get_planes(); the sampler's texel-major copy is data, and the kernel's backward hands the planes'
+                # gradient back in (3,C,R,R) directly
+                planes_cm = enc.get_planes()
+                with torch.no_grad():
+                    tm = enc.get_planes_texel_major()
+                return _field.fused_field(tm, x, d, *Ws, self.bound, planes_cm)
+            tm = enc.get_planes_texel_major()
+            return _field.fused_field(tm, x, d, *Ws, self.bound)
         sigma, geo_feat = self._sigma_mlp(x)
         return sigma, self._color_mlp(d, geo_feat)
 

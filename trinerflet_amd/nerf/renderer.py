@@ -161,9 +161,15 @@ class NeRFRenderer(nn.Module):
         # the march stops at the ray's exit from the box of the occupied cells (no sample lies behind it: the same samples
         # to the bit, raymarching.clip_fars); the depth normalisation below keeps the box's far (renderer.py:318)
         fars_aabb = fars
-        if getattr(self, "clip_far_to_occupancy", True) and not self.training:     # (no gain for the training march)
-            fars = raymarching.clip_fars(rays_o, rays_d, fars, raymarching.occupied_box(
-                self.density_bitfield, self.cascade, self.grid_size, self.bound))
+        if getattr(self, "clip_far_to_occupancy", True):
+            # (TrainStep, whose march runs beside other kernels on a side stream, measured no gain from the clip; this
+            #  in-line march of the module path does: the count pass no longer walks the empty cells behind the object)
+            bf = self.density_bitfield
+            key = (bf.data_ptr(), bf._version)
+            if getattr(self, "_occ_box_key", None) != key:      # the box belongs to a bitfield: rebuilt when that changes
+                self._occ_box_cached = raymarching.occupied_box(bf, self.cascade, self.grid_size, self.bound)
+                self._occ_box_key = key
+            fars = raymarching.clip_fars(rays_o, rays_d, fars, self._occ_box_cached)
         if bg_color is None:
             bg_color = 1
         results = {}
@@ -366,9 +372,12 @@ class NeRFRenderer(nn.Module):
         return self._morton_xyz
 
     def _cell_centres(self, coords):
-        """2 * c / (H - 1) - 1 (renderer.py:416,475) with a TRUE division: torch's GPU kernel for `tensor / python_scalar`
-        multiplies by the scalar's reciprocal, which differs from the reference's CPU-or-CUDA quotient in the last bit for
-        one cell coordinate in nine; dividing by a tensor takes the correctly rounded path."""
+        """2 * c / (H - 1) - 1 (renderer.py:416,475) with a TRUE division.  torch's GPU kernel for `tensor / python_scalar`
+        multiplies by the scalar's reciprocal; torch's CPU kernel divides.  Parity here is with the reference RUN ON CPU
+        (the generator of tests/golden/grid_reference.npz, the only way the reference runs in the build container): the
+        true division reproduces its cell centres bit for bit.  The reference on CUDA takes the reciprocal shortcut itself,
+        so this is one ulp away from THAT run for about one coordinate in nine -- far below the jitter of half a cell
+        added right after (INTEGRATION.md A.2 lists the deviation)."""
         den = torch.full((1,), float(self.grid_size - 1), dtype=torch.float32, device=coords.device)
         return 2 * coords.float() / den - 1
 
@@ -493,6 +502,8 @@ class NeRFRenderer(nn.Module):
         L.check(L.lib().tnl_packbits_dev(L.ptr(self.density_grid), L.u32(self.density_bitfield.numel()),
                                          L.f32(self.density_thresh), L.ptr(mean_dev), L.ptr(self.density_bitfield),
                                          L.stream()), "packbits_dev")
+        self.density_bitfield[:0].zero_()    # the kernel wrote the bitfield behind torch's back: bump its version counter (an
+        self._occ_box_key = None             # empty in-place op) so that whatever is cached against it is rebuilt (run_cuda's box)
         total_step = min(16, self.local_step)
         csum = self.step_counter[:total_step, 0].sum().reshape(1).double() if total_step > 0 else mean_dev.double() * 0
         mean_h, csum_h = torch.cat([mean_dev.double(), csum]).tolist()       # the refresh's one read-back (both exact in fp64)

@@ -97,7 +97,8 @@ class _packbits(Function):
         if bitfield is None:
             bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
         L.check(L.lib().tnl_packbits(L.ptr(grid), L.u32(N), L.f32(thresh), L.ptr(bitfield), L.stream()), "packbits")
-        return bitfield
+        bitfield[:0].zero_()      # the kernel wrote it in place: bump torch's version counter (an empty in-place op), so that
+        return bitfield           # anything cached against the bitfield's version (run_cuda's occupied box) notices
 
 
 packbits = _packbits.apply

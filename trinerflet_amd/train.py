@@ -29,6 +29,7 @@ Multi-GPU: rays are sharded across ranks, planes and MLP weight
 """
 import ctypes as C_
 import math
+import types
 
 import numpy as np
 
@@ -148,6 +149,10 @@ class _Flat:
         return report
 
 
+class _StepState(types.SimpleNamespace):
+    """What the stages of one TrainStep.step() hand to each other."""
+
+
 class TrainStep:
     def __init__(self, model, lr=1e-2, wavelet_regularization=0.4, iters=30000, warmup_steps=0,
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
@@ -242,13 +247,11 @@ class TrainStep:
         self._sd_hook = model.register_state_dict_pre_hook(_flush_before_state_dict)
         self.deferred_flushes = 0
         self.last_flush_records = 0
-        # clip_far: march each ray only to its exit from the occupied cells' box (raymarching.clip_fars: the same samples
-        # to the bit).  It halves an 800 x 800 render (NeRFRenderer.run_cuda has it on), but the training step measured
-        # SLOWER with it at every start position of the side work (base: 4.43 / 4.52 / 4.36 / 4.49 against 4.41 / 4.35 /
-        # 4.34 / 4.45 ms for start / fwd / bwd / adam): the shorter count pass moves the sort's atomic passes under other
-        # kernels of the step.  Where the side work starts with the step ("start": the small coefficient sets, whose march
-        # is partly exposed) it helps: small 2.28 -> 2.22 ms/step.  None = on exactly there.
-        self.clip_far = None
+        # clip_far_in_order: march each ray of a refresh step's in-order march only to its exit from the occupied cells' box
+        # (raymarching.clip_fars: the same samples to the bit).  Measured at base over whole periods: 3.98 ms / step with
+        # it, 3.91 without (the box + clip launches cost what the shorter count pass saves): off.  The module path's
+        # in-line march (renderer.run_cuda) does use the clip.
+        self.clip_far_in_order = False
         self._occ_box = None       # device [6], valid for the current density_bitfield
         # GradScaler state (torch.cuda.amp.GradScaler defaults: 2^16, x2 every 2000 clean steps, x0.5 on inf)
         self.scale = torch.full((1,), init_scale if fp16 else 1.0, dtype=torch.float32, device=dev)
@@ -261,14 +264,10 @@ class TrainStep:
         self.last = {}
         self.section_names = None   # see _mark
         self._mark_seq = 0
-        self.overlap_march = True   # run the march on a side stream underneath the plane rebuild
-        self.prefetch_at = "auto"   # "start" | "fwd" | "bwd" | "adam" | "auto": where step(next_rays=...) starts the next batch's march
+        self.overlap_march = True   # the next batch's march + tile sort on a side stream (False: in order, kernels alone)
         self.live_col_align = 32    # column granule of the live rectangles (see _live_rects)
         self.live_bands = live_bands
-        self.split_phase2_at = "pg"  # prefetch_at = "split": phase 2 after the field backward ("bwd") or after the tile reduction ("pg")
-        self.adam_reserve = False   # experiments: limit the Adam pass's residency (LDS reservation) whenever side work may run beside it
         self._side = None
-        self.side_cus = 0           # > 0: the side stream may only use this many compute units (see _make_side_stream)
         self._prefetched = None     # (key, marched tensors) of a march started for the following call
         self._stale_params = self._stale_moments = False
         self.post_refresh = None    # optional callable run right after every density-grid refresh
@@ -676,161 +675,114 @@ class TrainStep:
             self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale, None, s0 * n0 * n0, s1 * n0 * n0)
 
     # ------------------------------------------------------------------------------------------
+    # One step = the stages below, in this order (each ends with a _mark: bench.py times the sections between them).
     def step(self, rays_o, rays_d, gt_rgb, noises=None, n_global_rays=None, bg_color=None, next_rays=None):
         """rays_o, rays_d: [N,3]; gt_rgb: [N,3] (already blended with the background, utils.py:574-577).
         bg_color: None (the constructor's background_color) or a per-ray [N,3] tensor (--train_rand_bg,
         utils.py:568-570).  next_rays: optional (rays_o, rays_d[, noises]) of the FOLLOWING call: its march is
-        then started on the side stream underneath this step's field / gradient / optimiser kernels (the march
+        then started on the side stream underneath this step's gradient / optimiser kernels (the march
         reads only rays and the occupancy bitfield), and the next call picks it up if it is given the same
         tensors.  Returns the (unscaled) loss as a device scalar; details in self.last."""
-        model, enc = self.model, self.enc
-        model.train()
-        lib = L.lib()
-        C, R, H = self.C, self.R, self.H
+        self.model.train()
         N = rays_o.shape[0]
-        n_glob = n_global_rays if n_global_rays is not None else N * self.world
-
+        st = _StepState(rays_o=rays_o, rays_d=rays_d, gt_rgb=gt_rgb, noises=noises, bg_color=bg_color, next_rays=next_rays,
+                        N=N, n_glob=n_global_rays if n_global_rays is not None else N * self.world,
+                        refresh=self.update_extra_interval > 0 and self.global_step % self.update_extra_interval == 0)
         self._mark("begin")
-        refresh = self.update_extra_interval > 0 and self.global_step % self.update_extra_interval == 0
+        self._stage_pickup(st)         # the march started during the previous call, or one started now on the side stream
+        self._stage_planes(st)         # (replay of the deferred pass) -> plane rebuild -> [grid refresh + new window]
+        self._stage_march(st)          # wait for / run the march; samples of this step
+        self._stage_render(st)         # fused field, compositing, loss and its gradient w.r.t. the rendered colours
+        self._stage_backward(st)       # compositing backward, fused field backward, [next batch's side work], plane gradient
+        self._stage_optimise(st)       # GradScaler probe, adjoint IDWT, Adam(+L1) passes, step epilogue
+        return st.loss
 
-        def march(o=rays_o, d=rays_d, nz=noises, sort_stream=None):
-            nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_train, model.min_near)
-            if self.clip_far if self.clip_far is not None else self._prefetch_mode() == "start":
-                # stop at the exit from the occupied cells' box: the same samples, without the probe chain through the
-                # empty cells behind the object (raymarching.clip_fars).  The box belongs to the current bitfield: it is
-                # rebuilt after every refresh (below) and whenever the window is recomputed.
-                if self._occ_box is None:
-                    self._occ_box = raymarching.occupied_box(model.density_bitfield, model.cascade, model.grid_size,
-                                                             float(model.bound))
-                fars = raymarching.clip_fars(o, d, fars, self._occ_box)
-            counter = model.step_counter[model.local_step % 16]
-            counter.zero_()
-            model.local_step += 1
-            # with a fixed sample budget the march also counts the samples per plane tile (first pass of the tile sort)
-            fused_sort = self.binned and R % 32 == 0 and model.mean_count > 0
-            sort_ws = None
-            if fused_sort:
-                mc = model.mean_count + (128 - model.mean_count % 128)    # the wrapper's budget rule (align = 128)
-                sort_ws = F_.plane_grad_sort_workspace(mc, R, self.dev)
-            out = raymarching.march_rays_train(
-                o, d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars,
-                counter, model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, nz,
-                model.mean_count <= 0,   # zero fill only when the buffers are sized by the worst case (first steps)
-                (R, sort_ws) if fused_sort else None)
-            # the field forward needs the march only; the tile sort of the plane gradient (needed much later, by the
-            # tile reduction) rides behind it on the same stream and gets its own event
-            ev_march = torch.cuda.Event()
-            ev_march.record()
-            # the tile sort of the plane gradient needs only the positions: it rides with the march (side stream); an
-            # in-order march (refresh steps: the bitfield has just changed) hands its scan + fill passes to sort_stream,
-            # beside the field forward
-            if fused_sort and sort_stream is not None:
-                assert out[0].shape[0] == mc
-                sort_stream.wait_event(ev_march)
-                with torch.cuda.stream(sort_stream):
-                    F_.plane_grad_sort_counted(sort_ws, out[0], float(model.bound), R, counter)
-                    ev_sort = torch.cuda.Event()
-                    ev_sort.record()
-                for t_ in (counter, *out, sort_ws):
-                    if torch.is_tensor(t_):
-                        t_.record_stream(sort_stream)
-                return (counter, *out, sort_ws), (ev_march, ev_sort)
-            if fused_sort:
-                assert out[0].shape[0] == mc
+    def _march(self, o, d, nz, sort_stream=None, clip=False):
+        """near/far -> march_rays_train (+ the tile sort of the plane gradient, which needs only the positions).  Returns
+        ((counter, xyzs, dirs, deltas, rays, sort_ws), (event after the march, event after the sort)).  sort_stream: the
+        sort's scan + fill passes go there (refresh steps: beside the field forward).  clip: march each ray only to its
+        exit from the occupied cells' box (raymarching.clip_fars: the same samples to the bit)."""
+        model, R = self.model, self.R
+        nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_train, model.min_near)
+        if clip:
+            if self._occ_box is None:
+                self._occ_box = raymarching.occupied_box(model.density_bitfield, model.cascade, model.grid_size,
+                                                         float(model.bound))
+            fars = raymarching.clip_fars(o, d, fars, self._occ_box)
+        counter = model.step_counter[model.local_step % 16]
+        counter.zero_()
+        model.local_step += 1
+        # with a fixed sample budget the march also counts the samples per plane tile (first pass of the tile sort)
+        fused_sort = self.binned and R % 32 == 0 and model.mean_count > 0
+        sort_ws = None
+        if fused_sort:
+            mc = model.mean_count + (128 - model.mean_count % 128)    # the wrapper's budget rule (align = 128)
+            sort_ws = F_.plane_grad_sort_workspace(mc, R, self.dev)
+        out = raymarching.march_rays_train(
+            o, d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars,
+            counter, model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, nz,
+            model.mean_count <= 0,   # zero fill only when the buffers are sized by the worst case (first steps)
+            (R, sort_ws) if fused_sort else None)
+        # the field forward needs the march only; the tile sort (needed much later, by the tile reduction) gets its own event
+        ev_march = torch.cuda.Event()
+        ev_march.record()
+        if fused_sort and sort_stream is not None:
+            assert out[0].shape[0] == mc
+            sort_stream.wait_event(ev_march)
+            with torch.cuda.stream(sort_stream):
                 F_.plane_grad_sort_counted(sort_ws, out[0], float(model.bound), R, counter)
-            else:
-                sort_ws = F_.plane_grad_sort(out[0], float(model.bound), R, counter) if (self.binned and R % 32 == 0) \
-                    else torch.empty(0, device=self.dev)
-            ev_sort = torch.cuda.Event()
-            ev_sort.record()
-            return (counter, *out, sort_ws), (ev_march, ev_sort)
-
-        def march_on_side(*a):
-            main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = self._make_side_stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                out = march(*a)
-            for t_ in out[0]:
-                t_.record_stream(main)
-            return out
-
-        # "split" placement: the next batch's march in two phases on the side stream (tnl_march_rays_train_binned_phase) --
-        # the count pass (a serial walk per ray: ~940 waves of pure latency that fit beside the field kernels' waves)
-        # before the field forward, the wide passes (ray records, emission + tile counts, tile sort) after the field
-        # backward, so that they are done before the Adam pass starts.
-        def march_phase1(o, d, nz):
-            main = torch.cuda.current_stream()
-            if self._side is None:
-                self._side = self._make_side_stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_train, model.min_near)
-                counter = model.step_counter[model.local_step % 16]
-                counter.zero_()
-                model.local_step += 1
-                mc = model.mean_count + (128 - model.mean_count % 128)
-                Nn = o.shape[0]
-                st = dict(
-                    counter=counter, mc=mc, nears=nears, fars=fars, o=o.contiguous(), d=d.contiguous(),
-                    nz=nz.contiguous() if nz is not None else torch.rand(Nn, dtype=torch.float32, device=self.dev),
-                    xyzs=torch.empty(mc, 3, dtype=torch.float32, device=self.dev),
-                    dirs=torch.empty(mc, 3, dtype=torch.float32, device=self.dev),
-                    deltas=torch.empty(mc, 2, dtype=torch.float32, device=self.dev),
-                    rays=torch.empty(Nn, 3, dtype=torch.int32, device=self.dev),
-                    sort_ws=F_.plane_grad_sort_workspace(mc, R, self.dev))
-                nws = lib.tnl_march_rays_train_workspace_rec(L.u32(Nn), L.u32(self.max_steps))
-                assert nws > 0
-                st["ws"], st["nws"] = torch.empty(nws, dtype=torch.int32, device=self.dev), nws
-                self._march_phase(st, 1)
-            return st
-
-        def march_phase2(st):
-            main = torch.cuda.current_stream()
-            self._side.wait_stream(main)         # not before the launch stream got here (after the field backward)
-            with torch.cuda.stream(self._side):
-                self._march_phase(st, 2)
-                ev_march = torch.cuda.Event()
-                ev_march.record()
-                F_.plane_grad_sort_counted(st["sort_ws"], st["xyzs"], float(model.bound), R, st["counter"])
                 ev_sort = torch.cuda.Event()
                 ev_sort.record()
-            out = (st["counter"], st["xyzs"], st["dirs"], st["deltas"], st["rays"], st["sort_ws"])
-            for t_ in out:
-                t_.record_stream(main)
-            return out, (ev_march, ev_sort)
+            for t_ in (counter, *out, sort_ws):
+                if torch.is_tensor(t_):
+                    t_.record_stream(sort_stream)
+            return (counter, *out, sort_ws), (ev_march, ev_sort)
+        if fused_sort:
+            assert out[0].shape[0] == mc
+            F_.plane_grad_sort_counted(sort_ws, out[0], float(model.bound), R, counter)
+        else:
+            sort_ws = F_.plane_grad_sort(out[0], float(model.bound), R, counter) if (self.binned and R % 32 == 0) \
+                else torch.empty(0, device=self.dev)
+        ev_sort = torch.cuda.Event()
+        ev_sort.record()
+        return (counter, *out, sort_ws), (ev_march, ev_sort)
 
+    def _march_on_side(self, o, d, nz):
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            out = self._march(o, d, nz)
+        for t_ in out[0]:
+            t_.record_stream(main)
+        return out
+
+    def _stage_pickup(self, st):
         # The march (one ray per lane, latency-bound, ~1/8 of the chip's wave slots) depends only on the rays and
-        # the occupancy bitfield, not on the planes: it runs on a side stream underneath the HBM-bound plane
-        # rebuild.  On grid-refresh steps the bitfield changes first, so there the march stays in order.
-        side = None
+        # the occupancy bitfield, not on the planes: it runs on a side stream.  On grid-refresh steps the bitfield
+        # changes first, so there the march stays in order (_stage_march).
+        model = self.model
+        st.side, st.marched = None, None
         pre = self._prefetched
-        if pre is not None and not refresh and self._prefetch_matches(pre[0], rays_o, rays_d, noises):
+        if pre is not None and not st.refresh and self._prefetch_matches(pre[0], st.rays_o, st.rays_d, st.noises):
             self._prefetched = None
-            marched, side = pre[1], self._side          # started during the previous call
+            st.marched, st.side = pre[1], self._side          # started during the previous call
         else:
             self._drop_prefetch()                       # other rays than announced (or a refresh): marched for nothing
-            if self.overlap_march and not refresh and model.mean_count > 0:
-                marched, side = march_on_side(), self._side
-        if self._pending and (refresh or not self._roi_valid):
+            if self.overlap_march and not st.refresh and model.mean_count > 0:
+                st.marched, st.side = self._march_on_side(st.rays_o, st.rays_d, st.noises), self._side
+
+    def _stage_planes(self, st):
+        model = self.model
+        if self._pending and (st.refresh or not self._roi_valid):
             self.flush_deferred()
             self._mark("adam_catchup")
-        if self.use_roi and not refresh and not self._roi_valid:
+        if self.use_roi and not st.refresh and not self._roi_valid:
             self._roi, self._roi_valid = self._compute_roi(), True
-        # where the next batch's side work starts (see _prefetch_mode): "start" = here, "fwd" = before the field forward,
-        # "bwd" = after the field backward, "adam" = together with the Adam pass
-        pf = self._prefetch_mode()
-        split = pf == "split" and self._can_split_prefetch(next_rays)
-        if pf == "split" and not split:
-            pf = "bwd"
-        phase1 = None
-        early = pf in ("start", "fwd") and not refresh
-        if early and pf == "start":
-            self._prefetch_next(next_rays, march_on_side)
-        tm = self.rebuild_planes(roi=self.use_roi and not refresh)
+        st.tm = self.rebuild_planes(roi=self.use_roi and not st.refresh)
         self._mark("idwt_fwd")
-        if refresh:
+        if st.refresh:
             if self.world > 1:
                 # every rank evaluates 1/world of the candidate cells; the all-gather keeps the replicas' grids (hence
                 # bitfield, occupancy window and collective sizes) bit-identical
@@ -847,153 +799,138 @@ class TrainStep:
             if self.use_roi:
                 self._roi, self._roi_valid = self._compute_roi(), True
             self._mark("grid_refresh")
-        packed = F_.pack_weights(*self.Ws, C, H)
-        sort_beside = False
-        if side is None:
+
+    def _stage_march(self, st):
+        model, R = self.model, self.R
+        st.packed = F_.pack_weights(*self.Ws, self.C, self.H)
+        st.sort_beside = False
+        if st.side is None:
             if self.overlap_march and self.binned and R % 32 == 0 and model.mean_count > 0:
                 if self._side is None:
-                    self._side = self._make_side_stream()
-                marched = march(sort_stream=self._side)      # samples in order, sort passes beside the field forward
-                sort_beside = True
+                    self._side = torch.cuda.Stream()
+                # samples in order (refresh steps: the bitfield has just changed), the sort passes beside the field forward
+                st.marched = self._march(st.rays_o, st.rays_d, st.noises, sort_stream=self._side, clip=self.clip_far_in_order)
+                st.sort_beside = True
             else:
-                marched = march()
-        marched, (ev_march, ev_sort) = marched
-        if side is not None:
+                st.marched = self._march(st.rays_o, st.rays_d, st.noises, clip=self.clip_far_in_order)
+        marched, (ev_march, st.ev_sort) = st.marched
+        if st.side is not None:
             torch.cuda.current_stream().wait_event(ev_march)
-        counter, xyzs, dirs, deltas, rays, sort_ws = marched
-        M = xyzs.shape[0]
+        st.counter, st.xyzs, st.dirs, st.deltas, st.rays, st.sort_ws = marched
+        st.M = st.xyzs.shape[0]
         self._mark("march")
-        if early and pf == "fwd":
-            self._prefetch_next(next_rays, march_on_side)
-        if split:
-            slot_step = model.local_step
-            phase1 = (self._prefetch_key(next_rays), march_phase1(next_rays[0], next_rays[1],
-                                                                  next_rays[2] if len(next_rays) > 2 else None), slot_step)
+
+    def _stage_render(self, st):
+        model, lib = self.model, L.lib()
+        C, R, H, N, M = self.C, self.R, self.H, st.N, st.M
         # rows past counter[0] are the zero padding of the sample budget: skipped on the device
-        sigma, rgb, feats = F_.field_forward(tm, xyzs, dirs, packed, float(model.bound), C, R, H, save_feats=True,
-                                             m_actual=counter)
-        sigma_field = sigma   # exp(logit) as the field produced it: the hidden-128 backward reads it
+        sigma, st.rgb, st.feats = F_.field_forward(st.tm, st.xyzs, st.dirs, st.packed, float(model.bound), C, R, H,
+                                                   save_feats=True, m_actual=st.counter)
+        st.sigma_field = sigma   # exp(logit) as the field produced it: the hidden-128 backward reads it
         if model.density_scale != 1:
             sigma = sigma * model.density_scale
+        st.sigma = sigma
         self._mark("field_fwd")
-        ws = torch.empty(N, dtype=torch.float32, device=self.dev)
-        depth = torch.empty(N, dtype=torch.float32, device=self.dev)
-        image = torch.empty(N, 3, dtype=torch.float32, device=self.dev)
-        L.check(lib.tnl_composite_rays_train_forward(L.ptr(sigma), L.ptr(rgb), L.ptr(deltas), L.ptr(rays), L.u32(M),
-                                                     L.u32(N), L.f32(self.T_thresh), L.ptr(ws), L.ptr(depth),
-                                                     L.ptr(image), L.stream()), "composite_rays_train_forward")
+        st.ws = torch.empty(N, dtype=torch.float32, device=self.dev)
+        st.depth = torch.empty(N, dtype=torch.float32, device=self.dev)
+        st.image = torch.empty(N, 3, dtype=torch.float32, device=self.dev)
+        L.check(lib.tnl_composite_rays_train_forward(L.ptr(sigma), L.ptr(st.rgb), L.ptr(st.deltas), L.ptr(st.rays), L.u32(M),
+                                                     L.u32(N), L.f32(self.T_thresh), L.ptr(st.ws), L.ptr(st.depth),
+                                                     L.ptr(st.image), L.stream()), "composite_rays_train_forward")
         # image + (1 - ws) * bg (renderer.py:317), MSE mean over rays and channels (utils.py:595) and d(scaled loss):
         # one launch (csrc/loss.hip)
-        bg = self.bg if bg_color is None else bg_color
-        pred = torch.empty(N, 3, dtype=torch.float32, device=self.dev)
-        g_pred = torch.empty(N, 3, dtype=torch.float32, device=self.dev)
-        g_ws = torch.empty(N, dtype=torch.float32, device=self.dev)
+        bg = self.bg if st.bg_color is None else st.bg_color
+        st.pred = torch.empty(N, 3, dtype=torch.float32, device=self.dev)
+        st.g_pred = torch.empty(N, 3, dtype=torch.float32, device=self.dev)
+        st.g_ws = torch.empty(N, dtype=torch.float32, device=self.dev)
         # one launch: MSE / L1 / non-finite accumulators and the MLP gradient zeroed, 1 / loss scale (csrc/stepstate.hip)
-        mse_local = torch.empty((), dtype=torch.float32, device=self.dev)
+        st.mse_local = torch.empty((), dtype=torch.float32, device=self.dev)
         L.check(lib.tnl_step_prologue(L.ptr(self.scale), L.ptr(self.inv_scale), L.ptr(self.abs_sum),
-                                      L.ptr(self.nonfinite), L.ptr(mse_local), L.ptr(self.mlp.grad),
+                                      L.ptr(self.nonfinite), L.ptr(st.mse_local), L.ptr(self.mlp.grad),
                                       L.u32(self.mlp.grad.numel()), L.stream()), "step_prologue")
         bg_rays = bg.to(torch.float32).contiguous() if torch.is_tensor(bg) else None
-        L.check(lib.tnl_mse_loss(L.ptr(image), L.ptr(ws), L.ptr(gt_rgb.contiguous()), L.f32(0.0 if bg_rays is not None else bg),
-                                 L.ptr(bg_rays), L.u32(N), L.f32(1.0 / (3.0 * n_glob)), L.ptr(self.scale), L.ptr(pred),
-                                 L.ptr(g_pred), L.ptr(g_ws), L.ptr(mse_local), L.stream()), "mse_loss")
+        L.check(lib.tnl_mse_loss(L.ptr(st.image), L.ptr(st.ws), L.ptr(st.gt_rgb.contiguous()),
+                                 L.f32(0.0 if bg_rays is not None else bg), L.ptr(bg_rays), L.u32(N),
+                                 L.f32(1.0 / (3.0 * st.n_glob)), L.ptr(self.scale), L.ptr(st.pred), L.ptr(st.g_pred),
+                                 L.ptr(st.g_ws), L.ptr(st.mse_local), L.stream()), "mse_loss")
+        self._mark("composite_fwd_loss")
+
+    def _stage_backward(self, st):
+        model, lib = self.model, L.lib()
+        C, R, H, N, M = self.C, self.R, self.H, st.N, st.M
         # rows behind the sample count are never read (m_actual) and the composite backward zeroes the in-buffer tail
         # of a ray the budget dropped: no zero fill of the two gradient buffers (raymarching.py:283-284)
         g_sigma = torch.empty(M, dtype=torch.float32, device=self.dev)
         g_rgb = torch.empty(M, 3, dtype=torch.float32, device=self.dev)
-        self._mark("composite_fwd_loss")
-        L.check(lib.tnl_composite_rays_train_backward(L.ptr(g_ws), L.ptr(g_pred), L.ptr(sigma), L.ptr(rgb),
-                                                      L.ptr(deltas), L.ptr(rays), L.ptr(ws), L.ptr(image), L.u32(M),
+        L.check(lib.tnl_composite_rays_train_backward(L.ptr(st.g_ws), L.ptr(st.g_pred), L.ptr(st.sigma), L.ptr(st.rgb),
+                                                      L.ptr(st.deltas), L.ptr(st.rays), L.ptr(st.ws), L.ptr(st.image), L.u32(M),
                                                       L.u32(N), L.f32(self.T_thresh), L.ptr(g_sigma), L.ptr(g_rgb),
                                                       L.stream()), "composite_rays_train_backward")
         if model.density_scale != 1:
             g_sigma = g_sigma * model.density_scale
         self._mark("composite_bwd")
-        g_cm = None
-        lr_t = self.lr * lr_factor(self.global_step, self.iters, self.warmup)
-        l1 = self.lam / (self.J * self.coef_numel) if (self.J > 0 and self.lam > 0) else 0.0
-        inv_scale = self.inv_scale
+        st.roi = self._roi if (self.use_roi and self.binned and R % 32 == 0) else None
         if self.binned and R % 32 == 0:
             # no global float atomics: dF -> fp16 -> tile-sorted matrix-core accumulation (csrc/scatter.hip), written
             # straight in the (3,C,R,R) layout the adjoint IDWT reads
-            roi = self._roi if self.use_roi else None
-            if roi is None:
-                g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=self.dev)
+            if st.roi is None:
+                st.g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=self.dev)
             else:
-                g_cm = torch.empty(3 * C, roi[7], roi[6], dtype=torch.float32, device=self.dev)
+                st.g_cm = torch.empty(3 * C, st.roi[7], st.roi[6], dtype=torch.float32, device=self.dev)
             dfeat = torch.empty(3, M, C, dtype=torch.float16, device=self.dev)   # plane-major, see field_bwd.hip
-            F_.field_backward(g_sigma, g_rgb, sigma_field, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
-                              g_cm, self.mlp.grad, m_actual=counter, dfeat=dfeat)
+            F_.field_backward(g_sigma, g_rgb, st.sigma_field, None, st.feats, st.xyzs, st.dirs, st.packed, float(model.bound),
+                              C, R, H, st.g_cm, self.mlp.grad, m_actual=st.counter, dfeat=dfeat)
             self._mark("field_bwd")
             # The following batch's march + tile sort (ALU/latency-bound, few waves) start here, underneath the
-            # HBM-bound tail of the step (tile reduction, adjoint IDWT; in the multi-GPU modes the collectives).
-            # Measured at base: started before the MFMA field kernels it costs them the same 0.5 ms (a field wave owns
-            # its SIMD's whole register file -- 480 / 2 x 242 registers -- so the march cannot co-reside with them and
-            # is time-sliced in); started under Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms
-            # stay exposed.  At the small configuration (dense tail 0.5 ms) 1 ms of the march stays exposed either way.
-            under_adam = self._prefetch_under_adam(next_rays)
-            if phase1 is not None and self.split_phase2_at == "bwd":
-                self._prefetched = (phase1[0], march_phase2(phase1[1]), phase1[2])
-                phase1 = None
-            elif phase1 is None and not under_adam and not early:
-                self._prefetch_next(next_rays, march_on_side)
-            if side is not None or sort_beside:
-                torch.cuda.current_stream().wait_event(ev_sort)
+            # HBM-bound tail of the step (tile reduction, adjoint IDWT, Adam; in the multi-GPU modes the collectives):
+            # the two MFMA field kernels own their SIMDs' whole register files, so side work beside them is time-sliced
+            # in at their cost (docs/EXPERIMENTS.md: the start positions measured in rounds 2 and 3).
+            self._prefetch_next(st.next_rays)
+            if st.side is not None or st.sort_beside:
+                torch.cuda.current_stream().wait_event(st.ev_sort)
             if self.deterministic:
-                F_.order_tile_lists(sort_ws, R, xyzs.shape[0])
-            F_.plane_grad_reduce(sort_ws, dfeat, xyzs, float(model.bound), C, R, g_cm, channel_major=True,
-                                 nonfinite_flag=self.nonfinite, roi=self._roi10() if roi is not None else None)
+                F_.order_tile_lists(st.sort_ws, R, st.xyzs.shape[0])
+            F_.plane_grad_reduce(st.sort_ws, dfeat, st.xyzs, float(model.bound), C, R, st.g_cm, channel_major=True,
+                                 nonfinite_flag=self.nonfinite, roi=self._roi10() if st.roi is not None else None)
             self._mark("plane_grad_binned")
-            if phase1 is not None:          # split_phase2_at == "pg": the wide passes beside adjoint + Adam
-                self._prefetched = (phase1[0], march_phase2(phase1[1]), phase1[2])
-                phase1 = None
-            if self.world > 1:
-                dist.all_reduce(self.mlp.grad, group=self.pg)
+            st.grad_tm = None
+        else:
+            st.g_cm = None
+            st.grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
+            F_.field_backward(g_sigma, g_rgb, st.sigma_field, None, st.feats, st.xyzs, st.dirs, st.packed, float(model.bound),
+                              C, R, H, st.grad_tm, self.mlp.grad, m_actual=st.counter)
+            self._mark("field_bwd")
+            self._prefetch_next(st.next_rays)
+
+    def _stage_optimise(self, st):
+        lib = L.lib()
+        lr_t = self.lr * lr_factor(self.global_step, self.iters, self.warmup)
+        l1 = self.lam / (self.J * self.coef_numel) if (self.J > 0 and self.lam > 0) else 0.0
+        inv_scale = self.inv_scale
+        if self.world > 1:
+            dist.all_reduce(self.mlp.grad, group=self.pg)
+        if st.g_cm is not None:
             # GradScaler probe BEFORE the dense backward, so that the optimiser can be fused into it: the plane
             # gradient reports non-finite values through the tile kernel's flag, the MLP gradient is 13.5k floats
             found_inf = self._scaler_probe(self.mlp.grad, None, self.nonfinite)
             self._mark("scaler_probe")
             if self.fuse_adam:
-                s0, s1 = self._adjoint(None, g_cm, fuse=(lr_t, l1, found_inf, inv_scale))
+                s0, s1 = self._adjoint(None, st.g_cm, fuse=(lr_t, l1, found_inf, inv_scale))
                 self._mark("idwt_adjoint_adam")
             else:
-                s0, s1 = self._adjoint(None, g_cm, roi=roi)
+                s0, s1 = self._adjoint(None, st.g_cm, roi=st.roi)
                 self._mark("idwt_adjoint")
-                rects = self._rects if (roi is not None and self._rect_ok) else None
-                # large coefficient sets: the next batch's march + tile sort start together with the Adam pass, whose
-                # workgroups are limited to 4 per CU (an unused 40-KB LDS reservation) so that the side stream finds
-                # wave slots; the tile reduction and the adjoint above then ran undisturbed
-                reserve = under_adam or (self.adam_reserve and next_rays is not None)
-                lib.tnl_adam_set_lds_reservation(L.u32(40960 if reserve else 0))
-                try:
-                    if under_adam:
-                        self._prefetch_next(next_rays, march_on_side)
-                    if self.defer_adam and rects is not None:
-                        self._adam_levels_live(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
-                    else:
-                        self._adam_levels(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
-                finally:
-                    if reserve:
-                        lib.tnl_adam_set_lds_reservation(L.u32(0))   # process-global: never leave it set
+                rects = self._rects if (st.roi is not None and self._rect_ok) else None
+                if self.defer_adam and rects is not None:
+                    self._adam_levels_live(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
+                else:
+                    self._adam_levels(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
                 self._mark("adam_coef")
                 if self._pending == 16:     # the ring is full (a whole density-grid period at the default interval)
                     self.flush_deferred()
                     self._mark("adam_catchup")
         else:
-            grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=self.dev)
-            F_.field_backward(g_sigma, g_rgb, sigma_field, None, feats, xyzs, dirs, packed, float(model.bound), C, R, H,
-                              grad_tm, self.mlp.grad, m_actual=counter)
-            self._mark("field_bwd")
-            # The following batch's march + tile sort (ALU/latency-bound, few waves) start here, underneath the
-            # HBM-bound tail of the step (tile reduction, adjoint IDWT; in the multi-GPU modes the collectives).
-            # Measured at base: started before the MFMA field kernels it costs them the same 0.5 ms (a field wave owns
-            # its SIMD's whole register file -- 480 / 2 x 242 registers -- so the march cannot co-reside with them and
-            # is time-sliced in); started under Adam alone it starves (Adam's workgroups hold every slot) and 0.7 ms
-            # stay exposed.  At the small configuration (dense tail 0.5 ms) 1 ms of the march stays exposed either way.
-            self._prefetch_next(next_rays, march_on_side)
-            if self.world > 1:
-                dist.all_reduce(self.mlp.grad, group=self.pg)
-            s0, s1 = self._adjoint(grad_tm, None)
+            s0, s1 = self._adjoint(st.grad_tm, None)
             self._mark("idwt_adjoint")
             # GradScaler: skip the step when any gradient is non-finite.  A non-finite plane gradient always
             # reaches the coarse LL gradient through the low-pass adjoint, so checking LL + MLP grads suffices.
@@ -1015,64 +952,19 @@ class TrainStep:
         self.global_step += 1
         self._stale_params = self._stale_moments = True    # "sharded" mode: see sync_sharded_parameters
         if self.world > 1:
-            mse = mse_local.clone()
+            mse = st.mse_local.clone()
             dist.all_reduce(mse, group=self.pg)
             if self.dist_mode == "sharded":
                 dist.all_reduce(reg, group=self.pg)
         else:
-            mse = mse_local
-        loss = mse + reg
+            mse = st.mse_local
+        st.loss = mse + reg
         self._mark("tail")
-        self.last = {'mse': mse, 'wavelet_reg': reg, 'M': M, 'found_inf': found_inf, 'image': pred, 'ws': ws,
-                     'depth': depth, 'counter': counter, 'lr': lr_t}
-        return loss
+        self.last = {'mse': mse, 'wavelet_reg': reg, 'M': st.M, 'found_inf': found_inf, 'image': st.pred, 'ws': st.ws,
+                     'depth': st.depth, 'counter': st.counter, 'lr': lr_t}
 
-    def _make_side_stream(self):
-        """The stream of the next batch's march + tile sort.  side_cus > 0: confined to that many compute units spread
-        evenly over the device (tnl_stream_create_cu_mask), else an ordinary stream."""
-        n = int(self.side_cus)
-        if n <= 0:
-            return torch.cuda.Stream(priority=int(getattr(self, "side_priority", 0)))
-        total = torch.cuda.get_device_properties(self.dev).multi_processor_count
-        n = min(n, total)
-        words = (total + 31) // 32
-        mask = (C_.c_uint32 * words)()
-        for k in range(n):
-            cu = (k * total) // n
-            mask[cu // 32] |= 1 << (cu % 32)
-        out = C_.c_void_p()
-        L.check(L.lib().tnl_stream_create_cu_mask(mask, L.u32(words), C_.byref(out)), "stream_create_cu_mask")
-        self._side_raw = out
-        return torch.cuda.ExternalStream(out.value, device=self.dev)
-
-    def _prefetch_under_adam(self, next_rays):
-        """Where the next batch's march + tile sort go: right after the field backward (default), or together with the
-        Adam pass (prefetch_at = "adam"; see step())."""
-        return self._prefetch_mode() == "adam" and next_rays is not None and not self.fuse_adam
-
-    def _prefetch_mode(self):
-        """prefetch_at resolved.  Round-2 measurement at base (dense tail 0.4 + 0.4 + 1.85 ms since the column-walk IDWT
-        kernels; ms per step | Adam pass): bwd 5.39 | 2.06 -- the ~1 ms of side work no longer fits under tile reduction +
-        adjoint and spills into the Adam pass; start 5.54 | 1.84 (the march delays the field forward); fwd 5.27 | 1.84;
-        adam 5.26 | 1.98.  "fwd" (side work beside the two MFMA field kernels, whose waves leave half of each SIMD's
-        registers free) gives the shortest step with the HBM-bound dominant kernel alone on the GPU.  The small
-        configuration (dense tail 0.5 ms) starts it at the top of the step: 2.94 | 3.03 (fwd) | 3.04 (bwd) ms.
-        Round 3 (the side work is down to ~1 ms alone since the rays are marched once and the sort's hot counters are split):
-        "bwd" -- the side work under tile reduction + adjoint + Adam, the two MFMA field kernels alone on the GPU -- wins
-        again: base 4.19-4.25 against 4.28-4.35 ms for "fwd" over eight alternating runs on one box (field forward 0.83 ->
-        0.77, backward 0.90 -> 0.76, tile reduction 0.47 -> 0.40, Adam 0.84 -> 0.99), small 2.22 against 2.25-2.27
-        ("start"), large a tie (7.75-7.93); capping the Adam pass's residency beside it (adam_reserve) loses 0.1 ms.
-        "split" (tnl_march_rays_train_binned_phase: the count pass before the field forward, the wide passes -- emission,
-        tile counts, tile sort -- after the field backward or after the tile reduction) was built to get the side work out
-        from under the Adam pass: Adam does run clean then (0.99 -> 0.84 ms), but the wide passes cost whatever they run
-        beside 0.23-0.28 ms (tile reduction 0.41 -> 0.65, or adjoint 0.37 -> 0.65) against the 0.15 ms they cost Adam, and
-        the count pass costs the field forward 0.06: 4.39-4.44 against 4.23-4.35 ms per step.  Kept as an option."""
-        mode = self.prefetch_at
-        if mode == "auto":
-            mode = "bwd"
-        return mode
-
-    def _prefetch_next(self, next_rays, march_on_side):
+    def _prefetch_next(self, next_rays):
+        """Starts the following batch's march + tile sort on the side stream (see step(next_rays=...))."""
         model = self.model
         next_refresh = self.update_extra_interval > 0 and (self.global_step + 1) % self.update_extra_interval == 0
         if next_rays is None or not self.overlap_march or next_refresh or model.mean_count <= 0:
@@ -1082,7 +974,7 @@ class TrainStep:
         key = self._prefetch_key(next_rays)
         # the ring slot the march takes (run_cuda's local_step rule), so that a dropped prefetch gives back exactly it
         slot_step = model.local_step
-        self._prefetched = (key, march_on_side(no, nd, nn), slot_step)
+        self._prefetched = (key, self._march_on_side(no, nd, nn), slot_step)
 
     @staticmethod
     def _prefetch_key(next_rays):
@@ -1091,25 +983,6 @@ class TrainStep:
         no, nd = next_rays[0], next_rays[1]
         nn = next_rays[2] if len(next_rays) > 2 else None
         return tuple((t_, t_.data_ptr(), tuple(t_.shape), t_._version) if t_ is not None else None for t_ in (no, nd, nn))
-
-    def _can_split_prefetch(self, next_rays):
-        """The two-phase side work needs the fused tile count (fixed sample budget, binned mode), a following batch and
-        no refresh in between; the far clip is not part of it."""
-        model = self.model
-        next_refresh = self.update_extra_interval > 0 and (self.global_step + 1) % self.update_extra_interval == 0
-        this_refresh = self.update_extra_interval > 0 and self.global_step % self.update_extra_interval == 0
-        return (next_rays is not None and self.overlap_march and not next_refresh and not this_refresh
-                and model.mean_count > 0 and self.binned and self.R % 32 == 0 and not self.clip_far
-                and model.mean_count + 128 < 2 ** 31)
-
-    def _march_phase(self, st, phase):
-        model = self.model
-        L.check(L.lib().tnl_march_rays_train_binned_phase(
-            L.ptr(st["o"]), L.ptr(st["d"]), L.ptr(model.density_bitfield), L.f32(model.bound), L.f32(self.dt_gamma),
-            L.u32(self.max_steps), L.u32(st["o"].shape[0]), L.u32(model.cascade), L.u32(model.grid_size), L.u32(st["mc"]),
-            L.ptr(st["nears"]), L.ptr(st["fars"]), L.ptr(st["xyzs"]), L.ptr(st["dirs"]), L.ptr(st["deltas"]),
-            L.ptr(st["rays"]), L.ptr(st["counter"]), L.ptr(st["nz"]), L.ptr(st["ws"]), L.u32(st["nws"]), L.u32(self.R),
-            L.ptr(st["sort_ws"]), L.i32(phase), L.stream()), "march_rays_train_binned_phase")
 
     @staticmethod
     def _prefetch_matches(key, rays_o, rays_d, noises):

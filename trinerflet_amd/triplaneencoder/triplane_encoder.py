@@ -219,6 +219,96 @@ class _GridSample(Function):
         return g_tm, g_grid
 
 
+class _AbsMean(Function):
+    """mean |x| as one reduction pass, its gradient sign(x) * g / n as one pass (csrc/loss.hip)."""
+
+    @staticmethod
+    def usable(x):
+        return (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() > 0
+                and x.data_ptr() % 16 == 0)
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = L.lib()
+        ws = torch.empty(int(lib.tnl_abs_mean_workspace()), dtype=torch.uint8, device=x.device)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        L.check(lib.tnl_abs_mean_forward(L.ptr(x), L.u64(x.numel()), L.ptr(ws), L.ptr(out), L.stream()), "abs_mean_forward")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        g = g.to(torch.float32).contiguous()
+        L.check(L.lib().tnl_abs_mean_backward(L.ptr(x), L.u64(x.numel()), L.ptr(g), L.ptr(gx), L.stream()),
+                "abs_mean_backward")
+        return gx
+
+
+class _LazyAbs:
+    """What `coef.abs()` returns for the tensors get_wavelet_features() hands out: |coef| not yet evaluated.  `.mean()`
+    with no arguments -- the reference's regulariser, utils.py:639-655 -- runs the fused reduction; anything else
+    (another method, an operator, a torch function) evaluates torch.abs first and carries on with an ordinary tensor."""
+    __slots__ = ("_src", "_val")
+
+    def __init__(self, src):
+        self._src, self._val = src, None
+
+    def _tensor(self):
+        if self._val is None:
+            self._val = torch.abs(self._src)
+        return self._val
+
+    def mean(self, *args, **kwargs):
+        if not args and not kwargs and self._val is None and _AbsMean.usable(self._src):
+            return _AbsMean.apply(self._src)
+        return self._tensor().mean(*args, **kwargs)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in (torch.mean, torch.Tensor.mean) and len(args) == 1 and not kwargs and isinstance(args[0], _LazyAbs):
+            return args[0].mean()
+        conv = lambda a: a._tensor() if isinstance(a, _LazyAbs) else a
+        return func(*torch.utils._pytree.tree_map(conv, args), **torch.utils._pytree.tree_map(conv, kwargs))
+
+    def __getattr__(self, name):
+        return getattr(self._tensor(), name)
+
+    def __repr__(self):
+        return repr(self._tensor())
+
+    def __len__(self):
+        return len(self._tensor())
+
+    def __getitem__(self, k):
+        return self._tensor()[k]
+
+    def __neg__(self):
+        return -self._tensor()
+
+
+for _op in ("add", "radd", "sub", "rsub", "mul", "rmul", "truediv", "rtruediv", "pow", "rpow", "matmul", "lt", "le", "gt",
+            "ge", "eq", "ne"):
+    setattr(_LazyAbs, f"__{_op}__", (lambda name: lambda self, o: getattr(self._tensor(), name)(o))(f"__{_op}__"))
+
+
+class _CoefView(torch.Tensor):
+    """A coefficient Parameter as get_wavelet_features() hands it out (Tensor.as_subclass: same storage, same place in
+    the autograd graph).  Behaves like the parameter, except that `.abs()` is deferred (see _LazyAbs) so that the
+    regulariser's `val.abs().mean()` is one fused pass forward and one backward."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in (torch.abs, torch.Tensor.abs) and len(args) == 1 and not kwargs and type(args[0]) is _CoefView:
+            return _LazyAbs(args[0].as_subclass(torch.Tensor))
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        return torch.utils._pytree.tree_map(lambda t: t.as_subclass(torch.Tensor) if type(t) is _CoefView else t, out)
+
+
 class _IDWTBuffers(nn.Module):
     """Holds pytorch_wavelets.DWTInverse's filter buffers (g0_col, g1_col, g0_row, g1_row) so that
     reference checkpoints (`encoder.idwt.*` keys) load and save unchanged.  Not used for compute."""
@@ -377,8 +467,15 @@ class TriPlaneVolume(torch.nn.Module):
         self.planes_features_wavelet_coefs = nn.ParameterList(
             [nn.Parameter(torch.zeros(s)) for s in self.planes_features_wavelet_yh_shapes[:n_learn]])
 
+    fused_l1_views = True    # get_wavelet_features(): views whose .abs().mean() is one fused pass (False: the bare parameters)
+
     def get_wavelet_features(self):
-        return list(self.planes_features_wavelet_coefs) if self.inner_wavelet_scale > 1 else []
+        if self.inner_wavelet_scale <= 1:
+            return []
+        coefs = list(self.planes_features_wavelet_coefs)
+        if self.fused_l1_views and torch.is_grad_enabled() and all(_AbsMean.usable(c) for c in coefs):
+            return [c.as_subclass(_CoefView) for c in coefs]
+        return coefs
 
     def get_wavelet_features_upscaled(self):
         return self.upscale_wavelet_lst if self.upscale_enabled else []
