@@ -69,6 +69,8 @@ def build(workload, device, dist_mode, plane_dtype=None, shell=(0.8, 0.0), **ts_
                    background_color=0.0, dist_mode=dist_mode, **ts_kwargs)
     if os.environ.get("TNL_LIVE_BANDS"):      # A/B: 0 = whole live rectangles
         ts.live_bands = os.environ["TNL_LIVE_BANDS"] != "0"
+    if os.environ.get("TNL_EXCHANGE_BANDS"):  # the plane-gradient window reduced / exchanged in this many bands of rows
+        ts.overlap_exchange = int(os.environ["TNL_EXCHANGE_BANDS"])
     if os.environ.get("TNL_NO_OVERLAP"):      # experiments: march + tile sort in order on the launch stream (kernels alone)
         ts.overlap_march = False
     bitfield = torch.from_numpy(synthetic.sphere_bitfield(128, model.cascade, 1.5, shell[0], shell[1])).to(device)

@@ -138,7 +138,7 @@ def _build_roi(dev, R=256):
     return m
 
 
-def _run_roi(mode, rank, world, R=256, defer=None):
+def _run_roi(mode, rank, world, R=256, defer=None, overlap=0):
     from trinerflet_amd.train import TrainStep
     from trinerflet_amd import distributed as D
     dev = torch.device("cuda:0")
@@ -151,7 +151,7 @@ def _run_roi(mode, rank, world, R=256, defer=None):
     m = _build_roi(dev, R)
     bf = m.density_bitfield.clone()
     ts = TrainStep(m, lr=1e-2, wavelet_regularization=LAM, iters=1000, fp16=True, update_extra_interval=4, dist_mode=mode,
-                   defer_adam=defer)
+                   defer_adam=defer, overlap_exchange=overlap)
     ts.post_refresh = lambda: m.density_bitfield.copy_(bf)          # keep the analytic occupancy
     losses = []
     for it in range(6):
@@ -169,23 +169,27 @@ def _run_roi(mode, rank, world, R=256, defer=None):
     return (losses, params, live) if defer else (losses, params)
 
 
-def _roi_worker(rank, port, mode, out, R=256, defer=None):
+def _roi_worker(rank, port, mode, out, R=256, defer=None, overlap=0):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=2)
     try:
         torch.cuda.set_device(0)
-        out[rank] = _run_roi(mode, rank, 2, R, defer)
+        out[rank] = _run_roi(mode, rank, 2, R, defer, overlap)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["sharded", "allreduce"])
+@pytest.mark.parametrize("mode", ["sharded", "allreduce", "sharded-overlap"])
 def test_two_ranks_with_occupancy_window(cuda, mode):
+    """sharded-overlap: TrainStep(overlap_exchange=2) -- the window reduced and reduce-scattered in bands of rows, each
+    band's collective behind its tile reduction."""
     ref_losses, ref_params = _run_roi(None, 0, 1)
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_roi_worker, args=(port, mode, out), nprocs=2, join=True)
+    overlap = 2 if mode == "sharded-overlap" else 0
+    mode = mode.split("-")[0]
+    mp.spawn(_roi_worker, args=(port, mode, out, 256, None, overlap), nprocs=2, join=True)
     (l0, p0), (l1, p1) = out[0], out[1]
     assert np.allclose(l0, l1, rtol=1e-6) and np.allclose(l0, ref_losses, rtol=3e-3), (l0, l1, ref_losses)
     for k in ref_params:
@@ -194,7 +198,8 @@ def test_two_ranks_with_occupancy_window(cuda, mode):
         assert frac < 2e-2, (k, frac)
 
 
-def test_two_ranks_with_deferred_coefficient_pass(cuda):
+@pytest.mark.parametrize("overlap", [0, 3])
+def test_two_ranks_with_deferred_coefficient_pass(cuda, overlap):
     """TrainStep(defer_adam=True) under slice sharding (R = 512: the two finest levels have live rectangles): every rank
     replays its own slices; after the gather the replicas are identical, and outside the live rectangles -- where a
     coefficient's trajectory depends on nothing but its own p, m, v and the steps' scalars -- the two-rank run equals
@@ -203,7 +208,7 @@ def test_two_ranks_with_deferred_coefficient_pass(cuda):
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_roi_worker, args=(port, "sharded", out, 512, True), nprocs=2, join=True)
+    mp.spawn(_roi_worker, args=(port, "sharded", out, 512, True, overlap), nprocs=2, join=True)
     (l0, p0, live0), (l1, p1, _) = out[0], out[1]
     assert live0 == live and sum(lv is not None for lv in live) >= 1
     assert np.allclose(l0, l1, rtol=1e-6) and np.allclose(l0[:6], ref_losses[:6], rtol=3e-3), (l0, l1, ref_losses)

@@ -354,3 +354,30 @@ def test_side_work_beside_the_step_does_not_change_the_training(cuda):
             far = lambda x, y: int(((x - y).abs() > 2e-3 + 1e-3 * y.abs()).sum())
             assert far(b, a) <= 10 * far(c, a) + max(8, int(2e-4 * a.numel())), (pf, far(b, a), far(c, a))   # the count scatters
             assert float((a - b).abs().max()) < 2 * 7 * 1e-2, pf
+
+
+def test_banded_plane_gradient_equals_the_single_reduction_bit_for_bit(cuda):
+    """TrainStep(overlap_exchange=K): the plane-gradient window reduced in K bands of rows (each band's tiles in a launch
+    of its own, the results concatenated) is the same array as the single reduction -- with the ordered tile lists
+    (deterministic=True) the whole training run agrees to the bit (one process: no collective, only the banding)."""
+    from trinerflet_amd.train import TrainStep
+    N, bound = 4096, 1.0
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    o, d = synthetic.training_rays(N, n_cams=4, seed=7)
+    gt, nz = synthetic.target_colors(d), np.random.default_rng(1).random(N).astype(np.float32)
+    base = _model(cuda, R=512, scale=8, bound=bound)
+    bf = t(synthetic.sphere_bitfield(128, 1, bound, 0.5, 0.0))
+    base.density_bitfield.copy_(bf)
+    res = []
+    for K in (0, 3):
+        m = copy.deepcopy(base)
+        ts = TrainStep(m, update_extra_interval=4, deterministic=True, overlap_exchange=K)
+        ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf)
+        m.mean_count = 0
+        losses = [float(ts.step(t(o), t(d), t(gt), noises=t(nz))) for _ in range(6)]
+        assert ts._roi is not None and (K == 0 or len(ts._exchange_bands(ts._roi)) == K)
+        ts.flush_deferred()
+        res.append((losses, [p.detach().clone() for p in m.parameters()]))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-6)     # (the reported MSE is a float-atomic sum)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)

@@ -52,6 +52,21 @@ def reduce_scatter_slices(full, pg=None):
     return tmp[s0:s1].contiguous()
 
 
+def reduce_scatter_slices_async(full, pg=None):
+    """reduce_scatter_slices as (result tensor, wait): the collective is enqueued now -- on RCCL it runs on the process
+    group's own stream behind the work already queued on the CURRENT stream -- and wait() makes the stream current at
+    that time wait for it.  gloo (the CPU-testable transport) completes inside this call; wait() is then a no-op."""
+    world, rank = world_rank(pg)
+    if world == 1:
+        return full, (lambda: None)
+    if _native(pg):
+        s0, s1 = slice_range(full.shape[0], world, rank)
+        out = torch.empty((s1 - s0, *full.shape[1:]), dtype=full.dtype, device=full.device)
+        work = dist.reduce_scatter_tensor(out, full.contiguous(), group=pg, async_op=True)
+        return out, work.wait
+    return reduce_scatter_slices(full, pg), (lambda: None)
+
+
 def all_gather_slices(mine, pg=None):
     """mine: [S/G, ...] -> [S, ...] in rank order."""
     world, _ = world_rank(pg)

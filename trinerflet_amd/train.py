@@ -158,7 +158,7 @@ class TrainStep:
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
                  dist_mode=None, process_group=None, binned=True, fuse_adam=False, use_roi=True, tune_placement=None,
-                 defer_adam=None, deterministic=False, live_bands=True):
+                 defer_adam=None, deterministic=False, live_bands=True, overlap_exchange=0):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
@@ -265,6 +265,12 @@ class TrainStep:
         self.section_names = None   # see _mark
         self._mark_seq = 0
         self.overlap_march = True   # the next batch's march + tile sort on a side stream (False: in order, kernels alone)
+        # overlap_exchange = K > 1 ("sharded" mode with an occupancy window): the plane-gradient window is reduced and
+        # reduce-scattered in K bands of rows -- band b's collective runs on the communication stream while the tile
+        # reduction of band b + 1 runs on the launch stream; slice ownership and everything downstream are unchanged
+        # (the bands' results are concatenated into the [S/G, rh, rw] array the adjoint reads).  See DESIGN.md section 5.
+        self.overlap_exchange = int(overlap_exchange)
+        self._comm = None
         self.live_col_align = 32    # column granule of the live rectangles (see _live_rects)
         self.live_bands = live_bands
         self._side = None
@@ -565,7 +571,7 @@ class TrainStep:
         t = self.global_step + 1
         return lr_t / (1 - self.b1 ** t), math.sqrt(1 - self.b2 ** t)
 
-    def _adjoint(self, grad_tm, g_cm=None, fuse=None, roi=None):
+    def _adjoint(self, grad_tm, g_cm=None, fuse=None, roi=None, scattered=False):
         """plane gradient (texel-major [3,R,R,C], or already (3,C,R,R) in g_cm) -> coefficient / LL gradients.
         fuse=None: fills self.ll.grad / self.coef.grad (dense).  fuse=(lr_t, l1, found_inf, inv_scale): every
         level applies Adam(+L1) to its coefficients where their gradients are produced (no gradient buffer)."""
@@ -577,8 +583,10 @@ class TrainStep:
                     "planes_to_channel_major")
         S = 3 * C
         s0, s1 = 0, S
-        g = g_cm.view(S, R, R) if roi is None else g_cm     # roi: compact (S, rh, rw) window of the gradient
-        if self.dist_mode == "allreduce":
+        g = g_cm.view(S, R, R) if (roi is None and not scattered) else g_cm   # roi: compact (S, rh, rw) window of the gradient
+        if scattered:            # already reduce-scattered (banded exchange): this rank's slices only
+            s0, s1 = self._slice_range()
+        elif self.dist_mode == "allreduce":
             dist.all_reduce(g, group=self.pg)
         elif self.dist_mode == "sharded":
             s0, s1 = self._slice_range()
@@ -890,8 +898,37 @@ class TrainStep:
                 torch.cuda.current_stream().wait_event(st.ev_sort)
             if self.deterministic:
                 F_.order_tile_lists(st.sort_ws, R, st.xyzs.shape[0])
-            F_.plane_grad_reduce(st.sort_ws, dfeat, st.xyzs, float(model.bound), C, R, st.g_cm, channel_major=True,
-                                 nonfinite_flag=self.nonfinite, roi=self._roi10() if st.roi is not None else None)
+            st.scattered = False
+            bands = self._exchange_bands(st.roi)
+            if bands is None:
+                F_.plane_grad_reduce(st.sort_ws, dfeat, st.xyzs, float(model.bound), C, R, st.g_cm, channel_major=True,
+                                     nonfinite_flag=self.nonfinite, roi=self._roi10() if st.roi is not None else None)
+            else:
+                # band b: tile reduction of its rows on the launch stream, then its reduce-scatter on the communication
+                # stream (RCCL: behind an event) while band b + 1 is being reduced
+                if self._comm is None:
+                    self._comm = torch.cuda.Stream()
+                main = torch.cuda.current_stream()
+                parts, waits = [], []
+                for y0, hb in bands:
+                    buf = torch.empty(3 * C, hb, st.roi[6], dtype=torch.float32, device=self.dev)
+                    sub = list(st.roi)
+                    sub[3:6] = [oy + y0 for oy in st.roi[3:6]]
+                    sub[7] = hb
+                    F_.plane_grad_reduce(st.sort_ws, dfeat, st.xyzs, float(model.bound), C, R, buf, channel_major=True,
+                                         nonfinite_flag=self.nonfinite, roi=sub + [C, 0])
+                    self._comm.wait_stream(main)
+                    with torch.cuda.stream(self._comm):
+                        part, wait = D.reduce_scatter_slices_async(buf, self.pg if self.world > 1 else None)
+                    buf.record_stream(self._comm)
+                    parts.append(part)
+                    waits.append(wait)
+                for w in waits:
+                    w()
+                main.wait_stream(self._comm)
+                s0, s1 = self._slice_range() if self.world > 1 else (0, 3 * C)
+                st.g_cm = torch.cat([p_[: s1 - s0] if self.world == 1 else p_ for p_ in parts], dim=1)   # [S/G, rh, rw]
+                st.scattered = self.world > 1
             self._mark("plane_grad_binned")
             st.grad_tm = None
         else:
@@ -918,7 +955,7 @@ class TrainStep:
                 s0, s1 = self._adjoint(None, st.g_cm, fuse=(lr_t, l1, found_inf, inv_scale))
                 self._mark("idwt_adjoint_adam")
             else:
-                s0, s1 = self._adjoint(None, st.g_cm, roi=st.roi)
+                s0, s1 = self._adjoint(None, st.g_cm, roi=st.roi, scattered=getattr(st, "scattered", False))
                 self._mark("idwt_adjoint")
                 rects = self._rects if (st.roi is not None and self._rect_ok) else None
                 if self.defer_adam and rects is not None:
@@ -962,6 +999,24 @@ class TrainStep:
         self._mark("tail")
         self.last = {'mse': mse, 'wavelet_reg': reg, 'M': st.M, 'found_inf': found_inf, 'image': st.pred, 'ws': st.ws,
                      'depth': st.depth, 'counter': st.counter, 'lr': lr_t}
+
+    def _exchange_bands(self, roi):
+        """[(first row, rows)] of the bands the plane-gradient window is exchanged in, or None (one piece): overlap_exchange
+        K > 1, an occupancy window, the slice-sharded mode (or a single process, where only the banded reduction's own
+        cost shows: the measurement of DESIGN.md section 5), not the Adam-fused adjoint."""
+        K = self.overlap_exchange
+        if K <= 1 or roi is None or self.fuse_adam or (self.world > 1 and self.dist_mode != "sharded"):
+            return None
+        n64 = roi[7] // 64
+        K = min(K, n64)
+        if K <= 1:
+            return None
+        sizes = [(n64 // K + (1 if b < n64 % K else 0)) * 64 for b in range(K)]
+        out, y = [], 0
+        for hb in sizes:
+            out.append((y, hb))
+            y += hb
+        return out
 
     def _prefetch_next(self, next_rays):
         """Starts the following batch's march + tile sort on the side stream (see step(next_rays=...))."""
