@@ -30,6 +30,13 @@ def test_live_plus_catchup_equals_per_step_pass_bit_for_bit(cuda, l1):
     p0[::17] = 0.0                                                   # sign(0) = 0 coefficients
     m0 = torch.randn(numel, generator=g).to(cuda) * 1e-3
     v0 = torch.rand(numel, generator=g).to(cuda) * 1e-6
+    # a whole slice at the replay's fixed point p = m = v = 0 (untouched, zero-initialised coefficients: whole wavefronts
+    # of them skip the record loop and their stores) -- and one non-zero moment in its middle, which must still be replayed
+    z0 = (S - 1) * bands * n * n
+    p0[z0:] = 0.0
+    m0[z0:] = 0.0
+    v0[z0:] = 0.0
+    m0[z0 + 5000] = 1e-4
     live = [16, 0, 32, 8, 16, 0, 32, 40]                             # ox[3], oy[3], w, h
     grect = [20, 4, 36, 8, 24, 8, 24, 24]                            # inside live for every plane
     grads = [torch.randn(numel, generator=g).to(cuda) * 64.0 for _ in range(K)]

@@ -1,0 +1,20 @@
+# Every compile-time knob the kernels keep (an #ifndef default in csrc/): built in its non-default setting(s) and run
+# through the parity tests of the kernels it touches.  usage (GPU box): bash tools/knob_ci.sh   (~1 min per line)
+cd /root/repo
+run() {  # flags, test selection
+  TNL_HIPCC_FLAGS="$1" python -m trinerflet_amd.build --force > /dev/null 2>&1 || { echo "BUILD FAILED: $1"; return; }
+  echo "[$1] $(python -m pytest $2 -m gpu -x -q 2>&1 | tail -1)"
+}
+ADAM="tests/test_adam_deferred_gpu.py tests/test_train_gpu.py tests/test_optim_gpu.py"
+run "-DTNL_ADAM_PIECE=2048" "$ADAM"
+run "-DTNL_ADAM_UNROLL=1" "$ADAM"
+run "-DTNL_ADAM_UNROLL=4" "$ADAM"
+run "-DTNL_ADAM_ORDER=1" "$ADAM"
+run "-DTNL_ADAM_ORDER=2" "$ADAM"
+run "-DTNL_ADAM_STORE_ORDER=1" "$ADAM"
+run "-DTNL_ADAM_BLOCKS=2048" "$ADAM"
+run "-DTNL_RENDER_RT128=128" "tests/test_render_fused_gpu.py"
+run "-DTNL_IDWT_BWD_NT=0" "tests/test_idwt_walk_gpu.py tests/test_spans_gpu.py tests/test_roi_gpu.py"
+run "-DTNL_FWD_FB=8" "tests/test_idwt_walk_gpu.py tests/test_spans_gpu.py tests/test_roi_gpu.py"
+run "-DTNL_ROWS_STAMP=1" "tests/test_field_gpu.py"
+python -m trinerflet_amd.build --force > /dev/null

@@ -409,6 +409,14 @@ k_adam_l1_catchup(float* __restrict__ p, float* __restrict__ m, float* __restric
     float4 pi = zero, mi = zero, vi = zero, pj = zero, mj = zero, vj = zero;
     if (oi) { pi = ld_nt(p4 + i); mi = ld_nt(m4 + i); vi = ld_nt(v4 + i); }
     if (oj) { pj = ld_nt(p4 + j); mj = ld_nt(m4 + j); vj = ld_nt(v4 + j); }
+    // A coefficient with p = m = v = 0 is a fixed point of the replay (g = l1 sign(0) = 0): the wavelet levels start at
+    // zero, and outside the live pieces nothing but this recurrence ever touches them.  A wavefront whose 512 coefficients
+    // are all at that fixed point skips the (ALU-bound) record loop and the stores: the same bits, half the bytes.
+    {
+      auto bits = [](const float4& q) { return __float_as_uint(q.x) | __float_as_uint(q.y) | __float_as_uint(q.z) | __float_as_uint(q.w); };
+      const uint32_t any = (bits(pi) | bits(mi) | bits(vi) | bits(pj) | bits(mj) | bits(vj)) & 0x7fffffffu;
+      if (__ballot(any != 0u) == 0ull) continue;
+    }
     for (int r = 0; r < count; r++) {
       const AdamStepRec rec = ring[r];                      // uniform: a scalar load
       if (sums)

@@ -14,10 +14,7 @@ constexpr int TSY = 8;   // tile height
 // its sub-bins (consecutive in the scanned offsets), so the reduction kernel only reads offsets[bin * BIN_SUBS] and
 // offsets[(bin + 1) * BIN_SUBS].  Measured (ms per step | side work alone): small 1 sub-bin 2.66 | 1.23, 4: 2.36 | 0.82,
 // 8: 2.44 | 0.91, 32: 2.34 | 0.86; base (4x the tiles, cooler counters) unchanged at 5.24-5.31 | 1.01 for 1-16, worse at 32.
-#ifndef TNL_BIN_SUBS
-#define TNL_BIN_SUBS 4
-#endif
-constexpr int BIN_SUBS = TNL_BIN_SUBS;
+constexpr int BIN_SUBS = 4;   // (a constant, not a build knob: tests and tools read the lists through tnl_plane_grad_sort_layout)
 
 struct Foot {  // tiles touched by a bilinear footprint on one plane
   int tx0, ty0, tx1, ty1;

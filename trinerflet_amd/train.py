@@ -195,6 +195,7 @@ class TrainStep:
                         and enc.plane_dtype == torch.float16 and self.base_res == 0)
         self._roi = None          # 8 ints {ox[3], oy[3], rw, rh} or None (whole planes)
         self._roi_valid = False   # False: recompute from the bitfield before it is used
+        self._roi_request = None  # (pinned host buffer, device buffer, event, ...) of a window read-back in flight
         self._tm_full = None      # persistent fp16 [3,R,R,C]; the ROI steps refresh its window in place
         n0 = enc.planes_features.shape[-1]
         # gradient-support chain (windowed adjoint + rectangle-aware Adam): level sizes must be powers of two
@@ -323,6 +324,7 @@ class TrainStep:
         occupancy window is recomputed and a march already started for the following batch is dropped."""
         self.flush_deferred()
         self._roi_valid = False
+        self._roi_request = None
         self._occ_box = None
         self._drop_prefetch()
 
@@ -332,6 +334,14 @@ class TrainStep:
     def _compute_roi(self):
         """Window of the plane grid (per plane origin, common size, multiples of 64) that contains the bilinear
         footprint of every position inside an occupied cell of any cascade.  One small host read-back."""
+        self._request_roi()
+        return self._finish_roi()
+
+    def _request_roi(self):
+        """The device half of _compute_roi: two small kernels over the bitfield and an asynchronous copy of their 2 KB of
+        results into pinned host memory, behind an event.  A refresh step issues it right after the grid update and reads
+        the result (_finish_roi) only where the window is first needed -- before the plane gradient -- so the host does not
+        stall the launch stream in the middle of the step (0.3 ms per refresh: profiles/r03e_refresh_step_timeline.txt)."""
         model, R = self.model, self.R
         Hg, casc = model.grid_size, model.cascade
         bits = model.density_bitfield.view(casc, -1)                                       # [casc, H^3/8] uint8
@@ -355,7 +365,19 @@ class TrainStep:
             L.check(L.lib().tnl_occupancy_row_extents(L.ptr(bits), L.u32(bits.shape[1]), L.u32(casc), L.u32(Hg),
                                                       L.f32(float(model.bound)), L.u32(R), L.ptr(ext), L.stream()),
                     "occupancy_row_extents")
-        host = buf.cpu().numpy()                                    # the one read-back
+        host = torch.empty(nb + ne, dtype=torch.int32, pin_memory=True)
+        host.copy_(buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._roi_request = (host, buf, ev, nb, rows)
+
+    def _finish_roi(self):
+        model, R = self.model, self.R
+        Hg, casc = model.grid_size, model.cascade
+        host_t, _, ev, nb, rows = self._roi_request
+        self._roi_request = None
+        ev.synchronize()
+        host = host_t.numpy()
         if rows:
             self._row_ext = host[nb:].reshape(3, R // 8, 2).astype(np.int64)
         vals = [float("inf")] * 3 + [float("-inf")] * 3            # world-space box over the cascades
@@ -805,7 +827,8 @@ class TrainStep:
                 self.post_refresh()
             self._occ_box = None            # the bitfield changed: the march's far clip is rebuilt on first use
             if self.use_roi:
-                self._roi, self._roi_valid = self._compute_roi(), True
+                self._request_roi()         # read where the window is first needed (_stage_backward): no host stall here
+                self._roi_valid = True
             self._mark("grid_refresh")
 
     def _stage_march(self, st):
@@ -877,6 +900,8 @@ class TrainStep:
         if model.density_scale != 1:
             g_sigma = g_sigma * model.density_scale
         self._mark("composite_bwd")
+        if self._roi_request is not None:           # a refresh step: the new window, requested right after the grid update
+            self._roi = self._finish_roi()
         st.roi = self._roi if (self.use_roi and self.binned and R % 32 == 0) else None
         if self.binned and R % 32 == 0:
             # no global float atomics: dF -> fp16 -> tile-sorted matrix-core accumulation (csrc/scatter.hip), written
