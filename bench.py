@@ -108,20 +108,19 @@ def one_step(model, ts, bitfield, batch, mean_count, next_batch=None):
 def cpu_baseline(workload):
     """Reference operator set on the host cores (oracle/torch_baseline.py), BASELINE.md section 3's procedure: the dense
     part (plane rebuild, its backward, regulariser, Adam) at the FULL plane size, the per-ray part on a reduced ray count
-    scaled linearly; one warm-up step, then the median of 3 timed steps (section 3 asks for >= 5; 3 keeps the default run
-    within minutes -- the dense part alone is ~10 s per step at base)."""
+    scaled linearly; one warm-up step, then the median of 5 timed steps (section 3: >= 5)."""
     from oracle import torch_baseline as tb
     C, R, scale, H, N, lam = WORKLOADS[workload]
     # torch's CPU kernels stop scaling (and then regress) well before the 256 hardware threads of the GPU box's
     # host: 32 threads measured fastest there (8: 1.38 s, 16: 1.23 s, 32: 1.10 s, 64: 1.92 s for the same sample)
     cores = min(os.cpu_count() or 1, 32)
     Ns = max(N // 20, 64)
-    t = tb.time_step(C, R, scale, H, Ns, lam=lam, threads=cores, repeats=3, warmup=1)
+    t = tb.time_step(C, R, scale, H, Ns, lam=lam, threads=cores, repeats=5, warmup=1)
     dense, ray = t["dense_s"], t["ray_s"] * (N / Ns)
     return {"value": N / (dense + ray), "unit": "rays/s", "cores": cores, "kind": "port",
             "samples_per_s": N * 512 / (dense + ray),
             "split_s": {"dense_full_size": round(dense, 3), "per_ray_scaled": round(ray, 3)},
-            "sample": f"torch-CPU fp32 step, 1 warm-up + median of 3: dense part (IDWT fwd+bwd, L1, Adam over "
+            "sample": f"torch-CPU fp32 step, 1 warm-up + median of 5: dense part (IDWT fwd+bwd, L1, Adam over "
                       f"{3 * C * R * R / 1e6:.0f} M coefficients) at the full R={R}: {[round(v, 2) for v in t['dense_all_s']]} s; "
                       f"per-ray part (512 uniform steps/ray, renderer.run semantics, on the full-size planes) on {Ns} rays "
                       f"scaled x{N / Ns:.0f}: {[round(v, 2) for v in t['ray_all_s']]} s"}

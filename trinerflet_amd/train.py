@@ -196,6 +196,7 @@ class TrainStep:
         self._roi = None          # 8 ints {ox[3], oy[3], rw, rh} or None (whole planes)
         self._roi_valid = False   # False: recompute from the bitfield before it is used
         self._roi_request = None  # (pinned host buffer, device buffer, event, ...) of a window read-back in flight
+        self._roi_host = None
         self._tm_full = None      # persistent fp16 [3,R,R,C]; the ROI steps refresh its window in place
         n0 = enc.planes_features.shape[-1]
         # gradient-support chain (windowed adjoint + rectangle-aware Adam): level sizes must be powers of two
@@ -365,7 +366,9 @@ class TrainStep:
             L.check(L.lib().tnl_occupancy_row_extents(L.ptr(bits), L.u32(bits.shape[1]), L.u32(casc), L.u32(Hg),
                                                       L.f32(float(model.bound)), L.u32(R), L.ptr(ext), L.stream()),
                     "occupancy_row_extents")
-        host = torch.empty(nb + ne, dtype=torch.int32, pin_memory=True)
+        host = self._roi_host            # pinned, allocated once (a pinned allocation is a driver call)
+        if host is None or host.numel() != nb + ne:
+            host = self._roi_host = torch.empty(nb + ne, dtype=torch.int32, pin_memory=True)
         host.copy_(buf, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -377,7 +380,7 @@ class TrainStep:
         host_t, _, ev, nb, rows = self._roi_request
         self._roi_request = None
         ev.synchronize()
-        host = host_t.numpy()
+        host = host_t.numpy().copy()     # the pinned buffer is reused by the next request
         if rows:
             self._row_ext = host[nb:].reshape(3, R // 8, 2).astype(np.int64)
         vals = [float("inf")] * 3 + [float("-inf")] * 3            # world-space box over the cascades
