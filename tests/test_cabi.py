@@ -129,3 +129,28 @@ def test_ray_pool_has_no_cpu_path():
                    np.zeros((1, 4, 4, 3), np.float32), device="cpu")
     with pytest.raises(RuntimeError):
         pool.batch(0, 8)
+
+
+def test_eval_render_mode_selection():
+    """render(..., render_mode=...) names the form of run_cuda's eval branch explicitly; the older keywords still select
+    one when it is absent (passing an unrelated loop knob must not silently switch the path)."""
+    import torch
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, hidden_dim=64, hidden_dim_color=64,
+                    triplane_channels=16, triplane_resolution=64, triplane_wavelet_levels=1)
+    with torch.no_grad():
+        assert m._eval_render_mode({}) == "kernel"
+        assert m._eval_render_mode({"render_mode": "device_loop", "infer_min_step": 8}) == "device_loop"
+        assert m._eval_render_mode({"render_mode": "host_loop"}) == "host_loop"
+        assert m._eval_render_mode({"fused_render": True}) == "kernel"
+        assert m._eval_render_mode({"fused_render": False}) == "device_loop"
+        assert m._eval_render_mode({"device_loop": False}) == "host_loop"
+        assert m._eval_render_mode({"infer_min_step": 4}) == "device_loop"
+        with pytest.raises(ValueError):
+            m._eval_render_mode({"render_mode": "kernel", "infer_min_step": 8})
+        with pytest.raises(ValueError):
+            m._eval_render_mode({"render_mode": "loop"})
+    assert m._eval_render_mode({}) == "host_loop"          # under autograd only the reference's loop differentiates
+    m.force_modular = True
+    with torch.no_grad():
+        assert m._eval_render_mode({"render_mode": "kernel"}) == "host_loop"   # no fused field for this configuration
