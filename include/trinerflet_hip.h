@@ -193,9 +193,15 @@ TNL_API int tnl_idwt_level_backward_adam(const float *dout, uint32_t S, uint32_t
                                          const float *found_inf, float *abs_sum, void *stream);
 
 /* Layout change between the reference's (3,C,R,R) planes ("channel-major") and the sampler's
- * texel-major [3,R,R,C] storage.  half_out != 0 stores fp16 (e = 2), else fp32 (e = 4). */
+ * texel-major [3,R,R,C] storage.  half_out != 0 stores fp16 (e = 2), else fp32 (e = 4).  Both pointers 16-byte aligned.
+ * _win: only the window `roi` (10 host ints {ox[3], oy[3], rw, rh, C, 0}, rw % 64 == 0; as the *_roi entry points below)
+ * of each plane is converted -- both arrays keep their whole-plane shape, texels outside the window keep their contents.
+ * For the training forward of the module path: no sample of a batch marched through the current occupancy grid lies
+ * outside the grid's window (nerf/network.py), so 70 % of the 2.4 GB layout pass at the base geometry is never read. */
 TNL_API int tnl_planes_to_texel_major(const float *planes_cm, uint32_t C, uint32_t R, int half_out,
                                       void *planes_tm, void *stream);
+TNL_API int tnl_planes_to_texel_major_win(const float *planes_cm, uint32_t C, uint32_t R, int half_out,
+                                          void *planes_tm, const int32_t *roi, void *stream);
 /* fp16 (3,C,R,R) -> fp16 [3,R,R,C] (C % 8 == 0, R % 8 == 0) */
 TNL_API int tnl_planes_half_to_texel_major(const void *planes_cm_half, uint32_t C, uint32_t R,
                                            void *planes_tm_half, void *stream);
@@ -353,6 +359,16 @@ TNL_API int tnl_adam_l1_step_dev(float *p, float *grad, float *m, float *v, uint
                                  const float *opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
                                  const float *inv_scale_dev, float l1_coef, const float *found_inf,
                                  float *abs_sum, int zero_grad, void *stream);
+/* tnl_adam_l1_step_dev with a second L1 coefficient that exists only on the device (optim.FusedAdamL1, fold_l1):
+ * l1_scaled_dev[0] = d(scaled loss) / d(sum |p|), collected from the backward of the reference's regulariser
+ * (nerf/utils.py:639-655: v.abs().mean() * weight) instead of materialising sign(p) * s as a gradient and adding it to
+ * the data gradient (two whole-array passes); g = (grad + l1_scaled_dev[0] * sign(p)) * inv_scale_dev[0] + l1_coef *
+ * sign(p), evaluated as grad * inv + (l1 + s * inv) * sign(p).  A non-finite l1_scaled_dev[0] skips the update like
+ * found_inf.  May be NULL. */
+TNL_API int tnl_adam_l1_step_sink(float *p, float *grad, float *m, float *v, uint64_t n, float lr,
+                                  const float *opt_step_dev, float beta1, float beta2, float eps,
+                                  const float *inv_scale_dev, float l1_coef, const float *l1_scaled_dev,
+                                  const float *found_inf, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Background mix + MSE + gradient in one pass (csrc/loss.hip): pred = image + (1 - weights_sum) * bg

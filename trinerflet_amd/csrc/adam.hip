@@ -55,7 +55,8 @@ template <bool RECT, bool NTMP = false>
 __global__ void __launch_bounds__(256)
 k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, uint64_t n,
           AdamArgs a, const float* __restrict__ inv_scale_dev, const float* __restrict__ found_inf,
-          float* __restrict__ abs_sum, int zero_grad, const float* __restrict__ opt_step_dev, AdamRect rc) {
+          float* __restrict__ abs_sum, int zero_grad, const float* __restrict__ opt_step_dev, AdamRect rc,
+          const float* __restrict__ l1_dev) {
   if (opt_step_dev != nullptr) {
     // a.step_size carries the learning rate; the bias corrections come from the DEVICE count of optimiser steps
     // actually taken (torch.optim.Adam's per-parameter `step`, which GradScaler.step does not advance on a skipped
@@ -71,7 +72,14 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
     a.bias2_sqrt = bc[1];
   }
   if (inv_scale_dev != nullptr) a.inv_scale *= inv_scale_dev[0];
-  const bool skip = found_inf != nullptr && found_inf[0] != 0.f;
+  bool skip = found_inf != nullptr && found_inf[0] != 0.f;
+  if (l1_dev != nullptr) {
+    // an L1 term whose (loss-scaled) coefficient only exists on the device: d/dp of s * sum|p| is s * sign(p); it is
+    // unscaled like the data gradient it would have been added to.  A non-finite coefficient skips the update.
+    const float s = l1_dev[0] * a.inv_scale;
+    a.l1_coef += s;
+    skip = skip || !(fabsf(s) <= 3.0e38f);
+  }
   float acc = 0.f;
   const uint64_t n4 = n / 4;
   float4* p4 = reinterpret_cast<float4*>(p);
@@ -453,7 +461,8 @@ k_adam_l1_catchup(float* __restrict__ p, float* __restrict__ m, float* __restric
 static int adam_launch(float* p, float* grad, float* m, float* v, uint64_t n, float step_size, float bias2_sqrt,
                        float beta1, float beta2, float eps, float inv_scale, const float* inv_scale_dev,
                        float l1_coef, const float* found_inf, float* abs_sum, int zero_grad,
-                       const float* opt_step_dev, void* stream, const AdamRect* rect = nullptr) {
+                       const float* opt_step_dev, void* stream, const AdamRect* rect = nullptr,
+                       const float* l1_dev = nullptr) {
   if (n == 0) return 0;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
        reinterpret_cast<uintptr_t>(v)) & 15)
@@ -467,16 +476,16 @@ static int adam_launch(float* p, float* grad, float* m, float* v, uint64_t n, fl
   static const bool use_nt = getenv("TNL_ADAM_TEMPORAL") == nullptr;
   if (rect == nullptr && use_nt)
     hipLaunchKernelGGL((k_adam_l1<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v,
-                       n, a, inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, AdamRect{});
+                       n, a, inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, AdamRect{}, l1_dev);
   else if (rect != nullptr && use_nt)
     hipLaunchKernelGGL((k_adam_l1<true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n,
-                       a, inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, *rect);
+                       a, inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, *rect, l1_dev);
   else if (rect != nullptr)
     hipLaunchKernelGGL(k_adam_l1<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n, a,
-                       inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, *rect);
+                       inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, *rect, l1_dev);
   else
     hipLaunchKernelGGL(k_adam_l1<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n, a,
-                       inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, AdamRect{});
+                       inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, AdamRect{}, l1_dev);
   return (int)hipGetLastError();
 }
 
@@ -495,6 +504,15 @@ extern "C" int tnl_adam_l1_step_dev(float* p, float* grad, float* m, float* v, u
   if (opt_step_dev == nullptr) return (int)hipErrorInvalidValue;
   return adam_launch(p, grad, m, v, n, lr, 1.0f, beta1, beta2, eps, inv_scale, inv_scale_dev, l1_coef, found_inf,
                      abs_sum, zero_grad, opt_step_dev, stream);
+}
+
+extern "C" int tnl_adam_l1_step_sink(float* p, float* grad, float* m, float* v, uint64_t n, float lr,
+                                     const float* opt_step_dev, float beta1, float beta2, float eps,
+                                     const float* inv_scale_dev, float l1_coef, const float* l1_scaled_dev,
+                                     const float* found_inf, void* stream) {
+  if (opt_step_dev == nullptr) return (int)hipErrorInvalidValue;
+  return adam_launch(p, grad, m, v, n, lr, 1.0f, beta1, beta2, eps, 1.0f, inv_scale_dev, l1_coef, found_inf, nullptr, 0,
+                     opt_step_dev, stream, nullptr, l1_scaled_dev);
 }
 
 // One wavelet level [S][bands][n][n] whose gradient is stored only inside a per-plane rectangle (rect_host: ox[3],

@@ -990,21 +990,58 @@ k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __re
 
 template <bool HALF>
 __global__ void __launch_bounds__(NT)
-k_to_texel_major(const float* __restrict__ cm, int C, int R, void* __restrict__ tm) {
+k_to_texel_major(const float* __restrict__ cm, int C, int R, void* __restrict__ tm, Roi roi) {
+  // roi.rw != 0: only the window's row segments are launched; source and destination keep their whole-plane strides
+  // (the texels outside the window are left as they are).  16-byte loads along x, 16-byte stores along the channels.
   extern __shared__ float tile[];  // [C][TX+1]
-  const int p = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * TX;
-  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
-    const int c = idx / TX, xx = idx - c * TX;
-    tile[c * (TX + 1) + xx] = (x0 + xx < R) ? cm[(((size_t)p * C + c) * R + y) * R + x0 + xx] : 0.f;
+  const int p = blockIdx.z;
+  const int y = blockIdx.y + (roi.rw ? roi.oy[p] : 0), x0 = blockIdx.x * TX + (roi.rw ? roi.ox[p] : 0);
+  if ((R & 3) == 0) {
+    for (int idx = threadIdx.x; idx < C * (TX / 4); idx += NT) {
+      const int c = idx / (TX / 4), xx = (idx - c * (TX / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x0 + xx < R) v = *reinterpret_cast<const float4*>(cm + (((size_t)p * C + c) * R + y) * R + x0 + xx);
+      float* t = tile + c * (TX + 1) + xx;
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
+      const int c = idx / TX, xx = idx - c * TX;
+      tile[c * (TX + 1) + xx] = (x0 + xx < R) ? cm[(((size_t)p * C + c) * R + y) * R + x0 + xx] : 0.f;
+    }
   }
   __syncthreads();
   const size_t base = (((size_t)p * R + y) * R + x0) * C;
-  for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
-    const int xx = idx / C, c = idx - xx * C;
-    if (x0 + xx < R) {
-      const float v = tile[c * (TX + 1) + xx];
-      if (HALF) reinterpret_cast<__half*>(tm)[base + idx] = __float2half(v);
-      else reinterpret_cast<float*>(tm)[base + idx] = v;
+  if (HALF && (C & 7) == 0) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int CG = C / 8;
+    for (int idx = threadIdx.x; idx < TX * CG; idx += NT) {
+      const int xx = idx / CG, cg = idx - xx * CG;
+      if (x0 + xx < R) {
+        h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (_Float16)__float2half(tile[(cg * 8 + j) * (TX + 1) + xx]);
+        *reinterpret_cast<h8*>(reinterpret_cast<_Float16*>(tm) + base + (size_t)xx * C + cg * 8) = v;
+      }
+    }
+  } else if (!HALF && (C & 3) == 0) {
+    const int CG = C / 4;
+    for (int idx = threadIdx.x; idx < TX * CG; idx += NT) {
+      const int xx = idx / CG, cg = idx - xx * CG;
+      if (x0 + xx < R) {
+        const float* t = tile + (cg * 4) * (TX + 1) + xx;
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(tm) + base + (size_t)xx * C + cg * 4) =
+            make_float4(t[0], t[TX + 1], t[2 * (TX + 1)], t[3 * (TX + 1)]);
+      }
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < C * TX; idx += NT) {
+      const int xx = idx / C, c = idx - xx * C;
+      if (x0 + xx < R) {
+        const float v = tile[c * (TX + 1) + xx];
+        if (HALF) reinterpret_cast<__half*>(tm)[base + idx] = __float2half(v);
+        else reinterpret_cast<float*>(tm)[base + idx] = v;
+      }
     }
   }
 }
@@ -1330,18 +1367,33 @@ int tnl_idwt_level_backward_adam(const float* dout, uint32_t S, uint32_t n, int 
   return (int)hipGetLastError();
 }
 
-int tnl_planes_to_texel_major(const float* planes_cm, uint32_t C, uint32_t R, int half_out, void* planes_tm,
-                              void* stream) {
+static int planes_to_tm(const float* planes_cm, uint32_t C, uint32_t R, int half_out, void* planes_tm,
+                        const int32_t* roi_host, void* stream) {
   if (C == 0 || R == 0) return 0;
-  const dim3 grid(cdiv(R, TX), R, 3);
+  Roi roi;
+  if (!make_roi(roi_host, 3 * C, R, roi) || (roi.rw && (roi.spp != (int)C || roi.s0 != 0 || roi.rw % TX != 0)))
+    return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(planes_cm) | reinterpret_cast<uintptr_t>(planes_tm)) & 15) return (int)hipErrorInvalidValue;
+  const dim3 grid = roi.rw ? dim3(roi.rw / TX, roi.rh, 3) : dim3(cdiv(R, TX), R, 3);
   const size_t lds = (size_t)C * (TX + 1) * sizeof(float);
   if (half_out)
     hipLaunchKernelGGL(k_to_texel_major<true>, grid, dim3(NT), lds, (hipStream_t)stream, planes_cm, (int)C, (int)R,
-                       planes_tm);
+                       planes_tm, roi);
   else
     hipLaunchKernelGGL(k_to_texel_major<false>, grid, dim3(NT), lds, (hipStream_t)stream, planes_cm, (int)C, (int)R,
-                       planes_tm);
+                       planes_tm, roi);
   return (int)hipGetLastError();
+}
+
+int tnl_planes_to_texel_major(const float* planes_cm, uint32_t C, uint32_t R, int half_out, void* planes_tm,
+                              void* stream) {
+  return planes_to_tm(planes_cm, C, R, half_out, planes_tm, nullptr, stream);
+}
+
+int tnl_planes_to_texel_major_win(const float* planes_cm, uint32_t C, uint32_t R, int half_out, void* planes_tm,
+                                  const int32_t* roi, void* stream) {
+  if (roi == nullptr) return (int)hipErrorInvalidValue;
+  return planes_to_tm(planes_cm, C, R, half_out, planes_tm, roi, stream);
 }
 
 int tnl_planes_to_channel_major(const float* grad_tm, uint32_t C, uint32_t R, float* grad_cm, void* stream) {

@@ -30,15 +30,18 @@ def pack_weights(W0, W1, W2, W3, W4, C, H):
     return packed
 
 
-def field_forward(planes_tm, xyz, dirs, packed, bound, C, R, H, save_feats=False, geo_out=False, m_actual=None):
-    """Raw call.  dirs=None -> density only (returns sigma, geo[M,15] or None, feats)."""
+def field_forward(planes_tm, xyz, dirs, packed, bound, C, R, H, save_feats=False, geo_out=False, m_actual=None,
+                  zero_tail=False):
+    """Raw call.  dirs=None -> density only (returns sigma, geo[M,15] or None, feats).  m_actual (device int32): rows
+    from m_actual[0] on are not computed; their outputs are zeros with zero_tail, undefined otherwise."""
     M = xyz.shape[0]
     dev = xyz.device
-    sigma = torch.empty(M, dtype=torch.float32, device=dev)
+    new = torch.zeros if (zero_tail and m_actual is not None) else torch.empty
+    sigma = new(M, dtype=torch.float32, device=dev)
     if dirs is None:
-        second = torch.empty(M, 15, dtype=torch.float32, device=dev) if geo_out else None
+        second = new(M, 15, dtype=torch.float32, device=dev) if geo_out else None
     else:
-        second = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        second = new(M, 3, dtype=torch.float32, device=dev)
     feats = None
     if save_feats:
         # [M,3C] features; for hidden 128 the 16 sigma-net outputs per sample follow in the same allocation (kept alive by
@@ -70,10 +73,14 @@ class _FusedField(Function):
     binned_backward = True     # False: the plane gradient by global float atomics (tests compare the two)
 
     @staticmethod
-    def forward(ctx, planes_tm, xyz, dirs, W0, W1, W2, W3, W4, bound, planes_cm=None):
+    def forward(ctx, planes_tm, xyz, dirs, W0, W1, W2, W3, W4, bound, planes_cm=None, m_actual=None):
         """planes_cm (optional): the (3,C,R,R) planes the texel-major copy `planes_tm` was made from.  When given, the
         planes' gradient is returned for IT, already in its layout (the tile reduction writes channel-major directly),
-        and planes_tm is read as plain data -- the layout pass back to (3,C,R,R) (0.74 ms at base) disappears."""
+        and planes_tm is read as plain data -- the layout pass back to (3,C,R,R) (0.74 ms at base) disappears.
+        m_actual (optional, device int32): the march's sample count; rows from there on (the zero padding up to the
+        sample budget, raymarching.cu:312-480) are skipped -- outputs 0, no gradient -- in every kernel.  They are worth
+        nothing to the result (no ray owns them) but all sit on the texel of the origin: one tile's list in the
+        plane-gradient reduction then holds 2 % of the batch and its workgroup runs 1 ms after all others have finished."""
         L.require_cuda(planes_tm, xyz, dirs, W0)
         _, R, _, C = planes_tm.shape
         H = W0.shape[0]
@@ -81,7 +88,11 @@ class _FusedField(Function):
         dirs = dirs.detach().to(torch.float32).contiguous()
         packed = pack_weights(W0, W1, W2, W3, W4, C, H)
         need_grad = any(ctx.needs_input_grad)
-        sigma, rgb, feats = field_forward(planes_tm, xyz, dirs, packed, float(bound), C, R, H, save_feats=need_grad)
+        if m_actual is not None:
+            m_actual = m_actual.reshape(-1)[:1].to(torch.int32).clone()    # the caller's counter is a ring slot
+        sigma, rgb, feats = field_forward(planes_tm, xyz, dirs, packed, float(bound), C, R, H, save_feats=need_grad,
+                                          m_actual=m_actual, zero_tail=True)
+        ctx.m_actual = m_actual
         ctx.save_for_backward(xyz, dirs, packed, sigma, rgb, feats)
         ctx.dims = (C, R, H, float(bound), [tuple(w.shape) for w in (W0, W1, W2, W3, W4)])
         ctx.cm = planes_cm is not None and R % 32 == 0 and _FusedField.binned_backward
@@ -102,8 +113,9 @@ class _FusedField(Function):
             grad_cm = torch.zeros(3, C, R, R, dtype=torch.float32, device=dev)
             if xyz.shape[0] > 0:
                 dfeat = torch.empty(3, xyz.shape[0], C, dtype=torch.float16, device=dev)
-                field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_cm, gradW, dfeat=dfeat)
-                plane_grad_binned(dfeat, xyz, bound, C, R, grad_cm, channel_major=True, prezeroed=True)
+                field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_cm, gradW, dfeat=dfeat,
+                               m_actual=ctx.m_actual)
+                plane_grad_binned(dfeat, xyz, bound, C, R, grad_cm, m_actual=ctx.m_actual, channel_major=True, prezeroed=True)
             grad_tm = None
         elif R % 32 == 0 and xyz.shape[0] > 0 and _FusedField.binned_backward:
             # no global float atomics (round 4; before: 6.8 ms of a 24.5-ms step of the reference's loop at base, bound by
@@ -113,16 +125,18 @@ class _FusedField(Function):
             # gradient, which is what makes scaler.step() skip and back off.
             grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=dev)
             dfeat = torch.empty(3, xyz.shape[0], C, dtype=torch.float16, device=dev)
-            field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW, dfeat=dfeat)
-            plane_grad_binned(dfeat, xyz, bound, C, R, grad_tm, prezeroed=True)
+            field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW, dfeat=dfeat,
+                           m_actual=ctx.m_actual)
+            plane_grad_binned(dfeat, xyz, bound, C, R, grad_tm, m_actual=ctx.m_actual, prezeroed=True)
         else:
             grad_tm = torch.zeros(3, R, R, C, dtype=torch.float32, device=dev)
-            field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW)
+            field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_tm, gradW,
+                           m_actual=ctx.m_actual)
         gws, off = [], 0
         for a, b in shapes:
             gws.append(gradW[off:off + a * b].view(a, b))
             off += a * b
-        return (grad_tm, None, None, *gws, None, grad_cm if ctx.cm else None)
+        return (grad_tm, None, None, *gws, None, grad_cm if ctx.cm else None, None)
 
 
 fused_field = _FusedField.apply

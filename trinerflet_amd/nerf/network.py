@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from ..activation import trunc_exp
 from ..encoding import get_encoder
 from . import field as _field
+from .. import occupancy
 from .renderer import NeRFRenderer
 
 
@@ -117,12 +118,27 @@ class NeRFNetwork(NeRFRenderer):
                 # gradient back in (3,C,R,R) directly
                 planes_cm = enc.get_planes()
                 with torch.no_grad():
-                    tm = enc.get_planes_texel_major()
-                return _field.fused_field(tm, x, d, *Ws, self.bound, planes_cm)
+                    # called from run_cuda on a marched batch: only the occupancy window of the copy is made
+                    tm = enc.get_planes_texel_major(window=self._march_window)
+                return _field.fused_field(tm, x, d, *Ws, self.bound, planes_cm, self._march_count)
             tm = enc.get_planes_texel_major()
-            return _field.fused_field(tm, x, d, *Ws, self.bound)
+            return _field.fused_field(tm, x, d, *Ws, self.bound, None, self._march_count)
         sigma, geo_feat = self._sigma_mlp(x)
         return sigma, self._color_mlp(d, geo_feat)
+
+    def _occupancy_window(self):
+        """occupancy.window of the current density bitfield at the encoder's plane resolution, cached until the bitfield
+        changes (one small host read-back per density-grid refresh); None: whole planes."""
+        enc = self.encoder
+        R = getattr(enc, "plane_resolution", 0)
+        if not self.use_occupancy_window or not self.cuda_ray or R % 64 != 0 or not hasattr(enc, "get_planes_texel_major"):
+            return None
+        bf = self.density_bitfield
+        key = (bf.data_ptr(), bf._version, R)
+        if self._occ_window_key != key:
+            self._occ_window = occupancy.window(bf, self.cascade, self.grid_size, self.bound, R)
+            self._occ_window_key = key
+        return self._occ_window
 
     @torch.no_grad()
     def packed_weights(self):

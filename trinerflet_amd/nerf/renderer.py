@@ -52,6 +52,13 @@ class NeRFRenderer(nn.Module):
         self.min_near = min_near
         self.density_thresh = density_thresh
         self.bg_radius = bg_radius
+        # run_cuda -> forward, while the field is evaluated on a marched batch: the march's device counter, and the window
+        # of the planes such a batch can touch (NeRFNetwork._occupancy_window; None: whole planes)
+        self._march_count = None
+        self._march_window = None
+        self.use_occupancy_window = True
+        self._occ_window_key = None
+        self._occ_window = None
         aabb_train = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
         self.register_buffer('aabb_train', aabb_train)
         self.register_buffer('aabb_infer', aabb_train.clone())
@@ -180,7 +187,13 @@ class NeRFRenderer(nn.Module):
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
                 self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps, noises)
-            sigmas, rgbs = self(xyzs, dirs)
+            # rows past counter[0] are the zero padding up to the sample budget: the fused field skips them (field.py)
+            self._march_count = counter
+            self._march_window = self._occupancy_window() if hasattr(self, "_occupancy_window") else None
+            try:
+                sigmas, rgbs = self(xyzs, dirs)
+            finally:
+                self._march_count = self._march_window = None
             sigmas = self.density_scale * sigmas
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color

@@ -13,13 +13,43 @@ checkpoints stay as they are: state_dict() has torch.optim.Adam's layout (per pa
 torch.optim.Adam runs ~13 multi-tensor kernels over the parameters per step (6.9 ms at the base configuration's 403 M
 coefficients) plus GradScaler's unscale pass (0.9 ms); this pass takes ~2 ms.
 
+fold_l1 (default on): the reference's regulariser is `sum_k w_k * coef_k.abs().mean()` over the tensors
+TriPlaneVolume.get_wavelet_features() returns.  Through autograd its gradient costs a pass that writes sign(p) * s for
+every coefficient and a second one that adds it to the data gradient (0.63 + 0.95 ms at base).  With fold_l1 the
+backward of `.abs().mean()` (triplane_encoder._AbsMean) only adds its scalar s = grad_output / numel to this optimiser's
+per-parameter "sink" and returns no gradient; step() hands the sink to the kernel, which adds s * sign(p) to the
+gradient in registers (tnl_adam_l1_step_sink).  Same numbers up to one rounding (g * inv + (s * inv) * sign(p) instead of
+(g + s * sign(p)) * inv).  Only parameters of a live FusedAdamL1 are folded; with any other optimiser the regulariser's
+gradient is materialised as before.  Not compatible with GradScaler.unscale_() before step() (the sink is in scaled
+units): step() raises; construct with fold_l1=False for such loops.
+
 Arithmetic: the kernel's (m, v, p) update is torch's single-tensor Adam in fp32 with the bias corrections evaluated in
 double on the device from the parameter's own `step` (tests/test_optim_gpu.py holds it against torch.optim.Adam).
 Not supported (ValueError): amsgrad, maximize, differentiable, sparse gradients, non-fp32 or CPU parameters.
 """
+import weakref
+
 import torch
 
 from . import _lib as L
+
+
+class _L1Sink:
+    """One float per parameter of a FusedAdamL1 on one device: the sum of d(scaled loss)/d(sum |p|) since the last step."""
+
+    def __init__(self, owner, device, n):
+        self.owner = weakref.ref(owner)
+        self.vec = torch.zeros(n, dtype=torch.float32, device=device)
+        self.used = False
+
+    def add(self, idx, grad_output, numel):
+        """Called from the backward of coef.abs().mean(); False if the optimiser is gone (the caller then materialises)."""
+        opt = self.owner()
+        if opt is None or not opt.fold_l1:
+            return False
+        self.vec[idx:idx + 1].add_(grad_output.reshape(1).to(torch.float32), alpha=1.0 / numel)
+        self.used = True
+        return True
 
 
 class FusedAdamL1(torch.optim.Optimizer):
@@ -28,14 +58,43 @@ class FusedAdamL1(torch.optim.Optimizer):
     _step_supports_amp_scaling = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, *,
-                 maximize=False, l1=0.0):
+                 maximize=False, l1=0.0, fold_l1=True):
         if amsgrad or maximize:
             raise ValueError("FusedAdamL1: amsgrad / maximize are not built")
         if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
             raise ValueError("FusedAdamL1: invalid hyper-parameter")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
                         foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False, l1=l1)
+        self.fold_l1 = bool(fold_l1)
+        self._sinks = {}
         super().__init__(params, defaults)
+        self._attach_sinks()
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, "_sinks"):
+            self._attach_sinks()
+
+    def _attach_sinks(self):
+        """(Re)builds the per-device sinks and tags every fp32 device parameter with (sink, index)."""
+        by_dev = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.is_cuda and p.dtype == torch.float32:
+                    by_dev.setdefault(p.device, []).append(p)
+        self._sinks = {}
+        for dev, ps in by_dev.items():
+            sink = _L1Sink(self, dev, len(ps))
+            self._sinks[dev] = sink
+            for i, p in enumerate(ps):
+                p._tnl_l1_sink = (sink, i)
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none)
+        for sink in self._sinks.values():
+            if sink.used:
+                sink.vec.zero_()
+                sink.used = False
 
     def __setstate__(self, state):
         super().__setstate__(state)
@@ -63,13 +122,21 @@ class FusedAdamL1(torch.optim.Optimizer):
         lib = L.lib()
         # set by GradScaler.step around this call (and deleted after it); absent when the optimiser is stepped directly
         found_inf, grad_scale, inv_scale = getattr(self, "found_inf", None), getattr(self, "grad_scale", None), None
+        if found_inf is not None and grad_scale is None and any(s_.used for s_ in self._sinks.values()):
+            raise RuntimeError("FusedAdamL1(fold_l1=True): the folded L1 term is in loss-scaled units; GradScaler.unscale_() "
+                               "before step() is not supported -- construct with fold_l1=False")
         for group in self.param_groups:
             b1, b2 = group["betas"]
             lr = group["lr"]
             lr = float(lr) if not torch.is_tensor(lr) else float(lr.item())
             for p in group["params"]:
+                sink, sidx = getattr(p, "_tnl_l1_sink", (None, 0))
+                if sink is not None and not (sink.used and sink.owner() is self):
+                    sink = None
                 if p.grad is None:
-                    continue
+                    if sink is None:
+                        continue
+                    p.grad = torch.zeros_like(p)      # regulariser only (no data gradient reached this parameter)
                 g = p.grad
                 if g.is_sparse or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
                     raise ValueError("FusedAdamL1: dense contiguous fp32 device parameters only")
@@ -86,10 +153,17 @@ class FusedAdamL1(torch.optim.Optimizer):
                     use_g, use_inv = wd_g, None
                 else:
                     use_g, use_inv = g, inv_scale
-                L.check(lib.tnl_adam_l1_step_dev(
+                if sink is not None and use_inv is None and inv_scale is not None:
+                    raise ValueError("FusedAdamL1: weight_decay together with a folded L1 term under GradScaler is not built")
+                L.check(lib.tnl_adam_l1_step_sink(
                     L.ptr(p), L.ptr(use_g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.u64(p.numel()), L.f32(lr),
-                    L.ptr(st["step"].reshape(1)), L.f32(b1), L.f32(b2), L.f32(group["eps"]), L.f32(1.0), L.ptr(use_inv),
-                    L.f32(group["l1"]), L.ptr(found_inf.reshape(-1)), L.ptr(None), L.i32(0), L.stream()), "adam_l1_step_dev")
+                    L.ptr(st["step"].reshape(1)), L.f32(b1), L.f32(b2), L.f32(group["eps"]), L.ptr(use_inv),
+                    L.f32(group["l1"]), L.ptr(sink.vec[sidx:sidx + 1] if sink is not None else None),
+                    L.ptr(found_inf.reshape(-1)), L.stream()), "adam_l1_step_sink")
                 # torch: `step` advances only when the update is applied (GradScaler skips the whole step() otherwise)
                 st["step"].add_(1.0 - found_inf.reshape(()).to(torch.float32))
+        for sink in self._sinks.values():
+            if sink.used:
+                sink.vec.zero_()
+                sink.used = False
         return loss

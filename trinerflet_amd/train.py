@@ -38,6 +38,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 from . import distributed as D
+from . import occupancy
 from . import raymarching
 from .nerf import field as F_
 from .triplaneencoder.triplane_encoder import (_IDWTLevel, _ToTexelMajor, half_roi_into_texel_major, half_to_texel_major,
@@ -343,74 +344,18 @@ class TrainStep:
         results into pinned host memory, behind an event.  A refresh step issues it right after the grid update and reads
         the result (_finish_roi) only where the window is first needed -- before the plane gradient -- so the host does not
         stall the launch stream in the middle of the step (0.3 ms per refresh: profiles/r03e_refresh_step_timeline.txt)."""
-        model, R = self.model, self.R
-        Hg, casc = model.grid_size, model.cascade
-        bits = model.density_bitfield.view(casc, -1)                                       # [casc, H^3/8] uint8
-        # one device buffer for both results, initialised by two device fills, ONE read-back:
-        #   [casc][6] bounding boxes {H+1, H+1, H+1, -1, -1, -1} | [3][R/8][2] row pieces {INT_MAX, -1}
-        rows = self.live_bands and R % 8 == 0
-        nb, ne = casc * 6, (3 * (R // 8) * 2 if rows else 0)
-        buf = torch.empty(nb + ne, dtype=torch.int32, device=self.dev)
-        buf[:nb].view(casc, 2, 3)[:, 0].fill_(Hg + 1)
-        buf[:nb].view(casc, 2, 3)[:, 1].fill_(-1)
-        bounds = buf[:nb].view(casc, 6)
-        L.check(L.lib().tnl_occupancy_bounds(L.ptr(bits), L.u32(bits.shape[1]), L.u32(casc), L.ptr(bounds), L.stream()),
-                "occupancy_bounds")
+        model = self.model
         self._band_cache = {}
         self._row_ext = None
-        if rows:
-            # per plane and 8-texel row group the columns a sample can touch (see _level_needs)
-            ext = buf[nb:].view(-1, 2)
-            ext[:, 0].fill_(0x7fffffff)
-            ext[:, 1].fill_(-1)
-            L.check(L.lib().tnl_occupancy_row_extents(L.ptr(bits), L.u32(bits.shape[1]), L.u32(casc), L.u32(Hg),
-                                                      L.f32(float(model.bound)), L.u32(R), L.ptr(ext), L.stream()),
-                    "occupancy_row_extents")
-        host = self._roi_host            # pinned, allocated once (a pinned allocation is a driver call)
-        if host is None or host.numel() != nb + ne:
-            host = self._roi_host = torch.empty(nb + ne, dtype=torch.int32, pin_memory=True)
-        host.copy_(buf, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._roi_request = (host, buf, ev, nb, rows)
+        self._roi_request = occupancy.request(model.density_bitfield, model.cascade, model.grid_size, model.bound, self.R,
+                                              rows=self.live_bands, host=self._roi_host)
+        self._roi_host = self._roi_request[0]            # pinned, allocated once
 
     def _finish_roi(self):
-        model, R = self.model, self.R
-        Hg, casc = model.grid_size, model.cascade
-        host_t, _, ev, nb, rows = self._roi_request
-        self._roi_request = None
-        ev.synchronize()
-        host = host_t.numpy().copy()     # the pinned buffer is reused by the next request
-        if rows:
-            self._row_ext = host[nb:].reshape(3, R // 8, 2).astype(np.int64)
-        vals = [float("inf")] * 3 + [float("-inf")] * 3            # world-space box over the cascades
-        for k, bk in enumerate(host[:nb].reshape(casc, 6).tolist()):
-            if bk[3] < 0:
-                continue                                            # no occupied cell in this cascade
-            sk = min(2.0 ** k, float(model.bound))
-            for a in range(3):
-                vals[a] = min(vals[a], (bk[a] / Hg * 2 - 1) * sk)
-                vals[3 + a] = max(vals[3 + a], ((bk[3 + a] + 1) / Hg * 2 - 1) * sk)
-        if not all(math.isfinite(v) for v in vals):
-            vals = [0.0] * 6                                                                # empty grid: no samples
-        b = float(model.bound)
-
-        def texels(a):   # axis a -> [first, end) texel range incl. the +1 corner and one texel of slack each side
-            f0 = (min(max(vals[a] / b, -1.0), 1.0) + 1) / 2 * (R - 1)
-            f1 = (min(max(vals[3 + a] / b, -1.0), 1.0) + 1) / 2 * (R - 1)
-            t0 = max(int(math.floor(f0)) - 1, 0) // 64 * 64
-            t1 = min((int(math.floor(f1)) + 3 + 63) // 64 * 64, R)
-            return t0, t1
-        xa, ya = (0, 0, 1), (2, 1, 2)   # plane p samples (axis xa[p] -> texel x, axis ya[p] -> texel y)
-        xr = [texels(a) for a in xa]
-        yr = [texels(a) for a in ya]
-        rw = max(t1 - t0 for t0, t1 in xr)
-        rh = max(t1 - t0 for t0, t1 in yr)
-        if rw * rh > 0.8 * R * R:
-            return None
-        ox = [min(t0, R - rw) for t0, _ in xr]
-        oy = [min(t0, R - rh) for t0, _ in yr]
-        return ox + oy + [rw, rh]
+        model = self.model
+        req, self._roi_request = self._roi_request, None
+        roi, self._row_ext = occupancy.finish(req, model.cascade, model.grid_size, model.bound, self.R)
+        return roi
 
     def _forward_windows(self):
         """Per level the window of its OUTPUT that the next level needs: the finest level's window is the occupancy
@@ -517,6 +462,7 @@ class TrainStep:
             if roi:
                 enc.last_used_planes = None
                 enc._planes_tm = None
+                enc._planes_tm_window = None
                 return half_roi_into_texel_major(planes, self._tm_full, self._roi10(), plane_spans)
             if planes.dtype == torch.float16:
                 # the (3,C,R,R) fp32 planes never exist on this path: only the sampler's copy is installed in the
@@ -526,6 +472,7 @@ class TrainStep:
             else:
                 enc.last_used_planes = planes
                 enc._planes_tm = _ToTexelMajor.apply(planes, enc.plane_dtype == torch.float16)
+            enc._planes_tm_window = None          # whole copies
             self._tm_full = enc._planes_tm if self.use_roi else None
         return enc._planes_tm
 

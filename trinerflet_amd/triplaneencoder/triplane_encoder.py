@@ -139,11 +139,18 @@ class _ToTexelMajor(Function):
     """(3,C,R,R) fp32 -> [3,R,R,C] fp16|fp32 ; backward: fp32 [3,R,R,C] -> (3,C,R,R)."""
 
     @staticmethod
-    def forward(ctx, planes_cm, half):
+    def forward(ctx, planes_cm, half, window=None):
+        """window (8 ints, occupancy.window_from_bounds): only that part of each plane is converted; the rest of the
+        returned array is uninitialised (csrc: tnl_planes_to_texel_major_win)."""
         L.require_cuda(planes_cm)
         planes_cm = planes_cm.to(torch.float32).contiguous()
         _, C, R, _ = planes_cm.shape
         tm = torch.empty(3, R, R, C, dtype=torch.float16 if half else torch.float32, device=planes_cm.device)
+        if window is not None:
+            L.check(L.lib().tnl_planes_to_texel_major_win(L.ptr(planes_cm), L.u32(C), L.u32(R), L.i32(1 if half else 0),
+                                                          L.ptr(tm), L.roi_array(list(window) + [C, 0]), L.stream()),
+                    "planes_to_texel_major_win")
+            return tm
         L.check(L.lib().tnl_planes_to_texel_major(L.ptr(planes_cm), L.u32(C), L.u32(R), L.i32(1 if half else 0),
                                                   L.ptr(tm), L.stream()), "planes_to_texel_major")
         return tm
@@ -155,7 +162,7 @@ class _ToTexelMajor(Function):
         g_cm = torch.empty(3, C, R, R, dtype=torch.float32, device=g_tm.device)
         L.check(L.lib().tnl_planes_to_channel_major(L.ptr(g_tm), L.u32(C), L.u32(R), L.ptr(g_cm), L.stream()),
                 "planes_to_channel_major")
-        return g_cm, None
+        return g_cm, None, None
 
 
 class _Sample(Function):
@@ -228,32 +235,37 @@ class _AbsMean(Function):
                 and x.data_ptr() % 16 == 0)
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, sink=None):
         lib = L.lib()
         ws = torch.empty(int(lib.tnl_abs_mean_workspace()), dtype=torch.uint8, device=x.device)
         out = torch.empty((), dtype=torch.float32, device=x.device)
         L.check(lib.tnl_abs_mean_forward(L.ptr(x), L.u64(x.numel()), L.ptr(ws), L.ptr(out), L.stream()), "abs_mean_forward")
         ctx.save_for_backward(x)
+        # sink: (optim._L1Sink, index) of the PARAMETER x aliases, when it belongs to a live optim.FusedAdamL1(fold_l1=True):
+        # the gradient sign(x) * g / n is then applied inside the optimiser's pass from the scalar alone, not materialised
+        ctx.sink = sink
         return out
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
+        if ctx.sink is not None and ctx.sink[0].add(ctx.sink[1], g, x.numel()):
+            return None, None
         gx = torch.empty_like(x)
         g = g.to(torch.float32).contiguous()
         L.check(L.lib().tnl_abs_mean_backward(L.ptr(x), L.u64(x.numel()), L.ptr(g), L.ptr(gx), L.stream()),
                 "abs_mean_backward")
-        return gx
+        return gx, None
 
 
 class _LazyAbs:
     """What `coef.abs()` returns for the tensors get_wavelet_features() hands out: |coef| not yet evaluated.  `.mean()`
     with no arguments -- the reference's regulariser, utils.py:639-655 -- runs the fused reduction; anything else
     (another method, an operator, a torch function) evaluates torch.abs first and carries on with an ordinary tensor."""
-    __slots__ = ("_src", "_val")
+    __slots__ = ("_src", "_val", "_sink")
 
-    def __init__(self, src):
-        self._src, self._val = src, None
+    def __init__(self, src, sink=None):
+        self._src, self._val, self._sink = src, None, sink
 
     def _tensor(self):
         if self._val is None:
@@ -262,7 +274,7 @@ class _LazyAbs:
 
     def mean(self, *args, **kwargs):
         if not args and not kwargs and self._val is None and _AbsMean.usable(self._src):
-            return _AbsMean.apply(self._src)
+            return _AbsMean.apply(self._src, self._sink)
         return self._tensor().mean(*args, **kwargs)
 
     @classmethod
@@ -303,7 +315,7 @@ class _CoefView(torch.Tensor):
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         if func in (torch.abs, torch.Tensor.abs) and len(args) == 1 and not kwargs and type(args[0]) is _CoefView:
-            return _LazyAbs(args[0].as_subclass(torch.Tensor))
+            return _LazyAbs(args[0].as_subclass(torch.Tensor), getattr(args[0], "_tnl_l1_sink", None))
         with torch._C.DisableTorchFunctionSubclass():
             out = func(*args, **kwargs)
         return torch.utils._pytree.tree_map(lambda t: t.as_subclass(torch.Tensor) if type(t) is _CoefView else t, out)
@@ -428,6 +440,7 @@ class TriPlaneVolume(torch.nn.Module):
         R, C = self.plane_resolution, self.number_of_features
         self.last_used_planes = None
         self._planes_tm = None
+        self._planes_tm_window = None
         if self.inner_wavelet_scale <= 1:
             if planes_features is None:
                 planes_features = self.init_sigma * torch.randn(3, C, R, R)
@@ -474,7 +487,10 @@ class TriPlaneVolume(torch.nn.Module):
             return []
         coefs = list(self.planes_features_wavelet_coefs)
         if self.fused_l1_views and torch.is_grad_enabled() and all(_AbsMean.usable(c) for c in coefs):
-            return [c.as_subclass(_CoefView) for c in coefs]
+            views = [c.as_subclass(_CoefView) for c in coefs]
+            for v, c in zip(views, coefs):
+                v._tnl_l1_sink = getattr(c, "_tnl_l1_sink", None)     # set by optim.FusedAdamL1 on its parameters
+            return views
         return coefs
 
     def get_wavelet_features_upscaled(self):
@@ -529,6 +545,7 @@ class TriPlaneVolume(torch.nn.Module):
         planes, all_res = self.build_planes(get_all_resolutions, max_res, max_scale)
         self.last_used_planes = planes
         self._planes_tm = None
+        self._planes_tm_window = None
         if self.upscale_enabled:
             # :417-436: level k = the central crop of level k-1, refined by one IDWT level with its own wavelets
             up = planes
@@ -546,20 +563,29 @@ class TriPlaneVolume(torch.nn.Module):
             return all_res
         return planes
 
-    def get_planes_texel_major(self):
-        """[3,R,R,C] copy of get_planes() in `plane_dtype`, cached with it (what the samplers read)."""
+    def get_planes_texel_major(self, window=None):
+        """[3,R,R,C] copy of get_planes() in `plane_dtype`, cached with it (what the samplers read).
+        window (8 ints, occupancy.window_from_bounds; only honoured without autograd through the copy): the caller
+        promises to read nothing outside it -- a cached whole copy is served as it is, otherwise only the window is
+        converted and the copy is remembered as partial (a later request for more rebuilds it)."""
         if not self.is_plain():
             raise RuntimeError("the texel-major fast path only exists for the plain three-plane lookup")
         # A copy made under no_grad (the density-grid refresh queries the field inside @torch.no_grad; TrainStep installs
         # its own) must not be served to a later differentiable lookup: the planes would silently get no gradient.
         want_grad = torch.is_grad_enabled() and self.planes_features.requires_grad
-        if self._planes_tm is None or (want_grad and not self._planes_tm.requires_grad):
-            self._planes_tm = _ToTexelMajor.apply(self.get_planes(), self.plane_dtype == torch.float16)
+        if want_grad:
+            window = None
+        window = tuple(int(v) for v in window) if window is not None else None
+        have = self._planes_tm is not None and (self._planes_tm_window is None or self._planes_tm_window == window)
+        if not have or (want_grad and not self._planes_tm.requires_grad):
+            self._planes_tm = _ToTexelMajor.apply(self.get_planes(), self.plane_dtype == torch.float16, window)
+            self._planes_tm_window = window
         return self._planes_tm
 
     def reset_cahce(self):
         self.last_used_planes = None
         self._planes_tm = None
+        self._planes_tm_window = None
 
     def _project(self, plane_axes, coords):
         # project_into_planes (:293-300): [N,dim] -> [N,Np,dim-1]
