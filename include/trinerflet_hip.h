@@ -390,6 +390,10 @@ TNL_API int tnl_mse_loss(const float *image, const float *weights_sum, const flo
 TNL_API uint64_t tnl_abs_mean_workspace(void);
 TNL_API int tnl_abs_mean_forward(const float *x, uint64_t n, void *workspace, float *out, void *stream);
 TNL_API int tnl_abs_mean_backward(const float *x, uint64_t n, const float *grad_out, float *grad_x, void *stream);
+/* found_inf[0] = 1 if any of x[0..n) is inf or nan (left as it is otherwise): the inf check of
+ * torch.amp.GradScaler.step (grad_scaler.py: _check_inf_per_device -> _amp_foreach_non_finite_check_and_unscale_ with a
+ * scale of 1, which also writes every element back) as a read-only pass, 4 B per element.  x 16-byte aligned. */
+TNL_API int tnl_nonfinite_check(const float *x, uint64_t n, float *found_inf, void *stream);
 
 /* Measurement aid (bench.py): streaming copy of `bytes` (a multiple of 16) from src to dst, 16 bytes per lane,
  * non-temporal -- what this box's memory system gives a plain copy, printed beside the 8 TB/s HBM3E spec.  No

@@ -221,3 +221,52 @@ def test_folded_regulariser_equals_the_materialised_gradient(cuda):
     sb.unscale_(ob)
     with pytest.raises(RuntimeError):
         sb.step(ob)
+
+
+def test_read_only_inf_check_and_both_gradscaler_hand_overs(cuda):
+    """tnl_nonfinite_check at the edges of its partition, and FusedAdamL1.step driven through GradScaler's two contracts
+    (the scaler passed as `grad_scaler`; the found_inf / grad_scale attributes) giving the same update."""
+    from trinerflet_amd import _lib as L
+    from trinerflet_amd.optim import FusedAdamL1
+    n = 4 * 1024 * 4096 + 4 * 777 + 3
+    x = torch.randn(n, device=cuda)
+    found = torch.zeros(1, device=cuda)
+    chk = lambda: L.check(L.lib().tnl_nonfinite_check(L.ptr(x), L.u64(n), L.ptr(found), L.stream()), "chk")
+    chk()
+    assert float(found) == 0.0
+    for pos, val in ((0, float("inf")), (n - 1, float("nan")), (n - 4, float("-inf")), (4 * 1024 * 2000 + 5, float("nan")),
+                     (4 * 1024 * 4096 + 17, float("inf"))):
+        keep = float(x[pos])
+        x[pos] = val
+        found.zero_()
+        chk()
+        assert float(found) == 1.0, pos
+        x[pos] = keep
+    found.fill_(1.0)
+    chk()
+    assert float(found) == 1.0                     # never cleared
+    runs = []
+    for kwarg in (True, False):
+        ps = _params(cuda, 5)
+        opt = FusedAdamL1(_groups(ps), betas=(0.9, 0.99), eps=1e-15)
+        sc = torch.amp.GradScaler("cuda", init_scale=512.0, growth_interval=2)
+        for k in range(6):
+            opt.zero_grad()
+            loss = _loss(ps, k)
+            if k == 2:
+                loss = loss + ps[0].view(-1)[-1] * float("nan")
+            sc.scale(loss).backward()
+            if kwarg:
+                sc.step(opt)
+            else:                                   # what GradScaler.step does for an optimiser without the keyword
+                state = sc._per_optimizer_states[id(opt)]
+                sc._check_inf_per_device(opt)
+                opt.grad_scale, opt.found_inf = sc._get_scale_async(), sum(state["found_inf_per_device"].values())
+                opt.step()
+                del opt.grad_scale, opt.found_inf
+                state["stage"] = torch.amp.grad_scaler.OptState.STEPPED
+            sc.update()
+        runs.append(([p.detach().clone() for p in ps], float(sc.get_scale()), [float(opt.state[p]["step"]) for p in ps]))
+    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2] == [5.0] * 5
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)

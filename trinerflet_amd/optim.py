@@ -23,10 +23,18 @@ gradient in registers (tnl_adam_l1_step_sink).  Same numbers up to one rounding 
 gradient is materialised as before.  Not compatible with GradScaler.unscale_() before step() (the sink is in scaled
 units): step() raises; construct with fold_l1=False for such loops.
 
+GradScaler's inf check: for an optimiser with _step_supports_amp_scaling, GradScaler.step runs
+_amp_foreach_non_finite_check_and_unscale_ over all gradients with a scale of 1 -- a pass that reads AND rewrites every
+element (0.9 ms per step at base).  step() therefore takes the scaler itself (the `grad_scaler` keyword GradScaler passes
+to optimisers that declare it; torch announces its removal with a FutureWarning, silenced here; without it the attributes
+path above is used) and checks the gradients with a read-only pass (tnl_nonfinite_check, 0.3 ms), recording the result
+where GradScaler.update() looks for it.
+
 Arithmetic: the kernel's (m, v, p) update is torch's single-tensor Adam in fp32 with the bias corrections evaluated in
 double on the device from the parameter's own `step` (tests/test_optim_gpu.py holds it against torch.optim.Adam).
 Not supported (ValueError): amsgrad, maximize, differentiable, sparse gradients, non-fp32 or CPU parameters.
 """
+import warnings
 import weakref
 
 import torch
@@ -67,6 +75,7 @@ class FusedAdamL1(torch.optim.Optimizer):
                         foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False, l1=l1)
         self.fold_l1 = bool(fold_l1)
         self._sinks = {}
+        warnings.filterwarnings("ignore", message="GradScaler is going to stop passing itself", category=FutureWarning)
         super().__init__(params, defaults)
         self._attach_sinks()
 
@@ -113,8 +122,41 @@ class FusedAdamL1(torch.optim.Optimizer):
             st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=p.device).reshape(())
         return st
 
+    def _check_grads(self, device):
+        """GradScaler's found_inf over this optimiser's gradients: [1] float on `device`, 1 if any is inf / nan."""
+        lib = L.lib()
+        found = torch.zeros(1, dtype=torch.float32, device=device)
+        rest = []
+        for group in self.param_groups:
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if (g.device == device and g.dtype == torch.float32 and not g.is_sparse and g.is_contiguous()
+                        and g.numel() >= 65536 and g.data_ptr() % 16 == 0):
+                    L.check(lib.tnl_nonfinite_check(L.ptr(g), L.u64(g.numel()), L.ptr(found), L.stream()), "nonfinite_check")
+                else:
+                    rest.append(g)
+        if rest:
+            if any(g.device != device for g in rest):
+                raise ValueError("FusedAdamL1: parameters on more than one device")
+            torch._amp_foreach_non_finite_check_and_unscale_(rest, found, torch.ones((), dtype=torch.float32, device=device))
+        return found
+
+    def _amp_state(self, scaler):
+        """(found_inf, grad_scale) when GradScaler.step hands itself over (see the module docstring)."""
+        from torch.amp.grad_scaler import OptState
+        state = scaler._per_optimizer_states[id(self)]
+        scale = scaler._get_scale_async()
+        if state["stage"] is OptState.READY:
+            found = self._check_grads(scale.device)
+            state["found_inf_per_device"] = {found.device: found}
+            return found, scale
+        # scaler.unscale_(self) ran: its verdict stands and the gradients are in true units
+        return sum(t.to(scale.device, non_blocking=True) for t in state["found_inf_per_device"].values()), None
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scaler=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -122,9 +164,12 @@ class FusedAdamL1(torch.optim.Optimizer):
         lib = L.lib()
         # set by GradScaler.step around this call (and deleted after it); absent when the optimiser is stepped directly
         found_inf, grad_scale, inv_scale = getattr(self, "found_inf", None), getattr(self, "grad_scale", None), None
+        if grad_scaler is not None:
+            found_inf, grad_scale = self._amp_state(grad_scaler)
         if found_inf is not None and grad_scale is None and any(s_.used for s_ in self._sinks.values()):
             raise RuntimeError("FusedAdamL1(fold_l1=True): the folded L1 term is in loss-scaled units; GradScaler.unscale_() "
                                "before step() is not supported -- construct with fold_l1=False")
+        steps = []
         for group in self.param_groups:
             b1, b2 = group["betas"]
             lr = group["lr"]
@@ -161,7 +206,9 @@ class FusedAdamL1(torch.optim.Optimizer):
                     L.f32(group["l1"]), L.ptr(sink.vec[sidx:sidx + 1] if sink is not None else None),
                     L.ptr(found_inf.reshape(-1)), L.stream()), "adam_l1_step_sink")
                 # torch: `step` advances only when the update is applied (GradScaler skips the whole step() otherwise)
-                st["step"].add_(1.0 - found_inf.reshape(()).to(torch.float32))
+                steps.append(st["step"])
+        if steps:
+            torch._foreach_add_(steps, 1.0 - found_inf.reshape(()).to(torch.float32))
         for sink in self._sinks.values():
             if sink.used:
                 sink.vec.zero_()
