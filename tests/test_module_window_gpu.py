@@ -100,3 +100,49 @@ def test_partial_copy_is_replaced_when_more_is_asked_for(cuda):
         again = enc.get_planes_texel_major()
         assert again is not part and enc._planes_tm_window is None and torch.equal(again, whole)
         assert enc.get_planes_texel_major(window=win) is again            # a whole copy serves every window
+
+
+def test_windowed_rebuild_under_autograd_and_the_refresh_sequence(cuda):
+    """get_planes() of a training iteration builds only the window (and says so on the tensor); the density-grid refresh that
+    follows it in the reference's loop (utils.py:1138-1146) needs every texel: the cached planes are replaced by whole,
+    still differentiable ones, and the iteration's gradients reach the parameters."""
+    m = _model(cuda)
+    enc = m.encoder
+    o, d = synthetic.training_rays(2048, n_cams=12, seed=3, H=100, W=100)
+    o, d = torch.from_numpy(o).to(cuda), torch.from_numpy(d).to(cuda)
+    nz = torch.rand(o.shape[0], device=cuda, generator=torch.Generator(device=cuda).manual_seed(4))
+    enc.reset_cahce()
+    planes = enc.get_planes()
+    win = m._occupancy_window()
+    assert planes._tnl_window == tuple(win) and planes.requires_grad
+    with torch.no_grad():
+        enc.reset_cahce()
+        whole = enc.get_planes().clone()
+        assert getattr(enc.get_planes(), "_tnl_window", None) is None           # no_grad: always whole
+    enc.reset_cahce()
+    planes = enc.get_planes()
+    for p in range(3):
+        sl = (slice(win[3 + p], win[3 + p] + win[7]), slice(win[p], win[p] + win[6]))
+        assert torch.equal(planes[p][:, sl[0], sl[1]], whole[p][:, sl[0], sl[1]])
+    # the refresh: density queries all over the volume
+    m.update_extra_state()
+    after = enc.get_planes()
+    assert getattr(after, "_tnl_window", None) is None and after.requires_grad and torch.equal(after.detach(), whole)
+    m.mean_count = 0
+    m.zero_grad(set_to_none=True)
+    out = m.render(o[None], d[None], staged=False, bg_color=0.0, perturb=True, force_all_rays=False, noises=nz, dt_gamma=0,
+                   max_steps=256)
+    (out["image"][0] ** 2).mean().backward()
+    assert all(p.grad is not None and float(p.grad.abs().max()) > 0 for p in enc.planes_features_wavelet_coefs)
+    # a field query outside run_cuda while only a window exists: whole planes are built first
+    m.density_bitfield.copy_(torch.from_numpy(synthetic.sphere_bitfield(128, m.cascade, 1.5, 0.45, 0.0)).to(cuda))
+    enc.reset_cahce()
+    assert enc.get_planes()._tnl_window == tuple(win)
+    x = (torch.rand(4096, 3, device=cuda) * 2 - 1) * 1.4                    # all over the volume
+    dd = torch.nn.functional.normalize(torch.randn(4096, 3, device=cuda), dim=-1)
+    s1, c1 = m(x, dd)
+    assert getattr(enc.get_planes(), "_tnl_window", None) is None
+    with torch.no_grad():
+        enc.reset_cahce()
+        s0, c0 = m(x, dd)
+    assert torch.equal(s1.detach(), s0) and torch.equal(c1.detach(), c0)

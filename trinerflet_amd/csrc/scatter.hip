@@ -148,7 +148,8 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
                   const float2* __restrict__ epos, float grad_scale,
                   float* __restrict__ grad_out, int layout, int* __restrict__ nonfinite_flag, Roi roi) {
   // layout: bit 0 = channel-major (3,C,R,R) output; bit 1 = the caller zero-filled the output (one contiguous fill):
-  // untouched tiles are then skipped instead of being zeroed here in 128-byte row pieces
+  // untouched tiles are then skipped instead of being zeroed here in 128-byte row pieces; bit 2 (with a ROI) = the output
+  // is the whole (3,C,R,R) array, of which only the window is written
   const int channel_major = layout & 1;
   constexpr int NTEX = TSX * TSY;
   constexpr int TILE_F = NTEX * C;
@@ -186,8 +187,10 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
   const int beg = offsets[bin * BIN_SUBS], end = offsets[(bin + 1) * BIN_SUBS];   // all sub-bins of the tile
   const int x_lo = tx * TSX, y_lo = ty * TSY;
   // channel-major output addressing: row stride, slice stride and origin of the (possibly compact) window
-  const int ow = roi.rw ? roi.rw : R, oh = roi.rw ? roi.rh : R;
-  const int x_out = x_lo - (roi.rw ? roi.ox[p] : 0), y_out = y_lo - (roi.rw ? roi.oy[p] : 0);
+  // (layout bit 2: the window's tiles only, but written at their place in the whole (3,C,R,R) array)
+  const bool compact = roi.rw != 0 && !(layout & 4);
+  const int ow = compact ? roi.rw : R, oh = compact ? roi.rh : R;
+  const int x_out = x_lo - (compact ? roi.ox[p] : 0), y_out = y_lo - (compact ? roi.oy[p] : 0);
   if (beg == end) {  // untouched tile: this store replaces the zero fill of the gradient
     if (layout & 2) return;
     if (!channel_major) {

@@ -73,14 +73,18 @@ class _FusedField(Function):
     binned_backward = True     # False: the plane gradient by global float atomics (tests compare the two)
 
     @staticmethod
-    def forward(ctx, planes_tm, xyz, dirs, W0, W1, W2, W3, W4, bound, planes_cm=None, m_actual=None):
+    def forward(ctx, planes_tm, xyz, dirs, W0, W1, W2, W3, W4, bound, planes_cm=None, m_actual=None, window=None):
         """planes_cm (optional): the (3,C,R,R) planes the texel-major copy `planes_tm` was made from.  When given, the
         planes' gradient is returned for IT, already in its layout (the tile reduction writes channel-major directly),
         and planes_tm is read as plain data -- the layout pass back to (3,C,R,R) (0.74 ms at base) disappears.
         m_actual (optional, device int32): the march's sample count; rows from there on (the zero padding up to the
         sample budget, raymarching.cu:312-480) are skipped -- outputs 0, no gradient -- in every kernel.  They are worth
         nothing to the result (no ray owns them) but all sit on the texel of the origin: one tile's list in the
-        plane-gradient reduction then holds 2 % of the batch and its workgroup runs 1 ms after all others have finished."""
+        plane-gradient reduction then holds 2 % of the batch and its workgroup runs 1 ms after all others have finished.
+        window (optional, 8 ints; needs planes_cm): the occupancy window planes_cm was built for
+        (triplane_encoder._IDWTChainWin) -- every sample lies inside it.  The gradient returned for planes_cm is then
+        written inside the window only (no zero fill of the whole planes; the rest is UNINITIALISED), which is all its
+        producer's backward reads."""
         L.require_cuda(planes_tm, xyz, dirs, W0)
         _, R, _, C = planes_tm.shape
         H = W0.shape[0]
@@ -93,6 +97,7 @@ class _FusedField(Function):
         sigma, rgb, feats = field_forward(planes_tm, xyz, dirs, packed, float(bound), C, R, H, save_feats=need_grad,
                                           m_actual=m_actual, zero_tail=True)
         ctx.m_actual = m_actual
+        ctx.window = [int(v) for v in window] if (window is not None and planes_cm is not None) else None
         ctx.save_for_backward(xyz, dirs, packed, sigma, rgb, feats)
         ctx.dims = (C, R, H, float(bound), [tuple(w.shape) for w in (W0, W1, W2, W3, W4)])
         ctx.cm = planes_cm is not None and R % 32 == 0 and _FusedField.binned_backward
@@ -110,12 +115,18 @@ class _FusedField(Function):
         nw = sum(a * b for a, b in shapes)
         gradW = torch.zeros(nw, dtype=torch.float32, device=dev)
         if ctx.cm:
-            grad_cm = torch.zeros(3, C, R, R, dtype=torch.float32, device=dev)
+            win = ctx.window if xyz.shape[0] > 0 else None
+            grad_cm = (torch.empty if win is not None else torch.zeros)(3, C, R, R, dtype=torch.float32, device=dev)
             if xyz.shape[0] > 0:
                 dfeat = torch.empty(3, xyz.shape[0], C, dtype=torch.float16, device=dev)
                 field_backward(g_sigma, g_rgb, sigma, rgb, feats, xyz, dirs, packed, bound, C, R, H, grad_cm, gradW, dfeat=dfeat,
                                m_actual=ctx.m_actual)
-                plane_grad_binned(dfeat, xyz, bound, C, R, grad_cm, m_actual=ctx.m_actual, channel_major=True, prezeroed=True)
+                if win is not None:
+                    plane_grad_binned(dfeat, xyz, bound, C, R, grad_cm, m_actual=ctx.m_actual, channel_major=True,
+                                      roi=win + [C, 0], roi_in_place=True)
+                else:
+                    plane_grad_binned(dfeat, xyz, bound, C, R, grad_cm, m_actual=ctx.m_actual, channel_major=True,
+                                      prezeroed=True)
             grad_tm = None
         elif R % 32 == 0 and xyz.shape[0] > 0 and _FusedField.binned_backward:
             # no global float atomics (round 4; before: 6.8 ms of a 24.5-ms step of the reference's loop at base, bound by
@@ -136,7 +147,7 @@ class _FusedField(Function):
         for a, b in shapes:
             gws.append(gradW[off:off + a * b].view(a, b))
             off += a * b
-        return (grad_tm, None, None, *gws, None, grad_cm if ctx.cm else None, None)
+        return (grad_tm, None, None, *gws, None, grad_cm if ctx.cm else None, None, None)
 
 
 fused_field = _FusedField.apply
@@ -205,12 +216,13 @@ def plane_grad_reduce(ws, dfeat, xyz, bound, C, R, grad_out, grad_scale=1.0, cha
 
 
 def plane_grad_binned(dfeat, xyz, bound, C, R, grad_out, m_actual=None, grad_scale=1.0, channel_major=False,
-                      nonfinite_flag=None, roi=None, prezeroed=False):
+                      nonfinite_flag=None, roi=None, prezeroed=False, roi_in_place=False):
     """fp16 feature gradients (plane-major [3,M,C], as field_backward(dfeat=...) writes them) -> plane gradient fp32
     by tile-sorted matrix-core reduction
     (csrc/scatter.hip): [3,R,R,C], or (3,C,R,R) with channel_major=True; writes every tile of grad_out.
     roi (8 ints): only the window's tiles, grad_out compact (3C, rh, rw), channel_major required.
-    prezeroed: grad_out was zero-filled by the caller; untouched tiles are skipped (whole planes: 1.39 -> 0.7 ms at base)."""
+    prezeroed: grad_out was zero-filled by the caller; untouched tiles are skipped (whole planes: 1.39 -> 0.7 ms at base).
+    roi_in_place (with roi): grad_out is the whole (3,C,R,R) array; only the window is written, every texel of it."""
     lib = L.lib()
     M = xyz.shape[0]
     nbytes = lib.tnl_plane_grad_binned_workspace(L.u32(M), L.u32(R))
@@ -219,6 +231,7 @@ def plane_grad_binned(dfeat, xyz, bound, C, R, grad_out, m_actual=None, grad_sca
     ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz.device)
     L.check(lib.tnl_plane_grad_binned_roi(L.ptr(dfeat), L.ptr(xyz), L.f32(bound), L.u32(M), L.ptr(m_actual),
                                           L.u32(C), L.u32(R), L.f32(grad_scale), L.ptr(grad_out),
-                                          L.i32(int(channel_major) | (2 if prezeroed else 0)), L.ptr(nonfinite_flag), L.roi_array(roi),
+                                          L.i32(int(channel_major) | (2 if prezeroed else 0) | (4 if (roi_in_place and roi is not None) else 0)),
+                                          L.ptr(nonfinite_flag), L.roi_array(roi),
                                           L.ptr(ws), L.stream()),
             "plane_grad_binned")

@@ -47,6 +47,9 @@ class NeRFNetwork(NeRFRenderer):
         self.hidden_dim = hidden_dim
         self.geo_feat_dim = geo_feat_dim
         self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=2048 * bound, bound=bound, **kwargs)
+        if hasattr(self.encoder, "window_provider"):
+            # a training iteration's get_planes() (under autograd) rebuilds only what this density grid's samples can read
+            self.encoder.window_provider = self._occupancy_window
 
         # sigma network (network.py:37-52): bias-free Linear layers
         sigma_net = []
@@ -117,10 +120,16 @@ class NeRFNetwork(NeRFRenderer):
                 # get_planes(); the sampler's texel-major copy is data, and the kernel's backward hands the planes'
                 # gradient back in (3,C,R,R) directly
                 planes_cm = enc.get_planes()
+                mw = tuple(int(v) for v in self._march_window) if self._march_window is not None else None
+                pw = getattr(planes_cm, "_tnl_window", None)
+                if pw is not None and pw != mw:
+                    # only a window of the planes exists and these positions are not known to lie inside it (a call from
+                    # outside run_cuda, or a density grid that changed since get_planes()): whole, differentiable planes
+                    planes_cm, pw = enc.get_planes_whole(), None
                 with torch.no_grad():
                     # called from run_cuda on a marched batch: only the occupancy window of the copy is made
-                    tm = enc.get_planes_texel_major(window=self._march_window)
-                return _field.fused_field(tm, x, d, *Ws, self.bound, planes_cm, self._march_count)
+                    tm = enc.get_planes_texel_major(window=mw)
+                return _field.fused_field(tm, x, d, *Ws, self.bound, planes_cm, self._march_count, pw)
             tm = enc.get_planes_texel_major()
             return _field.fused_field(tm, x, d, *Ws, self.bound, None, self._march_count)
         sigma, geo_feat = self._sigma_mlp(x)

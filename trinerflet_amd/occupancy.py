@@ -95,3 +95,28 @@ def finish(req, cascade, grid_size, bound, R):
 
 def window(bitfield, cascade, grid_size, bound, R):
     return finish(request(bitfield, cascade, grid_size, bound, R), cascade, grid_size, bound, R)[0]
+
+
+def level_windows(roi, J, R):
+    """Per IDWT level (0 = coarsest) the window of its OUTPUT that the next level needs: the finest level's window is the
+    occupancy window `roi`; below it, the next window halved and grown by 8 texels (the kernels stage a 4-texel halo),
+    aligned outward to 64 with a common size over the planes.  None where the whole plane is needed anyway."""
+    wins = [None] * J
+    if roi is None or J == 0:
+        return wins
+    wins[J - 1] = list(roi)
+    for lvl in range(J - 2, -1, -1):
+        nxt = wins[lvl + 1]
+        m = R >> (J - 1 - lvl)              # output size of this level
+        if nxt is None or m % 64 != 0:
+            break
+        lo_x = [max((nxt[p] // 2 - 8) // 64 * 64, 0) for p in range(3)]
+        lo_y = [max((nxt[3 + p] // 2 - 8) // 64 * 64, 0) for p in range(3)]
+        hi_x = [min(((nxt[p] + nxt[6]) // 2 + 8 + 63) // 64 * 64, m) for p in range(3)]
+        hi_y = [min(((nxt[3 + p] + nxt[7]) // 2 + 8 + 63) // 64 * 64, m) for p in range(3)]
+        rw = max(h - l for l, h in zip(lo_x, hi_x))
+        rh = max(h - l for l, h in zip(lo_y, hi_y))
+        if rw * rh > 0.8 * m * m:
+            break
+        wins[lvl] = [min(l, m - rw) for l in lo_x] + [min(l, m - rh) for l in lo_y] + [rw, rh]
+    return wins

@@ -358,28 +358,8 @@ class TrainStep:
         return roi
 
     def _forward_windows(self):
-        """Per level the window of its OUTPUT that the next level needs: the finest level's window is the occupancy
-        window; below it, the next window halved and grown by 8 texels (the kernel stages a 4-texel halo), aligned
-        outward to 64 with a common size over the planes.  None where the whole plane is needed anyway."""
-        wins = [None] * self.J
-        if self._roi is None:
-            return wins
-        wins[self.J - 1] = list(self._roi)
-        for lvl in range(self.J - 2, -1, -1):
-            nxt = wins[lvl + 1]
-            m = self.R >> (self.J - 1 - lvl)              # output size of this level
-            if nxt is None or m % 64 != 0:
-                break
-            lo_x = [max((nxt[p] // 2 - 8) // 64 * 64, 0) for p in range(3)]
-            lo_y = [max((nxt[3 + p] // 2 - 8) // 64 * 64, 0) for p in range(3)]
-            hi_x = [min(((nxt[p] + nxt[6]) // 2 + 8 + 63) // 64 * 64, m) for p in range(3)]
-            hi_y = [min(((nxt[3 + p] + nxt[7]) // 2 + 8 + 63) // 64 * 64, m) for p in range(3)]
-            rw = max(h - l for l, h in zip(lo_x, hi_x))
-            rh = max(h - l for l, h in zip(lo_y, hi_y))
-            if rw * rh > 0.8 * m * m:
-                break
-            wins[lvl] = [min(l, m - rw) for l in lo_x] + [min(l, m - rh) for l in lo_y] + [rw, rh]
-        return wins
+        """Per level the window of its OUTPUT that the next level needs (occupancy.level_windows)."""
+        return occupancy.level_windows(self._roi, self.J, self.R)
 
     def _idwt_level_win(self, x, yh, win, s0=0, spans=None):
         """One non-finest level restricted to the window of its output (fp32, full-size array, rest undefined)."""

@@ -90,6 +90,63 @@ class _IDWTLevel(Function):
         return dx, dyh, None
 
 
+class _IDWTChainWin(Function):
+    """All J levels of build_planes() (triplane_encoder.py:364-405, plain geometry) with the result restricted to the
+    occupancy window `roi` (8 ints, occupancy.window_from_bounds) of the finest grid: every level computes only the window
+    of its output the next level needs (occupancy.level_windows); the rest of the returned (3,C,R,R) array is
+    UNINITIALISED.  backward: the incoming gradient is read inside `roi` only (what the fused field's backward writes
+    when it is given the same window); each level's coefficient gradient is written inside the rectangle of coarse
+    tiles the window reaches and is zero elsewhere (tnl_idwt_level_backward_win's support chain).  Inside the window /
+    rectangles both directions equal the whole-plane levels bit for bit (the same kernels, fewer workgroups)."""
+
+    @staticmethod
+    def forward(ctx, wave_id, roi, ll, *coefs):
+        from .. import occupancy
+        L.require_cuda(ll)
+        lib = L.lib()
+        J, C = len(coefs), ll.shape[1]
+        R = ll.shape[-1] << J
+        wins = occupancy.level_windows(list(roi), J, R)
+        x = ll.detach().to(torch.float32).contiguous()
+        for lvl in range(J):
+            yh = coefs[lvl].detach().to(torch.float32).contiguous()
+            n = x.shape[-1]
+            out = torch.empty(3, C, 2 * n, 2 * n, dtype=torch.float32, device=x.device)
+            if wins[lvl] is None:
+                L.check(lib.tnl_idwt_level_forward(L.ptr(x), L.ptr(yh), L.u32(3 * C), L.u32(n), L.i32(wave_id), L.ptr(out),
+                                                   L.stream()), "idwt_level_forward")
+            else:
+                L.check(lib.tnl_idwt_level_forward_win(L.ptr(x), L.ptr(yh), L.u32(3 * C), L.u32(n), L.i32(wave_id),
+                                                       L.ptr(out), L.roi_array(list(wins[lvl]) + [C, 0]), L.stream()),
+                        "idwt_level_forward_win")
+            x = out
+        ctx.meta = (wave_id, tuple(int(v) for v in roi), J, C, R)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        wave_id, roi, J, C, R = ctx.meta
+        lib = L.lib()
+        g = g.to(torch.float32).contiguous()
+        dev = g.device
+        win = list(roi)
+        grads = [None] * J
+        for lvl in reversed(range(J)):
+            n = R >> (J - lvl)
+            # the coarsest dx is the LL parameter's gradient: like the band gradients it must be zero outside the rectangle
+            dx = (torch.zeros if lvl == 0 else torch.empty)(3, C, n, n, dtype=torch.float32, device=dev)
+            dyh = torch.zeros(3, C, 3, n, n, dtype=torch.float32, device=dev)
+            rect = (ctypes.c_int32 * 8)()
+            L.check(lib.tnl_idwt_level_backward_win(L.ptr(g), L.u32(3 * C), L.u32(n), L.i32(wave_id), L.ptr(dx), L.ptr(dyh),
+                                                    L.roi_array(win + [C, 0]), L.i32(1), rect, L.stream()),
+                    "idwt_level_backward_win")
+            win = list(rect)
+            grads[lvl] = dyh
+            g = dx
+        return (None, None, g, *grads)
+
+
 def idwt_level_half(x, yh, wave_id):
     """Finest level straight to fp16 (no autograd): x (3,C,n,n), yh (3,C,3,n,n) fp32 -> (3,C,2n,2n) fp16."""
     x = x.detach().to(torch.float32).contiguous()
@@ -441,6 +498,7 @@ class TriPlaneVolume(torch.nn.Module):
         self.last_used_planes = None
         self._planes_tm = None
         self._planes_tm_window = None
+        self.window_provider = None      # callable -> occupancy window or None (see _autograd_window); set by NeRFNetwork
         if self.inner_wavelet_scale <= 1:
             if planes_features is None:
                 planes_features = self.init_sigma * torch.randn(3, C, R, R)
@@ -502,6 +560,39 @@ class TriPlaneVolume(torch.nn.Module):
             return None
         return torch.exp(self.lbound_scale.abs())
 
+    def _autograd_window(self, max_res=-1, max_scale=-1, get_all_resolutions=False):
+        """The occupancy window get_planes() may restrict a DIFFERENTIABLE rebuild to, or None (whole planes).
+        window_provider (set by NeRFNetwork: its density grid's window at this plane resolution) is only consulted while
+        autograd records -- a training iteration's get_planes() (reconstruction/nerf/utils.py:1138-1140); under no_grad
+        (evaluation, the density-grid refresh) planes are always whole.  The windowed result is UNINITIALISED outside the
+        window (see _IDWTChainWin): readers that need more ask through get_planes_whole() / get_planes_texel_major()."""
+        prov = self.window_provider
+        if (prov is None or not torch.is_grad_enabled() or not self.planes_features.requires_grad or get_all_resolutions
+                or max_res > 0 or max_scale > 0 or not self.is_plain() or self.upscale_enabled
+                or self.apply_activation_on_features or self.inner_wavelet_scale <= 1
+                or self.planes_features_wavelet_all_level != len(self.planes_features_wavelet_coefs)
+                or (self.wavelet_base_resolution and self.planes_features_wavelet_pad > 0)):
+            return None
+        n0, J = self.planes_features.shape[-1], len(self.planes_features_wavelet_coefs)
+        if n0 < 32 or (n0 & (n0 - 1)) != 0 or (n0 << J) % 64 != 0 or not self.planes_features.is_cuda:
+            return None
+        return prov()
+
+    def get_planes_whole(self):
+        """get_planes() with every texel valid: a windowed cached result is replaced by a whole, still differentiable
+        rebuild (the caller may be inside no_grad -- the density-grid refresh -- while the iteration's render, which
+        follows, must reach the parameters through the cached planes)."""
+        planes = self.get_planes()
+        if getattr(planes, "_tnl_window", None) is None:
+            return planes
+        prov, self.window_provider = self.window_provider, None
+        try:
+            self.reset_cahce()
+            with torch.enable_grad():
+                return self.get_planes()
+        finally:
+            self.window_provider = prov
+
     def build_planes(self, get_all_resolutions=False, max_res=-1, max_scale=-1, planes_features=None, coefs=None,
                      all_level=None, inner_wavelet_scale=None):
         # reference: triplane_encoder.py:364-405
@@ -542,6 +633,14 @@ class TriPlaneVolume(torch.nn.Module):
         # regardless of the arguments)
         if self.last_used_planes is not None:
             return self.last_used_planes
+        window = self._autograd_window(max_res, max_scale, get_all_resolutions)
+        if window is not None:
+            planes = _IDWTChainWin.apply(self.wave_id, window, self.planes_features, *self.planes_features_wavelet_coefs)
+            planes._tnl_window = tuple(int(v) for v in window)      # read by nerf/network.py and get_planes_texel_major
+            self.last_used_planes = planes
+            self._planes_tm = None
+            self._planes_tm_window = None
+            return planes
         planes, all_res = self.build_planes(get_all_resolutions, max_res, max_scale)
         self.last_used_planes = planes
         self._planes_tm = None
@@ -578,7 +677,10 @@ class TriPlaneVolume(torch.nn.Module):
         window = tuple(int(v) for v in window) if window is not None else None
         have = self._planes_tm is not None and (self._planes_tm_window is None or self._planes_tm_window == window)
         if not have or (want_grad and not self._planes_tm.requires_grad):
-            self._planes_tm = _ToTexelMajor.apply(self.get_planes(), self.plane_dtype == torch.float16, window)
+            planes = self.get_planes()
+            if getattr(planes, "_tnl_window", None) is not None and planes._tnl_window != window:
+                planes = self.get_planes_whole()     # only a window of the cached planes exists, and not the one asked for
+            self._planes_tm = _ToTexelMajor.apply(planes, self.plane_dtype == torch.float16, window)
             self._planes_tm_window = window
         return self._planes_tm
 
