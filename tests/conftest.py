@@ -23,3 +23,13 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _library_defaults():
+    """trinerflet_amd.install_dropin() (tests of the drop-in boundary call it) turns the windowed rebuild under autograd on
+    for encoders built afterwards; every test starts from the library's own default."""
+    mod = sys.modules.get("trinerflet_amd.triplaneencoder.triplane_encoder")
+    if mod is not None:
+        mod.WINDOWED_AUTOGRAD = False
+    yield

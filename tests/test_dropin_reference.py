@@ -93,6 +93,11 @@ def test_main_nerf_import_block_after_install_dropin():
             assert callable(getattr(raymarching, f))
         from shencoder import SHEncoder
         from encoding import get_encoder
+        # install_dropin() opts the encoders it will serve into the windowed rebuild under autograd (the reference's loop
+        # discards get_planes()'s result); install_dropin(windowed_autograd=False) leaves whole planes
+        assert te.WINDOWED_AUTOGRAD is True
+        trinerflet_amd.install_dropin(windowed_autograd=False)
+        assert te.WINDOWED_AUTOGRAD is False
         print("IMPORT_BLOCK_OK")
     """))
     assert "IMPORT_BLOCK_OK" in out

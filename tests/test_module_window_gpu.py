@@ -16,6 +16,7 @@ def _model(cuda, R=512, C=16, fp16=True):
                     density_thresh=10, bg_radius=-1, hidden_dim=64, hidden_dim_color=64, triplane_channels=C,
                     triplane_resolution=R, triplane_wavelet_levels=8, wavelet_type="bior6.8",
                     plane_dtype=torch.float16 if fp16 else torch.float32).to(cuda)
+    m.encoder.windowed_autograd = True                # what install_dropin() turns on (TriPlaneVolume._autograd_window)
     synthetic.init_field_parameters(m, seed=0)
     m.density_bitfield.copy_(torch.from_numpy(synthetic.sphere_bitfield(128, m.cascade, 1.5, 0.45, 0.0)).to(cuda))
     m.train()
@@ -146,3 +147,22 @@ def test_windowed_rebuild_under_autograd_and_the_refresh_sequence(cuda):
         enc.reset_cahce()
         s0, c0 = m(x, dd)
     assert torch.equal(s1.detach(), s0) and torch.equal(c1.detach(), c0)
+
+
+def test_windowed_rebuild_is_opt_in_and_readers_outside_autograd_get_every_texel(cuda):
+    from trinerflet_amd.triplaneencoder import triplane_encoder as te
+    assert te.WINDOWED_AUTOGRAD is False                              # the library default (install_dropin() turns it on)
+    m = _model(cuda, R=256)
+    enc = m.encoder
+    enc.windowed_autograd = False
+    enc.reset_cahce()
+    assert getattr(enc.get_planes(), "_tnl_window", None) is None      # default: whole planes, whatever the density grid
+    with torch.no_grad():
+        whole = enc.get_planes().clone()
+    enc.windowed_autograd = True
+    enc.reset_cahce()
+    part = enc.get_planes()
+    assert part._tnl_window is not None and enc.get_planes() is part  # under autograd the windowed cache is served
+    with torch.no_grad():                                              # save_triplane, evaluation, ...
+        seen = enc.get_planes()
+    assert getattr(seen, "_tnl_window", None) is None and torch.equal(seen.detach(), whole) and seen.requires_grad

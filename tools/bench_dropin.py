@@ -30,6 +30,7 @@ def dropin_ms_per_step(workload, device, batches, mean_count, steps=32, optimize
                         density_thresh=10, bg_radius=-1, hidden_dim=H, hidden_dim_color=H, triplane_channels=C,
                         triplane_resolution=R, triplane_wavelet_levels=scale, wavelet_type="bior6.8",
                         plane_dtype=torch.float32 if planes == "fp32" else torch.float16).to(device)
+    model.encoder.windowed_autograd = True            # what install_dropin() turns on for main_nerf.py
     synthetic.init_field_parameters(model, seed=0)
     bitfield = torch.from_numpy(synthetic.sphere_bitfield(128, model.cascade, 1.5, 0.8, 0.0)).to(device)
     model.density_bitfield.copy_(bitfield)

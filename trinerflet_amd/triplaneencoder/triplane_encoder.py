@@ -393,7 +393,13 @@ class _IDWTBuffers(nn.Module):
         self.register_buffer('g1_row', g1.reshape(1, 1, 1, -1))
 
 
+# default of TriPlaneVolume.windowed_autograd for encoders constructed from now on (install_dropin() sets it)
+WINDOWED_AUTOGRAD = False
+
+
 class TriPlaneVolume(torch.nn.Module):
+    _upgrading = False
+
     def __init__(self, number_of_features=3, plane_resolution=224, init_sigma=0.1, lbound=1,
                  viewdir_plane_resolution=32,
                  two_planes_per_axis=False,
@@ -499,6 +505,7 @@ class TriPlaneVolume(torch.nn.Module):
         self._planes_tm = None
         self._planes_tm_window = None
         self.window_provider = None      # callable -> occupancy window or None (see _autograd_window); set by NeRFNetwork
+        self.windowed_autograd = WINDOWED_AUTOGRAD     # opt-in: see _autograd_window
         if self.inner_wavelet_scale <= 1:
             if planes_features is None:
                 planes_features = self.init_sigma * torch.randn(3, C, R, R)
@@ -562,12 +569,17 @@ class TriPlaneVolume(torch.nn.Module):
 
     def _autograd_window(self, max_res=-1, max_scale=-1, get_all_resolutions=False):
         """The occupancy window get_planes() may restrict a DIFFERENTIABLE rebuild to, or None (whole planes).
+        Opt-in (self.windowed_autograd; trinerflet_amd.install_dropin() turns the module default WINDOWED_AUTOGRAD on):
+        the contract is then "while autograd records, get_planes() is valid, and differentiable, inside the occupancy
+        window only" -- which is all the reference's training loop asks of it (reconstruction/nerf/utils.py:1138-1140
+        discards the result; the renderer samples marched positions, all inside the window).  A caller that reads or
+        differentiates the whole array under autograd must leave the option off or use get_planes_whole().
         window_provider (set by NeRFNetwork: its density grid's window at this plane resolution) is only consulted while
-        autograd records -- a training iteration's get_planes() (reconstruction/nerf/utils.py:1138-1140); under no_grad
-        (evaluation, the density-grid refresh) planes are always whole.  The windowed result is UNINITIALISED outside the
-        window (see _IDWTChainWin): readers that need more ask through get_planes_whole() / get_planes_texel_major()."""
+        autograd records; under no_grad (evaluation, save_triplane, the density-grid refresh) planes are always whole,
+        and this module's own readers (forward(), get_planes_texel_major()) upgrade a windowed cache when they need more.
+        The windowed result is UNINITIALISED outside the window (see _IDWTChainWin)."""
         prov = self.window_provider
-        if (prov is None or not torch.is_grad_enabled() or not self.planes_features.requires_grad or get_all_resolutions
+        if (prov is None or not self.windowed_autograd or not torch.is_grad_enabled() or not self.planes_features.requires_grad or get_all_resolutions
                 or max_res > 0 or max_scale > 0 or not self.is_plain() or self.upscale_enabled
                 or self.apply_activation_on_features or self.inner_wavelet_scale <= 1
                 or self.planes_features_wavelet_all_level != len(self.planes_features_wavelet_coefs)
@@ -582,16 +594,20 @@ class TriPlaneVolume(torch.nn.Module):
         """get_planes() with every texel valid: a windowed cached result is replaced by a whole, still differentiable
         rebuild (the caller may be inside no_grad -- the density-grid refresh -- while the iteration's render, which
         follows, must reach the parameters through the cached planes)."""
-        planes = self.get_planes()
-        if getattr(planes, "_tnl_window", None) is None:
-            return planes
-        prov, self.window_provider = self.window_provider, None
+        self._upgrading = True
         try:
-            self.reset_cahce()
-            with torch.enable_grad():
-                return self.get_planes()
+            planes = self.get_planes()
+            if getattr(planes, "_tnl_window", None) is None:
+                return planes
+            prov, self.window_provider = self.window_provider, None
+            try:
+                self.reset_cahce()
+                with torch.enable_grad():
+                    return self.get_planes()
+            finally:
+                self.window_provider = prov
         finally:
-            self.window_provider = prov
+            self._upgrading = False
 
     def build_planes(self, get_all_resolutions=False, max_res=-1, max_scale=-1, planes_features=None, coefs=None,
                      all_level=None, inner_wavelet_scale=None):
@@ -632,6 +648,9 @@ class TriPlaneVolume(torch.nn.Module):
         # reference: triplane_encoder.py:407-439 (note: like the reference, a cached result is returned
         # regardless of the arguments)
         if self.last_used_planes is not None:
+            if (getattr(self.last_used_planes, "_tnl_window", None) is not None and not torch.is_grad_enabled()
+                    and not self._upgrading):
+                return self.get_planes_whole()       # a reader outside autograd gets every texel
             return self.last_used_planes
         window = self._autograd_window(max_res, max_scale, get_all_resolutions)
         if window is not None:
@@ -677,7 +696,11 @@ class TriPlaneVolume(torch.nn.Module):
         window = tuple(int(v) for v in window) if window is not None else None
         have = self._planes_tm is not None and (self._planes_tm_window is None or self._planes_tm_window == window)
         if not have or (want_grad and not self._planes_tm.requires_grad):
-            planes = self.get_planes()
+            self._upgrading = True               # (a windowed cache is fine here when it is the window asked for)
+            try:
+                planes = self.get_planes()
+            finally:
+                self._upgrading = False
             if getattr(planes, "_tnl_window", None) is not None and planes._tnl_window != window:
                 planes = self.get_planes_whole()     # only a window of the cached planes exists, and not the one asked for
             self._planes_tm = _ToTexelMajor.apply(planes, self.plane_dtype == torch.float16, window)
