@@ -352,7 +352,11 @@ def dropin_figure(workload, device, batches, mean_count):
                    "change at main_nerf.py:119 to trinerflet_amd.optim.FusedAdamL1 (INTEGRATION.md); fp16 planes = the "
                    "encoder's default plane_dtype.  Round 3 measured 30.7 ms/step for this loop over a trajectory (24.5 "
                    "steady state): since then the autograd backward goes through the tile-sorted reduction instead of "
-                   "global float atomics, the regulariser's |x|.mean() is one fused pass, Adam one pass per parameter")
+                   "global float atomics, the regulariser's |x|.mean() is one fused pass forward and a scalar handed to the "
+                   "optimiser backward (FusedAdamL1 fold_l1), Adam one pass per parameter, GradScaler's inf check a "
+                   "read-only pass, the sample budget's zero padding is skipped, and (install_dropin()'s "
+                   "windowed_autograd, on in these figures) the plane rebuild / layout pass / adjoint cover the occupancy "
+                   "window only")
     return out
 
 
