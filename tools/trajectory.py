@@ -158,17 +158,24 @@ def run_fused(workload, device, steps=512, num_rays=60000, scene=None, batches=N
     }
 
 
-def run_reference_loop(workload, device, steps=512, num_rays=60000, scene=None, batches=None, seed=0):
+def run_reference_loop(workload, device, steps=512, num_rays=60000, scene=None, batches=None, seed=0, fast=False):
     """The reference Trainer's loop (train_one_epoch2 + train_step, fp16=True: autocast around the render, planes built
-    in fp32 outside it) on the drop-in modules, fp32 planes."""
+    in fp32 outside it) on the drop-in modules, fp32 planes.  fast: what INTEGRATION.md A.1 describes -- the same loop with
+    trinerflet_amd.optim.FusedAdamL1 (regulariser folded in, read-only inf check) and install_dropin()'s windowed rebuild
+    under autograd, on the encoder's default fp16 sampler planes."""
     from trinerflet_amd.train import lr_factor
     train, valid = scene if scene is not None else make_scene(device)
-    model, lam = make_model(workload, device, plane_dtype=torch.float32, seed=seed)
+    model, lam = make_model(workload, device, plane_dtype=torch.float16 if fast else torch.float32, seed=seed)
     model.mark_untrained_grid(train.poses, train.intrinsics)
     model.train()
     if batches is None:
         batches = batches_of(train, steps, num_rays, seed)
-    opt = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)            # main_nerf.py:119
+    if fast:
+        from trinerflet_amd.optim import FusedAdamL1
+        model.encoder.windowed_autograd = True
+        opt = FusedAdamL1(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    else:
+        opt = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)        # main_nerf.py:119
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda k: lr_factor(k, steps, 0))        # main_nerf.py:129
     scaler = torch.amp.GradScaler("cuda")
     torch.manual_seed(1234)
@@ -225,11 +232,14 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--scene", default="sphere", choices=["sphere", "detail"])
     ap.add_argument("--deterministic", action="store_true", help="the fused runs with TrainStep(deterministic=True)")
+    ap.add_argument("--dropin-fast", action="store_true",
+                    help="also the reference's loop with FusedAdamL1 + the windowed rebuild under autograd (INTEGRATION.md A.1)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     scene = make_scene(dev, scene=args.scene)
     batches = batches_of(scene[0], args.steps, args.rays)
-    rep = {"psnr_runs": {"fused_fp16": [], "fused_fp16_no_pieces": [], "fused_fp32_planes": [], "reference_loop": []}}
+    rep = {"psnr_runs": {"fused_fp16": [], "fused_fp16_no_pieces": [], "fused_fp32_planes": [], "reference_loop": [],
+                         "dropin_fast_loop": []}}
     for _ in range(args.repeat):
         fused = run_fused(args.workload, dev, args.steps, args.rays, scene, batches,
                           ts_kwargs={"deterministic": True} if args.deterministic else None)
@@ -259,6 +269,12 @@ def main():
             rep["reference_loop"] = ref
             rep["psnr_runs"]["reference_loop"].append(ref["held_out_psnr_db"])
             rep["psnr_difference_db"] = round(fused["held_out_psnr_db"] - ref["held_out_psnr_db"], 4)
+        if args.dropin_fast:
+            fl = run_reference_loop(args.workload, dev, args.steps, args.rays, scene, batches, fast=True)
+            fl.pop("_model")
+            torch.cuda.empty_cache()
+            rep["dropin_fast_loop"] = fl
+            rep["psnr_runs"]["dropin_fast_loop"].append(fl["held_out_psnr_db"])
         print({k: v for k, v in rep["psnr_runs"].items() if v}, file=sys.stderr)
     s = json.dumps(rep, indent=1)
     print(s)
