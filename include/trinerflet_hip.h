@@ -280,6 +280,9 @@ TNL_API int tnl_field_backward(const float *grad_sigma, const float *grad_rgb, c
  * so the layout-change pass disappears).  channel_major | 2: the caller has zero-filled grad_out (one contiguous fill) and
  * untouched tiles are skipped instead of being zeroed tile by tile -- the faster form for WHOLE planes, of which a scene
  * touches a third (the drop-in autograd path; TrainStep's windowed call keeps the in-kernel zeroes).
+ * channel_major | 4 (the *_roi / _reduce entries, with a roi): only the window's tiles are launched and every texel of the
+ * window is written, but at its place in the WHOLE (3,C,R,R) array (the rest of grad_out is not touched) -- the gradient
+ * the windowed autograd rebuild's backward reads (triplane_encoder._IDWTChainWin).
  * grad_scale multiplies dfeat.  R % 32 == 0, C in {16,32,48}.
  * nonfinite_flag (device int32, may be NULL) is set to 1 if any stored value is inf/nan (GradScaler probe).
  * Replaces torch grid_sampler_2d_backward + the autograd zero fill. */
