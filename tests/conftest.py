@@ -32,4 +32,7 @@ def _library_defaults():
     mod = sys.modules.get("trinerflet_amd.triplaneencoder.triplane_encoder")
     if mod is not None:
         mod.WINDOWED_AUTOGRAD = False
+    opt = sys.modules.get("trinerflet_amd.optim")
+    if opt is not None:
+        opt.unpatch_torch_adam()
     yield

@@ -270,3 +270,25 @@ def test_read_only_inf_check_and_both_gradscaler_hand_overs(cuda):
     assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2] == [5.0] * 5
     for a, b in zip(runs[0][0], runs[1][0]):
         assert torch.equal(a, b)
+
+
+def test_patched_torch_adam_hands_out_the_fused_optimiser_where_it_can_stand_in(cuda):
+    """install_dropin(fused_adam=True) -> optim.patch_torch_adam(): main_nerf.py:119's torch.optim.Adam(model.get_params(lr),
+    betas=(0.9, 0.99), eps=1e-15) becomes a FusedAdamL1 (dense fp32 device parameters, plain options); anything else is
+    torch's own Adam."""
+    from trinerflet_amd import optim
+    real = torch.optim.Adam
+    try:
+        optim.patch_torch_adam()
+        ps = _params(cuda, 7)
+        o = torch.optim.Adam(_groups(ps, 1e-2), lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+        assert type(o) is optim.FusedAdamL1 and isinstance(o, torch.optim.Optimizer)
+        assert o.param_groups[1]["weight_decay"] == 1e-2 and o.param_groups[0]["betas"] == (0.9, 0.99)
+        torch.optim.lr_scheduler.LambdaLR(o, lambda k: 0.5)                       # main_nerf.py:129 accepts it
+        assert type(torch.optim.Adam(ps, amsgrad=True)) is real
+        assert type(torch.optim.Adam(ps, fused=True)) is real
+        assert type(torch.optim.Adam([torch.nn.Parameter(torch.zeros(3, dtype=torch.float64, device=cuda))])) is real
+        assert type(torch.optim.Adam(ps + [torch.nn.Parameter(torch.zeros(3))])) is real          # a CPU parameter among them
+    finally:
+        optim.unpatch_torch_adam()
+    assert torch.optim.Adam is real

@@ -24,7 +24,7 @@ def install_backends():
         sys.path.insert(0, _BACKENDS)
 
 
-def install_dropin(windowed_autograd=True):
+def install_dropin(windowed_autograd=True, fused_adam=False):
     """Register the MI355X build under the reference's top-level names (main_nerf.py:15-16 puts aux_libs/ on sys.path
     and reconstruction/ is the script directory):
 
@@ -38,9 +38,16 @@ def install_dropin(windowed_autograd=True):
     windowed_autograd: encoders constructed afterwards rebuild / differentiate only the occupancy window of the planes
     in a training iteration's get_planes() (TriPlaneVolume._autograd_window: enough for the reference's Trainer, whose
     loop discards get_planes()'s result and renders marched samples; 8.4 -> 7.1 ms per step at the base configuration).
-    Pass False for code that reads whole planes under autograd."""
+    Pass False for code that reads whole planes under autograd.
+
+    fused_adam: `torch.optim.Adam(...)` over dense fp32 device parameters returns trinerflet_amd.optim.FusedAdamL1
+    (optim.patch_torch_adam: one pass per parameter, the regulariser's gradient and GradScaler's work folded in; same
+    state_dict layout), so that main_nerf.py:119 needs no edit either: 14.5 -> 7.1 ms per step at the base configuration.
+    Off by default -- it replaces a name in torch's namespace for the whole process."""
     install_backends()
     importlib.import_module("trinerflet_amd.triplaneencoder.triplane_encoder").WINDOWED_AUTOGRAD = bool(windowed_autograd)
+    optim = importlib.import_module("trinerflet_amd.optim")
+    (optim.patch_torch_adam if fused_adam else optim.unpatch_torch_adam)()
     for name in _TOP:
         sys.modules[name] = importlib.import_module(f"trinerflet_amd.{name}")
     sys.modules["triplaneencoder.triplane_encoder"] = importlib.import_module(

@@ -214,3 +214,42 @@ class FusedAdamL1(torch.optim.Optimizer):
                 sink.vec.zero_()
                 sink.used = False
         return loss
+
+
+_ORIG_ADAM = None
+
+
+def patch_torch_adam():
+    """install_dropin(fused_adam=True): `torch.optim.Adam(...)` returns a FusedAdamL1 when every parameter is a dense fp32
+    device tensor and no option outside FusedAdamL1's set is asked for -- reconstruction/main_nerf.py:119 then needs no edit
+    at all -- and the real torch.optim.Adam in every other case.  `torch.optim.Adam` stays a class; isinstance(opt,
+    torch.optim.Optimizer) holds for both results, isinstance(opt, torch.optim.Adam) only for the real one.
+    unpatch_torch_adam() restores it."""
+    global _ORIG_ADAM
+    if _ORIG_ADAM is not None:
+        return
+    orig = torch.optim.Adam
+    _ORIG_ADAM = orig
+
+    class Adam(orig):
+        def __new__(cls, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
+            params = list(params)
+            groups = params if (params and isinstance(params[0], dict)) else [{"params": params}]
+            flat = [p for g in groups for p in (g["params"] if isinstance(g["params"], (list, tuple)) else [g["params"]])]
+            plain = (not amsgrad and not any(kw.get(k) for k in ("maximize", "foreach", "capturable", "differentiable", "fused"))
+                     and not any(g.get("amsgrad") or g.get("maximize") for g in groups)
+                     and not torch.is_tensor(lr) and len(flat) > 0
+                     and all(torch.is_tensor(p) and p.is_cuda and p.dtype == torch.float32 and not p.is_sparse for p in flat))
+            if plain:
+                return FusedAdamL1(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+            return orig(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
+
+    Adam.__name__ = Adam.__qualname__ = "Adam"
+    torch.optim.Adam = Adam
+
+
+def unpatch_torch_adam():
+    global _ORIG_ADAM
+    if _ORIG_ADAM is not None:
+        torch.optim.Adam = _ORIG_ADAM
+        _ORIG_ADAM = None
