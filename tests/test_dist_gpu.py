@@ -18,6 +18,12 @@ pytestmark = pytest.mark.gpu
 C, R, SCALE, H, N, BOUND, LAM = 16, 64, 4, 64, 512, 1.5, 0.2
 
 
+def _manager():
+    """The result dict's server process, started with `spawn`: the default (fork) would clone THIS process after it has
+    initialised the GPU, and a clone that inherits device tensors dies as soon as its garbage collector frees one."""
+    return mp.get_context("spawn").Manager()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -97,7 +103,7 @@ def _refresh_worker(rank, port, out):
 
 def test_grid_refresh_is_replicated(cuda):
     port = _free_port()
-    mgr = mp.Manager()
+    mgr = _manager()
     out = mgr.dict()
     mp.spawn(_refresh_worker, args=(port, out), nprocs=2, join=True)
     g0, b0, m0, pg0, pb0, pm0 = out[0]
@@ -111,7 +117,7 @@ def test_grid_refresh_is_replicated(cuda):
 def test_two_ranks_equal_one(cuda, mode):
     ref_losses, ref_params, ref_g = _run(_build(cuda), None, 0, N, N)
     port = _free_port()
-    mgr = mp.Manager()
+    mgr = _manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(port, mode, out), nprocs=2, join=True)
     assert set(out.keys()) == {0, 1}
@@ -185,7 +191,7 @@ def test_two_ranks_with_occupancy_window(cuda, mode):
     band's collective behind its tile reduction."""
     ref_losses, ref_params = _run_roi(None, 0, 1)
     port = _free_port()
-    mgr = mp.Manager()
+    mgr = _manager()
     out = mgr.dict()
     overlap = 2 if mode == "sharded-overlap" else 0
     mode = mode.split("-")[0]
@@ -206,7 +212,7 @@ def test_two_ranks_with_deferred_coefficient_pass(cuda, overlap):
     the one-rank run bit for bit."""
     ref_losses, ref_params, live = _run_roi(None, 0, 1, 512, True)
     port = _free_port()
-    mgr = mp.Manager()
+    mgr = _manager()
     out = mgr.dict()
     mp.spawn(_roi_worker, args=(port, "sharded", out, 512, True, overlap), nprocs=2, join=True)
     (l0, p0, live0), (l1, p1, _) = out[0], out[1]
@@ -262,7 +268,7 @@ def _run_trainer(world):
 def test_trainer_on_two_ranks(cuda):
     ref_loss, ref_psnr, _ = _run_trainer(1)
     port = _free_port()
-    mgr = mp.Manager()
+    mgr = _manager()
     out = mgr.dict()
     mp.spawn(_trainer_worker, args=(port, out), nprocs=2, join=True)
     (l0, p0, w0), (l1, p1, w1) = out[0], out[1]
@@ -331,7 +337,7 @@ def test_sharded_full_checkpoint_resume(cuda, tmp_path):
     for tag, resume_at in (("straight", None), ("resumed", 2)):
         ws = str(tmp_path / tag)
         os.makedirs(ws)
-        mgr = mp.Manager()
+        mgr = _manager()
         out = mgr.dict()
         mp.spawn(_sharded_ckpt_worker, args=(_free_port(), ws, resume_at, out), nprocs=2, join=True)
         (l0, p0, s0, e0), (l1, p1, s1, _) = out[0], out[1]
@@ -403,7 +409,7 @@ def _run_on(dev, mode, lo, hi, n_global, steps=2):
 def test_rccl_collectives_and_sharded_step(cuda):
     _need_two_gpus()
     ref_losses, ref_params, _ = _run(_build(cuda), None, 0, N, N)
-    mgr = mp.Manager()
+    mgr = _manager()
     out = mgr.dict()
     mp.spawn(_nccl_worker, args=(_free_port(), out), nprocs=2, join=True)
     (l0, p0), (l1, p1) = out[0], out[1]

@@ -131,6 +131,11 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
   };
   auto finish = [&](uint64_t i, Quad& q) {
     if (!skip) {
+      // (p = m = v = g = 0 stays there -- see k_adam_l1_live: nothing to compute, nothing to store, the gradient is
+      //  already the zero a zero_grad would write)
+      auto bits = [](const float4& t) { return __float_as_uint(t.x) | __float_as_uint(t.y) | __float_as_uint(t.z) | __float_as_uint(t.w); };
+      const uint32_t any = (bits(q.pp) | bits(q.gg) | bits(q.mm) | bits(q.vv)) & 0x7fffffffu;
+      if (__ballot(any != 0u) == 0ull) return;
       adam1(q.pp.x, q.gg.x, q.mm.x, q.vv.x, a, acc);
       adam1(q.pp.y, q.gg.y, q.mm.y, q.vv.y, a, acc);
       adam1(q.pp.z, q.gg.z, q.mm.z, q.vv.z, a, acc);
@@ -302,6 +307,14 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
   };
   auto finish = [&](Quad& q) {
     if (!skip) {
+      // p = m = v = g = 0 is a fixed point of the update (the L1 term is l1 * sign(0) = 0): the reference initialises the
+      // wavelet levels to zero and a coefficient no sample's gradient has reached yet is still there.  A wavefront whose
+      // coefficients are all at it skips the arithmetic and, what counts, the 12 bytes per coefficient of stores --
+      // the same bits.  (bench.py's SURVEY 8(d) field starts from non-zero coefficients: no effect on the headline;
+      // a real trajectory spends its first hundreds of steps with most of the fine levels at zero.)
+      auto bits = [](const float4& t) { return __float_as_uint(t.x) | __float_as_uint(t.y) | __float_as_uint(t.z) | __float_as_uint(t.w); };
+      const uint32_t any = (bits(q.pp) | bits(q.gg) | bits(q.mm) | bits(q.vv)) & 0x7fffffffu;
+      if (__ballot(any != 0u) == 0ull) return;
       adam1(q.pp.x, q.gg.x, q.mm.x, q.vv.x, a, acc);
       adam1(q.pp.y, q.gg.y, q.mm.y, q.vv.y, a, acc);
       adam1(q.pp.z, q.gg.z, q.mm.z, q.vv.z, a, acc);

@@ -8,6 +8,8 @@ other shapes take the modular path (HIP lookup + HIP SH + torch nn.Linear), whic
 uses (only NeRFRenderer.run, the non-cuda_ray renderer, calls it).  The background network
 (bg_radius > 0, network.py:79-100) is not on the hot path and raises NotImplementedError.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -17,6 +19,30 @@ from ..encoding import get_encoder
 from . import field as _field
 from .. import occupancy
 from .renderer import NeRFRenderer
+
+
+class _WindowProvider:
+    """encoder.window_provider: the owning network's occupancy window, through a WEAK reference -- a bound method would
+    close a cycle network -> encoder -> network, and a model's 5 GB of device tensors would wait for the cycle collector
+    instead of being freed with the last reference."""
+
+    def __init__(self, owner):
+        self._ref = weakref.ref(owner)
+
+    def __call__(self):
+        owner = self._ref()
+        return owner._occupancy_window() if owner is not None else None
+
+    def __deepcopy__(self, memo):           # copy.deepcopy(model): the copy's encoder asks the COPY
+        owner = self._ref()
+        return _WindowProvider(memo.get(id(owner), owner)) if owner is not None else self
+
+    def __reduce__(self):                   # pickled models: re-attached by NeRFNetwork.__setstate__
+        return (_no_window, ())
+
+
+def _no_window():
+    return None
 
 
 class NeRFNetwork(NeRFRenderer):
@@ -49,7 +75,7 @@ class NeRFNetwork(NeRFRenderer):
         self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=2048 * bound, bound=bound, **kwargs)
         if hasattr(self.encoder, "window_provider"):
             # a training iteration's get_planes() (under autograd) rebuilds only what this density grid's samples can read
-            self.encoder.window_provider = self._occupancy_window
+            self.encoder.window_provider = _WindowProvider(self)
 
         # sigma network (network.py:37-52): bias-free Linear layers
         sigma_net = []
@@ -75,6 +101,11 @@ class NeRFNetwork(NeRFRenderer):
         self.density_blob_std = density_blob_std
         self.mlp_weight_decay = mlp_weight_decay
         self.force_modular = False  # tests flip this to compare the two GPU paths
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        if hasattr(self.encoder, "window_provider"):
+            self.encoder.window_provider = _WindowProvider(self)
 
     # ------------------------------------------------------------------------------------------
     def _fused_ok(self):
