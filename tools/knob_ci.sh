@@ -13,6 +13,7 @@ run "-DTNL_ADAM_ORDER=1" "$ADAM"
 run "-DTNL_ADAM_ORDER=2" "$ADAM"
 run "-DTNL_ADAM_STORE_ORDER=1" "$ADAM"
 run "-DTNL_ADAM_BLOCKS=2048" "$ADAM"
+run "-DTNL_ADAM_ZERO_SKIP=0" "$ADAM"
 run "-DTNL_RENDER_RT128=128" "tests/test_render_fused_gpu.py"
 run "-DTNL_IDWT_BWD_NT=0" "tests/test_idwt_walk_gpu.py tests/test_spans_gpu.py tests/test_roi_gpu.py"
 run "-DTNL_FWD_FB=8" "tests/test_idwt_walk_gpu.py tests/test_spans_gpu.py tests/test_roi_gpu.py"

@@ -26,6 +26,9 @@
 #ifndef TNL_ADAM_STORE_ORDER
 #define TNL_ADAM_STORE_ORDER 0
 #endif
+#ifndef TNL_ADAM_ZERO_SKIP
+#define TNL_ADAM_ZERO_SKIP 1   // wavefronts at the p = m = v = g = 0 fixed point skip arithmetic and stores (A/B knob)
+#endif
 #ifndef TNL_ADAM_BLOCKS
 #define TNL_ADAM_BLOCKS 4096
 #endif
@@ -131,15 +134,16 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
   };
   auto finish = [&](uint64_t i, Quad& q) {
     if (!skip) {
-      // (p = m = v = g = 0 stays there -- see k_adam_l1_live: nothing to compute, nothing to store, the gradient is
-      //  already the zero a zero_grad would write)
+      // (p = m = v = g = 0 stays there -- see k_adam_l1_live: the stores are skipped, the gradient is already the zero a
+      //  zero_grad would write)
       auto bits = [](const float4& t) { return __float_as_uint(t.x) | __float_as_uint(t.y) | __float_as_uint(t.z) | __float_as_uint(t.w); };
       const uint32_t any = (bits(q.pp) | bits(q.gg) | bits(q.mm) | bits(q.vv)) & 0x7fffffffu;
-      if (__ballot(any != 0u) == 0ull) return;
+      const bool moved = !TNL_ADAM_ZERO_SKIP || __ballot(any != 0u) != 0ull;
       adam1(q.pp.x, q.gg.x, q.mm.x, q.vv.x, a, acc);
       adam1(q.pp.y, q.gg.y, q.mm.y, q.vv.y, a, acc);
       adam1(q.pp.z, q.gg.z, q.mm.z, q.vv.z, a, acc);
       adam1(q.pp.w, q.gg.w, q.mm.w, q.vv.w, a, acc);
+      if (!moved) return;
 #if TNL_ADAM_STORE_ORDER == 0
       if (NTMP) { st_nt(p4 + i, q.pp); st_nt(m4 + i, q.mm); st_nt(v4 + i, q.vv); }
       else { p4[i] = q.pp; m4[i] = q.mm; v4[i] = q.vv; }
@@ -309,16 +313,18 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
     if (!skip) {
       // p = m = v = g = 0 is a fixed point of the update (the L1 term is l1 * sign(0) = 0): the reference initialises the
       // wavelet levels to zero and a coefficient no sample's gradient has reached yet is still there.  A wavefront whose
-      // coefficients are all at it skips the arithmetic and, what counts, the 12 bytes per coefficient of stores --
-      // the same bits.  (bench.py's SURVEY 8(d) field starts from non-zero coefficients: no effect on the headline;
-      // a real trajectory spends its first hundreds of steps with most of the fine levels at zero.)
+      // coefficients are all at it skips the 12 bytes per coefficient of stores -- the same bits.  Only the stores: the
+      // arithmetic stays unconditional (zeros in, zeros out); with the whole update behind the branch the pass lost
+      // 0.05-0.1 ms at the base configuration, whose SURVEY 8(d) field starts from non-zero coefficients and never skips.
+      // A real trajectory spends its first hundreds of steps with most of the fine levels at zero.
       auto bits = [](const float4& t) { return __float_as_uint(t.x) | __float_as_uint(t.y) | __float_as_uint(t.z) | __float_as_uint(t.w); };
       const uint32_t any = (bits(q.pp) | bits(q.gg) | bits(q.mm) | bits(q.vv)) & 0x7fffffffu;
-      if (__ballot(any != 0u) == 0ull) return;
+      const bool moved = !TNL_ADAM_ZERO_SKIP || __ballot(any != 0u) != 0ull;
       adam1(q.pp.x, q.gg.x, q.mm.x, q.vv.x, a, acc);
       adam1(q.pp.y, q.gg.y, q.mm.y, q.vv.y, a, acc);
       adam1(q.pp.z, q.gg.z, q.mm.z, q.vv.z, a, acc);
       adam1(q.pp.w, q.gg.w, q.mm.w, q.vv.w, a, acc);
+      if (!moved) return;
       st_nt(reinterpret_cast<float4*>(pb + q.e), q.pp);
       st_nt(reinterpret_cast<float4*>(mb + q.e), q.mm);
       st_nt(reinterpret_cast<float4*>(vb + q.e), q.vv);
