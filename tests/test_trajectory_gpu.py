@@ -1,12 +1,14 @@
 """north_star: "PSNR within 0.1 dB of reference" at a README geometry, on a REAL trajectory.
 
 Base configuration (README.md:46-58: C = 32, R = 2048, scale 32, hidden 64, 60 000 rays) from an untrained occupancy
-grid (mark_untrained_grid, real refreshes every 16 steps, nothing re-imposed), 512 steps on the analytic sphere scene,
-twice on the same batches / perturbation noise / refresh draws:
+grid (mark_untrained_grid, real refreshes every 16 steps, nothing re-imposed), 512 steps, per seed on the same batches /
+perturbation noise / refresh draws / initialisation:
   * the fused fp16-plane TrainStep (the bench's headline path: occupancy window, live rectangles, deferred optimiser pass),
   * the loop the reference's Trainer runs (utils.py:1134-1175) on the drop-in modules with fp32 planes: autograd,
-    torch.optim.Adam(eps 1e-15), torch GradScaler, LambdaLR(decay_function).
-Held-out PSNR (PSNRMeter semantics, utils.py:245-285; 4 unseen cameras) must agree within 0.1 dB.
+    torch.optim.Adam(eps 1e-15), torch GradScaler, LambdaLR(decay_function),
+  * that loop with FusedAdamL1 and the windowed rebuild under autograd.
+Held-out PSNR (PSNRMeter semantics, utils.py:245-285; 4 unseen cameras), means over the seeds, must agree within 0.1 dB.
+All runs use the ordered plane-gradient reduction, so every number of this file is reproducible to the bit.
 tools/trajectory.py is the same code as a script; bench.py reports the fused run as config.trajectory."""
 import importlib.util
 import json
@@ -27,10 +29,16 @@ def _traj():
     return mod
 
 
-def _psnr_pairs(cuda, scene_name, k_fused=2, k_ref=3, k_fast=2):
-    """k_fused runs of the fused fp16-plane TrainStep (the second and later ones with deterministic=True: the ordered
-    plane-gradient reduction) and k_ref runs of the reference-precision loop, all on the same batches / perturbation
-    noise / refresh draws; returns the report."""
+def _psnr_pairs(cuda, scene_name, seeds=(0, 1)):
+    """Per seed (batch order, perturbation noise, model initialisation): the fused fp16-plane TrainStep, the
+    reference-precision loop, and that loop as INTEGRATION.md A.1 leaves it (FusedAdamL1 + windowed rebuild) -- all three
+    with the ordered plane-gradient reduction (TrainStep(deterministic=True) / _FusedField.deterministic), i.e.
+    reproducible to the bit.  Training is chaotic in the last bits (Adam with eps 1e-15 amplifies the summation order of
+    the default, atomics-ordered tile lists; the occupancy grid follows): unordered runs scatter by +-0.06 dB around
+    these, and means of two against three such runs crossed the 0.1 dB bar by chance once in eight
+    (profiles/r04c_psnr_dropin_fast_*.json hold unordered runs).  Seeds 0 and 1: with seed 2 the detail scene's
+    trajectory is itself unstable -- three unordered runs of EITHER loop span 0.35 / 0.64 dB (fused 20.67 / 20.86 / 21.02,
+    reference loop 20.51 / 21.07 / 21.15 dB; seed 1: 21.35-21.40 vs 21.43) -- so a pair of single runs says nothing there."""
     import gc
     gc.collect()
     torch.cuda.empty_cache()        # what earlier tests left in this process's caching allocator is not "in use"
@@ -40,35 +48,30 @@ def _psnr_pairs(cuda, scene_name, k_fused=2, k_ref=3, k_fast=2):
     T = _traj()
     steps = int(os.environ.get("TNL_TRAJ_STEPS", "512"))
     scene = T.make_scene(cuda, scene=scene_name)
-    batches = T.batches_of(scene[0], steps, 60000)
-    fused_runs, ref_runs = [], []
-    for k in range(k_fused):
-        fused = T.run_fused("base", cuda, steps, 60000, scene, batches, ts_kwargs={"deterministic": k > 0})
+    fused_runs, ref_runs, fast_runs, energy = [], [], [], None
+    for seed in seeds:
+        batches = T.batches_of(scene[0], steps, 60000, seed)
+        fused = T.run_fused("base", cuda, steps, 60000, scene, batches, seed=seed, ts_kwargs={"deterministic": True})
         model = fused.pop("_model")
-        if k == 0:
+        if energy is None:
             energy = T.level_energy(model)
         del model
         fused_runs.append(fused)
         torch.cuda.empty_cache()
-    for k in range(k_ref):
-        ref = T.run_reference_loop("base", cuda, steps, 60000, scene, batches)
-        ref.pop("_model")
-        ref_runs.append(ref)
-        torch.cuda.empty_cache()
-    fast_runs = []
-    for k in range(k_fast):       # the same loop as INTEGRATION.md A.1 leaves it: FusedAdamL1 + the windowed rebuild under autograd
-        fl = T.run_reference_loop("base", cuda, steps, 60000, scene, batches, fast=True)
-        fl.pop("_model")
-        fast_runs.append(fl)
-        torch.cuda.empty_cache()
+        for fast, runs in ((False, ref_runs), (True, fast_runs)):
+            r = T.run_reference_loop("base", cuda, steps, 60000, scene, batches, seed=seed, fast=fast, deterministic=True)
+            r.pop("_model")
+            runs.append(r)
+            torch.cuda.empty_cache()
     pf = [r["held_out_psnr_db"] for r in fused_runs]
     pr = [r["held_out_psnr_db"] for r in ref_runs]
     pq = [r["held_out_psnr_db"] for r in fast_runs]
-    rep = {"scene": scene_name, "fused": fused_runs[0], "reference_loop": ref_runs[0], "psnr_fused_db": pf,
-           "psnr_reference_loop_db": pr, "level_energy_fused": energy,
-           "psnr_mean_difference_db": round(sum(pf) / len(pf) - sum(pr) / len(pr), 4),
+    mean = lambda v: sum(v) / len(v)
+    rep = {"scene": scene_name, "seeds": list(seeds), "fused": fused_runs[0], "reference_loop": ref_runs[0],
+           "psnr_fused_db": pf, "psnr_reference_loop_db": pr, "level_energy_fused": energy,
+           "psnr_mean_difference_db": round(mean(pf) - mean(pr), 4),
            "psnr_dropin_fast_loop_db": pq, "dropin_fast_loop_ms_per_step": [r["wall_ms_per_step"] for r in fast_runs],
-           "psnr_fast_loop_mean_difference_db": round(sum(pq) / len(pq) - sum(pr) / len(pr), 4) if pq else None}
+           "psnr_fast_loop_mean_difference_db": round(mean(pq) - mean(pr), 4)}
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, f"trajectory_base_{scene_name}.json"), "w") as f:
@@ -78,28 +81,18 @@ def _psnr_pairs(cuda, scene_name, k_fused=2, k_ref=3, k_fast=2):
 
 def _check_psnr(rep, steps_floor_db):
     fused, ref = rep["fused"], rep["reference_loop"]
-    msg = (f"[{rep['scene']}] fused fp16 planes {rep['psnr_fused_db']} dB vs reference loop fp32 planes "
-           f"{rep['psnr_reference_loop_db']} dB (means differ by {rep['psnr_mean_difference_db']:+.3f} dB); fused "
-           f"{fused['wall_ms_per_step']:.2f} ms/step over the trajectory ({fused['second_half_ms_per_step']:.2f} in its second "
-           f"half), reference loop {ref['wall_ms_per_step']:.1f} ms/step; window {fused['window_first_last']}, samples/step "
+    msg = (f"[{rep['scene']}] seeds {rep['seeds']}: fused fp16 planes {rep['psnr_fused_db']} dB vs reference loop fp32 planes "
+           f"{rep['psnr_reference_loop_db']} dB (means differ by {rep['psnr_mean_difference_db']:+.3f} dB); reference's loop "
+           f"with FusedAdamL1 + windowed rebuild {rep['psnr_dropin_fast_loop_db']} dB "
+           f"({rep['psnr_fast_loop_mean_difference_db']:+.3f} dB); ordered reductions (slower): fused "
+           f"{fused['wall_ms_per_step']:.2f} ms/step, reference loop {ref['wall_ms_per_step']:.1f}, fast loop "
+           f"{rep['dropin_fast_loop_ms_per_step']}; window {fused['window_first_last']}, samples/step "
            f"{fused['samples_per_step_first_last']}; level energy {rep['level_energy_fused']}")
     print(msg)
     assert min(rep["psnr_fused_db"]) > steps_floor_db and min(rep["psnr_reference_loop_db"]) > steps_floor_db, msg
-    # north_star: PSNR within 0.1 dB of the reference.  Both loops are chaotic in the last bits (float atomics in the
-    # reference-precision backward, tile-list order in the fused one; Adam with eps 1e-15 amplifies either, and the
-    # occupancy grid they prune with follows): single runs scatter by ~0.05 dB (profiles/r03e_psnr_spread.json), so the
-    # bar is held on the MEANS of two fused runs (one of them with the ordered, reproducible reduction) and three
-    # reference-loop runs.
+    # north_star: PSNR within 0.1 dB of the reference -- on the means over the seeds, every run reproducible
     assert abs(rep["psnr_mean_difference_db"]) < 0.1, msg
-    # the reference's loop with the one-line optimiser change and install_dropin()'s windowed rebuild:
-    # the same training up to rounding (the regulariser's gradient folded into the pass, fp16 sampler planes); two runs
-    # against three, single runs scatter by +-0.06 dB: 0.15 dB on the means (profiles/r04c_psnr_dropin_fast_*.json: -0.08
-    # and -0.02 dB on means of three)
-    if rep.get("psnr_dropin_fast_loop_db"):
-        msg += (f"; reference's loop with FusedAdamL1 + windowed rebuild {rep['psnr_dropin_fast_loop_db']} dB "
-                f"({rep['psnr_fast_loop_mean_difference_db']:+.3f} dB on the means), {rep['dropin_fast_loop_ms_per_step']} ms/step")
-        print(msg)
-        assert abs(rep["psnr_fast_loop_mean_difference_db"]) < 0.15, msg
+    assert abs(rep["psnr_fast_loop_mean_difference_db"]) < 0.1, msg
     return msg
 
 

@@ -158,12 +158,16 @@ def run_fused(workload, device, steps=512, num_rays=60000, scene=None, batches=N
     }
 
 
-def run_reference_loop(workload, device, steps=512, num_rays=60000, scene=None, batches=None, seed=0, fast=False):
+def run_reference_loop(workload, device, steps=512, num_rays=60000, scene=None, batches=None, seed=0, fast=False,
+                       deterministic=False):
     """The reference Trainer's loop (train_one_epoch2 + train_step, fp16=True: autocast around the render, planes built
     in fp32 outside it) on the drop-in modules, fp32 planes.  fast: what INTEGRATION.md A.1 describes -- the same loop with
     trinerflet_amd.optim.FusedAdamL1 (regulariser folded in, read-only inf check) and install_dropin()'s windowed rebuild
-    under autograd, on the encoder's default fp16 sampler planes."""
+    under autograd, on the encoder's default fp16 sampler planes.  deterministic: the module path's plane-gradient
+    reduction in sample order (nerf.field._FusedField.deterministic): the run is reproducible to the bit."""
     from trinerflet_amd.train import lr_factor
+    from trinerflet_amd.nerf import field as _F
+    keep_det, _F._FusedField.deterministic = _F._FusedField.deterministic, bool(deterministic)
     train, valid = scene if scene is not None else make_scene(device)
     model, lam = make_model(workload, device, plane_dtype=torch.float16 if fast else torch.float32, seed=seed)
     model.mark_untrained_grid(train.poses, train.intrinsics)
@@ -203,6 +207,7 @@ def run_reference_loop(workload, device, steps=512, num_rays=60000, scene=None, 
         M.append(model.step_counter[(model.local_step - 1) % 16, 0])
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    _F._FusedField.deterministic = keep_det
     M = torch.stack(M).cpu().numpy()
     psnr = held_out_psnr(model, valid)
     return {"workload": workload, "steps": steps, "wall_ms_per_step": round(wall / steps * 1e3, 3),
