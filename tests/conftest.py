@@ -35,4 +35,9 @@ def _library_defaults():
     opt = sys.modules.get("trinerflet_amd.optim")
     if opt is not None:
         opt.unpatch_torch_adam()
+    fld = sys.modules.get("trinerflet_amd.nerf.field")
+    if fld is not None:
+        fld._FusedField.deterministic = False
+        fld._FusedField.early_sort = True
+        fld._FusedField.binned_backward = True
     yield

@@ -102,10 +102,14 @@ def test_fused_loop_reaches_the_psnr_of_the_autograd_loop(cuda):
     # (1) fused
     m1 = copy.deepcopy(base)
     torch.manual_seed(123)
-    ts = TrainStep(m1, lr=1e-2, wavelet_regularization=lam, iters=iters, warmup_steps=0, fp16=True)
+    # (both loops with the ordered plane-gradient reduction: the comparison is reproducible to the bit)
+    ts = TrainStep(m1, lr=1e-2, wavelet_regularization=lam, iters=iters, warmup_steps=0, fp16=True, deterministic=True)
     for o, d, gt, nz in batches:
         ts.step(o, d, gt, noises=nz)
     # (2) the reference Trainer's loop on the drop-in modules
+    from trinerflet_amd.nerf import field as _field
+    monkey = (_field._FusedField, _field._FusedField.deterministic)
+    _field._FusedField.deterministic = True
     m2 = copy.deepcopy(base)
     m2.train()
     torch.manual_seed(123)
@@ -128,6 +132,7 @@ def test_fused_loop_reaches_the_psnr_of_the_autograd_loop(cuda):
         scaler.step(opt)
         scaler.update()
         sched.step()
+    monkey[0].deterministic = monkey[1]
     p1, p2 = psnr(m1), psnr(m2)
     assert p1 > 20 and p2 > 20, (p1, p2)
     assert abs(p1 - p2) < 0.1, (p1, p2)
