@@ -548,6 +548,20 @@ TNL_API int tnl_adam_l1_step_rect(float *p, float *grad, float *m, float *v, uin
                                   const float *opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
                                   const float *inv_scale_dev, float l1_coef, const float *found_inf,
                                   float *abs_sum, void *stream);
+/* For TrainStep's captured steps (train.py, graph=True): the same passes with nothing passed by value that changes from
+ * step to step.  _record_step_dev: tnl_adam_record_step with the learning rate read from device memory; _step_rec /
+ * _step_rect_rec: tnl_adam_l1_step_dev / _rect with the step's scalars read from the ring slot `step_rec` that record
+ * wrote (4 floats: lr / (1 - beta1^t), sqrt(1 - beta2^t), skip, pad -- the expressions the kernels otherwise evaluate
+ * themselves: the same bits). */
+TNL_API int tnl_adam_record_step_dev(float *ring, int32_t slot, const float *lr_dev, const float *opt_step_dev, float beta1,
+                                     float beta2, const float *found_inf, void *stream);
+TNL_API int tnl_adam_l1_step_rec(float *p, float *grad, float *m, float *v, uint64_t n, const float *step_rec, float beta1,
+                                 float beta2, float eps, const float *inv_scale_dev, float l1_coef,
+                                 const float *found_inf, float *abs_sum, void *stream);
+TNL_API int tnl_adam_l1_step_rect_rec(float *p, float *grad, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n,
+                                      uint32_t spp, uint32_t s0, const int32_t *rect, const float *step_rec, float beta1,
+                                      float beta2, float eps, const float *inv_scale_dev, float l1_coef,
+                                      const float *found_inf, float *abs_sum, void *stream);
 /* Live / deferred split of a level's optimiser pass between two density-grid refreshes (TrainStep; no reference
  * counterpart -- the reference runs torch.optim.Adam over every coefficient every step, main_nerf.py:119).
  * A coefficient outside `live` (8 host ints like `rect`: the footprint the windowed plane rebuild reads united with

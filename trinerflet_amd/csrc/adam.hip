@@ -54,13 +54,21 @@ __device__ __forceinline__ void st_nt(float4* p, const float4& v) {
   __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
 }
 
+// one slot of the step ring (k_adam_record): the step's bias-corrected scalars and GradScaler's verdict
+struct AdamStepRec { float step_size, bias2_sqrt, skip, pad; };
+
 template <bool RECT, bool NTMP = false>
 __global__ void __launch_bounds__(256)
 k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, uint64_t n,
           AdamArgs a, const float* __restrict__ inv_scale_dev, const float* __restrict__ found_inf,
           float* __restrict__ abs_sum, int zero_grad, const float* __restrict__ opt_step_dev, AdamRect rc,
-          const float* __restrict__ l1_dev) {
-  if (opt_step_dev != nullptr) {
+          const float* __restrict__ l1_dev, const AdamStepRec* __restrict__ rec) {
+  if (rec != nullptr) {
+    // the step's scalars as k_adam_record wrote them (the same double-precision expressions as below, evaluated once):
+    // nothing of this launch depends on a host value that changes from step to step -- a captured graph can replay it
+    a.step_size = rec->step_size;
+    a.bias2_sqrt = rec->bias2_sqrt;
+  } else if (opt_step_dev != nullptr) {
     // a.step_size carries the learning rate; the bias corrections come from the DEVICE count of optimiser steps
     // actually taken (torch.optim.Adam's per-parameter `step`, which GradScaler.step does not advance on a skipped
     // iteration) -- so the host never has to read found_inf back
@@ -213,12 +221,13 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
 // steps for everything outside the rectangle in registers: one 24-byte pass per flush instead of one per step, the
 // same operations in the same order -- bit-identical p, m, v.
 // ---------------------------------------------------------------------------------------------
-struct AdamStepRec { float step_size, bias2_sqrt, skip, pad; };
 constexpr int ADAM_REPLAY_MAX = 16;
 
 __global__ void k_adam_record(AdamStepRec* __restrict__ ring, int slot, float lr, const float* __restrict__ opt_step_dev,
-                              double beta1, double beta2, const float* __restrict__ found_inf) {
+                              double beta1, double beta2, const float* __restrict__ found_inf,
+                              const float* __restrict__ lr_dev) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (lr_dev != nullptr) lr = lr_dev[0];
   const double t = (double)opt_step_dev[0] + 1.0;          // k_adam_l1's expressions
   AdamStepRec r;
   r.step_size = (float)((double)lr / (1.0 - pow(beta1, t)));
@@ -481,7 +490,7 @@ static int adam_launch(float* p, float* grad, float* m, float* v, uint64_t n, fl
                        float beta1, float beta2, float eps, float inv_scale, const float* inv_scale_dev,
                        float l1_coef, const float* found_inf, float* abs_sum, int zero_grad,
                        const float* opt_step_dev, void* stream, const AdamRect* rect = nullptr,
-                       const float* l1_dev = nullptr) {
+                       const float* l1_dev = nullptr, const AdamStepRec* rec = nullptr) {
   if (n == 0) return 0;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(m) |
        reinterpret_cast<uintptr_t>(v)) & 15)
@@ -495,16 +504,16 @@ static int adam_launch(float* p, float* grad, float* m, float* v, uint64_t n, fl
   static const bool use_nt = getenv("TNL_ADAM_TEMPORAL") == nullptr;
   if (rect == nullptr && use_nt)
     hipLaunchKernelGGL((k_adam_l1<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v,
-                       n, a, inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, AdamRect{}, l1_dev);
+                       n, a, inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, AdamRect{}, l1_dev, rec);
   else if (rect != nullptr && use_nt)
     hipLaunchKernelGGL((k_adam_l1<true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n,
-                       a, inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, *rect, l1_dev);
+                       a, inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, *rect, l1_dev, rec);
   else if (rect != nullptr)
     hipLaunchKernelGGL(k_adam_l1<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n, a,
-                       inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, *rect, l1_dev);
+                       inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, *rect, l1_dev, rec);
   else
     hipLaunchKernelGGL(k_adam_l1<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, n, a,
-                       inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, AdamRect{}, l1_dev);
+                       inv_scale_dev, found_inf, abs_sum, zero_grad, opt_step_dev, AdamRect{}, l1_dev, rec);
   return (int)hipGetLastError();
 }
 
@@ -536,13 +545,12 @@ extern "C" int tnl_adam_l1_step_sink(float* p, float* grad, float* m, float* v, 
 
 // One wavelet level [S][bands][n][n] whose gradient is stored only inside a per-plane rectangle (rect_host: ox[3],
 // oy[3], w, h in the level's own n x n coordinates, as returned by tnl_idwt_level_backward_win; multiples of 4).
-extern "C" int tnl_adam_l1_step_rect(float* p, float* grad, float* m, float* v, uint32_t S, uint32_t bands, uint32_t n,
-                                     uint32_t spp, uint32_t s0, const int32_t* rect_host, float lr,
-                                     const float* opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
-                                     const float* inv_scale_dev, float l1_coef, const float* found_inf,
-                                     float* abs_sum, void* stream) {
-  if (opt_step_dev == nullptr || rect_host == nullptr || n == 0 || (n & (n - 1)) != 0 || n % 4 != 0 || bands == 0 ||
-      spp == 0)
+static int adam_rect_launch(float* p, float* grad, float* m, float* v, uint32_t S, uint32_t bands, uint32_t n, uint32_t spp,
+                            uint32_t s0, const int32_t* rect_host, float lr, const float* opt_step_dev, const AdamStepRec* rec,
+                            float beta1, float beta2, float eps, float inv_scale, const float* inv_scale_dev, float l1_coef,
+                            const float* found_inf, float* abs_sum, void* stream) {
+  if ((opt_step_dev == nullptr && rec == nullptr) || rect_host == nullptr || n == 0 || (n & (n - 1)) != 0 || n % 4 != 0 ||
+      bands == 0 || spp == 0)
     return (int)hipErrorInvalidValue;
   AdamRect rc;
   for (int k = 0; k < 3; k++) { rc.rx[k] = rect_host[k]; rc.ry[k] = rect_host[3 + k]; }
@@ -555,7 +563,36 @@ extern "C" int tnl_adam_l1_step_rect(float* p, float* grad, float* m, float* v, 
   while ((1u << rc.log2n) < n) rc.log2n++;
   rc.bands = (int)bands; rc.spp = (int)spp; rc.s0 = (int)s0;
   return adam_launch(p, grad, m, v, (uint64_t)S * bands * n * n, lr, 1.0f, beta1, beta2, eps, inv_scale, inv_scale_dev,
-                     l1_coef, found_inf, abs_sum, 0, opt_step_dev, stream, &rc);
+                     l1_coef, found_inf, abs_sum, 0, opt_step_dev, stream, &rc, nullptr, rec);
+}
+
+extern "C" int tnl_adam_l1_step_rect(float* p, float* grad, float* m, float* v, uint32_t S, uint32_t bands, uint32_t n,
+                                     uint32_t spp, uint32_t s0, const int32_t* rect_host, float lr,
+                                     const float* opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
+                                     const float* inv_scale_dev, float l1_coef, const float* found_inf,
+                                     float* abs_sum, void* stream) {
+  return adam_rect_launch(p, grad, m, v, S, bands, n, spp, s0, rect_host, lr, opt_step_dev, nullptr, beta1, beta2, eps,
+                          inv_scale, inv_scale_dev, l1_coef, found_inf, abs_sum, stream);
+}
+
+// The same two passes with the step's scalars read from a slot of the step ring (tnl_adam_record_step[_dev]) instead of
+// being derived from a learning rate passed by value: no argument changes from step to step (TrainStep's captured graphs).
+extern "C" int tnl_adam_l1_step_rec(float* p, float* grad, float* m, float* v, uint64_t n, const float* step_rec, float beta1,
+                                    float beta2, float eps, const float* inv_scale_dev, float l1_coef,
+                                    const float* found_inf, float* abs_sum, void* stream) {
+  if (step_rec == nullptr) return (int)hipErrorInvalidValue;
+  return adam_launch(p, grad, m, v, n, 0.f, 1.0f, beta1, beta2, eps, 1.0f, inv_scale_dev, l1_coef, found_inf, abs_sum, 0,
+                     nullptr, stream, nullptr, nullptr, reinterpret_cast<const AdamStepRec*>(step_rec));
+}
+
+extern "C" int tnl_adam_l1_step_rect_rec(float* p, float* grad, float* m, float* v, uint32_t S, uint32_t bands, uint32_t n,
+                                         uint32_t spp, uint32_t s0, const int32_t* rect_host, const float* step_rec,
+                                         float beta1, float beta2, float eps, const float* inv_scale_dev, float l1_coef,
+                                         const float* found_inf, float* abs_sum, void* stream) {
+  if (step_rec == nullptr) return (int)hipErrorInvalidValue;
+  return adam_rect_launch(p, grad, m, v, S, bands, n, spp, s0, rect_host, 0.f, nullptr,
+                          reinterpret_cast<const AdamStepRec*>(step_rec), beta1, beta2, eps, 1.0f, inv_scale_dev, l1_coef,
+                          found_inf, abs_sum, stream);
 }
 
 static int fill_rect(AdamRect& rc, const int32_t* h, uint32_t n, uint32_t bands, uint32_t spp, uint32_t s0) {
@@ -575,7 +612,16 @@ extern "C" int tnl_adam_record_step(float* ring, int32_t slot, float lr, const f
                                     float beta2, const float* found_inf, void* stream) {
   if (ring == nullptr || opt_step_dev == nullptr || slot < 0 || slot >= ADAM_REPLAY_MAX) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(k_adam_record, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<AdamStepRec*>(ring),
-                     (int)slot, lr, opt_step_dev, adam_decimal(beta1), adam_decimal(beta2), found_inf);
+                     (int)slot, lr, opt_step_dev, adam_decimal(beta1), adam_decimal(beta2), found_inf, (const float*)nullptr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tnl_adam_record_step_dev(float* ring, int32_t slot, const float* lr_dev, const float* opt_step_dev, float beta1,
+                                        float beta2, const float* found_inf, void* stream) {
+  if (ring == nullptr || opt_step_dev == nullptr || lr_dev == nullptr || slot < 0 || slot >= ADAM_REPLAY_MAX)
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_adam_record, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<AdamStepRec*>(ring),
+                     (int)slot, 0.f, opt_step_dev, adam_decimal(beta1), adam_decimal(beta2), found_inf, lr_dev);
   return (int)hipGetLastError();
 }
 

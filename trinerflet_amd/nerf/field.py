@@ -222,13 +222,23 @@ def order_tile_lists(ws, R, M):
     w32 = ws.view(torch.int32)
     offsets = w32[off_idx:off_idx + nb + 1]
     tile_off = offsets[::subs].long()                      # nb / subs + 1 boundaries (the last = total entries)
-    total = int(tile_off[-1])
-    if total == 0:
-        return
+    if torch.cuda.is_current_stream_capturing():
+        # no read-back inside a stream capture (TrainStep(graph=True, deterministic=True)): the whole capacity of 12 M
+        # slots is sorted, the unused ones (index >= total, a device-side comparison) behind all lists
+        total = 12 * M
+        idx = torch.arange(total, device=ws.device)
+        used = idx < tile_off[-1]
+    else:
+        total = int(tile_off[-1])
+        if total == 0:
+            return
+        idx, used = torch.arange(total, device=ws.device), None
     entries = w32[ent_idx:ent_idx + total]
     pos = w32[pos_idx:pos_idx + 2 * total].view(total, 2)  # the entries' (fx, fy), moved with their ids
-    seg = torch.searchsorted(tile_off[1:].contiguous(), torch.arange(total, device=ws.device), right=True)
+    seg = torch.searchsorted(tile_off[1:].contiguous(), idx, right=True)
     key = (seg << 32) | (entries.long() & 0xFFFFFFFF)
+    if used is not None:
+        key = torch.where(used, key, torch.full_like(key, 1 << 62))
     skey, perm = torch.sort(key)
     entries.copy_((skey & 0xFFFFFFFF).to(torch.int32))
     pos.copy_(pos[perm])

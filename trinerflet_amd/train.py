@@ -159,7 +159,7 @@ class TrainStep:
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
                  dist_mode=None, process_group=None, binned=True, fuse_adam=False, use_roi=True, tune_placement=None,
-                 defer_adam=None, deterministic=False, live_bands=True, overlap_exchange=0):
+                 defer_adam=None, deterministic=False, live_bands=True, overlap_exchange=0, graph=False):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
@@ -278,6 +278,21 @@ class TrainStep:
         self.live_bands = live_bands
         self._side = None
         self._prefetched = None     # (key, marched tensors) of a march started for the following call
+        # graph: the steady-state steps of a density-grid period (positions 1 .. 14: not the refresh step, not the step whose
+        # optimiser pass fills the ring and replays it) are captured once as HIP graphs -- one per position, since the ring
+        # slots are launch arguments -- and replayed while the occupancy window, its pieces and the sample budget stay what
+        # they were (see _graph_step).  ~40 launches become one; measured 3.79 -> 3.52 ms for such a step at the base
+        # configuration (tools/exp_graph_step.py).  Off by default; single-process only.
+        self.graph = bool(graph)
+        self._graphs = {}           # period position -> _StepGraph
+        self._graph_key = None      # what the captured launches depend on besides the ring position
+        self._graph_pool = None
+        self._graph_in = None       # static input tensors the captured launches read
+        self._cap_stream = None
+        self._capturing = False
+        self._lr_dev = None
+        self.graph_replays = 0      # counters for reports / tests
+        self.graph_captures = 0
         self._stale_params = self._stale_moments = False
         self.post_refresh = None    # optional callable run right after every density-grid refresh
         self.section_events = None  # set to [] to record HIP events (on the launch stream) around every stage
@@ -648,6 +663,8 @@ class TrainStep:
         st = _StepState(rays_o=rays_o, rays_d=rays_d, gt_rgb=gt_rgb, noises=noises, bg_color=bg_color, next_rays=next_rays,
                         N=N, n_glob=n_global_rays if n_global_rays is not None else N * self.world,
                         refresh=self.update_extra_interval > 0 and self.global_step % self.update_extra_interval == 0)
+        if self.graph and self._graph_eligible(st):
+            return self._graph_step(st)
         self._mark("begin")
         self._stage_pickup(st)         # the march started during the previous call, or one started now on the side stream
         self._stage_planes(st)         # (replay of the deferred pass) -> plane rebuild -> [grid refresh + new window]
@@ -934,7 +951,14 @@ class TrainStep:
                 self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum)
                 self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
             self._mark("adam_coef")
-        self._adam(self.mlp, lr_t, 0.0, found_inf, inv_scale)
+        if self._capturing:
+            mlp = self.mlp
+            L.check(lib.tnl_adam_l1_step_rec(L.ptr(mlp.data), L.ptr(mlp.grad), L.ptr(mlp.m), L.ptr(mlp.v), L.u64(mlp.total),
+                                             L.ptr(self._ring[4 * self._last_slot:]), L.f32(self.b1), L.f32(self.b2),
+                                             L.f32(self.eps), L.ptr(inv_scale), L.f32(0.0), L.ptr(found_inf), L.ptr(None),
+                                             L.stream()), "adam_l1_step_rec")
+        else:
+            self._adam(self.mlp, lr_t, 0.0, found_inf, inv_scale)
         # optimiser-step count, GradScaler.update(), L1 value: one launch
         reg = torch.empty((), dtype=torch.float32, device=self.dev)
         L.check(lib.tnl_step_epilogue(L.ptr(found_inf), L.ptr(self.opt_steps), L.ptr(self.scale),
@@ -954,6 +978,158 @@ class TrainStep:
         self._mark("tail")
         self.last = {'mse': mse, 'wavelet_reg': reg, 'M': st.M, 'found_inf': found_inf, 'image': st.pred, 'ws': st.ws,
                      'depth': st.depth, 'counter': st.counter, 'lr': lr_t}
+
+    # ------------------------------------------------------------------------------------------
+    # captured steps (graph=True)
+    def _graph_position(self):
+        return self.global_step % self.update_extra_interval if self.update_extra_interval > 0 else -1
+
+    def _graph_eligible(self, st):
+        """A step whose every launch argument is fixed by (period position, occupancy window and its pieces, sample
+        budget, batch size): a steady-state step of the windowed, deferred path with the prefetched march of this batch
+        at hand and the following batch announced."""
+        j = self._graph_position()
+        model = self.model
+        if (self.world != 1 or not (1 <= j <= min(self.update_extra_interval, 16) - 2) or st.refresh or self.section_events is not None
+                or not (self.binned and self.use_roi and self.defer_adam and self._rect_ok and self.overlap_march)
+                or self.fuse_adam or self.overlap_exchange > 1 or self._roi is None or not self._roi_valid
+                or self._roi_request is not None or self._rects_roi is not self._roi or self._live is None
+                or self._pending != j or self._pending >= 15 or st.noises is None or st.bg_color is not None
+                or torch.is_tensor(self.bg) or st.next_rays is None or len(st.next_rays) < 3 or st.next_rays[2] is None
+                or model.mean_count <= 0 or self._prefetched is None or self.R % 32 != 0):
+            return False
+        pre = self._prefetched
+        if not self._prefetch_matches(pre[0], st.rays_o, st.rays_d, st.noises):
+            return False
+        g = self._graphs.get(j)
+        if g is not None and (g.pending != self._pending or g.local_step_mod != model.local_step % 16):
+            return False
+        return all(t_.dtype == torch.float32 and t_.is_contiguous() for t_ in
+                   (st.rays_o, st.rays_d, st.gt_rgb, st.noises, *st.next_rays[:3]))
+
+    def _graph_signature(self, st):
+        roi = tuple(self._roi)
+        ext = None if self._row_ext is None else hash(self._row_ext.tobytes())
+        tup = lambda rs: tuple(None if r is None else tuple(int(x) for x in r) for r in rs)
+        return (roi, ext, tup(self._rects), tup(self._live), int(self.model.mean_count), st.N, st.n_glob, float(self.bg),
+                bool(self.deterministic), bool(self.live_bands), self.update_extra_interval, self.max_steps, self.dt_gamma)
+
+    def drop_graphs(self):
+        self._graphs = {}
+        self._graph_key = None
+
+    def _graph_step(self, st):
+        """One captured step: inputs copied into the static buffers the launches read, the learning rate into its device
+        word, then one graph launch (captured on first use).  Host-side state moves as an eager step moves it."""
+        model, dev = self.model, self.dev
+        j = self._graph_position()
+        sig = self._graph_signature(st)
+        if sig != self._graph_key:
+            self._graphs, self._graph_key = {}, sig
+        N = st.N
+        if self._graph_in is None or self._graph_in["o"].shape[0] != N:
+            mk = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+            self._graph_in = {"o": mk(N, 3), "d": mk(N, 3), "gt": mk(N, 3), "nz": mk(N), "o2": mk(N, 3), "d2": mk(N, 3),
+                              "nz2": mk(N)}
+            self._graphs = {}
+        if self._lr_dev is None:
+            self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+            self._cap_stream = torch.cuda.Stream()
+        gi, nxt = self._graph_in, st.next_rays
+        if nxt[0].shape[0] != N:
+            return self._eager_step(st)
+        lr_t = self.lr * lr_factor(self.global_step, self.iters, self.warmup)
+        pre = self._prefetched
+        g = self._graphs.get(j)
+        main = torch.cuda.current_stream()
+        if self._side is not None:
+            main.wait_stream(self._side)           # the prefetch of an eager step may still be running
+        torch._foreach_copy_([gi["o"], gi["d"], gi["gt"], gi["nz"], gi["o2"], gi["d2"], gi["nz2"]],
+                             [st.rays_o, st.rays_d, st.gt_rgb, st.noises, nxt[0], nxt[1], nxt[2]])
+        self._lr_dev.fill_(lr_t)
+        if g is None:
+            # device tables the stage methods build lazily on a period's first windowed step (host-to-device copies are
+            # not allowed inside a capture): now
+            self._forward_spans()
+            self._adjoint_spans()
+            g = self._capture_step(st, j, pre)
+            self._graphs[j] = g
+            self.graph_captures += 1
+        else:
+            # the march this step consumes: where the captured launches expect it
+            src = [t_ for t_ in pre[1][0] if torch.is_tensor(t_)]
+            dst = [t_ for t_ in g.in_marched if torch.is_tensor(t_)]
+            if any(a is not b for a, b in zip(src, dst)):
+                torch._foreach_copy_(dst, src)
+            # host-side state, as the stage methods leave it
+            self._prefetched = None
+            model.local_step += 1                  # the ring slot the prefetched march (of the NEXT batch) takes
+            self._pending += 1
+            self.deferred_steps += 1
+            self.global_step += 1
+            self._stale_params = self._stale_moments = True
+        g.graph.replay()
+        self.graph_replays += 1
+        # the graph joined its side work before it ended: whoever consumes the prefetch -- the next captured step (which
+        # does not look at events) or an eager one -- is ordered behind it by the launch stream alone; the events the
+        # capture recorded are not real ones, an eager consumer gets one recorded here
+        ev = torch.cuda.Event()
+        ev.record()
+        self._prefetched = (self._prefetch_key(nxt), (g.out_prefetch[0], (ev, ev)), g.slot_step_of(model))
+        self.last = dict(g.last)
+        self.last["lr"] = lr_t
+        return g.loss
+
+    def _eager_step(self, st):
+        self._mark("begin")
+        self._stage_pickup(st)
+        self._stage_planes(st)
+        self._stage_march(st)
+        self._stage_render(st)
+        self._stage_backward(st)
+        self._stage_optimise(st)
+        return st.loss
+
+    def _capture_step(self, st, j, pre):
+        """Runs the stage methods of an eager step under stream capture (nothing executes: the caller replays the graph
+        once); the host-side state changes they make are the step's."""
+        model = self.model
+        gi = self._graph_in
+        g = types.SimpleNamespace()
+        g.graph = torch.cuda.CUDAGraph()
+        g.in_marched = pre[1][0]
+        g.pending = self._pending
+        g.local_step_mod = model.local_step % 16
+        g.slot_step_of = lambda m: m.local_step - 1
+        # what the captured launches point at and this object would otherwise let go at the next refresh
+        g.keep = (self._band_cache, self._live_bands, self._live, self._rects, gi, self._tm_full, pre)
+        st.rays_o, st.rays_d, st.gt_rgb, st.noises = gi["o"], gi["d"], gi["gt"], gi["nz"]
+        st.next_rays = (gi["o2"], gi["d2"], gi["nz2"])
+        main = torch.cuda.current_stream()
+        self._cap_stream.wait_stream(main)
+        self._capturing = True
+        try:
+            with torch.cuda.graph(g.graph, pool=self._graph_pool, stream=self._cap_stream):
+                # the prefetched march is complete (the launch stream waited for the side stream); its events belong to
+                # uncaptured work and cannot be waited for in here: stand-ins recorded inside the capture
+                e = torch.cuda.Event()
+                e.record()
+                st.marched, st.side = (pre[1][0], (e, e)), self._side
+                self._prefetched = None
+                self._stage_planes(st)
+                self._stage_march(st)
+                self._stage_render(st)
+                self._stage_backward(st)
+                self._stage_optimise(st)
+                torch.cuda.current_stream().wait_stream(self._side)     # a graph cannot leave a forked stream open
+        finally:
+            self._capturing = False
+        main.wait_stream(self._cap_stream)
+        g.loss, g.last = st.loss, dict(self.last)
+        g.out_prefetch = self._prefetched[1]
+        return g
 
     def _exchange_bands(self, roi):
         """[(first row, rows)] of the bands the plane-gradient window is exchanged in, or None (one piece): overlap_exchange
@@ -1168,9 +1344,14 @@ class TrainStep:
             self.last_live_bands = self._live_bands
             self._defer_ctx = (s0, s1, l1)
         slot = self._pending
-        L.check(lib.tnl_adam_record_step(L.ptr(self._ring), L.i32(slot), L.f32(lr_t), L.ptr(self.opt_steps),
-                                         L.f32(self.b1), L.f32(self.b2), L.ptr(found_inf), L.stream()),
-                "adam_record_step")
+        if self._capturing:      # the learning rate from device memory: no launch argument changes from step to step
+            L.check(lib.tnl_adam_record_step_dev(L.ptr(self._ring), L.i32(slot), L.ptr(self._lr_dev), L.ptr(self.opt_steps),
+                                                 L.f32(self.b1), L.f32(self.b2), L.ptr(found_inf), L.stream()),
+                    "adam_record_step_dev")
+        else:
+            L.check(lib.tnl_adam_record_step(L.ptr(self._ring), L.i32(slot), L.f32(lr_t), L.ptr(self.opt_steps),
+                                             L.f32(self.b1), L.f32(self.b2), L.ptr(found_inf), L.stream()),
+                    "adam_record_step")
         # every level in ONE launch: its live rectangle, or the whole level where nothing is deferred
         J, cf = self.J, self.coef
         sizes = [cf.params[lvl].shape[-1] for lvl in range(J)]
@@ -1189,11 +1370,19 @@ class TrainStep:
         n0 = self.ll.params[0].shape[-1]
         ll = self.ll
         off = s0 * n0 * n0
-        L.check(lib.tnl_adam_l1_step_rect(
-            L.ptr(ll.data[off:]), L.ptr(ll.grad[off:]), L.ptr(ll.m[off:]), L.ptr(ll.v[off:]), L.u32(ns), L.u32(1),
-            L.u32(n0), L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*rects[0]), L.f32(lr_t), L.ptr(self.opt_steps),
-            L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0), L.ptr(inv_scale), L.f32(0.0),
-            L.ptr(found_inf), L.ptr(None), L.stream()), "adam_l1_step_rect")
+        if self._capturing:      # the step's scalars from the ring slot just written (the same bits)
+            L.check(lib.tnl_adam_l1_step_rect_rec(
+                L.ptr(ll.data[off:]), L.ptr(ll.grad[off:]), L.ptr(ll.m[off:]), L.ptr(ll.v[off:]), L.u32(ns), L.u32(1),
+                L.u32(n0), L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*rects[0]), L.ptr(self._ring[4 * slot:]),
+                L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.ptr(inv_scale), L.f32(0.0),
+                L.ptr(found_inf), L.ptr(None), L.stream()), "adam_l1_step_rect_rec")
+        else:
+            L.check(lib.tnl_adam_l1_step_rect(
+                L.ptr(ll.data[off:]), L.ptr(ll.grad[off:]), L.ptr(ll.m[off:]), L.ptr(ll.v[off:]), L.u32(ns), L.u32(1),
+                L.u32(n0), L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*rects[0]), L.f32(lr_t), L.ptr(self.opt_steps),
+                L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0), L.ptr(inv_scale), L.f32(0.0),
+                L.ptr(found_inf), L.ptr(None), L.stream()), "adam_l1_step_rect")
+        self._last_slot = slot
         if any(lv is not None for lv in self._live):
             self._pending += 1
             self.deferred_steps += 1
