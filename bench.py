@@ -54,8 +54,12 @@ WORKLOADS = {
 }
 
 
+GRAPH = False   # TrainStep(graph=...) for every model this run builds: set in main() (--graph / --no-graph)
+
+
 def build(workload, device, dist_mode, plane_dtype=None, shell=(0.8, 0.0), **ts_kwargs):
     from trinerflet_amd import synthetic
+    ts_kwargs.setdefault("graph", GRAPH and dist_mode is None)
     from trinerflet_amd.nerf.network import NeRFNetwork
     from trinerflet_amd.train import TrainStep
     C, R, scale, H, N, lam = WORKLOADS[workload]
@@ -510,6 +514,11 @@ def main():
     ap.add_argument("--workload", default="base", choices=sorted(WORKLOADS))
     ap.add_argument("--dist-mode", default="sharded", choices=["sharded", "allreduce"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="the steady-state steps of a density-grid period replayed as captured HIP graphs (TrainStep(graph=True)). "
+                         "Off by default: measured at base, natural loop, steady positions 3.50 ms eager vs 3.61-3.68 ms "
+                         "captured (the capture joins the side stream at the end of every step and pays an input copy, a fill "
+                         "and a cross-stream wait per replay; the ~0.1 ms of dispatch gaps it removes do not cover that)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the measured configuration); gloo only to dry-run the N>1 code on one GPU")
     ap.add_argument("--same-device", action="store_true", help="all ranks on cuda:0 (dry-run with --backend gloo)")
@@ -548,6 +557,8 @@ def main():
         if world > 1:
             dist.barrier()
 
+    global GRAPH
+    GRAPH = world == 1 and args.graph
     model, ts, bitfield, N = build(args.workload, device, args.dist_mode if world > 1 else None)
     if os.environ.get("TNL_CLIP_FAR"):      # A/B: the in-order march of refresh steps clipped to the occupied box (default on)
         ts.clip_far_in_order = os.environ["TNL_CLIP_FAR"] != "0"
@@ -599,6 +610,12 @@ def main():
     ts.section_names = {SECTION_PREV[dominant], dominant}
     if dominant == "idwt_fwd":
         ts.section_names.add("adam_catchup")          # a replay of the deferred pass may sit between "begin" and the rebuild
+    if ts.graph:
+        # captured steps: nothing can be timed INSIDE a replayed graph (an event recorded during the capture has no
+        # elapsed time: hipErrorInvalidHandle), and an event between the stages would split the graph at a point where
+        # the side stream is forked.  The timed region runs without events; the dominant section's duration comes from
+        # the instrumented eager pass right after it (same process, same state, the same kernels with the same arguments).
+        ts.section_events, ts.section_names = None, None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -630,8 +647,14 @@ def main():
     torch.cuda.synchronize()
     sec = ts.section_times()
     sec_instrumented_dominant = sec.get(dominant)
+    dom_timing = "HIP events on the launch stream inside the timed steps"
     if dom_ms == dom_ms:
         sec[dominant] = dom_ms
+    else:       # captured steps: see above
+        dom_ms = sec_instrumented_dominant
+        dom_timing = ("HIP events on the launch stream in the instrumented eager pass of min(K, 16) steps right after the timed "
+                      "region -- the timed region replays captured graphs, inside which nothing can be timed (an event "
+                      "recorded during a capture has no elapsed time on HIP)")
     # the same sections with NOTHING beside them (the next batch's march + tile sort in order on the launch stream
     # instead of on the side stream): what each kernel does alone, for `roofline.alone` and `kernels[*].alone_ms`
     ts.section_events, ts.section_names = [], None
@@ -810,6 +833,12 @@ def main():
                        "sections_note": f"{dominant}: HIP events inside the timed steps; the other sections: an "
                                         "instrumented pass after them (an event at every boundary costs 6-8 us)",
                        "kernels": kernels,
+                       "captured_steps": None if not ts.graph else {
+                           "replays": ts.graph_replays, "captures": ts.graph_captures,
+                           "note": "TrainStep(graph=True): positions 1..14 of a density-grid period (not the refresh step, not "
+                                   "the step whose optimiser pass fills the 16-slot ring and replays it) are replayed as "
+                                   "captured HIP graphs, one per ring position; bit-identical to the eager launches "
+                                   "(tests/test_graph_step_gpu.py)"},
                        "roi_window": roi_window,
                        "adam_placement": plc,
                        "adam_deferred": adam_deferred,
@@ -824,7 +853,7 @@ def main():
                          "traffic_source": pmc_src,
                          "algorithmic_bytes_per_launch": spec[dominant]["bytes"] / n_dom,
                          "algorithmic_flops_per_launch": spec[dominant]["flops"] / n_dom,
-                         "avg_launch_ms": dom_ms / n_dom, "launches_per_step": n_dom,
+                         "avg_launch_ms": dom_ms / n_dom, "launches_per_step": n_dom, "timing": dom_timing,
                          "per_step": {"algorithmic_bytes": spec[dominant]["bytes"], "algorithmic_flops": spec[dominant]["flops"],
                                       "traffic_bytes": None if dtr is None else dtr["bytes"], "ms": dom_ms,
                                       "ms_instrumented_pass": sec_instrumented_dominant,
