@@ -637,6 +637,11 @@ def main():
     elapsed = float(tmax.item())
 
     timed_flushes, timed_deferred = ts.deferred_flushes - flushes0, ts.deferred_steps - deferred0
+    captured_steps = None if not ts.graph else {
+        "replays": ts.graph_replays, "captures": ts.graph_captures,
+        "note": "TrainStep(graph=True): positions 1..14 of a density-grid period (not the refresh step, not the step whose "
+                "optimiser pass fills the 16-slot ring and replays it) are replayed as captured HIP graphs, one per ring "
+                "position; bit-identical to the eager launches (tests/test_graph_step_gpu.py)"}
     # the dominant section's time from the HIP events recorded inside the timed region ...
     dom_ms = ts.section_times().get(dominant, float("nan"))
     # ... and every section's, for the other figures, from an instrumented pass AFTER it (not part of the K steps)
@@ -833,12 +838,7 @@ def main():
                        "sections_note": f"{dominant}: HIP events inside the timed steps; the other sections: an "
                                         "instrumented pass after them (an event at every boundary costs 6-8 us)",
                        "kernels": kernels,
-                       "captured_steps": None if not ts.graph else {
-                           "replays": ts.graph_replays, "captures": ts.graph_captures,
-                           "note": "TrainStep(graph=True): positions 1..14 of a density-grid period (not the refresh step, not "
-                                   "the step whose optimiser pass fills the 16-slot ring and replays it) are replayed as "
-                                   "captured HIP graphs, one per ring position; bit-identical to the eager launches "
-                                   "(tests/test_graph_step_gpu.py)"},
+                       "captured_steps": captured_steps,
                        "roi_window": roi_window,
                        "adam_placement": plc,
                        "adam_deferred": adam_deferred,
