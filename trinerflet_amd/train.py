@@ -289,6 +289,7 @@ class TrainStep:
         self._graph_pool = None
         self._graph_in = None       # static input tensors the captured launches read
         self._cap_stream = None
+        self._graph_done = None
         self._capturing = False
         self._lr_dev = None
         self.graph_replays = 0      # counters for reports / tests
@@ -1037,6 +1038,8 @@ class TrainStep:
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
             self._cap_stream = torch.cuda.Stream()
+            self._graph_done = torch.cuda.Event()
+            self._graph_done.record()
         gi, nxt = self._graph_in, st.next_rays
         if nxt[0].shape[0] != N:
             return self._eager_step(st)
@@ -1044,8 +1047,10 @@ class TrainStep:
         pre = self._prefetched
         g = self._graphs.get(j)
         main = torch.cuda.current_stream()
-        if self._side is not None:
-            main.wait_stream(self._side)           # the prefetch of an eager step may still be running
+        from_graph = pre[1][1][0] is self._graph_done
+        if self._side is not None and not from_graph:
+            main.wait_stream(self._side)           # the prefetch of an EAGER step may still be running (a captured step
+            #                                        joined its side work before it ended)
         torch._foreach_copy_([gi["o"], gi["d"], gi["gt"], gi["nz"], gi["o2"], gi["d2"], gi["nz2"]],
                              [st.rays_o, st.rays_d, st.gt_rgb, st.noises, nxt[0], nxt[1], nxt[2]])
         self._lr_dev.fill_(lr_t)
@@ -1075,8 +1080,7 @@ class TrainStep:
         # the graph joined its side work before it ended: whoever consumes the prefetch -- the next captured step (which
         # does not look at events) or an eager one -- is ordered behind it by the launch stream alone; the events the
         # capture recorded are not real ones, an eager consumer gets one recorded here
-        ev = torch.cuda.Event()
-        ev.record()
+        ev = self._graph_done                      # (one event recorded once, long complete: waiting for it is free)
         self._prefetched = (self._prefetch_key(nxt), (g.out_prefetch[0], (ev, ev)), g.slot_step_of(model))
         self.last = dict(g.last)
         self.last["lr"] = lr_t
