@@ -362,6 +362,8 @@ TNL_API int tnl_adam_l1_step_dev(float *p, float *grad, float *m, float *v, uint
                                  const float *opt_step_dev, float beta1, float beta2, float eps, float inv_scale,
                                  const float *inv_scale_dev, float l1_coef, const float *found_inf,
                                  float *abs_sum, int zero_grad, void *stream);
+/* zero_grad: bit 0 = write zeros over the gradient after reading it; bit 1 = store p / m / v even for wavefronts whose
+ * p = m = v = g are all zero (the update's fixed point, normally skipped: the same bits) -- for timing probes. */
 /* tnl_adam_l1_step_dev with a second L1 coefficient that exists only on the device (optim.FusedAdamL1, fold_l1):
  * l1_scaled_dev[0] = d(scaled loss) / d(sum |p|), collected from the backward of the reference's regulariser
  * (nerf/utils.py:639-655: v.abs().mean() * weight) instead of materialising sign(p) * s as a gradient and adding it to

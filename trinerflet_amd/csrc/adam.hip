@@ -146,7 +146,7 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
       //  zero_grad would write)
       auto bits = [](const float4& t) { return __float_as_uint(t.x) | __float_as_uint(t.y) | __float_as_uint(t.z) | __float_as_uint(t.w); };
       const uint32_t any = (bits(q.pp) | bits(q.gg) | bits(q.mm) | bits(q.vv)) & 0x7fffffffu;
-      const bool moved = !TNL_ADAM_ZERO_SKIP || __ballot(any != 0u) != 0ull;
+      const bool moved = !TNL_ADAM_ZERO_SKIP || (zero_grad & 2) || __ballot(any != 0u) != 0ull;   // bit 1: always store
       adam1(q.pp.x, q.gg.x, q.mm.x, q.vv.x, a, acc);
       adam1(q.pp.y, q.gg.y, q.mm.y, q.vv.y, a, acc);
       adam1(q.pp.z, q.gg.z, q.mm.z, q.vv.z, a, acc);
@@ -162,7 +162,7 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
     } else {
       acc += fabsf(q.pp.x) + fabsf(q.pp.y) + fabsf(q.pp.z) + fabsf(q.pp.w);
     }
-    if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (zero_grad & 1) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   };
   // TNL_ADAM_UNROLL float4 per thread and trip, all loads first (bytes in flight per wave)
   constexpr int U = TNL_ADAM_UNROLL;
@@ -198,7 +198,7 @@ k_adam_l1(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, f
     } else {
       acc += fabsf(pp);
     }
-    if (zero_grad) g[i] = 0.f;
+    if (zero_grad & 1) g[i] = 0.f;
   }
   if (abs_sum != nullptr) {
 #pragma unroll

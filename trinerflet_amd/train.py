@@ -515,7 +515,9 @@ class TrainStep:
             "adam_l1_step")
 
     def _time_adam_pass(self, data, grad, m, v, reps=3):
-        """Milliseconds of one k_adam_l1 pass over whole arrays with lr = 0 (nothing changes when g = m = v = 0)."""
+        """Milliseconds of one k_adam_l1 pass over whole arrays with lr = 0 (nothing changes when g = m = v = 0).  The pass
+        is asked to store every wavefront (zero_grad bit 1): candidate buffers and zero-initialised coefficient sets would
+        otherwise take the zero fixed-point shortcut (no stores, twice as fast) and every placement would look perfect."""
         one = torch.ones(1, dtype=torch.float32, device=data.device)
         zero = torch.zeros(1, dtype=torch.float32, device=data.device)
 
@@ -523,7 +525,7 @@ class TrainStep:
             L.check(L.lib().tnl_adam_l1_step_dev(
                 L.ptr(data), L.ptr(grad), L.ptr(m), L.ptr(v), L.u64(data.numel()), L.f32(0.0), L.ptr(one),
                 L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0), None, L.f32(0.0), L.ptr(zero), None,
-                L.i32(0), L.stream()), "adam_l1_step (placement probe)")
+                L.i32(2), L.stream()), "adam_l1_step (placement probe)")   # 2: the stores are not skipped for all-zero wavefronts
         run()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
