@@ -121,7 +121,9 @@ def cpu_baseline(workload):
     Ns = max(N // 20, 64)
     t = tb.time_step(C, R, scale, H, Ns, lam=lam, threads=cores, repeats=5, warmup=1)
     dense, ray = t["dense_s"], t["ray_s"] * (N / Ns)
-    return {"value": N / (dense + ray), "unit": "rays/s", "cores": cores, "kind": "port",
+    return {"value": N / (dense + ray), "unit": "rays/s", "cores": cores, "host_threads": os.cpu_count(), "kind": "port",
+            "sample_short": f"torch-CPU fp32 step on {cores} threads of {os.cpu_count()}: dense part (IDWT fwd+bwd, L1, Adam) at full "
+                            f"R={R}, per-ray part on {Ns} of {N} rays scaled x{N / Ns:.0f}; 1 warm-up + median of 5",
             "samples_per_s": N * 512 / (dense + ray),
             "split_s": {"dense_full_size": round(dense, 3), "per_ray_scaled": round(ray, 3)},
             "sample": f"torch-CPU fp32 step, 1 warm-up + median of 5: dense part (IDWT fwd+bwd, L1, Adam over "
@@ -505,6 +507,70 @@ def roof(spec, name, ms_):
         out["frac_mfma"] = round(tfl / MFMA_PEAK_TFLOPS, 4)
     return out
 
+def _num(v, nd=4):
+    """Scalars of the printed line: floats rounded to `nd` significant-enough digits, everything else unchanged."""
+    if isinstance(v, float):
+        return float(f"{v:.{nd + 3}g}")
+    return v
+
+
+def compact_line(out):
+    """The ONE stdout line of the contract, derived from the full record `out` (which goes to gpurun_out/bench_detail.json):
+    the contract's keys, a flat `config` of scalars, `roofline` (scalars + a 3-entry `top` of scalars) and `cpu_baseline`
+    (scalars).  Kept below 4 KB so that any driver-side line buffer holds it."""
+    cfg, rf = out["config"], out["roofline"]
+    flat = {"workload": cfg["workload"]}
+    for k in ("rays_per_step_per_gpu", "rays_per_step_global", "samples_per_step_per_gpu", "sample_budget_M", "samples_per_sec",
+              "ms_per_step_over_whole_periods", "fp32_planes_ms_per_step", "no_roi_ms_per_step", "thin_shell_ms_per_step",
+              "parallelism"):
+        if k in cfg:
+            flat[k] = _num(cfg[k])
+    col = cfg.get("collectives")
+    flat["collectives"] = None if col is None else f"{col['backend']} x{col['world_size']}"
+    if col is not None and col.get("bytes_on_the_wire"):
+        for k, v in col["bytes_on_the_wire"].items():
+            if isinstance(v, (int, float)):
+                flat["wire_" + k] = _num(float(v))
+    tj = cfg.get("trajectory")
+    if isinstance(tj, dict):
+        flat["trajectory_512_steps_ms_per_step"] = tj.get("wall_ms_per_step")
+        flat["trajectory_held_out_psnr_db"] = tj.get("held_out_psnr_db")
+    inf = cfg.get("inference")
+    if isinstance(inf, dict):
+        flat["test_render_800x800_4096_steps_ms"] = inf.get("ms_per_image")
+    dr = cfg.get("dropin_autograd_ms_per_step")
+    if isinstance(dr, dict):
+        flat["reference_loop_on_dropin_ms_per_step"] = dr.get("fused_adam_fp16_planes")
+    for wl, rep in (cfg.get("other_workloads") or {}).items():
+        flat[f"{wl}_ms_per_step"] = rep.get("ms_per_step")
+    for k, v in (cfg.get("sections_ms") or {}).items():
+        flat["ms_" + k] = _num(v)
+    flat["detail"] = "gpurun_out/bench_detail.json"
+    top = [{"section": e["section"], "ms": e["ms_per_step"], "bound": e["bound"], "achieved": _num(e["achieved"]),
+            "unit": e["unit"], "frac": _num(e["frac"]), "traffic_over_algorithmic": e.get("traffic_over_algorithmic")}
+           for e in rf["top"]]
+    roofline = {k: _num(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    roofline.update({"kernel": " + ".join(SECTION_KERNELS[top_section(rf)]), "section": top_section(rf),
+                     "launches_per_step": rf["launches_per_step"], "avg_launch_ms": _num(rf["avg_launch_ms"]),
+                     "algorithmic_bytes_per_launch": _num(rf["algorithmic_bytes_per_launch"]),
+                     "algorithmic_flops_per_launch": _num(rf["algorithmic_flops_per_launch"]),
+                     "alone_frac": None if not rf.get("alone") else rf["alone"]["frac"],
+                     "measured_copy_GB/s": rf.get("measured_copy_GB/s"), "top": top})
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = flat
+    line["roofline"] = roofline
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = {"value": _num(cb["value"]), "unit": cb["unit"], "cores": cb["cores"],
+                                "host_threads": cb.get("host_threads"), "kind": cb["kind"],
+                                "sample": cb["sample_short"]}
+    return line
+
+
+def top_section(rf):
+    return rf["section"]
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -843,7 +909,7 @@ def main():
                        "adam_placement": plc,
                        "adam_deferred": adam_deferred,
                        **extras},
-            "roofline": {"bound": dom.get("bound"), "kernel": f"{' + '.join(SECTION_KERNELS[dominant])} (section '{dominant}' of the "
+            "roofline": {"bound": dom.get("bound"), "section": dominant, "kernel": f"{' + '.join(SECTION_KERNELS[dominant])} (section '{dominant}' of the "
                                                               f"step: its {n_dom} launch(es) per step)",
                          "why_this_kernel": "the section with the largest per-step time (median over the 16 steps of the instrumented set-up pass): "
                                             + ", ".join(f"{k} {pre.get(k, float('nan')):.3f} ms" for k in sorted(SECTION_PREV, key=lambda k: -pre.get(k, 0.0))),
@@ -879,7 +945,21 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload)
         if args.sections:
             print(json.dumps(sec, indent=1), file=sys.stderr)
-        print(json.dumps(out))
+        # The whole record (per-kernel tables, trajectory, inference, other workloads, notes) goes to a side file; the
+        # stdout line is the contract's keys only, flat and short (round 4's 22 KB line was not parsed by the driver).
+        detail_path = os.environ.get("TNL_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+        try:
+            os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+            with open(detail_path, "w") as fh:
+                json.dump(out, fh, indent=1)
+            print(f"bench.py: full record -> {detail_path}", file=sys.stderr)
+        except OSError as e:
+            print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+        sys.stderr.flush()
+        line = json.dumps(compact_line(out))
+        assert len(line) < 4096, len(line)
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

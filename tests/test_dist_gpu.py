@@ -433,4 +433,4 @@ def test_bench_two_gpus_over_rccl(cuda):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
         d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-        assert d["n_gpus"] == 2 and d["config"]["collectives"]["backend"] == "nccl" and d["value"] > 0
+        assert d["n_gpus"] == 2 and d["config"]["collectives"] == "nccl x2" and d["value"] > 0

@@ -8,9 +8,9 @@ cd /root/repo
 OUT=/root/repo/gpurun_out/$TAG
 mkdir -p $OUT
 if [ "$WL" = "base" ]; then
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+TNL_BENCH_DETAIL=$OUT/bench_detail.json python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 else
-python bench.py --workload $WL --no-extras --no-cpu-baseline > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
+TNL_BENCH_DETAIL=$OUT/bench_${WL}_detail.json python bench.py --workload $WL --no-extras --no-cpu-baseline > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
 fi
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 /root/repo/bench.py --workload $WL --steps 32 --warmup 16 --no-cpu-baseline --no-extras > $OUT/bench_traced.json 2>/dev/null
