@@ -550,6 +550,8 @@ def compact_line(out):
             "unit": e["unit"], "frac": _num(e["frac"]), "traffic_over_algorithmic": e.get("traffic_over_algorithmic")}
            for e in rf["top"]]
     roofline = {k: _num(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    if roofline["achieved"] is not None and roofline["peak"]:
+        roofline["frac"] = roofline["achieved"] / roofline["peak"]          # exactly A / P of the printed A and P
     roofline.update({"kernel": " + ".join(SECTION_KERNELS[top_section(rf)]), "section": top_section(rf),
                      "launches_per_step": rf["launches_per_step"], "avg_launch_ms": _num(rf["avg_launch_ms"]),
                      "algorithmic_bytes_per_launch": _num(rf["algorithmic_bytes_per_launch"]),
