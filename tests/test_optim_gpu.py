@@ -223,6 +223,65 @@ def test_folded_regulariser_equals_the_materialised_gradient(cuda):
         sb.step(ob)
 
 
+def test_parameters_frozen_by_clear_grad_are_skipped_like_torch_adam_skips_them(cuda):
+    """Trainer.clear_grad() (nerf/utils.py:1105-1114, --min_wavelet_resolution_to_learn > 0) sets .grad = None after
+    backward for the MLP, the LL band and the coarse wavelet levels.  torch.optim.Adam leaves such parameters, their
+    moments and their `step` alone; with fold_l1 the regulariser's term sits in the sink, not in .grad, and must be dropped
+    with it (round 4 stepped every fp32 parameter once any term was folded)."""
+    from trinerflet_amd.optim import FusedAdamL1
+    ma, mb = _tiny_encoder_model(cuda, 5), _tiny_encoder_model(cuda, 5)
+    mb.load_state_dict(ma.state_dict())
+    min_res = 64
+
+    def clear_grad(model):
+        with torch.no_grad():
+            wavelet_grad = [v.grad for v in model.encoder.parameters()]
+            for v in model.parameters():
+                v.grad = None
+            for i, v in enumerate(model.encoder.parameters()):
+                if v.shape[-1] > min_res:
+                    v.grad = wavelet_grad[i]
+    oa = torch.optim.Adam(list(ma.parameters()), lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    ob = FusedAdamL1(list(mb.parameters()), lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    sa, sb = (torch.amp.GradScaler("cuda", init_scale=256.0) for _ in range(2))
+    before = {k: v.detach().clone() for k, v in mb.named_parameters()}
+    for k in range(4):
+        for m, opt, sc in ((ma, oa, sa), (mb, ob, sb)):
+            opt.zero_grad(set_to_none=True)
+            if k == 2:       # one step with everything learnable in between: moments of the later-frozen parameters exist
+                sc.scale(_reg_loss(m.encoder, k) + sum((p ** 2).sum() for p in m.sigma_net.parameters())).backward()
+            else:
+                sc.scale(_reg_loss(m.encoder, k)).backward()
+                clear_grad(m)
+            sc.step(opt)
+            sc.update()
+    frozen = learned = 0
+    for (name, a), (_, b) in zip(ma.named_parameters(), mb.named_parameters()):
+        sta, stb = oa.state.get(a, {}), ob.state.get(b, {})
+        assert float(sta.get("step", 0.0)) == float(stb.get("step", 0.0)), name
+        if float(sta.get("step", 0.0)) <= 1.0:
+            frozen += 1
+        else:
+            learned += 1
+            assert not torch.equal(b.detach(), before[name])
+        x, y = b.detach().cpu().numpy(), a.detach().cpu().numpy()
+        bad = np.abs(x - y) > 3e-5 * np.abs(y) + 3e-7
+        assert bad.mean() < 2e-4, (name, bad.mean())
+        if "exp_avg" in sta:
+            np.testing.assert_allclose(stb["exp_avg"].cpu().numpy(), sta["exp_avg"].cpu().numpy(), rtol=1e-4, atol=1e-8)
+    assert frozen >= 3 and learned >= 1
+    assert not any(s_.used for s_ in ob._sinks.values())
+    # opt-in: a parameter only the regulariser reached (no data gradient at all) is stepped
+    oc = FusedAdamL1(list(mb.encoder.planes_features_wavelet_coefs), lr=1e-2, l1_without_grad=True)
+    oc.zero_grad(set_to_none=True)
+    wf = mb.encoder.get_wavelet_features()
+    sum(v.abs().mean() for v in wf).backward()
+    assert all(p.grad is None for p in mb.encoder.planes_features_wavelet_coefs)
+    ref = [p.detach().clone() for p in mb.encoder.planes_features_wavelet_coefs]
+    oc.step()
+    assert all(not torch.equal(p.detach(), r) for p, r in zip(mb.encoder.planes_features_wavelet_coefs, ref))
+
+
 def test_read_only_inf_check_and_both_gradscaler_hand_overs(cuda):
     """tnl_nonfinite_check at the edges of its partition, and FusedAdamL1.step driven through GradScaler's two contracts
     (the scaler passed as `grad_scaler`; the found_inf / grad_scale attributes) giving the same update."""

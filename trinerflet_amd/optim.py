@@ -20,7 +20,9 @@ backward of `.abs().mean()` (triplane_encoder._AbsMean) only adds its scalar s =
 per-parameter "sink" and returns no gradient; step() hands the sink to the kernel, which adds s * sign(p) to the
 gradient in registers (tnl_adam_l1_step_sink).  Same numbers up to one rounding (g * inv + (s * inv) * sign(p) instead of
 (g + s * sign(p)) * inv).  Only parameters of a live FusedAdamL1 are folded; with any other optimiser the regulariser's
-gradient is materialised as before.  Not compatible with GradScaler.unscale_() before step() (the sink is in scaled
+gradient is materialised as before.  A parameter whose .grad is None at step() is skipped as torch.optim.Adam skips it,
+its folded term dropped (Trainer.clear_grad(), utils.py:1105-1114, freezes levels that way); l1_without_grad=True steps a
+parameter that only the regulariser reached.  Not compatible with GradScaler.unscale_() before step() (the sink is in scaled
 units): step() raises; construct with fold_l1=False for such loops.
 
 GradScaler's inf check: for an optimiser with _step_supports_amp_scaling, GradScaler.step runs
@@ -48,7 +50,16 @@ class _L1Sink:
     def __init__(self, owner, device, n):
         self.owner = weakref.ref(owner)
         self.vec = torch.zeros(n, dtype=torch.float32, device=device)
-        self.used = False
+        self.touched = set()          # indices of the parameters a folded term was added for since the last step
+
+    @property
+    def used(self):
+        return bool(self.touched)
+
+    def clear(self):
+        if self.touched:
+            self.vec.zero_()
+            self.touched.clear()
 
     def add(self, idx, grad_output, numel):
         """Called from the backward of coef.abs().mean(); False if the optimiser is gone (the caller then materialises)."""
@@ -56,7 +67,7 @@ class _L1Sink:
         if opt is None or not opt.fold_l1:
             return False
         self.vec[idx:idx + 1].add_(grad_output.reshape(1).to(torch.float32), alpha=1.0 / numel)
-        self.used = True
+        self.touched.add(idx)
         return True
 
 
@@ -66,7 +77,7 @@ class FusedAdamL1(torch.optim.Optimizer):
     _step_supports_amp_scaling = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, *,
-                 maximize=False, l1=0.0, fold_l1=True):
+                 maximize=False, l1=0.0, fold_l1=True, l1_without_grad=False):
         if amsgrad or maximize:
             raise ValueError("FusedAdamL1: amsgrad / maximize are not built")
         if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
@@ -74,6 +85,7 @@ class FusedAdamL1(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
                         foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False, l1=l1)
         self.fold_l1 = bool(fold_l1)
+        self.l1_without_grad = bool(l1_without_grad)
         self._sinks = {}
         warnings.filterwarnings("ignore", message="GradScaler is going to stop passing itself", category=FutureWarning)
         super().__init__(params, defaults)
@@ -101,9 +113,7 @@ class FusedAdamL1(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none)
         for sink in self._sinks.values():
-            if sink.used:
-                sink.vec.zero_()
-                sink.used = False
+            sink.clear()
 
     def __setstate__(self, state):
         super().__setstate__(state)
@@ -176,12 +186,16 @@ class FusedAdamL1(torch.optim.Optimizer):
             lr = float(lr) if not torch.is_tensor(lr) else float(lr.item())
             for p in group["params"]:
                 sink, sidx = getattr(p, "_tnl_l1_sink", (None, 0))
-                if sink is not None and not (sink.used and sink.owner() is self):
+                if sink is not None and not (sidx in sink.touched and sink.owner() is self):
                     sink = None
                 if p.grad is None:
-                    if sink is None:
+                    # torch.optim.Adam skips a parameter without a gradient, and so does this pass -- its folded L1 term
+                    # included: the reference's Trainer.clear_grad() (nerf/utils.py:1105-1114) freezes coarse levels by
+                    # setting .grad = None AFTER backward, and the term sitting in the sink must not outlive that.  A
+                    # parameter that only the regulariser reaches is stepped when asked for (l1_without_grad=True).
+                    if sink is None or not self.l1_without_grad:
                         continue
-                    p.grad = torch.zeros_like(p)      # regulariser only (no data gradient reached this parameter)
+                    p.grad = torch.zeros_like(p)
                 g = p.grad
                 if g.is_sparse or p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
                     raise ValueError("FusedAdamL1: dense contiguous fp32 device parameters only")
@@ -210,9 +224,7 @@ class FusedAdamL1(torch.optim.Optimizer):
         if steps:
             torch._foreach_add_(steps, 1.0 - found_inf.reshape(()).to(torch.float32))
         for sink in self._sinks.values():
-            if sink.used:
-                sink.vec.zero_()
-                sink.used = False
+            sink.clear()
         return loss
 
 
