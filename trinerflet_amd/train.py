@@ -434,6 +434,8 @@ class TrainStep:
         written into the persistent texel-major array; the encoder's own plane cache is dropped."""
         enc = self.enc
         fast = (self.J > 0 and enc.plane_dtype == torch.float16 and self.C % 8 == 0 and self.R % 16 == 0)
+        if self._roi_request is not None:       # a refresh step that did not reach its backward (it raised): take its window now
+            self._roi = self._finish_roi()
         roi = roi and self._roi is not None and self._tm_full is not None
         if not roi:
             self.flush_deferred()     # whole planes read every coefficient
@@ -755,6 +757,8 @@ class TrainStep:
 
     def _stage_planes(self, st):
         model = self.model
+        if self._roi_request is not None:       # see rebuild_planes: never run a step on the window of the previous grid
+            self._roi = self._finish_roi()
         if self._pending and (st.refresh or not self._roi_valid):
             self.flush_deferred()
             self._mark("adam_catchup")
