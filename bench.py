@@ -595,9 +595,13 @@ def main():
                     help="weak: every rank its own 60 000 rays per step; strong: the 60 000 rays of a step split over the ranks")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary figures (whole-plane / fp32-plane step times, inference, live PMC traffic)")
+    ap.add_argument("--single-rank-collectives", action="store_true",
+                    help="one GPU, but the N-GPU code path: a process group of ONE rank over --backend and "
+                         "TrainStep(single_rank_collectives=True) -- every collective of the sharded step is issued (RCCL "
+                         "kernels on its own stream); what the exchange's launches cost without any wire")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # a rocprofv3 --pmc pass of pmc_traffic_live
     args = ap.parse_args()
-    if args.pmc_child:
+    if args.pmc_child or args.single_rank_collectives:
         args.no_extras = args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -616,6 +620,14 @@ def main():
         else:
             dist.init_process_group("gloo")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    lone = world == 1 and args.single_rank_collectives
+    if lone:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        kw = {"device_id": device} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
 
     from trinerflet_amd import build as tbuild
     from trinerflet_amd import _lib
@@ -627,7 +639,8 @@ def main():
 
     global GRAPH
     GRAPH = world == 1 and args.graph
-    model, ts, bitfield, N = build(args.workload, device, args.dist_mode if world > 1 else None)
+    model, ts, bitfield, N = build(args.workload, device, args.dist_mode if (world > 1 or lone) else None,
+                                   **({"single_rank_collectives": True} if lone else {}))
     if os.environ.get("TNL_CLIP_FAR"):      # A/B: the in-order march of refresh steps clipped to the occupied box (default on)
         ts.clip_far_in_order = os.environ["TNL_CLIP_FAR"] != "0"
     n_global = N * world
@@ -886,8 +899,8 @@ def main():
                                    f"fp16 planes + fp16 MFMA MLP, fp32 masters, Adam+L1",
                        "rays_per_step_per_gpu": N, "rays_per_step_global": n_global,
                        "samples_per_step_per_gpu": samples_per_step,
-                       "sample_budget_M": mean_count, "parallelism": f"ray-dp{world}" + (f"+{args.dist_mode}" if world > 1 else ""),
-                       "collectives": None if world == 1 else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                       "sample_budget_M": mean_count, "parallelism": f"ray-dp{world}" + (f"+{args.dist_mode}" if (world > 1 or lone) else ""),
+                       "collectives": None if (world == 1 and not lone) else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                                                "bytes_on_the_wire": wire},
                        "samples_per_sec": samples_per_step * world * args.steps / elapsed,
                        "ms_per_step_over_whole_periods": round(whole_periods_ms, 4),
@@ -962,7 +975,7 @@ def main():
         assert len(line) < 4096, len(line)
         sys.stdout.write(line + "\n")
         sys.stdout.flush()
-    if world > 1:
+    if world > 1 or lone:
         dist.destroy_process_group()
 
 

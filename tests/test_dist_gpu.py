@@ -132,6 +132,42 @@ def test_two_ranks_equal_one(cuda, mode):
         assert frac < 5e-3, (k, frac)
 
 
+# ---- Trainer.test(): the rows of every pose striped over the ranks + one all-gather per image (utils.py:1269-1289)
+def _test_frames(world, rank, pg=None):
+    from trinerflet_amd.raypool import RayPool
+    from trinerflet_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    m = _build(dev)
+    with torch.no_grad():                       # an opaque-enough field: the frames are not a flat background
+        m.sigma_net[-1].weight.mul_(4.0)
+    hh, ww = 37, 40                             # 37 rows over 2 ranks: a ragged last stripe
+    poses, intr, images = synthetic.sphere_dataset(3, hh, ww, seed=1)
+    pool = RayPool(poses, intr, hh, ww, images, device=dev)
+    tr = Trainer("t", m, workspace=None, num_rays=512, fp16=True, dist_mode="sharded" if world > 1 else None,
+                 process_group=pg, max_steps=256)
+    assert tr.world == world and tr.rank == rank
+    return tr.test(pool)
+
+
+def _test_frames_worker(rank, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    try:
+        torch.cuda.set_device(0)
+        out[rank] = _test_frames(2, rank)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_striped_test_render_equals_the_one_rank_frames(cuda):
+    ref = _test_frames(1, 0)
+    assert ref.shape == (3, 37, 40, 3) and ref.dtype == np.uint8 and ref.std() > 5
+    mgr = _manager()
+    out = mgr.dict()
+    mp.spawn(_test_frames_worker, args=(_free_port(), out), nprocs=2, join=True)
+    assert np.array_equal(out[0], ref) and np.array_equal(out[1], ref)
+
+
 # ---- the occupancy window / gradient-support chain under rank sharding (R = 256: window and rectangles are active)
 def _build_roi(dev, R=256):
     from trinerflet_amd.nerf.network import NeRFNetwork
@@ -352,6 +388,74 @@ def test_sharded_full_checkpoint_resume(cuda, tmp_path):
     # re-marks the untrained cells; so the comparison is on what training reached.
     np.testing.assert_allclose(res["resumed"][0], res["straight"][0], rtol=2e-2)
     assert abs(res["straight"][1] - res["resumed"][1]) < 0.5
+
+
+# ---- RCCL on the ONE GPU a box has: a process group of a single rank.  distributed.FORCE_COLLECTIVES (set by
+# TrainStep(single_rank_collectives=True)) makes the lone rank issue every collective instead of returning its input, so
+# the `_native` branches of trinerflet_amd/distributed.py -- reduce_scatter_tensor, all_gather_into_tensor, async_op=True +
+# work.wait, all_reduce -- and the sharded TrainStep's call sequence run over RCCL for real (ncclCommInitRank, RCCL's
+# kernels on its own stream, the event hand-overs of overlap_exchange), which no gloo test does.
+def _rccl_one_rank_worker(_, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from trinerflet_amd import distributed as D
+        from trinerflet_amd.train import TrainStep
+        assert D._native(None)
+        D.FORCE_COLLECTIVES = True
+        S, R = 12, 64
+        full = torch.randn(S, R, R, generator=torch.Generator().manual_seed(5)).to(dev)
+        mine = D.reduce_scatter_slices(full)
+        assert mine.data_ptr() != full.data_ptr() and torch.equal(mine, full)            # a real collective's output
+        part, wait = D.reduce_scatter_slices_async(full * 2)
+        wait()
+        assert torch.equal(part, full * 2)
+        g = D.all_gather_slices(mine.half())
+        assert g.data_ptr() != mine.data_ptr() and torch.equal(g, full.half())
+        t = torch.full((3,), 2.0, device=dev)
+        assert torch.equal(D.all_reduce_(t).cpu(), torch.full((3,), 2.0))
+        D.FORCE_COLLECTIVES = False
+
+        # the sharded step with the banded exchange over RCCL == the plain one-process step, to the bit
+        o, d = synthetic.training_rays(2048, n_cams=4, seed=7)
+        gt = synthetic.target_colors(d)
+        noise = np.random.default_rng(0).random(2048).astype(np.float32)
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        res = []
+        for kw in ({}, {"dist_mode": "sharded", "overlap_exchange": 3, "single_rank_collectives": True},
+                   {"dist_mode": "allreduce", "single_rank_collectives": True}):
+            torch.manual_seed(0)
+            m = _build_roi(dev, 256)
+            bf = m.density_bitfield.clone()
+            ts = TrainStep(m, lr=1e-2, wavelet_regularization=LAM, iters=1000, fp16=True, update_extra_interval=4,
+                           deterministic=True, **kw)
+            assert ts.multi == bool(kw) and ts.world == 1 and ts.dist_mode == kw.get("dist_mode")
+            ts.post_refresh = lambda m=m, bf=bf: m.density_bitfield.copy_(bf)
+            losses = [float(ts.step(tt(o), tt(d), tt(gt), noises=tt(noise), n_global_rays=2048)) for _ in range(6)]
+            if kw.get("overlap_exchange"):
+                assert len(ts._exchange_bands(ts._roi)) == 3
+            ts.sync_sharded_parameters(moments=True)
+            res.append((losses, {k: v.detach().cpu().numpy() for k, v in m.named_parameters()},
+                        ts.coef.m.detach().cpu().numpy()))
+            D.FORCE_COLLECTIVES = False
+        out[0] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_single_rank_group_runs_the_native_collectives_and_the_sharded_step(cuda):
+    mgr = _manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_one_rank_worker, args=(_free_port(), out), nprocs=1, join=True)
+    plain, sharded, allred = out[0]
+    for other in (sharded, allred):
+        np.testing.assert_allclose(other[0], plain[0], rtol=2e-6)        # (the reported MSE / L1 value are float-atomic sums)
+        for k in plain[1]:
+            assert np.array_equal(other[1][k], plain[1][k]), k
+        assert np.array_equal(other[2], plain[2])
 
 
 # ---- RCCL (backend "nccl"), one process per GPU: only on a box that has at least two (the driver's 8-GPU node; the

@@ -11,6 +11,15 @@ import torch
 import torch.distributed as dist
 
 
+# True: a process group of one rank still issues every collective (TrainStep(single_rank_collectives=True): the RCCL
+# calls of the N-GPU step executed on a one-GPU box); False: a lone rank returns its input untouched
+FORCE_COLLECTIVES = False
+
+
+def _alone(world):
+    return world == 1 and not (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+
+
 def world_rank(pg=None):
     if not dist.is_available() or not dist.is_initialized():
         return 1, 0
@@ -40,7 +49,7 @@ def _native(pg):
 def reduce_scatter_slices(full, pg=None):
     """full: [S, ...] on every rank -> sum over ranks of the caller's block [S/G, ...]."""
     world, rank = world_rank(pg)
-    if world == 1:
+    if _alone(world):
         return full
     s0, s1 = slice_range(full.shape[0], world, rank)
     if _native(pg):
@@ -57,7 +66,7 @@ def reduce_scatter_slices_async(full, pg=None):
     group's own stream behind the work already queued on the CURRENT stream -- and wait() makes the stream current at
     that time wait for it.  gloo (the CPU-testable transport) completes inside this call; wait() is then a no-op."""
     world, rank = world_rank(pg)
-    if world == 1:
+    if _alone(world):
         return full, (lambda: None)
     if _native(pg):
         s0, s1 = slice_range(full.shape[0], world, rank)
@@ -70,7 +79,7 @@ def reduce_scatter_slices_async(full, pg=None):
 def all_gather_slices(mine, pg=None):
     """mine: [S/G, ...] -> [S, ...] in rank order."""
     world, _ = world_rank(pg)
-    if world == 1:
+    if _alone(world):
         return mine
     mine = mine.contiguous()
     if _native(pg):
@@ -84,6 +93,6 @@ def all_gather_slices(mine, pg=None):
 
 def all_reduce_(t, pg=None, op=None):
     world, _ = world_rank(pg)
-    if world > 1:
+    if not _alone(world):
         dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=pg)
     return t

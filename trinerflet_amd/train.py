@@ -158,7 +158,7 @@ class TrainStep:
     def __init__(self, model, lr=1e-2, wavelet_regularization=0.4, iters=30000, warmup_steps=0,
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
-                 dist_mode=None, process_group=None, binned=True, fuse_adam=False, use_roi=True, tune_placement=None,
+                 dist_mode=None, process_group=None, single_rank_collectives=False, binned=True, fuse_adam=False, use_roi=True, tune_placement=None,
                  defer_adam=None, deterministic=False, live_bands=True, overlap_exchange=0, graph=False):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
@@ -301,10 +301,16 @@ class TrainStep:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist_mode and dist.is_initialized()) else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
-        self.dist_mode = dist_mode if self.world > 1 else None
+        # multi: the distributed code path is the one that runs.  single_rank_collectives=True takes it in a process group
+        # of ONE rank as well (every collective issued, on RCCL each a real reduce_scatter_tensor / all_gather_into_tensor /
+        # all_reduce over the group): the way to execute the 8-GPU call sequence on a one-GPU box (tests/test_dist_gpu.py)
+        self.multi = self.world > 1 or bool(single_rank_collectives and dist_mode and dist.is_initialized())
+        if self.multi and self.world == 1:
+            D.FORCE_COLLECTIVES = True
+        self.dist_mode = dist_mode if self.multi else None
         if self.dist_mode == "sharded":
             assert (3 * self.C) % self.world == 0, "3*channels must be divisible by the world size"
-        if self.world > 1:
+        if self.multi:
             # the density-grid refresh splits the 128^3 cells (and the H^3/4 picks of a partial refresh) evenly over
             # the ranks before an all-gather of equal shards (renderer.update_extra_state)
             g3 = model.grid_size ** 3
@@ -767,7 +773,7 @@ class TrainStep:
         st.tm = self.rebuild_planes(roi=self.use_roi and not st.refresh)
         self._mark("idwt_fwd")
         if st.refresh:
-            if self.world > 1:
+            if self.multi:
                 # every rank evaluates 1/world of the candidate cells; the all-gather keeps the replicas' grids (hence
                 # bitfield, occupancy window and collective sizes) bit-identical
                 model.update_extra_state(shard=(self.rank, self.world, lambda t: D.all_gather_slices(t, self.pg)))
@@ -898,16 +904,16 @@ class TrainStep:
                                          nonfinite_flag=self.nonfinite, roi=sub + [C, 0])
                     self._comm.wait_stream(main)
                     with torch.cuda.stream(self._comm):
-                        part, wait = D.reduce_scatter_slices_async(buf, self.pg if self.world > 1 else None)
+                        part, wait = D.reduce_scatter_slices_async(buf, self.pg if self.multi else None)
                     buf.record_stream(self._comm)
                     parts.append(part)
                     waits.append(wait)
                 for w in waits:
                     w()
                 main.wait_stream(self._comm)
-                s0, s1 = self._slice_range() if self.world > 1 else (0, 3 * C)
-                st.g_cm = torch.cat([p_[: s1 - s0] if self.world == 1 else p_ for p_ in parts], dim=1)   # [S/G, rh, rw]
-                st.scattered = self.world > 1
+                s0, s1 = self._slice_range() if self.multi else (0, 3 * C)
+                st.g_cm = torch.cat([p_[: s1 - s0] if not self.multi else p_ for p_ in parts], dim=1)   # [S/G, rh, rw]
+                st.scattered = self.multi
             self._mark("plane_grad_binned")
             st.grad_tm = None
         else:
@@ -923,7 +929,7 @@ class TrainStep:
         lr_t = self.lr * lr_factor(self.global_step, self.iters, self.warmup)
         l1 = self.lam / (self.J * self.coef_numel) if (self.J > 0 and self.lam > 0) else 0.0
         inv_scale = self.inv_scale
-        if self.world > 1:
+        if self.multi:
             dist.all_reduce(self.mlp.grad, group=self.pg)
         if st.g_cm is not None:
             # GradScaler probe BEFORE the dense backward, so that the optimiser can be fused into it: the plane
@@ -974,7 +980,7 @@ class TrainStep:
                                       L.ptr(reg), L.stream()), "step_epilogue")
         self.global_step += 1
         self._stale_params = self._stale_moments = True    # "sharded" mode: see sync_sharded_parameters
-        if self.world > 1:
+        if self.multi:
             mse = st.mse_local.clone()
             dist.all_reduce(mse, group=self.pg)
             if self.dist_mode == "sharded":
@@ -997,7 +1003,7 @@ class TrainStep:
         at hand and the following batch announced."""
         j = self._graph_position()
         model = self.model
-        if (self.world != 1 or not (1 <= j <= min(self.update_extra_interval, 16) - 2) or st.refresh or self.section_events is not None
+        if (self.multi or not (1 <= j <= min(self.update_extra_interval, 16) - 2) or st.refresh or self.section_events is not None
                 or not (self.binned and self.use_roi and self.defer_adam and self._rect_ok and self.overlap_march)
                 or self.fuse_adam or self.overlap_exchange > 1 or self._roi is None or not self._roi_valid
                 or self._roi_request is not None or self._rects_roi is not self._roi or self._live is None
@@ -1146,7 +1152,7 @@ class TrainStep:
         K > 1, an occupancy window, the slice-sharded mode (or a single process, where only the banded reduction's own
         cost shows: the measurement of DESIGN.md section 5), not the Adam-fused adjoint."""
         K = self.overlap_exchange
-        if K <= 1 or roi is None or self.fuse_adam or (self.world > 1 and self.dist_mode != "sharded"):
+        if K <= 1 or roi is None or self.fuse_adam or (self.multi and self.dist_mode != "sharded"):
             return None
         n64 = roi[7] // 64
         K = min(K, n64)
@@ -1210,7 +1216,7 @@ class TrainStep:
         found = torch.empty(1, dtype=torch.float32, device=self.dev)
         L.check(L.lib().tnl_scaler_probe(L.ptr(g0), L.u32(g0.numel()), L.ptr(g1), L.u32(0 if g1 is None else g1.numel()),
                                          L.ptr(flag), L.ptr(probe), L.ptr(found), L.stream()), "scaler_probe")
-        if self.world > 1:
+        if self.multi:
             dist.all_reduce(probe, group=self.pg)
             return (~torch.isfinite(probe)).to(torch.float32)
         return found
@@ -1433,7 +1439,7 @@ class TrainStep:
         self.flush_deferred()
         out = self.deferred_reg.clone()
         self.deferred_reg.zero_()
-        if self.world > 1 and self.dist_mode == "sharded":
+        if self.multi and self.dist_mode == "sharded":
             dist.all_reduce(out, group=self.pg)
         return out
 

@@ -32,6 +32,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import distributed as D
 from .train import TrainStep, lr_factor
 
 
@@ -199,8 +200,11 @@ class Trainer:
     # evaluation (utils.py:681-735 eval_step / test_step, :1229-1388 evaluate_one_epoch / test)
     # ----------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def render_image(self, pool, index, max_steps=None, perturb=False):
-        """All rays of one pose through the renderer's inference branch -> (pred [H,W,3], depth [H,W], gt or None)."""
+    def render_image(self, pool, index, max_steps=None, perturb=False, rows=None):
+        """All rays of one pose through the renderer's inference branch -> (pred [H,W,3], depth [H,W], gt or None).
+        rows (LongTensor of image rows on the device): only those rows are rendered -> ([len(rows),W,3], [len(rows),W],
+        gt rows); every ray is marched, evaluated and composited on its own, so a row's pixels do not depend on which
+        other rows share the launch (test(): rows striped over the ranks)."""
         model = self.model
         was_training = model.training
         model.eval()
@@ -208,11 +212,15 @@ class Trainer:
         #                                       evaluate_one_epoch / test call this on all ranks before striping)
         self.model.encoder.reset_cahce()      # the training loop only refreshes the occupancy window of the planes
         data = pool.image_rays(index, bg_color=self.background_color)
+        H, W = pool.H, pool.W
+        if rows is not None:
+            sel = lambda t: None if t is None else t.reshape(H, W, -1).index_select(0, rows).reshape(-1, t.shape[-1])
+            data = {"rays_o": sel(data["rays_o"]), "rays_d": sel(data["rays_d"]), "gt_rgb": sel(data["gt_rgb"])}
+            H = int(rows.numel())
         out = model.render(data["rays_o"].unsqueeze(0), data["rays_d"].unsqueeze(0), staged=True,
                            bg_color=self.background_color, perturb=perturb, dt_gamma=self.dt_gamma,
                            max_steps=max_steps or self.max_steps,
                            **({"infer_min_step": self.infer_min_step} if self.infer_min_step != 1 else {}))
-        H, W = pool.H, pool.W
         pred = out["image"].reshape(H, W, 3)
         depth = out["depth"].reshape(H, W)
         gt = data["gt_rgb"].reshape(H, W, 3) if data["gt_rgb"] is not None else None
@@ -243,13 +251,24 @@ class Trainer:
     evaluate = evaluate_one_epoch
 
     def test(self, pool, save_path=None, max_steps=None):
-        """Render every pose (test_step); returns [B,H,W,3] uint8 on the host and, if a path is given, writes
-        binary PPMs there (the reference writes PNG + MP4 through cv2 / imageio, which this build does not carry)."""
+        """Render every pose (test_step); returns [B,H,W,3] uint8 on the host (on every rank) and, if a path is given,
+        rank 0 writes binary PPMs there (the reference writes PNG + MP4 through cv2 / imageio, which this build does not
+        carry).  Multi-GPU (the live form of the all_gather at reconstruction/nerf/utils.py:1269-1289): the ROWS of each
+        image are striped over the ranks -- rank r renders rows r, r + G, r + 2G, ...: balanced whatever the image shows,
+        and it also splits a single pose -- and one all-gather per image of the uint8 rows puts the frame together; the
+        pixels are those of the one-rank render bit for bit (tests/test_dist_gpu.py)."""
         frames = []
         self.ts.sync_sharded_parameters()
+        H, W, G = pool.H, pool.W, self.world
+        per = -(-H // G)                                    # rows per rank (the last stripes of a ragged H are padding)
+        mine = (torch.arange(per, device=self.device) * G + self.rank).clamp_(max=H - 1) if G > 1 else None
         for i in range(pool.B):
-            pred, _, _ = self.render_image(pool, i, max_steps=max_steps)
-            frames.append((pred.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy())
+            pred, _, _ = self.render_image(pool, i, max_steps=max_steps, rows=mine)
+            u8 = (pred.clamp(0, 1) * 255).to(torch.uint8)
+            if G > 1:
+                allr = D.all_gather_slices(u8.unsqueeze(0), self.pg)            # [G, per, W, 3] in rank order
+                u8 = allr.permute(1, 0, 2, 3).reshape(per * G, W, 3)[:H]       # row j*G + r <- (r, j)
+            frames.append(u8.cpu().numpy())
         frames = np.stack(frames)
         if save_path is not None and self.rank == 0:
             os.makedirs(save_path, exist_ok=True)
