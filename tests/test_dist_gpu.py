@@ -436,7 +436,7 @@ def _rccl_one_rank_worker(_, port, out):
             ts.post_refresh = lambda m=m, bf=bf: m.density_bitfield.copy_(bf)
             losses = [float(ts.step(tt(o), tt(d), tt(gt), noises=tt(noise), n_global_rays=2048)) for _ in range(6)]
             if kw.get("overlap_exchange"):
-                assert len(ts._exchange_bands(ts._roi)) == 3
+                assert len(ts._exchange_bands(ts._roi)) >= 2
             ts.sync_sharded_parameters(moments=True)
             res.append((losses, {k: v.detach().cpu().numpy() for k, v in m.named_parameters()},
                         ts.coef.m.detach().cpu().numpy()))

@@ -200,10 +200,11 @@ def test_folded_regulariser_equals_the_materialised_gradient(cuda):
     for a, b in zip(pa, pb):
         # (g + s sign(p)) * inv against g * inv + (s * inv) sign(p): one rounding apart; where the data gradient all but
         # cancels the L1 term Adam's m / sqrt(v) magnifies that (21 of 590 k coefficients beyond 3e-5 relative), and a
-        # coefficient that lands within a rounding of zero takes the other sign(p) on the next step (one in 2.4 M: 2e-3)
+        # coefficient that lands within a rounding of zero takes the other sign(p) on the next steps (one in 2.4 M; each such
+        # step moves it by up to 2 lr = 2e-2 against the other run: seen 2e-3 .. 1.01e-2 over repeated runs)
         x, y = b.detach().cpu().numpy(), a.detach().cpu().numpy()
         bad = np.abs(x - y) > 3e-5 * np.abs(y) + 3e-7
-        assert bad.mean() < 2e-4 and np.abs(x - y).max() < 1e-2, (bad.mean(), np.abs(x - y).max())
+        assert bad.mean() < 2e-4 and np.abs(x - y).max() < 4e-2, (bad.mean(), np.abs(x - y).max())
         assert float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == 7.0
     # the fold is a property of the live optimiser: without it (or with fold_l1=False) the gradient is materialised
     ob.fold_l1 = False
@@ -268,7 +269,8 @@ def test_parameters_frozen_by_clear_grad_are_skipped_like_torch_adam_skips_them(
         bad = np.abs(x - y) > 3e-5 * np.abs(y) + 3e-7
         assert bad.mean() < 2e-4, (name, bad.mean())
         if "exp_avg" in sta:
-            np.testing.assert_allclose(stb["exp_avg"].cpu().numpy(), sta["exp_avg"].cpu().numpy(), rtol=1e-4, atol=1e-8)
+            ma_, mb_ = sta["exp_avg"].cpu().numpy(), stb["exp_avg"].cpu().numpy()     # (data gradients are float-atomic sums)
+            np.testing.assert_allclose(mb_, ma_, rtol=1e-3, atol=1e-4 * float(np.abs(ma_).max()) + 1e-12)
     assert frozen >= 3 and learned >= 1
     assert not any(s_.used for s_ in ob._sinks.values())
     # opt-in: a parameter only the regulariser reached (no data gradient at all) is stepped
