@@ -3,7 +3,7 @@ sys.path.insert(0, '/root/repo')
 import trinerflet_amd._lib as L
 from trinerflet_amd import raymarching, synthetic
 lib = L.lib(); dev = torch.device('cuda:0')
-for (bound, Cc, Hg, N) in ((1.0, 1, 128, 61440), (2.0, 2, 128, 61440)):
+for (bound, Cc, Hg, N) in ((1.0, 1, 128, 61440), (2.0, 2, 128, 61440), (1.5, 2, 128, 60000)):   # the last: the base workload's
     max_steps = 1024
     rng = np.random.default_rng(11)
     poses = synthetic.hemisphere_poses(100, seed=2)
@@ -16,7 +16,7 @@ for (bound, Cc, Hg, N) in ((1.0, 1, 128, 61440), (2.0, 2, 128, 61440)):
     noise = torch.from_numpy(rng.random(N).astype(np.float32)).to(dev)
     nws = lib.tnl_march_rays_train_workspace_rec(L.u32(N), L.u32(max_steps))
     ws = torch.empty(nws, dtype=torch.int32, device=dev)
-    M = 4_000_000
+    M = 6_000_000
     xyzs, dirs, deltas = torch.empty(M, 3, device=dev), torch.empty(M, 3, device=dev), torch.empty(M, 2, device=dev)
     rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
     counter = torch.zeros(2, dtype=torch.int32, device=dev)

@@ -141,13 +141,20 @@ __device__ __forceinline__ MarchProbe march_probe(const MarchCtx& m, float tt_, 
   return q;
 }
 
-// an empty cell: jump to the first chain point behind its exit
-__device__ __forceinline__ void march_skip(const MarchCtx& m, const MarchProbe& q, float& t) {
+// an empty cell probed at t: the t behind its exit (raymarching.cu:386-392) -- the march resumes at the first chain
+// point that is not below it
+__device__ __forceinline__ float march_skip_target(const MarchCtx& m, const MarchProbe& q, float t) {
 #pragma clang fp contract(off)
   const float tx = fmaf(((float)q.nx + 0.5f + 0.5f * signf_(m.dx)) * m.rH * 2 - 1, q.mip_bound, -q.x) * m.rdx;
   const float ty = fmaf(((float)q.ny + 0.5f + 0.5f * signf_(m.dy)) * m.rH * 2 - 1, q.mip_bound, -q.y) * m.rdy;
   const float tz = fmaf(((float)q.nz + 0.5f + 0.5f * signf_(m.dz)) * m.rH * 2 - 1, q.mip_bound, -q.z) * m.rdz;
-  const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+  return t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+}
+
+// an empty cell: jump to the first chain point behind its exit
+__device__ __forceinline__ void march_skip(const MarchCtx& m, const MarchProbe& q, float& t) {
+#pragma clang fp contract(off)
+  const float tt = march_skip_target(m, q, t);
   if (m.fast) {
     do { t += m.dt0; } while (t < tt);
   } else {

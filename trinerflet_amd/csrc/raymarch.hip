@@ -194,6 +194,9 @@ __global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thr
 // training march: count -> (block sums) -> scan + write -> finalize
 // ---------------------------------------------------------------------------------------------
 constexpr int MARCH_BLOCK = 256;
+#ifndef TNL_MARCH_WAVE
+#define TNL_MARCH_WAVE 1     // 0: the per-lane count pass everywhere (A/B builds)
+#endif
 
 __device__ __forceinline__ int wave_incl_scan_add_i(int v, int lane) {
 #pragma unroll
@@ -242,6 +245,193 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
   }
   int total;
   block_excl_scan_256(ns, smem4, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Count pass, ONE WAVEFRONT PER RAY (round 5).  k_march_train_count above walks a ray on one lane: a serial chain of
+// ~60-instruction dependent probes per visited point, 789 us at base with 0.9 waves per SIMD.  With dt_gamma = 0 (every
+// README configuration: MarchCtx::fast) the points a ray can visit are a fixed CHAIN t_0, t_1 = fl(t_0 + dt), t_2 = ...
+// that does not depend on the occupancy: an occupied point steps to the next chain point, an empty one to the first
+// chain point not below its cell's exit (march_skip: `do t += dt while (t < tt)`).  So the 64 lanes take 64 CONSECUTIVE
+// chain points: every lane probes its point (position -> cell -> bit) and, where the cell is empty, finds the chain index
+// the march would resume at; the visit order is then resolved by a scalar pointer chase over the wave's masks -- a whole
+// run of occupied points is one hop (count trailing ones of the ballot), an empty point one v_readlane.  Which points
+// are probed does not change a result: the samples are exactly the occupied chain points the serial march visits.
+//
+// The chain itself is a serial float accumulation.  Inside one binade [2^e, 2^(e+1)) it is an exact arithmetic
+// progression: every t there is a multiple of u = 2^(e-23), so fl(t + dt) = t + qu with qu = rn(dt / u) u whenever dt / u
+// is not a tie -- qu is measured with one real add (fl(T0 + dt) - T0, exact) and the tie excluded by |dt - qu| != u / 2
+// (exact).  A chunk whose 64 points stay in T0's binade (and whose 63 qu is exact) is lane j: T0 + j qu; any other chunk
+// (two per ray: t crosses 2 and 4) runs the 64 dependent adds on every lane.  The next chunk's base is always the real
+// add t_63 + dt.  Bit-identical counts and records (tests/test_raymarching_gpu.py::test_march_60k_rays_bit_exact).
+// ---------------------------------------------------------------------------------------------
+template <bool REC>
+__global__ void __launch_bounds__(MARCH_BLOCK)
+k_march_train_count_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                         const uint8_t* __restrict__ grid, float bound, uint32_t max_steps, uint32_t N, uint32_t C,
+                         uint32_t H, const float* __restrict__ nears, const float* __restrict__ fars,
+                         const float* __restrict__ noises, int* __restrict__ num_steps_out, float* __restrict__ tbuf) {
+#pragma clang fp contract(off)
+  __shared__ float s_t[MARCH_BLOCK];        // the chunk's chain points, per wave (read by the same wave only)
+  __shared__ uint32_t s_lut[256];            // expand_bits(i): the Morton code of a cell is three look-ups (H <= 256)
+  s_lut[threadIdx.x] = expand_bits(threadIdx.x);
+  __syncthreads();
+  // the ray index is wave-uniform BY CONSTRUCTION (readfirstlane): the ray's constants are scalar loads and the whole
+  // visit-order chase below compiles to scalar code (left to its divergence analysis the compiler kept the chase index in
+  // a vector register and ran every hop under saved exec masks: ~60 vector instructions per hop, 683 us at base)
+  const uint32_t n = blockIdx.x * (MARCH_BLOCK / WAVE) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const int lane = threadIdx.x % WAVE;
+  if (n >= N) return;
+  MarchCtx m;
+  march_init(m, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, 0.f, max_steps, C, H, grid);
+  const float dt = m.dt0, far = fars[n];
+  float T0 = nears[n];
+  T0 = fmaf(clampf_(T0 * 0.f, m.dt_min, m.dt_max), noises[n], T0);   // dt_gamma = 0 (k_march_train_count's expression)
+  const int limit = (int)max_steps;
+  int count = 0;
+  float pend = -__builtin_inff();          // a skip that left the previous chunk: resume at the first t >= pend
+  float* trec = REC ? tbuf + (size_t)n * max_steps : nullptr;
+  const float flane = (float)lane;
+  // march_probe / march_skip_target of the fast path (dt_gamma = 0, <= 2 cascades) with the per-ray constants hoisted and
+  // the exact-by-construction steps folded -- the same values bit for bit:
+  //   0.5f * a * Hf == a * (0.5f * Hf) and v * rH * 2 == v * (2 rH) (a scaling by two commutes with the rounding),
+  //   (float)nx + 0.5f + 0.5f * sign(d) == (float)(nx + (d is not negative)) (small integers and halves are exact),
+  //   (uint32_t)((float)level * H3) == level ? H^3 : 0
+  const float hH = 0.5f * m.Hf, rH2 = m.rH * 2, hmax = (float)(m.H - 1);
+  const int incx = __float_as_uint(m.dx) >> 31 ? 0 : 1, incy = __float_as_uint(m.dy) >> 31 ? 0 : 1,
+            incz = __float_as_uint(m.dz) >> 31 ? 0 : 1;
+  const uint32_t H3u = H * H * H;
+  const bool lut = H <= 256;
+  const unsigned long long* grid64 = reinterpret_cast<const unsigned long long*>(grid);
+  auto uni = [](float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); };
+  while (true) {
+    // the ray's running state is wave-uniform; saying so (readfirstlane) keeps it in scalar registers and the loops below
+    // scalar branches
+    T0 = uni(T0);
+    pend = uni(pend);
+    count = __builtin_amdgcn_readfirstlane(count);
+    if (!(T0 < far && count < limit)) break;
+    // ---- this lane's chain point
+    float tj;
+    const uint32_t eb = __float_as_uint(T0) & 0x7f800000u;                    // T0 > 0: its exponent field
+    const float T1 = T0 + dt;
+    const float qu = T1 - T0;
+    const float uh = __uint_as_float(eb - (24u << 23));                      // u / 2
+    const float top = __uint_as_float(eb + (1u << 23));                      // 2^(e+1)
+    const float p63 = 63.0f * qu;
+    const float ru = __uint_as_float((277u << 23) - eb);                       // 1 / u (eb > 30 << 23 below)
+    const bool closed = __builtin_amdgcn_readfirstlane((int)(eb > (30u << 23) && (__float_as_uint(T1) & 0x7f800000u) == eb && fabsf(dt - qu) != uh &&
+                        63.0f * (qu * ru) < 16777216.0f && T0 + p63 < top)) != 0;
+    const float rqu = __builtin_amdgcn_rcpf(qu);        // for the index guess only
+    float tlast;
+    if (closed) {       // wave-uniform
+      tj = T0 + flane * qu;
+      tlast = T0 + p63;
+    } else {
+      float acc = T0;
+      tj = T0;
+      for (int i = 1; i < WAVE; i++) {
+        acc += dt;
+        if (lane == i) tj = acc;
+      }
+      tlast = acc;
+    }
+    const float Tnext = tlast + dt;
+    // ---- probe it
+    const bool valid = tj < far;
+    const float px = clampf_(fmaf(tj, m.dx, m.ox), -m.bound, m.bound);
+    const float py = clampf_(fmaf(tj, m.dy, m.oy), -m.bound, m.bound);
+    const float pz = clampf_(fmaf(tj, m.dz, m.oz), -m.bound, m.bound);
+    const bool lv1 = (m.two_levels && fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))) >= 1.0f) || m.level_dt0 > 0;
+    const float mipb = lv1 ? m.mb1 : m.mb0, rb = lv1 ? m.rb1 : m.rb0;
+    const int nx = (int)clampf_(fmaf(px, rb, 1.0f) * hH, 0.0f, hmax);
+    const int ny = (int)clampf_(fmaf(py, rb, 1.0f) * hH, 0.0f, hmax);
+    const int nz = (int)clampf_(fmaf(pz, rb, 1.0f) * hH, 0.0f, hmax);
+    const uint32_t mort = lut ? (s_lut[nx] | (s_lut[ny] << 1) | (s_lut[nz] << 2)) : morton3D_(nx, ny, nz);
+    const uint32_t index = (lv1 ? H3u : 0u) + mort;
+    const bool occ = valid && ((grid64[index >> 6] >> (index & 63u)) & 1ull);
+    const float ex = fmaf((float)(nx + incx) * rH2 - 1, mipb, -px) * m.rdx;
+    const float ey = fmaf((float)(ny + incy) * rH2 - 1, mipb, -py) * m.rdy;
+    const float ez = fmaf((float)(nz + incz) * rH2 - 1, mipb, -pz) * m.rdz;
+    const float tt = tj + fmaxf(0.0f, fminf(ex, fminf(ey, ez)));
+    // first chain point of this chunk not below the cell's exit, > lane (WAVE: it lies behind the chunk): index guess from
+    // the progression, settled against the neighbours' actual t (the spacing changes by < 2^-15 relative across a
+    // binade, so the guess is off by one at most; a plain search over the chunk's t backs it up)
+    int nxt = WAVE;
+    s_t[threadIdx.x] = tj;
+    __builtin_amdgcn_wave_barrier();          // (one wave writes and reads its 64 entries: LDS keeps a wave's accesses in order)
+    if (!(tlast < tt)) {
+      const float steps = (tt - tj) * rqu;
+      int g = lane + (steps > 80.0f ? 80 : (int)ceilf(steps));
+      g = g < lane + 1 ? lane + 1 : (g > WAVE - 1 ? WAVE - 1 : g);
+      const float* tw = s_t + (threadIdx.x - lane);
+      const float ta = tw[g - 1], tb = tw[g], tc = tw[g + 1 > WAVE - 1 ? WAVE - 1 : g + 1];
+      if (g - 1 > lane && ta >= tt && !(g - 2 > lane && tw[g - 2] >= tt)) nxt = g - 1;
+      else if (tb >= tt && (g - 1 == lane || ta < tt)) nxt = g;
+      else if (g + 1 < WAVE && tc >= tt && tb < tt) nxt = g + 1;
+      else {
+        for (int i = lane + 1; i < WAVE; i++)
+          if (tw[i] >= tt) { nxt = i; break; }
+      }
+    }
+    // ---- the visit order
+    const unsigned long long occm = __ballot(occ), validm = __ballot(valid), gem = __ballot(tj >= pend);
+    // Empty space is a chain of short hops (a cell is 5-7 chain points long): three rounds of pointer doubling on the
+    // vector unit make an empty point's pointer run through up to eight empty points, up to the first point the chase has
+    // to look at (occupied, behind far, or behind the chunk: `ttl` is then the exit the last hop carried).
+    float ttl = tt;
+    {
+      const unsigned long long stopm = occm | ~validm;
+#pragma unroll
+      for (int round = 0; round < 3; round++) {
+        const int pa = nxt < WAVE ? nxt : WAVE - 1;
+        const int pn = __shfl(nxt, pa);
+        const float tn = __shfl(ttl, pa);
+        if (nxt < WAVE && !((stopm >> pa) & 1ull)) { nxt = pn; ttl = tn; }
+      }
+    }
+    unsigned long long taken = 0ull;
+    int v = __builtin_amdgcn_readfirstlane(gem ? (int)__builtin_ctzll(gem) : WAVE);
+    if (gem) pend = -__builtin_inff();         // (a chunk that lies entirely below the exit keeps it)
+    bool done = false;
+    const int count0 = count;
+    while (v < WAVE) {
+      if (!((validm >> v) & 1ull)) { done = true; break; }
+      if ((occm >> v) & 1ull) {
+        const unsigned long long rest = ~(occm >> v);
+        int run = rest ? (int)__builtin_ctzll(rest) : WAVE;
+        run = run < WAVE - v ? run : WAVE - v;
+        const int room = limit - count;
+        const bool last = run >= room;
+        run = last ? room : run;
+        taken |= (run >= 64 ? ~0ull : ((1ull << run) - 1ull)) << v;
+        count += run;
+        v += run;
+        if (last) { done = true; break; }
+      } else {
+        const int hop = __builtin_amdgcn_readlane(nxt, v);
+        if (hop >= WAVE) { pend = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ttl), v)); v = WAVE; }
+        else v = hop;
+      }
+      v = __builtin_amdgcn_readfirstlane(v);
+      count = __builtin_amdgcn_readfirstlane(count);
+    }
+    if (REC && ((taken >> lane) & 1ull))
+      trec[count0 + __builtin_popcountll(taken & ((1ull << lane) - 1ull))] = tj;
+    if (done) break;
+    T0 = Tnext;
+  }
+  if (lane == 0) num_steps_out[n] = count;
+}
+
+// block_sums of k_march_train_count for the per-wave count pass: the sample counts of 256 consecutive rays summed
+__global__ void __launch_bounds__(MARCH_BLOCK)
+k_march_block_sums(const int* __restrict__ num_steps, uint32_t N, int* __restrict__ block_sums) {
+  __shared__ int smem4[4];
+  const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+  int total;
+  block_excl_scan_256(n < N ? num_steps[n] : 0, smem4, &total);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
@@ -1138,7 +1328,12 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
   if (need_rec != 0 && workspace_words >= need_rec) {
     // one march: the count pass records each sample's t, the samples are written from the record
     float* tbuf = reinterpret_cast<float*>(workspace + ((tnl_march_rays_train_workspace(N) + 3) & ~3u));
-    if (wide_bitfield(grid, C, H))
+    if (wide_bitfield(grid, C, H) && dt_gamma == 0.f && C <= 2 && TNL_MARCH_WAVE) {
+      // one wavefront per ray over 64 consecutive chain points (see k_march_train_count_wave)
+      hipLaunchKernelGGL((k_march_train_count_wave<true>), dim3(cdiv(N, MARCH_BLOCK / WAVE)), dim3(MARCH_BLOCK), 0, st, rays_o,
+                         rays_d, grid, bound, max_steps, N, C, H, nears, fars, noises, num_steps, tbuf);
+      hipLaunchKernelGGL(k_march_block_sums, dim3(nb), dim3(MARCH_BLOCK), 0, st, num_steps, N, block_sums);
+    } else if (wide_bitfield(grid, C, H))
       hipLaunchKernelGGL((k_march_train_count<true, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid,
                          bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf);
     else
