@@ -75,6 +75,10 @@ def build(workload, device, dist_mode, plane_dtype=None, shell=(0.8, 0.0), **ts_
         ts.live_bands = os.environ["TNL_LIVE_BANDS"] != "0"
     if os.environ.get("TNL_EXCHANGE_BANDS"):  # the plane-gradient window reduced / exchanged in this many bands of rows
         ts.overlap_exchange = int(os.environ["TNL_EXCHANGE_BANDS"])
+    if os.environ.get("TNL_SIDE_COUNT_FORM"):  # A/B: count pass of the prefetched march (0 wavefront per ray, 1 ray per lane)
+        ts.side_count_form = int(os.environ["TNL_SIDE_COUNT_FORM"])
+    if os.environ.get("TNL_PREFETCH_AT"):     # A/B: where the next batch's march + tile sort start (bwd | reduce | adjoint)
+        ts.prefetch_at = os.environ["TNL_PREFETCH_AT"]
     if os.environ.get("TNL_NO_OVERLAP"):      # experiments: march + tile sort in order on the launch stream (kernels alone)
         ts.overlap_march = False
     bitfield = torch.from_numpy(synthetic.sphere_bitfield(128, model.cascade, 1.5, shell[0], shell[1])).to(device)

@@ -113,6 +113,14 @@ TNL_API int tnl_march_rays_train_binned(const float *rays_o, const float *rays_d
                                  int32_t *rays, int32_t *counter, const float *noises,
                                  int32_t *workspace, uint32_t workspace_words, uint32_t R, void *sort_workspace, void *stream);
 
+/* Form of the count pass of the two calls above (no reference predecessor; raymarching.cu:312-398 walks one ray per
+ * thread).  0 (default): one WAVEFRONT per ray over 64 consecutive chain points wherever it applies (dt_gamma = 0, at
+ * most two cascades, 8-byte aligned bitfield) -- 3x shorter alone (789 -> 263 us at 60 000 base rays), the form for a
+ * march the caller waits for; 1: one ray per lane everywhere -- a seventh of the instructions at one wave per SIMD, the
+ * form for a march that runs BESIDE other kernels on a second stream (TrainStep's prefetch of the next batch).  Same
+ * outputs bit for bit.  Process-wide; returns the previous value (any other argument only queries). */
+TNL_API int tnl_march_count_form(int form);
+
 /* raymarching.h:14 composite_rays_train_forward ; kernel raymarching.cu:501-577.
  * One 64-lane wavefront per ray; transmittance by a wavefront product scan. */
 TNL_API int tnl_composite_rays_train_forward(const float *sigmas, const float *rgbs,

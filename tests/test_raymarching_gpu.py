@@ -52,9 +52,20 @@ def test_morton_roundtrip_and_packbits(cuda):
         assert np.array_equal(bf.cpu().numpy(), cref.packbits(grid, 0.1))
 
 
+@pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("shell", [False, True])
 @pytest.mark.parametrize("perturb", [False, True])
-def test_march_train_exact(cuda, rays, shell, perturb):
+def test_march_train_exact(cuda, rays, shell, perturb, form):
+    """form: tnl_march_count_form -- 0 the wavefront-per-ray count pass (64 consecutive chain points per wave), 1 one ray
+    per lane; both against the oracle's serial march, bit for bit."""
+    from trinerflet_amd import raymarching
+    with raymarching.count_form(form):
+        _march_train_exact(cuda, rays, shell, perturb)
+    from trinerflet_amd import _lib as L
+    assert L.lib().tnl_march_count_form(L.i32(-1)) == 0           # restored (an argument other than 0 / 1 only queries)
+
+
+def _march_train_exact(cuda, rays, shell, perturb):
     from trinerflet_amd import raymarching
     o, d, aabb, nears, fars = rays
     bf = scene.sphere_bitfield(HG, CAS, BOUND, 0.8, 0.7 if shell else 0.0)
@@ -78,6 +89,38 @@ def test_march_train_exact(cuda, rays, shell, perturb):
         assert np.array_equal(xyzs.cpu().numpy(), xr[:m])           # bit-exact sample positions
         assert np.array_equal(dirs.cpu().numpy(), dr[:m])
         assert np.array_equal(deltas.cpu().numpy(), lr[:m])
+
+
+@pytest.mark.parametrize("case", ["one_cascade", "bound2", "cap64", "near_tiny", "cap7_dense"])
+def test_march_wavefront_form_edge_cases(cuda, case):
+    """The wavefront-per-ray count pass where its closed-form chain does not apply or its bookkeeping is stressed: one
+    cascade, bound 2 (long rays: t crosses 2 and 4), a sample cap of 64 / 7 per ray (the cap ends a run inside a chunk),
+    min_near 0.01 (t starts in binades where 63 steps are no longer exact: the serial chunk form), a fully occupied grid."""
+    from trinerflet_amd import raymarching
+    bound, cas, max_steps, min_near, shell = {"one_cascade": (1.0, 1, 1024, 0.2, (0.8, 0.3)), "bound2": (2.0, 2, 1024, 0.2, (0.9, 0.0)),
+                                              "cap64": (1.5, 2, 64, 0.2, (0.8, 0.0)), "near_tiny": (1.5, 2, 512, 0.01, (1.4, 0.0)),
+                                              "cap7_dense": (1.5, 2, 7, 0.2, None)}[case]
+    o, d = scene.training_rays(3000, n_cams=6, seed=9)
+    if case == "near_tiny":
+        o *= 0.3            # cameras inside the box: the rays start at t = min_near
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = cref.near_far_from_aabb(o, d, aabb, min_near)
+    bf = np.full(cas * HG ** 3 // 8, 255, np.uint8) if shell is None else scene.sphere_bitfield(HG, cas, bound, *shell)
+    noises = np.random.default_rng(2).random(o.shape[0]).astype(np.float32)
+    M = o.shape[0] * max_steps
+    xr, dr, lr, rr, cr = cref.march_rays_train(o, d, bound, bf, cas, HG, nears, fars, noises, M, max_steps=max_steps)
+    assert int(cr[0]) > 1000
+    if case.startswith("cap"):
+        assert (rr[:, 2] == max_steps).mean() > 0.3           # the cap binds
+    for form in (0, 1):
+        with raymarching.count_form(form):
+            counter = torch.zeros(2, dtype=torch.int32, device=cuda)
+            xyzs, dirs, deltas, rays_t = raymarching.march_rays_train(
+                _t(o, cuda), _t(d, cuda), bound, _t(bf, cuda), cas, HG, _t(nears, cuda), _t(fars, cuda), counter, -1, True,
+                -1, True, 0, max_steps, _t(noises, cuda))
+        m = xyzs.shape[0]
+        assert np.array_equal(counter.cpu().numpy(), cr) and np.array_equal(rays_t.cpu().numpy(), rr), (case, form)
+        assert np.array_equal(xyzs.cpu().numpy(), xr[:m]) and np.array_equal(deltas.cpu().numpy(), lr[:m]), (case, form)
 
 
 def test_march_with_unaligned_bitfield(cuda, rays):

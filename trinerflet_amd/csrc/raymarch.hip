@@ -1308,6 +1308,9 @@ uint32_t tnl_march_rays_train_workspace_rec(uint32_t N, uint32_t max_steps) {
   return w > 0xffffffffull ? 0u : (uint32_t)w;
 }
 
+// tnl_march_count_form: 0 = the per-wavefront count pass wherever it applies, 1 = always one ray per lane
+static int g_count_form = 0;
+
 static int march_rays_train_impl(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                                  float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                  const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
@@ -1328,7 +1331,7 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
   if (need_rec != 0 && workspace_words >= need_rec) {
     // one march: the count pass records each sample's t, the samples are written from the record
     float* tbuf = reinterpret_cast<float*>(workspace + ((tnl_march_rays_train_workspace(N) + 3) & ~3u));
-    if (wide_bitfield(grid, C, H) && dt_gamma == 0.f && C <= 2 && TNL_MARCH_WAVE) {
+    if (wide_bitfield(grid, C, H) && dt_gamma == 0.f && C <= 2 && TNL_MARCH_WAVE && g_count_form != 1) {
       // one wavefront per ray over 64 consecutive chain points (see k_march_train_count_wave)
       hipLaunchKernelGGL((k_march_train_count_wave<true>), dim3(cdiv(N, MARCH_BLOCK / WAVE)), dim3(MARCH_BLOCK), 0, st, rays_o,
                          rays_d, grid, bound, max_steps, N, C, H, nears, fars, noises, num_steps, tbuf);
@@ -1362,6 +1365,12 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
   }
   hipLaunchKernelGGL(k_march_train_finalize, dim3(1), dim3(MARCH_BLOCK), 0, st, block_sums, nb, N, counter);
   return launch_status();
+}
+
+int tnl_march_count_form(int form) {
+  const int prev = g_count_form;
+  if (form == 0 || form == 1) g_count_form = form;
+  return prev;
 }
 
 int tnl_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,

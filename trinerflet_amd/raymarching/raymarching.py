@@ -11,7 +11,7 @@ from torch.autograd import Function
 from .. import _lib as L
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "occupied_box", "clip_fars",
-           "march_rays_train", "composite_rays_train", "march_rays", "composite_rays", "compact_rays"]
+           "march_rays_train", "count_form", "composite_rays_train", "march_rays", "composite_rays", "compact_rays"]
 
 
 def _f32c(t):
@@ -168,6 +168,23 @@ class _march_rays_train(Function):
 
 
 march_rays_train = _march_rays_train.apply
+
+
+class count_form:
+    """with raymarching.count_form(1): ... -- the count pass of march_rays_train inside the block walks one ray per lane
+    (tnl_march_count_form: the small-footprint form for a march enqueued beside other kernels); 0 = the default, one
+    wavefront per ray.  Process-wide switch of the library, restored on exit."""
+
+    def __init__(self, form):
+        self.form = int(form)
+
+    def __enter__(self):
+        self.prev = L.lib().tnl_march_count_form(L.i32(self.form))
+        return self
+
+    def __exit__(self, *exc):
+        L.lib().tnl_march_count_form(L.i32(self.prev))
+        return False
 
 
 class _composite_rays_train(Function):

@@ -295,6 +295,10 @@ class TrainStep:
         self.graph_replays = 0      # counters for reports / tests
         self.graph_captures = 0
         self._stale_params = self._stale_moments = False
+        # where the following batch's march + tile sort start on the side stream (binned mode): behind the field backward
+        # ("bwd"), behind the tile reduction ("reduce") or behind the adjoint IDWT ("adjoint")
+        self.prefetch_at = "bwd"
+        self.side_count_form = 1     # raymarching.count_form of the prefetched march (0: the wavefront-per-ray count pass)
         self.post_refresh = None    # optional callable run right after every density-grid refresh
         self.section_events = None  # set to [] to record HIP events (on the launch stream) around every stage
         # distributed
@@ -740,7 +744,10 @@ class TrainStep:
         if self._side is None:
             self._side = torch.cuda.Stream()
         self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
+        # beside the step's kernels the count pass runs one ray per lane: a seventh of the wavefront form's instructions at
+        # one wave per SIMD (3x longer alone, but it takes almost nothing from the kernels it runs next to: A/B at base,
+        # wavefront form on the side stream 4.13-4.26 ms per step at every start position vs 3.9)
+        with torch.cuda.stream(self._side), raymarching.count_form(self.side_count_form):
             out = self._march(o, d, nz)
         for t_ in out[0]:
             t_.record_stream(main)
@@ -878,7 +885,8 @@ class TrainStep:
             # HBM-bound tail of the step (tile reduction, adjoint IDWT, Adam; in the multi-GPU modes the collectives):
             # the two MFMA field kernels own their SIMDs' whole register files, so side work beside them is time-sliced
             # in at their cost (docs/EXPERIMENTS.md: the start positions measured in rounds 2 and 3).
-            self._prefetch_next(st.next_rays)
+            if self.prefetch_at == "bwd":
+                self._prefetch_next(st.next_rays)
             if st.side is not None or st.sort_beside:
                 torch.cuda.current_stream().wait_event(st.ev_sort)
             if self.deterministic:
@@ -914,6 +922,8 @@ class TrainStep:
                 s0, s1 = self._slice_range() if self.multi else (0, 3 * C)
                 st.g_cm = torch.cat([p_[: s1 - s0] if not self.multi else p_ for p_ in parts], dim=1)   # [S/G, rh, rw]
                 st.scattered = self.multi
+            if self.prefetch_at == "reduce":
+                self._prefetch_next(st.next_rays)
             self._mark("plane_grad_binned")
             st.grad_tm = None
         else:
@@ -938,9 +948,13 @@ class TrainStep:
             self._mark("scaler_probe")
             if self.fuse_adam:
                 s0, s1 = self._adjoint(None, st.g_cm, fuse=(lr_t, l1, found_inf, inv_scale))
+                if self.prefetch_at == "adjoint":
+                    self._prefetch_next(st.next_rays)
                 self._mark("idwt_adjoint_adam")
             else:
                 s0, s1 = self._adjoint(None, st.g_cm, roi=st.roi, scattered=getattr(st, "scattered", False))
+                if self.prefetch_at == "adjoint":
+                    self._prefetch_next(st.next_rays)
                 self._mark("idwt_adjoint")
                 rects = self._rects if (st.roi is not None and self._rect_ok) else None
                 if self.defer_adam and rects is not None:
