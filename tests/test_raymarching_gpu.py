@@ -94,11 +94,11 @@ def _march_train_exact(cuda, rays, shell, perturb):
 @pytest.mark.parametrize("case", ["one_cascade", "bound2", "cap64", "near_tiny", "cap7_dense"])
 def test_march_wavefront_form_edge_cases(cuda, case):
     """The wavefront-per-ray count pass where its closed-form chain does not apply or its bookkeeping is stressed: one
-    cascade, bound 2 (long rays: t crosses 2 and 4), a sample cap of 64 / 7 per ray (the cap ends a run inside a chunk),
-    min_near 0.01 (t starts in binades where 63 steps are no longer exact: the serial chunk form), a fully occupied grid."""
+    cascade, bound 2 (long rays: t crosses 2 and 4), a sample cap of 64 / 7 per ray on a fully occupied grid (the cap ends a run inside a chunk),
+    min_near 0.01 (t starts in binades where 63 steps are no longer exact: the serial chunk form)."""
     from trinerflet_amd import raymarching
     bound, cas, max_steps, min_near, shell = {"one_cascade": (1.0, 1, 1024, 0.2, (0.8, 0.3)), "bound2": (2.0, 2, 1024, 0.2, (0.9, 0.0)),
-                                              "cap64": (1.5, 2, 64, 0.2, (0.8, 0.0)), "near_tiny": (1.5, 2, 512, 0.01, (1.4, 0.0)),
+                                              "cap64": (1.5, 2, 64, 0.2, None), "near_tiny": (1.5, 2, 512, 0.01, (1.4, 0.0)),
                                               "cap7_dense": (1.5, 2, 7, 0.2, None)}[case]
     o, d = scene.training_rays(3000, n_cams=6, seed=9)
     if case == "near_tiny":
@@ -111,7 +111,7 @@ def test_march_wavefront_form_edge_cases(cuda, case):
     xr, dr, lr, rr, cr = cref.march_rays_train(o, d, bound, bf, cas, HG, nears, fars, noises, M, max_steps=max_steps)
     assert int(cr[0]) > 1000
     if case.startswith("cap"):
-        assert (rr[:, 2] == max_steps).mean() > 0.3           # the cap binds
+        assert (rr[:, 2] == max_steps).mean() > 0.05          # the cap binds (dt = 2 sqrt(3) / max_steps: only on long rays)
     for form in (0, 1):
         with raymarching.count_form(form):
             counter = torch.zeros(2, dtype=torch.int32, device=cuda)
