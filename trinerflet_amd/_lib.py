@@ -10,7 +10,9 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrinerflet_hip.so")
+# TNL_LIB_PATH: another build of the same library (kernel experiments: tools/build_variant.py); the product loads the
+# in-tree build
+LIB_PATH = os.environ.get("TNL_LIB_PATH") or os.path.join(_HERE, "libtrinerflet_hip.so")
 HEADER = os.path.join(_HERE, "..", "include", "trinerflet_hip.h")
 
 _lib = None

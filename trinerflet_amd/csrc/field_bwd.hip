@@ -29,6 +29,10 @@
 #include "field_bwd_rows.h"
 #include "field_device.h"
 
+#ifndef TNL_BWD_EXP
+#define TNL_BWD_EXP 0   // timing-only experiment builds (WRONG results): bit 0 no weight-gradient tiles, bit 1 no stage
+#endif                  // writes, bit 2 no barriers inside the super-tile loop, bit 3 no dF stores (tools/build_variant.py)
+
 namespace {
 
 // Shared-stage form: NW = 4 waves per workgroup (one per SIMD, ~320-390 registers), 32 samples per wave, the weight
@@ -58,11 +62,13 @@ struct BwdGeom {
   static constexpr int STAGE_LD = G::F + 1;                       // floats per staged sample row
   static constexpr size_t XS_BYTES = (size_t)XBLKS * BLK;
   static constexpr size_t YS_BYTES = (size_t)G::OB * BLK;
-  static constexpr size_t STAGE_BYTES = ATOMIC ? (size_t)BW_WAVES * 32 * STAGE_LD * 4 : 0;
+  // PART 1: the saved sigma-net outputs (16 halfs per sample) of the NEXT super-tile arrive by LDS-DMA, 1 KiB per wave
+  static constexpr size_t STAGE_BYTES = ATOMIC ? (size_t)BW_WAVES * 32 * STAGE_LD * 4 : (PART == 1 ? (size_t)BW_WAVES * 1024 : 0);
   // fragments a launch touches: everything, or for PART 2 the forward layer-0 range [F0, F1) and the transposed
   // layer-1 / layer-0 range [T1, NTOT)
-  // PART 1 keeps [F3, T1) = layers 3, 4 forward and 4, 3, 2 transposed in LDS and reads layers 0..2 forward from L2.
-  static constexpr int NFRAG = PART == 2 ? (G::F1 - G::F0) + (G::NTOT - G::T1) : (PART == 1 ? G::T1 - G::F3 : G::NTOT);
+  // PART 1 keeps [F2, T1) = layers 2, 3, 4 forward and 4, 3, 2 transposed in LDS (round 5: layer 2's eight forward
+  // fragments too -- they were read from L2 at the top of every super-tile, one exposed round trip per tile).
+  static constexpr int NFRAG = PART == 2 ? (G::F1 - G::F0) + (G::NTOT - G::T1) : (PART == 1 ? G::T1 - G::F2 : G::NTOT);
   static constexpr size_t W_BYTES = (size_t)NFRAG * 1024;
   // the sample's features, published once per super-tile for the layer-0 weight gradient
   // (binned mode only: the atomic mode's fp32 staging area leaves no room at C = 48 and re-reads them instead)
@@ -85,6 +91,7 @@ typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_t;
 // byte offset of 8-byte chunk `chunk` (four consecutive features) of sample row `row` inside a 32-feature block
 __device__ __forceinline__ int img_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 __device__ __forceinline__ void st4(char* blk, int row, int chunk, half4v v) {
+  if (TNL_BWD_EXP & 2) return;
   *reinterpret_cast<half4v*>(blk + img_off(row, chunk)) = v;
 }
 // ds_read_b64_tr_b16: per 16-lane group a block of 4 rows x 16 columns of halfs, delivered column-major (lane i of the
@@ -99,6 +106,7 @@ __device__ __forceinline__ half4v tr4(const char* p) {
 // holding the 32 output / input features, t0 / t1 = this lane's transposed-read offsets (rows 8h + q and 8h + 4 + q).
 template <int ST>
 __device__ __forceinline__ f32x16 dw_tile(const char* yb, const char* xb, int t0, int t1, f32x16 acc) {
+  if (TNL_BWD_EXP & 1) return acc;
   // (written k-step by k-step, the compiler requests all 4 * ST/16 operand reads up front and then issues the MFMAs;
   // grouping the reads by hand in fours or eights makes it fall back to read, wait, MFMA per k-step)
 #pragma unroll
@@ -108,6 +116,36 @@ __device__ __forceinline__ f32x16 dw_tile(const char* yb, const char* xb, int t0
     acc = MFMA32(a, b, acc);
   }
   return acc;
+}
+
+// The A tiles a wave accumulates for one layer, as ONE software pipeline: the transposing reads of four k-steps (16
+// ds_read_b64_tr_b16) are requested a group ahead of the four MFMAs that take them, across tile boundaries (tile k's
+// operands come from blocks yb(k), xb(k)).  dw_tile above, left to the compiler, came out as `4 reads, wait, MFMA` per
+// k-step in the hidden-128 kernels: every MFMA behind a full LDS round trip.
+template <int ST, int A, class YB, class XB>
+__device__ __forceinline__ void dw_tiles(YB ybf, XB xbf, int t0, int t1, f32x16 (&dw)[A]) {
+  if (TNL_BWD_EXP & 1) return;
+  constexpr int NK = ST / 16, GK = 4, NG = NK / GK, TOT = A * NG;
+  static_assert(NK % GK == 0, "super-tile of a multiple of 64 samples");
+  half8 a[2][GK], b[2][GK];
+  auto ld = [&](int q) {
+    const char* yb = ybf(q / NG);
+    const char* xb = xbf(q / NG);
+#pragma unroll
+    for (int j = 0; j < GK; j++) {
+      const int ks = (q % NG) * GK + j;
+      a[q & 1][j] = __builtin_shufflevector(tr4(yb + t0 + 1024 * ks), tr4(yb + t1 + 1024 * ks), 0, 1, 2, 3, 4, 5, 6, 7);
+      b[q & 1][j] = __builtin_shufflevector(tr4(xb + t0 + 1024 * ks), tr4(xb + t1 + 1024 * ks), 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  ld(0);
+#pragma unroll
+  for (int q = 0; q < TOT; q++) {
+    if (q + 1 < TOT) ld(q + 1);
+#pragma unroll
+    for (int j = 0; j < GK; j++) dw[q / NG] = MFMA32(a[q & 1][j], b[q & 1][j], dw[q / NG]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 
 // publish an accumulator-layout tile (registers 4q..4q+3 = features 8q + 4h .. + 3 of the lane's sample) into a block
@@ -183,16 +221,16 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   char* const Yb[2] = {smem + B::XS_BYTES, smem + (B::DB ? XY : 0) + B::XS_BYTES};
   float* stage_all = reinterpret_cast<float*>(smem + (B::DB ? 2 : 1) * XY);
   char* Fs = smem + (B::DB ? 2 : 1) * XY + B::STAGE_BYTES;
-  auto stage_ready = [&]() { __syncthreads(); };                        // stage published -> stage read
-  auto sync_stage = [&]() { if (!B::DB) __syncthreads(); };             // stage reuse barrier (single-buffered stages)
+  auto stage_ready = [&]() { if (!(TNL_BWD_EXP & 4)) __syncthreads(); };                        // stage published -> stage read
+  auto sync_stage = [&]() { if (!B::DB && !(TNL_BWD_EXP & 4)) __syncthreads(); };             // stage reuse barrier (single-buffered stages)
   const half8* w = packed;    // forward fragments (and, outside PART 2, all of them)
   const half8* wH = packed;   // layers 3, 4 forward and 4, 3, 2 transposed
   const half8* wT = packed;   // transposed fragments of layers 1 and 0
   if (B::LDSW) {
     half8* wl = reinterpret_cast<half8*>(smem + B::BASE_BYTES);
     if (PART == 1) {
-      for (int i = threadIdx.x; i < (G::T1 - G::F3) * 64; i += BW_THREADS) wl[i] = packed[G::F3 * 64 + i];
-      wH = wl - G::F3 * 64;
+      for (int i = threadIdx.x; i < (G::T1 - G::F2) * 64; i += BW_THREADS) wl[i] = packed[G::F2 * 64 + i];
+      wH = wl - G::F2 * 64;
     } else if (PART == 2) {
       for (int i = threadIdx.x; i < G::F1 * 64; i += BW_THREADS) wl[i] = packed[i];
       for (int i = threadIdx.x; i < (G::NTOT - G::T1) * 64; i += BW_THREADS) wl[G::F1 * 64 + i] = packed[G::T1 * 64 + i];
@@ -256,8 +294,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
         for (int j = 0; j < 8; j++) in.dof[j] = (_Float16)0.f;
       }
     }
-    if (PART == 1) {
-      in.geo = *reinterpret_cast<const half8*>(geo_save + (size_t)il_ * 16 + 8 * h);
+    if (PART == 1) {     // (the sigma-net outputs `geo` come by LDS-DMA: dma_geo / the read at the top of the super-tile)
       in.sg = sigma[il_];
       return;
     }
@@ -270,12 +307,25 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       }
     }
   };
-  // the colour half of hidden 128 is register-bound: its 44 B of inputs are read in place
-  constexpr bool PREFETCH = PART != 1;
+  // Round 5: the colour half read its 64 B of inputs per sample in place at the top of every super-tile -- with one wave
+  // per SIMD a DRAM round trip (2-2.5 us under load) that nothing covered, a quarter of the launch.  Now the 8 scalars of
+  // the next super-tile are requested a tile ahead into registers and its 32 B of saved sigma-net outputs by LDS-DMA
+  // (global_load_lds_dwordx4, 1 KiB per wave: no registers held while in flight).
+  constexpr bool PREFETCH = true;
+  char* const gbuf = smem + (B::DB ? 2 : 1) * XY + (size_t)wv * 1024;     // PART 1: this wave's DMA target (STAGE_BYTES)
+  auto dma_geo = [&](uint32_t st_) {
+    const uint32_t i_ = st_ * ST + col;
+    const uint32_t il_ = i_ < M ? i_ : M - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(geo_save + (size_t)il_ * 16 + 8 * h),
+                                     (__attribute__((address_space(3))) void*)gbuf, 16, 0, 0);
+  };
   Inputs nxt;
-  if (PREFETCH && blockIdx.x < nst) load_inputs(blockIdx.x, nxt);
+  if (PREFETCH && blockIdx.x < nst) {
+    load_inputs(blockIdx.x, nxt);
+    if (PART == 1) dma_geo(blockIdx.x);
+  }
   for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
-    if (!B::LDSW || PART == 1) {
+    if (!B::LDSW) {
       // Weight fragments read from global memory (L2) inside the loop: the 8 layer-2 fragments of PART 1, and all 180
       // of the one-launch hidden-128 kernel (atomic mode only, the drop-in autograd path).  Keep the compiler from
       // hoisting these loop-invariant loads out of the super-tile loop: it tried to hold them all in registers and
@@ -291,7 +341,13 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     const uint32_t i = st * ST + col;
     const bool valid = i < M;
     if (!PREFETCH) load_inputs(st, nxt);
-    const Inputs in = nxt;
+    Inputs in = nxt;
+    if (PART == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this super-tile's DMA piece has landed
+      in.geo = *reinterpret_cast<const half8*>(gbuf + lane * 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... and is in registers before the next piece is requested
+      if (st + gridDim.x < nst) dma_geo(st + gridDim.x);
+    }
     if (PREFETCH && st + gridDim.x < nst) load_inputs(st + gridDim.x, nxt);
     const float px = in.px, py = in.py, pz = in.pz, dx = in.dx, dy = in.dy, dz = in.dz;
     const float g_s = in.g_s, g_c0 = in.g_c0, g_c1 = in.g_c1, g_c2 = in.g_c2;
@@ -306,16 +362,22 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     if (PART != 1) {
 #pragma unroll
       for (int ob = 0; ob < G::OB; ob++) acc0[ob] = zero16();
+      if (PART != 0) {   // split launches (one wave per SIMD): weight fragments a group ahead of their MFMAs
+        with_weights<G::KS0 * G::OB, G::OB>(
+            [&](int i) { return w[(G::F0 + (i % G::OB) * G::KS0 + i / G::OB) * 64 + lane]; },
+            [&](int i, const half8& f) { acc0[i % G::OB] = MFMA32(f, in.fk[i / G::OB], acc0[i % G::OB]); });
+      } else {
 #pragma unroll
-      for (int ks = 0; ks < G::KS0; ks++) {
+        for (int ks = 0; ks < G::KS0; ks++) {
 #pragma unroll
-        for (int ob = 0; ob < G::OB; ob++)
-          acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], in.fk[ks], acc0[ob]);
+          for (int ob = 0; ob < G::OB; ob++)
+            acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], in.fk[ks], acc0[ob]);
+        }
       }
     }
     Chain<C, H> ch;
     if (PART == 1) {
-      chain_colour<C, H, true>(w, wH, lane, h, in.geo, dx, dy, dz, ch);
+      chain_colour<C, H, true>(wH, wH, lane, h, in.geo, dx, dy, dz, ch);
     } else if (DO_COL) {
       chain_tail<C, H, false>(w, wH, lane, h, acc0, dx, dy, dz, ch);
     } else {
@@ -344,10 +406,14 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     // (Every wave accumulates A_l tiles per layer without a branch: behind `if (tile < NT_l)` the accumulators of that
     // block live in VGPRs and are copied into AGPRs and back around the MFMAs, 32 moves per tile and super-tile.  The
     // duplicates cost idle waves a few MFMAs and are dropped when the slabs are written.)
+    if (PART != 0) {
+      dw_tiles<SS, B::A4>([&](int) { return Ys; }, [&](int k) { return Xs + ((wv + NW * k) % B::NT4) * BLK; }, t0, t1, dw4);
+    } else {
 #pragma unroll
-    for (int k = 0; k < B::A4; k++) {
-      const int t = (wv + NW * k) % B::NT4;   // a wave without a tile of its own repeats another's
-      dw4[k] = dw_tile<SS>(Ys, Xs + t * BLK, t0, t1, dw4[k]);
+      for (int k = 0; k < B::A4; k++) {
+        const int t = (wv + NW * k) % B::NT4;   // a wave without a tile of its own repeats another's
+        dw4[k] = dw_tile<SS>(Ys, Xs + t * BLK, t0, t1, dw4[k]);
+      }
     }
     // (a gradient tile leaves the registers as soon as it is masked and converted: its two fp16 fragments feed the next
     // layer's MFMAs AND are what the stage receives -- put_frag of fragments 2ib, 2ib+1 writes exactly put_acc's chunks)
@@ -367,22 +433,40 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d4f[ks], h, scol);
     stage_ready();
+    if (PART != 0) {
+      dw_tiles<SS, B::A3>([&](int k) { return Ys + (((wv + NW * k) % B::NT3) / G::OB) * BLK; },
+                          [&](int k) { return Xs + (((wv + NW * k) % B::NT3) % G::OB) * BLK; }, t0, t1, dw3);
+    } else {
 #pragma unroll
-    for (int k = 0; k < B::A3; k++) {
-      const int t = (wv + NW * k) % B::NT3;   // a wave without a tile of its own repeats another's
-      dw3[k] = dw_tile<SS>(Ys + (t / G::OB) * BLK, Xs + (t % G::OB) * BLK, t0, t1, dw3[k]);
+      for (int k = 0; k < B::A3; k++) {
+        const int t = (wv + NW * k) % B::NT3;   // a wave without a tile of its own repeats another's
+        dw3[k] = dw_tile<SS>(Ys + (t / G::OB) * BLK, Xs + (t % G::OB) * BLK, t0, t1, dw3[k]);
+      }
     }
     half8 d3f[G::KH];
-#pragma unroll
-    for (int ib = 0; ib < G::OB; ib++) {
+    if (PART != 0) {
       f32x16 t = zero16();
+      with_weights<G::OB * G::KH, 4>([&](int i) { return wH[(G::T3 + i) * 64 + lane]; }, [&](int i, const half8& f) {
+        const int ib = i / G::KH, ks = i % G::KH;
+        if (ks == 0) t = zero16();
+        t = MFMA32(f, d4f[ks], t);
+        if (ks == G::KH - 1) {
+          d3f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h3[2 * ib]);
+          d3f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h3[2 * ib + 1]);
+        }
+      });
+    } else {
 #pragma unroll
-      for (int ks = 0; ks < G::KH; ks++) t = MFMA32(wH[(G::T3 + ib * G::KH + ks) * 64 + lane], d4f[ks], t);
-      d3f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h3[2 * ib]);
-      d3f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h3[2 * ib + 1]);
-      // hidden 128: one tile's eight weight fragments at a time (the scheduler otherwise requests all 32 up front and
-      // the kernel spills)
-      if (H > 64) __builtin_amdgcn_sched_barrier(0);
+      for (int ib = 0; ib < G::OB; ib++) {
+        f32x16 t = zero16();
+#pragma unroll
+        for (int ks = 0; ks < G::KH; ks++) t = MFMA32(wH[(G::T3 + ib * G::KH + ks) * 64 + lane], d4f[ks], t);
+        d3f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h3[2 * ib]);
+        d3f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h3[2 * ib + 1]);
+        // hidden 128: one tile's eight weight fragments at a time (the scheduler otherwise requests all 32 up front and
+        // the kernel spills)
+        if (H > 64) __builtin_amdgcn_sched_barrier(0);
+      }
     }
     sync_stage();
 
@@ -401,14 +485,20 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d3f[ks], h, scol);
     stage_ready();
-#pragma unroll
-    for (int k = 0; k < B::A2; k++) {
-      const int t = (wv + NW * k) % B::NT2;   // a wave without a tile of its own repeats another's
-      dw2[k] = dw_tile<SS>(Ys + t * BLK, Xs, t0, t1, dw2[k]);
-    }
     f32x16 dzz = zero16();
+    if (PART != 0) {
+      dw_tiles<SS, B::A2>([&](int k) { return Ys + ((wv + NW * k) % B::NT2) * BLK; }, [&](int) { return Xs; }, t0, t1, dw2);
+      with_weights<G::KH, 4>([&](int i) { return wH[(G::T2 + i) * 64 + lane]; },
+                             [&](int i, const half8& f) { dzz = MFMA32(f, d3f[i], dzz); });
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) dzz = MFMA32(wH[(G::T2 + ks) * 64 + lane], d3f[ks], dzz);
+      for (int k = 0; k < B::A2; k++) {
+        const int t = (wv + NW * k) % B::NT2;   // a wave without a tile of its own repeats another's
+        dw2[k] = dw_tile<SS>(Ys + t * BLK, Xs, t0, t1, dw2[k]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < G::KH; ks++) dzz = MFMA32(wH[(G::T2 + ks) * 64 + lane], d3f[ks], dzz);
+    }
     // dO fragment: slots rho = 0..14 <- d geo (rows 16..30 of dz = regs 8..15); slot rho = 15 <- d logit
     // trunc_exp backward (activation.py:14-17): g * exp(clamp(logit, -15, 15)); PART 1 has sigma = exp(logit) instead
     float dlogit;
@@ -433,10 +523,14 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h1[ks], h, scol);
     put_frag<BLK>(Ys, 0, dof, h, scol);   // features 0..15 of the block; 16..31 are never used
     stage_ready();
+    if (PART != 0) {
+      dw_tiles<SS, B::A1>([&](int) { return Ys; }, [&](int k) { return Xs + ((wv + NW * k) % B::NT1) * BLK; }, t0, t1, dw1);
+    } else {
 #pragma unroll
-    for (int k = 0; k < B::A1; k++) {
-      const int t = (wv + NW * k) % B::NT1;   // a wave without a tile of its own repeats another's
-      dw1[k] = dw_tile<SS>(Ys, Xs + t * BLK, t0, t1, dw1[k]);
+      for (int k = 0; k < B::A1; k++) {
+        const int t = (wv + NW * k) % B::NT1;   // a wave without a tile of its own repeats another's
+        dw1[k] = dw_tile<SS>(Ys, Xs + t * BLK, t0, t1, dw1[k]);
+      }
     }
     half8 d1f[G::KH];
 #pragma unroll
@@ -465,21 +559,22 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d1f[ks], h, scol);
     stage_ready();
+    if (PART != 0) {
+      dw_tiles<SS, B::A0>([&](int k) { return Ys + (((wv + NW * k) % B::NT0) / G::IB0) * BLK; },
+                          [&](int k) { return (B::EARLY_F ? Fs : Xs) + (((wv + NW * k) % B::NT0) % G::IB0) * BLK; }, t0, t1, dw0);
+    } else {
 #pragma unroll
-    for (int k = 0; k < B::A0; k++) {
-      const int t = (wv + NW * k) % B::NT0;   // a wave without a tile of its own repeats another's
-      dw0[k] = dw_tile<SS>(Ys + (t / G::IB0) * BLK, (B::EARLY_F ? Fs : Xs) + (t % G::IB0) * BLK, t0, t1, dw0[k]);
+      for (int k = 0; k < B::A0; k++) {
+        const int t = (wv + NW * k) % B::NT0;   // a wave without a tile of its own repeats another's
+        dw0[k] = dw_tile<SS>(Ys + (t / G::IB0) * BLK, (B::EARLY_F ? Fs : Xs) + (t % G::IB0) * BLK, t0, t1, dw0[k]);
+      }
     }
     // feature gradient dF^T = W0^T dH1^T
     if (!ATOMIC) {
       // binned mode: dF leaves as fp16, plane-major [3][M][C] (each plane's tile pass of scatter.hip then reads
       // whole 128-B lines of ITS channels; a [M][3C] row would hand it one useful 64-B third per line)
       typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-      for (int ib = 0; ib < G::IB0; ib++) {
-        f32x16 df = zero16();
-#pragma unroll
-        for (int ks = 0; ks < G::KH; ks++) df = MFMA32(wT[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
+      auto df_out = [&](int ib, const f32x16& df) {
         // Registers 4q..4q+3 hold features 32 ib + 8q + 4h .. +3 of sample r: a lane owns four 8-byte pieces of its
         // 64-byte row.  The two lanes of a sample trade two pieces each (v_permlane32_swap: lanes r and r + 32), after
         // which lane (r, h) holds features 32 ib + 16h .. +15 -- 32 contiguous bytes, two 16-byte stores instead of
@@ -509,12 +604,28 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
         for (int k = 0; k < 2; k++) {
           const int f0 = 32 * ib + 16 * h + 8 * k;
-          if (f0 < G::F && valid) {
+          if (f0 < G::F && valid && !(TNL_BWD_EXP & 8)) {
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             const u4 v = {pc[k][0], pc[k][1], pc[k + 2][0], pc[k + 2][1]};
             const int pl = f0 / C, fc = f0 - pl * C;   // 8 consecutive features never straddle planes (C % 8 == 0)
             *reinterpret_cast<u4*>(dfeat + ((size_t)pl * Mcap + i) * C + fc) = v;
           }
+        }
+      };
+      if (PART != 0) {
+        f32x16 df = zero16();
+        with_weights<G::IB0 * G::KH, 4>([&](int q) { return wT[(G::T0 + q) * 64 + lane]; }, [&](int q, const half8& f) {
+          if (q % G::KH == 0) df = zero16();
+          df = MFMA32(f, d1f[q % G::KH], df);
+          if (q % G::KH == G::KH - 1) df_out(q / G::KH, df);
+        });
+      } else {
+#pragma unroll
+        for (int ib = 0; ib < G::IB0; ib++) {
+          f32x16 df = zero16();
+#pragma unroll
+          for (int ks = 0; ks < G::KH; ks++) df = MFMA32(wT[(G::T0 + ib * G::KH + ks) * 64 + lane], d1f[ks], df);
+          df_out(ib, df);
         }
       }
     } else {
@@ -555,7 +666,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     }
     }  // DO_SIG
-    __syncthreads();  // Xs/Ys are rewritten by the next super-tile
+    if (!(TNL_BWD_EXP & 4)) __syncthreads();  // Xs/Ys are rewritten by the next super-tile
   }
   // ---- epilogue: this workgroup's weight-gradient slab
   float* slab = slabs + (size_t)blockIdx.x * G::NW;

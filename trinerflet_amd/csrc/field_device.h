@@ -121,6 +121,30 @@ __device__ __forceinline__ half8 gather_frag(const void* planes, int R, int p, i
   return f;
 }
 
+// N weight fragments wsrc(0..N-1), consumed in order by body(i, fragment): the fragments are requested GROUP at a time,
+// ONE GROUP AHEAD of the MFMAs that take them, with a scheduling fence per group.  One wave per SIMD issues in order and
+// nothing else covers an LDS read (ds_read_b128: ~100+ cycles): left alone the compiler places every read right in front
+// of its MFMA (`wait, MFMA, read` per 32-cycle MFMA -- profiles of the hidden-128 backward, round 5); here a group's reads
+// are in flight while the previous group's MFMAs execute.  Costs 2 * GROUP * 4 registers.
+template <int N, int GROUP, class WSrc, class Body>
+__device__ __forceinline__ void with_weights(WSrc wsrc, Body body) {
+  constexpr int NG = (N + GROUP - 1) / GROUP;
+  half8 buf[2][GROUP];
+#pragma unroll
+  for (int j = 0; j < GROUP; j++)
+    if (j < N) buf[0][j] = wsrc(j);
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+#pragma unroll
+    for (int j = 0; j < GROUP; j++)
+      if (g + 1 < NG && (g + 1) * GROUP + j < N) buf[(g + 1) & 1][j] = wsrc((g + 1) * GROUP + j);
+#pragma unroll
+    for (int j = 0; j < GROUP; j++)
+      if (g * GROUP + j < N) body(g * GROUP + j, buf[g & 1][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // the MLP chain on one 32-sample tile, shared by forward and backward-recompute
 // ---------------------------------------------------------------------------------------------
@@ -175,20 +199,31 @@ __device__ __forceinline__ void chain_colour(const half8* w, const half8* wH, in
 #pragma unroll
   for (int ks = 0; ks < G::KH; ks++)
     ch.h3[ks] = (ks & 1) ? acc_to_frag<true>(acc2[ks >> 1], 1) : acc_to_frag<true>(acc2[ks >> 1], 0);
-  f32x16 acc3[G::OB];
-#pragma unroll
-  for (int ob = 0; ob < G::OB; ob++) {
-    acc3[ob] = zero16();
-#pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) acc3[ob] = MFMA32(wH[(G::F3 + ob * G::KH + ks) * 64 + lane], ch.h3[ks], acc3[ob]);
-    if (FENCE) __builtin_amdgcn_sched_barrier(0);   // one tile's fragments at a time (register pressure of the split backward)
-  }
-#pragma unroll
-  for (int ks = 0; ks < G::KH; ks++)
-    ch.h4[ks] = (ks & 1) ? acc_to_frag<true>(acc3[ks >> 1], 1) : acc_to_frag<true>(acc3[ks >> 1], 0);
   f32x16 out = zero16();
+  if (FENCE) {     // the split backward of hidden 128 (one wave per SIMD): weight fragments a group ahead (with_weights)
+    f32x16 t3 = zero16();
+    with_weights<G::OB * G::KH, 4>([&](int i) { return wH[(G::F3 + i) * 64 + lane]; }, [&](int i, const half8& f) {
+      const int ob = i / G::KH, ks = i % G::KH;
+      if (ks == 0) t3 = zero16();
+      t3 = MFMA32(f, ch.h3[ks], t3);
+      if (ks == G::KH - 1) { ch.h4[2 * ob] = acc_to_frag<true>(t3, 0); ch.h4[2 * ob + 1] = acc_to_frag<true>(t3, 1); }
+    });
+    with_weights<G::KH, 4>([&](int i) { return wH[(G::F4 + i) * 64 + lane]; },
+                           [&](int i, const half8& f) { out = MFMA32(f, ch.h4[i], out); });
+  } else {
+    f32x16 acc3[G::OB];
 #pragma unroll
-  for (int ks = 0; ks < G::KH; ks++) out = MFMA32(wH[(G::F4 + ks) * 64 + lane], ch.h4[ks], out);
+    for (int ob = 0; ob < G::OB; ob++) {
+      acc3[ob] = zero16();
+#pragma unroll
+      for (int ks = 0; ks < G::KH; ks++) acc3[ob] = MFMA32(wH[(G::F3 + ob * G::KH + ks) * 64 + lane], ch.h3[ks], acc3[ob]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KH; ks++)
+      ch.h4[ks] = (ks & 1) ? acc_to_frag<true>(acc3[ks >> 1], 1) : acc_to_frag<true>(acc3[ks >> 1], 0);
+#pragma unroll
+    for (int ks = 0; ks < G::KH; ks++) out = MFMA32(wH[(G::F4 + ks) * 64 + lane], ch.h4[ks], out);
+  }
   ch.rgbl[0] = out[0]; ch.rgbl[1] = out[1]; ch.rgbl[2] = out[2];
 }
 
