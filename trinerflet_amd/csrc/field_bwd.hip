@@ -29,6 +29,21 @@
 #include "field_bwd_rows.h"
 #include "field_device.h"
 
+#ifndef TNL_WG
+#define TNL_WG 4        // weight fragments per group of with_weights in the split launches (A/B builds)
+#endif
+#ifndef TNL_DWG
+#define TNL_DWG 4       // k-steps per operand group of dw_tiles
+#endif
+#ifndef TNL_BWD_STAMP
+#define TNL_BWD_STAMP 0   // 1 / 2: wave 0 of workgroup 0 of the PART 1 / PART 2 launch records s_memtime at its phase boundaries
+#endif                    // (tools/bwd_stamps.py)
+#if TNL_BWD_STAMP
+__device__ unsigned long long g_bwd_stamps[64 * 32];
+extern "C" __attribute__((visibility("default"))) int tnl_debug_bwd_stamps(void* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bwd_stamps), sizeof(g_bwd_stamps));
+}
+#endif
 #ifndef TNL_BWD_EXP
 #define TNL_BWD_EXP 0   // timing-only experiment builds (WRONG results): bit 0 no weight-gradient tiles, bit 1 no stage
 #endif                  // writes, bit 2 no barriers inside the super-tile loop, bit 3 no dF stores (tools/build_variant.py)
@@ -125,7 +140,7 @@ __device__ __forceinline__ f32x16 dw_tile(const char* yb, const char* xb, int t0
 template <int ST, int A, class YB, class XB>
 __device__ __forceinline__ void dw_tiles(YB ybf, XB xbf, int t0, int t1, f32x16 (&dw)[A]) {
   if (TNL_BWD_EXP & 1) return;
-  constexpr int NK = ST / 16, GK = 4, NG = NK / GK, TOT = A * NG;
+  constexpr int NK = ST / 16, GK = TNL_DWG, NG = NK / GK, TOT = A * NG;
   static_assert(NK % GK == 0, "super-tile of a multiple of 64 samples");
   half8 a[2][GK], b[2][GK];
   auto ld = [&](int q) {
@@ -275,33 +290,39 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     float sg;
   };
   const _Float16* geo_save = feats + (size_t)((Mcap + 31) / 32 * 32) * G::F;
+  // load_inputs only REQUESTS (from the clamped row of a lane past the end); mask_inputs zeroes such a lane's values where
+  // they are consumed, a super-tile later.  (Round 5: the `v_ ? x : 0` selects used to sit right behind the loads -- a use
+  // of the loaded registers, so the "prefetch" waited out its own DRAM round trip at the top of every super-tile: 4 000
+  // of the sigma half's 13 600 cycles per super-tile, tools/bwd_stamps.py.)
   auto load_inputs = [&](uint32_t st_, Inputs& in) {
     const uint32_t i_ = st_ * ST + col;
-    const bool v_ = i_ < M;
-    const uint32_t il_ = v_ ? i_ : M - 1;
+    const uint32_t il_ = i_ < M ? i_ : M - 1;
     if (ATOMIC) { in.px = xyz[(size_t)il_ * 3]; in.py = xyz[(size_t)il_ * 3 + 1]; in.pz = xyz[(size_t)il_ * 3 + 2]; }
     else { in.px = in.py = in.pz = 0.f; }
     if (DO_COL) {
       in.dx = dirs[(size_t)il_ * 3]; in.dy = dirs[(size_t)il_ * 3 + 1]; in.dz = dirs[(size_t)il_ * 3 + 2];
-      in.g_s = v_ ? gsig[i_] : 0.f;
-      in.g_c0 = v_ ? grgb[(size_t)i_ * 3] : 0.f; in.g_c1 = v_ ? grgb[(size_t)i_ * 3 + 1] : 0.f;
-      in.g_c2 = v_ ? grgb[(size_t)i_ * 3 + 2] : 0.f;
+      in.g_s = gsig[il_];
+      in.g_c0 = grgb[(size_t)il_ * 3]; in.g_c1 = grgb[(size_t)il_ * 3 + 1]; in.g_c2 = grgb[(size_t)il_ * 3 + 2];
     } else {
       in.dx = in.dy = in.dz = in.g_s = in.g_c0 = in.g_c1 = in.g_c2 = 0.f;
       in.dof = *reinterpret_cast<const half8*>(dO + (size_t)il_ * 16 + 8 * h);
-      if (!v_) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) in.dof[j] = (_Float16)0.f;
-      }
     }
     if (PART == 1) {     // (the sigma-net outputs `geo` come by LDS-DMA: dma_geo / the read at the top of the super-tile)
       in.sg = sigma[il_];
       return;
     }
 #pragma unroll
-    for (int ks = 0; ks < G::KS0; ks++) {
+    for (int ks = 0; ks < G::KS0; ks++)
       in.fk[ks] = *reinterpret_cast<const half8*>(feats + feat_slot<G::KS0>(il_, ks, h));
-      if (!v_) {
+  };
+  auto mask_inputs = [&](Inputs& in, bool v_) {
+    if (v_) return;
+    in.g_s = in.g_c0 = in.g_c1 = in.g_c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) in.dof[j] = (_Float16)0.f;
+    if (PART != 1) {
+#pragma unroll
+      for (int ks = 0; ks < G::KS0; ks++) {
 #pragma unroll
         for (int j = 0; j < 8; j++) in.fk[ks][j] = (_Float16)0.f;
       }
@@ -323,8 +344,33 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
   if (PREFETCH && blockIdx.x < nst) {
     load_inputs(blockIdx.x, nxt);
     if (PART == 1) dma_geo(blockIdx.x);
+    // A use of the first super-tile's inputs in front of the loop: the compiler then waits for them HERE, and the wait at
+    // the loop's top only has the back edge to serve -- the loads issued a super-tile ago, which the dF stores behind
+    // them do not hold up (vmcnt(#stores)).  Without it the two incoming states merge to vmcnt(0) at the top of every
+    // super-tile: the wave sat out the acknowledgement of its own dF stores.
+    if (PART != 0) {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      if (PART == 2) {
+#pragma unroll
+        for (int ks = 0; ks < G::KS0; ks++) asm volatile("" ::"v"(__builtin_bit_cast(u32x4, nxt.fk[ks])));
+        asm volatile("" ::"v"(__builtin_bit_cast(u32x4, nxt.dof)));
+      } else {
+        asm volatile("" ::"v"(nxt.dx), "v"(nxt.dy), "v"(nxt.dz), "v"(nxt.g_s), "v"(nxt.g_c0), "v"(nxt.g_c1), "v"(nxt.g_c2), "v"(nxt.sg));
+      }
+    }
   }
+#if TNL_BWD_STAMP
+  int stamp_t = 0;
+#define BSTAMP() { __builtin_amdgcn_sched_barrier(0); if (stamp_on) { if (stamp_k < 32) g_bwd_stamps[stamp_t * 32 + stamp_k] = __builtin_readcyclecounter(); stamp_k++; } __builtin_amdgcn_sched_barrier(0); }
+#else
+#define BSTAMP()
+#endif
   for (uint32_t st = blockIdx.x; st < nst; st += gridDim.x) {
+#if TNL_BWD_STAMP
+    const bool stamp_on = PART == TNL_BWD_STAMP && blockIdx.x == 0 && threadIdx.x == 0 && stamp_t < 64;
+    int stamp_k = 0;
+    BSTAMP()   // 0: top
+#endif
     if (!B::LDSW) {
       // Weight fragments read from global memory (L2) inside the loop: the 8 layer-2 fragments of PART 1, and all 180
       // of the one-launch hidden-128 kernel (atomic mode only, the drop-in autograd path).  Keep the compiler from
@@ -342,6 +388,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     const bool valid = i < M;
     if (!PREFETCH) load_inputs(st, nxt);
     Inputs in = nxt;
+    mask_inputs(in, valid);
     if (PART == 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this super-tile's DMA piece has landed
       in.geo = *reinterpret_cast<const half8*>(gbuf + lane * 16);
@@ -363,7 +410,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
       for (int ob = 0; ob < G::OB; ob++) acc0[ob] = zero16();
       if (PART != 0) {   // split launches (one wave per SIMD): weight fragments a group ahead of their MFMAs
-        with_weights<G::KS0 * G::OB, G::OB>(
+        with_weights<G::KS0 * G::OB, TNL_WG>(
             [&](int i) { return w[(G::F0 + (i % G::OB) * G::KS0 + i / G::OB) * 64 + lane]; },
             [&](int i, const half8& f) { acc0[i % G::OB] = MFMA32(f, in.fk[i / G::OB], acc0[i % G::OB]); });
       } else {
@@ -375,6 +422,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
         }
       }
     }
+    BSTAMP()   // 1: inputs in registers, layer-0 forward issued
     Chain<C, H> ch;
     if (PART == 1) {
       chain_colour<C, H, true>(wH, wH, lane, h, in.geo, dx, dy, dz, ch);
@@ -385,6 +433,7 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       for (int ks = 0; ks < G::KH; ks++)
         ch.h1[ks] = (ks & 1) ? acc_to_frag<true>(acc0[ks >> 1], 1) : acc_to_frag<true>(acc0[ks >> 1], 0);
     }
+    BSTAMP()   // 2: forward chain done
     char *Xs, *Ys;
     half8 dof;
     if (DO_COL) {
@@ -402,7 +451,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h4[ks], h, scol);
     put_acc<1>(Ys, dz4, h, scol);   // rows 0..7 (rgb logits' gradient in rows 0..2); the rest of the block is never used
+    BSTAMP()   // 3: layer-4 stage written
     stage_ready();
+    BSTAMP()   // 4: barrier
     // (Every wave accumulates A_l tiles per layer without a branch: behind `if (tile < NT_l)` the accumulators of that
     // block live in VGPRs and are copied into AGPRs and back around the MFMAs, 32 moves per tile and super-tile.  The
     // duplicates cost idle waves a few MFMAs and are dropped when the slabs are written.)
@@ -424,7 +475,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       d4f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h4[2 * ib]);
       d4f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h4[2 * ib + 1]);
     }
+    BSTAMP()   // 5: layer-4 weight gradient + d4
     sync_stage();
+    BSTAMP()   // 6
 
     // ---- layer 3
     Xs = Xb[1]; Ys = Yb[1];
@@ -432,7 +485,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h3[ks], h, scol);
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d4f[ks], h, scol);
+    BSTAMP()   // 7: layer-3 stage written
     stage_ready();
+    BSTAMP()   // 8
     if (PART != 0) {
       dw_tiles<SS, B::A3>([&](int k) { return Ys + (((wv + NW * k) % B::NT3) / G::OB) * BLK; },
                           [&](int k) { return Xs + (((wv + NW * k) % B::NT3) % G::OB) * BLK; }, t0, t1, dw3);
@@ -445,15 +500,18 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
     half8 d3f[G::KH];
     if (PART != 0) {
-      f32x16 t = zero16();
-      with_weights<G::OB * G::KH, 4>([&](int i) { return wH[(G::T3 + i) * 64 + lane]; }, [&](int i, const half8& f) {
+      f32x16 ta = zero16(), tb = zero16();
+      auto post = [&](int ib, const f32x16& t) {
+        d3f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h3[2 * ib]);
+        d3f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h3[2 * ib + 1]);
+      };
+      with_weights<G::OB * G::KH, TNL_WG>([&](int i) { return wH[(G::T3 + i) * 64 + lane]; }, [&](int i, const half8& f) {
         const int ib = i / G::KH, ks = i % G::KH;
+        f32x16& t = (ib & 1) ? tb : ta;
         if (ks == 0) t = zero16();
         t = MFMA32(f, d4f[ks], t);
-        if (ks == G::KH - 1) {
-          d3f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h3[2 * ib]);
-          d3f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h3[2 * ib + 1]);
-        }
+        if (ks == TNL_WG - 1 && ib > 0) post(ib - 1, (ib & 1) ? ta : tb);     // behind the next tile's first MFMAs
+        if (i == G::OB * G::KH - 1) post(ib, t);
       });
     } else {
 #pragma unroll
@@ -468,7 +526,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
         if (H > 64) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    BSTAMP()   // 9: layer-3 weight gradient + d3
     sync_stage();
+    BSTAMP()   // 10
 
     // ---- layer 2: X = z, staged as [SH(16) | the 16 chain slots of the sigma net's outputs] (slot 0 = the logit, which
     // is no input of the colour net: slab_tile<2> drops that column and shifts the geo features back by one)
@@ -484,7 +544,9 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     }
 #pragma unroll
     for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d3f[ks], h, scol);
+    BSTAMP()   // 11: layer-2 stage written
     stage_ready();
+    BSTAMP()   // 12
     f32x16 dzz = zero16();
     if (PART != 0) {
       dw_tiles<SS, B::A2>([&](int k) { return Ys + ((wv + NW * k) % B::NT2) * BLK; }, [&](int) { return Xs; }, t0, t1, dw2);
@@ -511,66 +573,24 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
     dof = acc_to_frag<false>(dzz, 1);
     if (h == 1) dof[7] = (_Float16)dlogit;
     if (PART == 1 && valid) *reinterpret_cast<half8*>(dO + (size_t)i * 16 + 8 * h) = dof;
+    BSTAMP()   // 13: layer-2 weight gradient + dO
     sync_stage();
+    BSTAMP()   // 14
     } else {
       dof = in.dof;
     }
     if (DO_SIG) {
 
-    // ---- layer 1: X = H1, dY = dO in chain-slot order (slot 15 = the logit's gradient; slab_tile<1> maps the rows back)
-    Xs = Xb[1]; Ys = Yb[1];
-#pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h1[ks], h, scol);
-    put_frag<BLK>(Ys, 0, dof, h, scol);   // features 0..15 of the block; 16..31 are never used
-    stage_ready();
-    if (PART != 0) {
-      dw_tiles<SS, B::A1>([&](int) { return Ys; }, [&](int k) { return Xs + ((wv + NW * k) % B::NT1) * BLK; }, t0, t1, dw1);
-    } else {
-#pragma unroll
-      for (int k = 0; k < B::A1; k++) {
-        const int t = (wv + NW * k) % B::NT1;   // a wave without a tile of its own repeats another's
-        dw1[k] = dw_tile<SS>(Ys, Xs + t * BLK, t0, t1, dw1[k]);
-      }
-    }
     half8 d1f[G::KH];
+    auto compute_d1 = [&]() {
 #pragma unroll
-    for (int ib = 0; ib < G::OB; ib++) {
-      f32x16 t = MFMA32(wT[(G::T1 + ib) * 64 + lane], dof, zero16());
-      d1f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h1[2 * ib]);
-      d1f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h1[2 * ib + 1]);
-    }
-    sync_stage();
-
-    // ---- layer 0: X = F (natural k order) from the feature stage written at the top of the super-tile
-    Xs = Xb[0]; Ys = Yb[0];
-    if (!B::EARLY_F) {   // into Xs: re-read (L2-hot) in atomic mode, from registers in PART 2
-      const uint32_t il = valid ? i : M - 1;
-#pragma unroll
-      for (int ks = 0; ks < G::KS0; ks++) {
-        half8 fk = in.fk[ks];
-        if (PART != 2) {
-#pragma unroll
-          for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
-          if (valid) fk = *reinterpret_cast<const half8*>(feats + feat_slot<G::KS0>(il, ks, h));
-        }
-        put_nat<BLK>(Xs, ks, fk, h, scol);
+      for (int ib = 0; ib < G::OB; ib++) {
+        f32x16 t = MFMA32(wT[(G::T1 + ib) * 64 + lane], dof, zero16());
+        d1f[2 * ib] = relu_mask_frag(acc_to_frag<false>(t, 0), ch.h1[2 * ib]);
+        d1f[2 * ib + 1] = relu_mask_frag(acc_to_frag<false>(t, 1), ch.h1[2 * ib + 1]);
       }
-    }
-#pragma unroll
-    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d1f[ks], h, scol);
-    stage_ready();
-    if (PART != 0) {
-      dw_tiles<SS, B::A0>([&](int k) { return Ys + (((wv + NW * k) % B::NT0) / G::IB0) * BLK; },
-                          [&](int k) { return (B::EARLY_F ? Fs : Xs) + (((wv + NW * k) % B::NT0) % G::IB0) * BLK; }, t0, t1, dw0);
-    } else {
-#pragma unroll
-      for (int k = 0; k < B::A0; k++) {
-        const int t = (wv + NW * k) % B::NT0;   // a wave without a tile of its own repeats another's
-        dw0[k] = dw_tile<SS>(Ys + (t / G::IB0) * BLK, (B::EARLY_F ? Fs : Xs) + (t % G::IB0) * BLK, t0, t1, dw0[k]);
-      }
-    }
-    // feature gradient dF^T = W0^T dH1^T
-    if (!ATOMIC) {
+    };
+    auto dF_binned = [&]() {
       // binned mode: dF leaves as fp16, plane-major [3][M][C] (each plane's tile pass of scatter.hip then reads
       // whole 128-B lines of ITS channels; a [M][3C] row would hand it one useful 64-B third per line)
       typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -613,11 +633,16 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
         }
       };
       if (PART != 0) {
-        f32x16 df = zero16();
-        with_weights<G::IB0 * G::KH, 4>([&](int q) { return wT[(G::T0 + q) * 64 + lane]; }, [&](int q, const half8& f) {
-          if (q % G::KH == 0) df = zero16();
-          df = MFMA32(f, d1f[q % G::KH], df);
-          if (q % G::KH == G::KH - 1) df_out(q / G::KH, df);
+        // block ib's conversion / lane swap / stores are issued behind the FIRST group of block ib + 1's MFMAs (two
+        // accumulators alternate): the vector-ALU work of one block runs while the matrix pipe executes the next
+        f32x16 dfa = zero16(), dfb = zero16();
+        with_weights<G::IB0 * G::KH, TNL_WG>([&](int q) { return wT[(G::T0 + q) * 64 + lane]; }, [&](int q, const half8& f) {
+          const int ib = q / G::KH, ks = q % G::KH;
+          f32x16& df = (ib & 1) ? dfb : dfa;
+          if (ks == 0) df = zero16();
+          df = MFMA32(f, d1f[ks], df);
+          if (ks == TNL_WG - 1 && ib > 0) df_out(ib - 1, (ib & 1) ? dfa : dfb);
+          if (q == G::IB0 * G::KH - 1) df_out(ib, df);
         });
       } else {
 #pragma unroll
@@ -628,6 +653,71 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
           df_out(ib, df);
         }
       }
+    };
+    // PART 2 (round 5): d1 and the feature gradient FIRST, the two weight-gradient stages after them.  dF's stores were the
+    // last thing of the super-tile, and the wait for the next tile's prefetched inputs at the loop's top (the compiler
+    // merges it to vmcnt(0)) sat out their acknowledgement; now 4-5 k cycles of LDS work lie between them and that wait.
+    if (PART == 2) {
+      compute_d1();
+      dF_binned();
+      BSTAMP()   // PART 2: 2b: d1 + dF
+    }
+    // ---- layer 1: X = H1, dY = dO in chain-slot order (slot 15 = the logit's gradient; slab_tile<1> maps the rows back)
+    Xs = Xb[1]; Ys = Yb[1];
+#pragma unroll
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Xs, ks, ch.h1[ks], h, scol);
+    put_frag<BLK>(Ys, 0, dof, h, scol);   // features 0..15 of the block; 16..31 are never used
+    BSTAMP()   // PART 2: 3: layer-1 stage written
+    stage_ready();
+    BSTAMP()   // 4
+    if (PART != 0) {
+      dw_tiles<SS, B::A1>([&](int) { return Ys; }, [&](int k) { return Xs + ((wv + NW * k) % B::NT1) * BLK; }, t0, t1, dw1);
+    } else {
+#pragma unroll
+      for (int k = 0; k < B::A1; k++) {
+        const int t = (wv + NW * k) % B::NT1;   // a wave without a tile of its own repeats another's
+        dw1[k] = dw_tile<SS>(Ys, Xs + t * BLK, t0, t1, dw1[k]);
+      }
+    }
+    if (PART != 2) compute_d1();
+    BSTAMP()   // 5: layer-1 weight gradient + d1
+    sync_stage();
+    BSTAMP()   // 6
+
+    // ---- layer 0: X = F (natural k order) from the feature stage written at the top of the super-tile
+    Xs = Xb[0]; Ys = Yb[0];
+    if (!B::EARLY_F) {   // into Xs: re-read (L2-hot) in atomic mode, from registers in PART 2
+      const uint32_t il = valid ? i : M - 1;
+#pragma unroll
+      for (int ks = 0; ks < G::KS0; ks++) {
+        half8 fk = in.fk[ks];
+        if (PART != 2) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) fk[j] = (_Float16)0.f;
+          if (valid) fk = *reinterpret_cast<const half8*>(feats + feat_slot<G::KS0>(il, ks, h));
+        }
+        put_nat<BLK>(Xs, ks, fk, h, scol);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < G::KH; ks++) put_frag<BLK>(Ys, ks, d1f[ks], h, scol);
+    BSTAMP()   // 7: layer-0 stage written
+    stage_ready();
+    BSTAMP()   // 8
+    if (PART != 0) {
+      dw_tiles<SS, B::A0>([&](int k) { return Ys + (((wv + NW * k) % B::NT0) / G::IB0) * BLK; },
+                          [&](int k) { return (B::EARLY_F ? Fs : Xs) + (((wv + NW * k) % B::NT0) % G::IB0) * BLK; }, t0, t1, dw0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < B::A0; k++) {
+        const int t = (wv + NW * k) % B::NT0;   // a wave without a tile of its own repeats another's
+        dw0[k] = dw_tile<SS>(Ys + (t / G::IB0) * BLK, (B::EARLY_F ? Fs : Xs) + (t % G::IB0) * BLK, t0, t1, dw0[k]);
+      }
+    }
+    BSTAMP()   // 9: layer-0 weight gradient
+    // feature gradient dF^T = W0^T dH1^T
+    if (!ATOMIC) {
+      if (PART != 2) dF_binned();
     } else {
     // atomic mode: staged [sample][feature] fp32 in this wave's LDS region
 #pragma unroll
@@ -665,8 +755,13 @@ k_field_bwd(const float* __restrict__ gsig, const float* __restrict__ grgb, cons
       }
     }
     }
+    BSTAMP()   // 10: dF
     }  // DO_SIG
     if (!(TNL_BWD_EXP & 4)) __syncthreads();  // Xs/Ys are rewritten by the next super-tile
+    BSTAMP()   // closing barrier
+#if TNL_BWD_STAMP
+    if (stamp_on) stamp_t++;
+#endif
   }
   // ---- epilogue: this workgroup's weight-gradient slab
   float* slab = slabs + (size_t)blockIdx.x * G::NW;

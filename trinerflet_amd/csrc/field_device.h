@@ -201,12 +201,16 @@ __device__ __forceinline__ void chain_colour(const half8* w, const half8* wH, in
     ch.h3[ks] = (ks & 1) ? acc_to_frag<true>(acc2[ks >> 1], 1) : acc_to_frag<true>(acc2[ks >> 1], 0);
   f32x16 out = zero16();
   if (FENCE) {     // the split backward of hidden 128 (one wave per SIMD): weight fragments a group ahead (with_weights)
-    f32x16 t3 = zero16();
+    // (tile ob's conversion is issued behind the first group of tile ob + 1's MFMAs: two accumulators alternate)
+    f32x16 t3a = zero16(), t3b = zero16();
+    auto post3 = [&](int ob, const f32x16& t) { ch.h4[2 * ob] = acc_to_frag<true>(t, 0); ch.h4[2 * ob + 1] = acc_to_frag<true>(t, 1); };
     with_weights<G::OB * G::KH, 4>([&](int i) { return wH[(G::F3 + i) * 64 + lane]; }, [&](int i, const half8& f) {
       const int ob = i / G::KH, ks = i % G::KH;
+      f32x16& t3 = (ob & 1) ? t3b : t3a;
       if (ks == 0) t3 = zero16();
       t3 = MFMA32(f, ch.h3[ks], t3);
-      if (ks == G::KH - 1) { ch.h4[2 * ob] = acc_to_frag<true>(t3, 0); ch.h4[2 * ob + 1] = acc_to_frag<true>(t3, 1); }
+      if (ks == 3 && ob > 0) post3(ob - 1, (ob & 1) ? t3a : t3b);
+      if (i == G::OB * G::KH - 1) post3(ob, t3);
     });
     with_weights<G::KH, 4>([&](int i) { return wH[(G::F4 + i) * 64 + lane]; },
                            [&](int i, const half8& f) { out = MFMA32(f, ch.h4[i], out); });
