@@ -2,7 +2,9 @@ import sys, torch, numpy as np
 sys.path.insert(0, '/root/repo')
 import trinerflet_amd._lib as L
 from trinerflet_amd import raymarching, synthetic
+import os
 lib = L.lib(); dev = torch.device('cuda:0')
+lib.tnl_march_count_form(L.i32(int(os.environ.get('TNL_COUNT_FORM', '0'))))   # 0 wavefront per ray, 1 one ray per lane
 for (bound, Cc, Hg, N) in ((1.0, 1, 128, 61440), (2.0, 2, 128, 61440), (1.5, 2, 128, 60000)):   # the last: the base workload's
     max_steps = 1024
     rng = np.random.default_rng(11)

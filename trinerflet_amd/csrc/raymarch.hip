@@ -194,6 +194,9 @@ __global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thr
 // training march: count -> (block sums) -> scan + write -> finalize
 // ---------------------------------------------------------------------------------------------
 constexpr int MARCH_BLOCK = 256;
+#ifndef TNL_MARCH_FAST_LANE
+#define TNL_MARCH_FAST_LANE 1   // 0: the per-lane count pass through the generic march_run (A/B builds)
+#endif
 #ifndef TNL_MARCH_WAVE
 #define TNL_MARCH_WAVE 1     // 0: the per-lane count pass everywhere (A/B builds)
 #endif
@@ -224,6 +227,80 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* smem4, int* total
   return base + incl - v;
 }
 
+// The serial march of one ray on one lane (march_run<false, true, true, REC>) for the fast path of the level arithmetic
+// (dt_gamma = 0, <= 2 cascades, H <= 256), with the per-ray constants hoisted, the Morton code from a 256-entry LDS table
+// and the exact-by-construction steps folded -- the identities listed in k_march_train_count_wave, the same values bit
+// for bit.  A probe is a dependent chain (position -> cell -> word -> bit) at one wave per SIMD: its length is the
+// kernel's time (round 5: 789 -> see profiles/r05_*).
+struct FastProbe {
+  float x, y, z, mipb;
+  int nx, ny, nz;
+  bool occ;
+};
+
+template <bool REC>
+__device__ __forceinline__ uint32_t march_run_fast(const MarchCtx& m, float& t, float far, uint32_t limit, float* trec,
+                                                   const uint32_t* __restrict__ lut) {
+#pragma clang fp contract(off)
+  const float hH = 0.5f * m.Hf, rH2 = m.rH * 2, hmax = (float)(m.H - 1), dt = m.dt0;
+  const int incx = __float_as_uint(m.dx) >> 31 ? 0 : 1, incy = __float_as_uint(m.dy) >> 31 ? 0 : 1,
+            incz = __float_as_uint(m.dz) >> 31 ? 0 : 1;
+  const uint32_t H3u = m.H * m.H * m.H;
+  const unsigned long long* grid64 = reinterpret_cast<const unsigned long long*>(m.grid);
+  uint32_t cached_blk = 0xffffffffu;
+  unsigned long long cached_bits = 0ull;
+  auto probe = [&](float tt_) {
+    FastProbe q;
+    q.x = clampf_(fmaf(tt_, m.dx, m.ox), -m.bound, m.bound);
+    q.y = clampf_(fmaf(tt_, m.dy, m.oy), -m.bound, m.bound);
+    q.z = clampf_(fmaf(tt_, m.dz, m.oz), -m.bound, m.bound);
+    const bool lv1 = (m.two_levels && fmaxf(fabsf(q.x), fmaxf(fabsf(q.y), fabsf(q.z))) >= 1.0f) || m.level_dt0 > 0;
+    q.mipb = lv1 ? m.mb1 : m.mb0;
+    const float rb = lv1 ? m.rb1 : m.rb0;
+    q.nx = (int)clampf_(fmaf(q.x, rb, 1.0f) * hH, 0.0f, hmax);
+    q.ny = (int)clampf_(fmaf(q.y, rb, 1.0f) * hH, 0.0f, hmax);
+    q.nz = (int)clampf_(fmaf(q.z, rb, 1.0f) * hH, 0.0f, hmax);
+    const uint32_t index = (lv1 ? H3u : 0u) + (lut[q.nx] | (lut[q.ny] << 1) | (lut[q.nz] << 2));
+    const uint32_t blk = index >> 6;
+    if (blk != cached_blk) {
+      cached_bits = grid64[blk];
+      cached_blk = blk;
+    }
+    q.occ = (cached_bits >> (index & 63u)) & 1ull;
+    return q;
+  };
+  auto skip = [&](const FastProbe& q) {
+    const float ex = fmaf((float)(q.nx + incx) * rH2 - 1, q.mipb, -q.x) * m.rdx;
+    const float ey = fmaf((float)(q.ny + incy) * rH2 - 1, q.mipb, -q.y) * m.rdy;
+    const float ez = fmaf((float)(q.nz + incz) * rH2 - 1, q.mipb, -q.z) * m.rdz;
+    const float tt = t + fmaxf(0.0f, fminf(ex, fminf(ey, ez)));
+    do { t += dt; } while (t < tt);
+  };
+  uint32_t step = 0;
+  while (t < far && step < limit) {
+    const FastProbe a = probe(t);
+    const float t1 = t + dt;
+    const FastProbe b = probe(t1);
+    if (a.occ) {
+      if (REC) *trec++ = t;
+      t = t1;
+      step++;
+      if (t < far && step < limit) {
+        if (b.occ) {
+          if (REC) *trec++ = t;
+          t = t + dt;
+          step++;
+        } else {
+          skip(b);
+        }
+      }
+    } else {
+      skip(a);
+    }
+  }
+  return step;
+}
+
 template <bool WIDE, bool REC>
 __global__ void __launch_bounds__(MARCH_BLOCK)
 k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
@@ -232,6 +309,12 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
                     const float* __restrict__ fars, const float* __restrict__ noises,
                     int* __restrict__ num_steps_out, int* __restrict__ block_sums, float* __restrict__ tbuf) {
   __shared__ int smem4[4];
+  __shared__ uint32_t s_lut[MARCH_BLOCK];
+  const bool fast = WIDE && TNL_MARCH_FAST_LANE && dt_gamma == 0.f && C <= 2 && H <= 256;     // block-uniform
+  if (fast) {
+    s_lut[threadIdx.x] = expand_bits(threadIdx.x);
+    __syncthreads();
+  }
   const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
   int ns = 0;
   if (n < N) {
@@ -239,8 +322,11 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
     march_init(m, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, grid);
     float t = nears[n];
     t = fmaf(clampf_(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
-    ns = (int)march_run<false, WIDE, true, REC>(m, t, fars[n], max_steps, nullptr, nullptr, nullptr,
-                                                REC ? tbuf + (size_t)n * max_steps : nullptr);
+    if (fast)
+      ns = (int)march_run_fast<REC>(m, t, fars[n], max_steps, REC ? tbuf + (size_t)n * max_steps : nullptr, s_lut);
+    else
+      ns = (int)march_run<false, WIDE, true, REC>(m, t, fars[n], max_steps, nullptr, nullptr, nullptr,
+                                                  REC ? tbuf + (size_t)n * max_steps : nullptr);
     num_steps_out[n] = ns;
   }
   int total;
