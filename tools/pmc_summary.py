@@ -33,6 +33,8 @@ def load(root, counter):
 
 
 def main():
+    if len(sys.argv) != 5:
+        raise SystemExit(__doc__)
     fetch_dir, write_dir, prefix, per_step = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
     out = {}
     for counter, root in (("FETCH_SIZE", fetch_dir), ("WRITE_SIZE", write_dir)):
