@@ -30,8 +30,14 @@ namespace {
 // ran slower at base (1.03 vs 0.95 ms), and an 8-wave workgroup for hidden 128 -- two waves per SIMD sharing the 92 KB
 // of weights -- measured 1.61 vs 1.62 ms.  With all of a tile's loads in flight the kernel sits at the ~4 TB/s that
 // 64-byte texel gathers reach here: 3.6 GB in 0.81 ms at base, 5.4 GB in 1.5 ms at C = 48.)
+#ifndef TNL_FWD_LDSW
+#define TNL_FWD_LDSW 0
+#endif
+#ifndef TNL_FWD_MINWAVES
+#define TNL_FWD_MINWAVES 1     // A/B builds: minimum workgroups per CU the register allocation must allow
+#endif
 template <int C, int H, bool HALFP, bool DENSITY_ONLY, bool SAVE>
-__global__ void __launch_bounds__(FWD_THREADS)
+__global__ void __launch_bounds__(FWD_THREADS, TNL_FWD_MINWAVES)
 k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, const float* __restrict__ dirs,
             float bound, uint32_t M, int R, const half8* __restrict__ packed, float* __restrict__ sigma,
             float* __restrict__ rgb, _Float16* __restrict__ feats_save, _Float16* __restrict__ geo_save,
@@ -61,6 +67,9 @@ k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, cons
   };
   if (tile0 < ntiles) fetch_pos(tile0);
   for (uint32_t tile = tile0; tile < ntiles; tile += waves) {
+#if TNL_FWD_LDSW
+    asm volatile("" : "+s"(w));     // A/B: the weight fragments stay in LDS (no hoisting into 128 registers): two waves per SIMD
+#endif
     const uint32_t i = tile * 32 + r;
     const bool valid = i < M;
     const float px = npx, py = npy, pz = npz;
