@@ -110,10 +110,21 @@ class NeRFNetwork(NeRFRenderer):
     # ------------------------------------------------------------------------------------------
     def _fused_ok(self):
         enc = self.encoder
-        return (not self.force_modular and hasattr(enc, 'get_planes_texel_major') and enc.is_plain() and enc.dropout is None
-                and self.num_layers == 2 and self.num_layers_color == 3 and self.geo_feat_dim == 15
-                and getattr(self.encoder_dir, 'degree', 0) == 4 and self.density_blob_scale <= 1e-5
-                and _field.supported(enc.number_of_features, self.hidden_dim, self.hidden_dim_color))
+        ok = (not self.force_modular and hasattr(enc, 'get_planes_texel_major') and enc.is_plain() and enc.dropout is None
+              and self.num_layers == 2 and self.num_layers_color == 3 and self.geo_feat_dim == 15
+              and getattr(self.encoder_dir, 'degree', 0) == 4 and self.density_blob_scale <= 1e-5
+              and _field.supported(enc.number_of_features, self.hidden_dim, self.hidden_dim_color))
+        if not ok and not self.force_modular and not getattr(self, "_modular_warned", False):
+            # the reference's MLP is generic (network.py:32-76); the hand-written field exists for the three README shapes
+            self._modular_warned = True
+            import warnings
+            warnings.warn(
+                f"trinerflet_amd: this network (channels {getattr(enc, 'number_of_features', '?')}, hidden {self.hidden_dim} / "
+                f"{self.hidden_dim_color}, layers {self.num_layers} / {self.num_layers_color}, geo {self.geo_feat_dim}) is outside "
+                "the fused field's shapes {(16, 64), (32, 64), (48, 128)} x 2 / 3 layers x geo 15 x SH degree 4 (or the encoder uses "
+                "an option the fused lookup does not take): it runs the MODULAR path -- HIP triplane lookup + torch nn.Linear "
+                "(rocBLAS) + HIP SH / compositing -- correct, several times slower per sample", RuntimeWarning, stacklevel=3)
+        return ok
 
     def density_op(self, x, density):
         if self.density_blob_scale > 1e-5:  # network.py:111-117 (x is the ENCODED position there, kept as is)
