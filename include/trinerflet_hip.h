@@ -597,6 +597,13 @@ TNL_API int tnl_adam_l1_step_live(float *p, float *grad, float *m, float *v, uin
                                   const float *found_inf, float *abs_sum, void *stream);
 TNL_API int tnl_adam_record_step(float *ring, int32_t slot, float lr, const float *opt_step_dev, float beta1,
                                  float beta2, const float *found_inf, void *stream);
+/* tnl_adam_record_step for optim.FusedAdamL1's live / deferred split (round 5): the record's fourth float carries the
+ * step's folded L1 coefficient in true units, l1_scaled_dev[0] * inv_scale_dev[0] (tnl_adam_l1_step_sink's product; a
+ * non-finite one marks the step skipped); tnl_adam_l1_step_live[_bands] with that record as step_rec and
+ * tnl_adam_l1_catchup[_bands] add it to their l1_coef -- records written by tnl_adam_record_step carry 0 there. */
+TNL_API int tnl_adam_record_step_l1(float *ring, int32_t slot, float lr, const float *opt_step_dev, float beta1,
+                                    float beta2, const float *found_inf, const float *l1_scaled_dev,
+                                    const float *inv_scale_dev, void *stream);
 TNL_API int tnl_adam_l1_catchup(float *p, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n, uint32_t spp,
                                 uint32_t s0, const int32_t *live, const float *ring, int32_t count, float beta1,
                                 float beta2, float eps, float l1_coef, float *abs_sums, void *stream);

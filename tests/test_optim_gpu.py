@@ -353,3 +353,87 @@ def test_patched_torch_adam_hands_out_the_fused_optimiser_where_it_can_stand_in(
     finally:
         optim.unpatch_torch_adam()
     assert torch.optim.Adam is real
+
+
+def test_live_deferred_split_equals_the_whole_array_pass_bit_for_bit(cuda):
+    """FusedAdamL1(defer=True): with the windowed rebuild under autograd only the live rectangle of a wavelet level is stepped
+    every iteration, the rest replayed from a ring of step scalars (module docstring).  Against defer=False on the same
+    loop under GradScaler -- with a skipped (non-finite) iteration, a window change, a whole-plane read in between (the
+    density-grid refresh's get_planes_whole), more than 16 iterations in one period (ring full) and the folded regulariser
+    -- parameters and both moments after a flush are THE SAME BITS, and so are the optimiser's state_dict()s."""
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    from trinerflet_amd.optim import FusedAdamL1
+
+    def make():
+        m = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, hidden_dim=64, hidden_dim_color=64,
+                        triplane_channels=16, triplane_resolution=512, triplane_wavelet_levels=8).to(cuda)
+        g = torch.Generator(device=cuda).manual_seed(11)
+        with torch.no_grad():
+            for p in m.encoder.planes_features_wavelet_coefs:
+                p.copy_(torch.randn(p.shape, generator=g, device=cuda) * 0.05)
+        m.encoder.windowed_autograd = True
+        return m
+    ma, mb = make(), make()
+    mb.load_state_dict(ma.state_dict())
+    wins = [[128, 192, 64, 64, 128, 192, 256, 192], [64, 128, 192, 192, 64, 128, 256, 192]]
+    cur = {"w": wins[0]}
+    for m in (ma, mb):
+        m.encoder.window_provider = lambda: list(cur["w"])
+    pa, pb = list(ma.encoder.parameters()), list(mb.encoder.parameters())
+    oa = FusedAdamL1(pa, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, defer=False)
+    ob = FusedAdamL1(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    sa, sb = (torch.amp.GradScaler("cuda", init_scale=256.0, growth_interval=5) for _ in range(2))
+
+    def loss_of(m, k):
+        enc = m.encoder
+        enc.reset_cahce()
+        planes = enc.get_planes()
+        w = planes._tnl_window
+        data = sum((planes[p, :, w[3 + p]:w[3 + p] + w[7], w[p]:w[p] + w[6]] * (1.0 + 0.03 * k)).pow(2).mean() for p in range(3))
+        wf = enc.get_wavelet_features()
+        tot = sum(v.numel() for v in wf)
+        return data + 0.3 * sum(v.abs().mean() * (v.numel() / tot) for v in wf) / len(wf)
+    lagged = False
+    for k in range(44):
+        if k == 21:
+            cur["w"] = wins[1]
+        for m, opt, sc in ((ma, oa, sa), (mb, ob, sb)):
+            if k == 33:
+                with torch.no_grad():
+                    m.encoder.reset_cahce()
+                    m.encoder.get_planes()            # whole planes outside autograd: every coefficient is read
+            opt.zero_grad(set_to_none=True)
+            loss = loss_of(m, k)
+            if k == 7:
+                loss = loss + m.encoder.planes_features.view(-1)[0] * float("inf")
+            sc.scale(loss).backward()
+            sc.step(opt)
+            sc.update()
+        assert float(sa.get_scale()) == float(sb.get_scale()), k
+        if k == 12:      # mid-period: the deferred coefficients lag behind, the live ones do not
+            fine_a, fine_b = pa[-1] if pa[-1].dim() == 5 else pa[-2], pb[-1] if pb[-1].dim() == 5 else pb[-2]
+            lagged = not torch.equal(fine_a, fine_b)
+            d = ob._deferred[fine_b]
+            lv = d["live"]
+            assert d["pending"] > 0
+            for pl in range(3):
+                sl = (pl, slice(None), slice(None), slice(lv[3 + pl], lv[3 + pl] + lv[7]), slice(lv[pl], lv[pl] + lv[6]))
+                assert torch.equal(fine_a[sl], fine_b[sl])
+    # (at R = 512 only the finest level's live rectangle is small enough to split: one deferred step per iteration)
+    assert lagged and ob.deferred_steps >= 43 and ob.deferred_flushes >= 3 and oa.deferred_steps == 0      # ring full, window change, whole-plane read
+    sda, sdb = oa.state_dict(), ob.state_dict()            # (flushes)
+    assert all(d["pending"] == 0 for d in ob._deferred.values())
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b), a.shape
+        for key in ("exp_avg", "exp_avg_sq", "step"):
+            assert torch.equal(oa.state[a][key], ob.state[b][key]), (a.shape, key)
+    for ka in sda["state"]:
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(sda["state"][ka][key], sdb["state"][ka][key])
+    # the encoder's own state_dict flushes as well
+    ob.zero_grad(set_to_none=True)
+    sb.scale(loss_of(mb, 50)).backward()
+    sb.step(ob)
+    assert any(d["pending"] for d in ob._deferred.values())
+    mb.state_dict()
+    assert all(d["pending"] == 0 for d in ob._deferred.values())

@@ -225,7 +225,8 @@ constexpr int ADAM_REPLAY_MAX = 16;
 
 __global__ void k_adam_record(AdamStepRec* __restrict__ ring, int slot, float lr, const float* __restrict__ opt_step_dev,
                               double beta1, double beta2, const float* __restrict__ found_inf,
-                              const float* __restrict__ lr_dev) {
+                              const float* __restrict__ lr_dev, const float* __restrict__ l1_scaled_dev = nullptr,
+                              const float* __restrict__ inv_scale_dev = nullptr) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (lr_dev != nullptr) lr = lr_dev[0];
   const double t = (double)opt_step_dev[0] + 1.0;          // k_adam_l1's expressions
@@ -234,6 +235,15 @@ __global__ void k_adam_record(AdamStepRec* __restrict__ ring, int slot, float lr
   r.bias2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
   r.skip = (found_inf != nullptr && found_inf[0] != 0.f) ? 1.f : 0.f;
   r.pad = 0.f;
+  if (l1_scaled_dev != nullptr) {
+    // optim.FusedAdamL1's folded regulariser (k_adam_l1's l1_dev branch: the same product, the same skip rule): the step's
+    // L1 coefficient in true units rides in the record's fourth float, for the live pass and for the replay
+    float inv = 1.0f;
+    if (inv_scale_dev != nullptr) inv *= inv_scale_dev[0];
+    const float s = l1_scaled_dev[0] * inv;
+    r.pad = s;
+    if (!(fabsf(s) <= 3.0e38f)) r.skip = 1.f;
+  }
   ring[slot] = r;
 }
 
@@ -286,7 +296,10 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
     a.bias2_sqrt = bc[1];
   }
   if (inv_scale_dev != nullptr) a.inv_scale *= inv_scale_dev[0];
-  const bool skip = found_inf != nullptr && found_inf[0] != 0.f;
+  // (rec->skip is the same flag unless the record carries a folded L1 coefficient that is not finite; rec->pad is that
+  //  coefficient, 0 for TrainStep's records: l1 + 0 = l1)
+  const bool skip = (found_inf != nullptr && found_inf[0] != 0.f) || (rec != nullptr && rec->skip != 0.f);
+  const float l1_rec = rec != nullptr ? rec->pad : 0.f;
   int si = 0;
 #pragma unroll
   for (int k = 1; k < ADAM_MAX_SEGS; k++)
@@ -294,7 +307,7 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
   const LiveSeg& sg = segs.s[si];
   const AdamRect& live = sg.live;
   const AdamRect& gr = sg.gr;
-  a.l1_coef = sg.l1_coef;
+  a.l1_coef = sg.l1_coef + l1_rec;
   const uint32_t nblk = (si + 1 < segs.n ? segs.s[si + 1].blocks0 : gridDim.x) - sg.blocks0;
   float acc = 0.f;
   __shared__ int s_bt[5 * ADAM_MAX_BANDS + 1];
@@ -437,6 +450,7 @@ k_adam_l1_catchup(float* __restrict__ p, float* __restrict__ m, float* __restric
     return !(c >= x0 && c < x0 + 4 * s_bt[nb + 1 + b]);
   };
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float l1_base = a.l1_coef;
   for (uint64_t i = c0 + threadIdx.x; i < c1; i += 512) {
     const uint64_t j = i + 256;
     const bool oi = outside(i), oj = j < c1 && outside(j);
@@ -461,6 +475,7 @@ k_adam_l1_catchup(float* __restrict__ p, float* __restrict__ m, float* __restric
       if (rec.skip != 0.f) continue;                        // GradScaler skipped this step: nothing moves
       a.step_size = rec.step_size;
       a.bias2_sqrt = rec.bias2_sqrt;
+      a.l1_coef = l1_base + rec.pad;                        // (pad: a folded L1 coefficient of that step, else 0)
       float unused = 0.f;
       adam1(pi.x, 0.f, mi.x, vi.x, a, unused); adam1(pi.y, 0.f, mi.y, vi.y, a, unused);
       adam1(pi.z, 0.f, mi.z, vi.z, a, unused); adam1(pi.w, 0.f, mi.w, vi.w, a, unused);
@@ -613,6 +628,16 @@ extern "C" int tnl_adam_record_step(float* ring, int32_t slot, float lr, const f
   if (ring == nullptr || opt_step_dev == nullptr || slot < 0 || slot >= ADAM_REPLAY_MAX) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(k_adam_record, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<AdamStepRec*>(ring),
                      (int)slot, lr, opt_step_dev, adam_decimal(beta1), adam_decimal(beta2), found_inf, (const float*)nullptr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tnl_adam_record_step_l1(float* ring, int32_t slot, float lr, const float* opt_step_dev, float beta1,
+                                       float beta2, const float* found_inf, const float* l1_scaled_dev,
+                                       const float* inv_scale_dev, void* stream) {
+  if (ring == nullptr || opt_step_dev == nullptr || slot < 0 || slot >= ADAM_REPLAY_MAX) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_adam_record, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<AdamStepRec*>(ring),
+                     (int)slot, lr, opt_step_dev, adam_decimal(beta1), adam_decimal(beta2), found_inf, (const float*)nullptr,
+                     l1_scaled_dev, inv_scale_dev);
   return (int)hipGetLastError();
 }
 

@@ -120,3 +120,29 @@ def level_windows(roi, J, R):
             break
         wins[lvl] = [min(l, m - rw) for l in lo_x] + [min(l, m - rh) for l in lo_y] + [rw, rh]
     return wins
+
+
+def live_rects(wins, rects, sizes, col_align=32):
+    """Per level the rectangle (per plane origin, common size, columns in multiples of col_align, rows of 8; the level's own
+    coordinates) holding everything the windowed rebuild reads -- the level's output window `wins[lvl]` halved and grown by
+    6 (the longest filter, bior6.8, reaches 4-5 coefficients to either side) -- and everything the windowed adjoint writes
+    (`rects[lvl]`).  None: the whole level stays live.  sizes[lvl] = the level's n.  (TrainStep._live_rects and
+    optim.FusedAdamL1's deferred pass share this rule; tests/test_adam_deferred_gpu.py poisons everything outside.)"""
+    live = [None] * len(sizes)
+    for lvl, n in enumerate(sizes):
+        w, r = wins[lvl], rects[lvl]
+        if w is None or r is None:
+            continue
+
+        def span(o, size, ro, rsize, al):
+            lo = min(ro, max(o // 2 - 6, 0)) // al * al
+            hi = min((max(ro + rsize, (o + size) // 2 + 6) + al - 1) // al * al, n)
+            return lo, hi
+        xs = [span(w[p], w[6], r[p], r[6], col_align) for p in range(3)]
+        ys = [span(w[3 + p], w[7], r[3 + p], r[7], 8) for p in range(3)]
+        rw = max(h - l for l, h in xs)
+        rh = max(h - l for l, h in ys)
+        if rw * rh > 0.8 * n * n:
+            continue
+        live[lvl] = [min(l, n - rw) for l, _ in xs] + [min(l, n - rh) for l, _ in ys] + [rw, rh]
+    return live

@@ -32,16 +32,36 @@ to optimisers that declare it; torch announces its removal with a FutureWarning,
 path above is used) and checks the gradients with a read-only pass (tnl_nonfinite_check, 0.3 ms), recording the result
 where GradScaler.update() looks for it.
 
+Live / deferred split (defer=True, the default; round 5).  With install_dropin()'s windowed rebuild a wavelet level's
+gradient is zero outside a rectangle and nothing outside a slightly larger "live" rectangle is read by the renderer until
+the occupancy window changes (TriPlaneVolume leaves both on the parameter after backward: `_tnl_live`).  A coefficient out
+there still has to take Adam's step -- m and v decay, p coasts, the L1 term pulls -- but that update depends on nothing
+except its own three numbers and the step's scalars, so it is not done every step: step() updates the live rectangle only
+(tnl_adam_l1_step_live) and records the step's scalars (learning rate, bias corrections, skip flag, folded L1 coefficient)
+in a 16-slot ring per parameter; the rest is replayed in registers, all pending steps in one pass
+(tnl_adam_l1_catchup), when the ring is full, when the rectangle changes, before a whole-plane rebuild
+(TriPlaneVolume.build_planes, e.g. the density-grid refresh every 16 steps), before state_dict() of the optimiser or of
+the encoder, and on flush_deferred().  p, m, v after a flush are the bits the undeferred pass leaves
+(tests/test_optim_gpu.py).  Until then the deferred coefficients' VALUES lag: code that reads the parameter tensors
+directly (not through the encoder or a state_dict) calls trinerflet_amd.optim.flush_deferred() first; the regulariser's
+reported VALUE (`.abs().mean()` over whole levels) lags by up to a period for them, its gradient does not.  1.95 -> ~1 ms of
+the reference loop's 7.0 ms per step at the base configuration.
+
 Arithmetic: the kernel's (m, v, p) update is torch's single-tensor Adam in fp32 with the bias corrections evaluated in
 double on the device from the parameter's own `step` (tests/test_optim_gpu.py holds it against torch.optim.Adam).
 Not supported (ValueError): amsgrad, maximize, differentiable, sparse gradients, non-fp32 or CPU parameters.
 """
+import ctypes as C_
 import warnings
 import weakref
 
 import torch
 
 from . import _lib as L
+
+
+def _i32x8(v):
+    return (C_.c_int32 * 8)(*[int(x) for x in v[:8]])
 
 
 class _L1Sink:
@@ -71,13 +91,22 @@ class _L1Sink:
         return True
 
 
+_DEFERRING = weakref.WeakSet()       # live FusedAdamL1 instances that may hold deferred updates
+
+
+def flush_deferred(params=None):
+    """Replays the deferred part of every live FusedAdamL1's pending steps (for the given parameters, or all)."""
+    for opt in list(_DEFERRING):
+        opt.flush_deferred(params)
+
+
 class FusedAdamL1(torch.optim.Optimizer):
     # torch.amp.GradScaler: do not unscale the gradients in a pass of their own -- step() receives the scale
     # (self.grad_scale) and the non-finite flag (self.found_inf) and folds both into the update
     _step_supports_amp_scaling = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, *,
-                 maximize=False, l1=0.0, fold_l1=True, l1_without_grad=False):
+                 maximize=False, l1=0.0, fold_l1=True, l1_without_grad=False, defer=True):
         if amsgrad or maximize:
             raise ValueError("FusedAdamL1: amsgrad / maximize are not built")
         if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
@@ -86,6 +115,10 @@ class FusedAdamL1(torch.optim.Optimizer):
                         foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False, l1=l1)
         self.fold_l1 = bool(fold_l1)
         self.l1_without_grad = bool(l1_without_grad)
+        self.defer = bool(defer)
+        self._deferred = {}            # parameter -> {"ring", "pending", "live", "ctx"}: see the module docstring
+        self.deferred_steps = self.deferred_flushes = 0
+        _DEFERRING.add(self)
         self._sinks = {}
         warnings.filterwarnings("ignore", message="GradScaler is going to stop passing itself", category=FutureWarning)
         super().__init__(params, defaults)
@@ -112,8 +145,80 @@ class FusedAdamL1(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none)
+        for group in self.param_groups:      # what a windowed backward left on the parameters belongs to that gradient
+            for p in group["params"]:
+                if getattr(p, "_tnl_live", None) is not None:
+                    p._tnl_live = None
         for sink in self._sinks.values():
             sink.clear()
+
+    # ---- live / deferred split ---------------------------------------------------------------------------------------
+    def flush_deferred(self, params=None):
+        """Replay the pending steps outside the live rectangles (all parameters, or the given ones)."""
+        if not self._deferred:
+            return
+        want = None if params is None else {id(p) for p in params}
+        lib = L.lib()
+        for p, d in list(self._deferred.items()):
+            if d["pending"] == 0 or (want is not None and id(p) not in want):
+                continue
+            st = self.state[p]
+            b1, b2, eps, l1 = d["ctx"]
+            n, C = p.shape[-1], p.shape[1]
+            L.check(lib.tnl_adam_l1_catchup(L.ptr(p), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.u32(3 * C), L.u32(3),
+                                            L.u32(n), L.u32(C), L.u32(0), _i32x8(d["live"]),
+                                            L.ptr(d["ring"]), L.i32(d["pending"]), L.f32(b1), L.f32(b2), L.f32(eps), L.f32(l1),
+                                            L.ptr(None), L.stream()), "adam_l1_catchup")
+            d["pending"] = 0
+            self.deferred_flushes += 1
+
+    def state_dict(self):
+        self.flush_deferred()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self.flush_deferred()
+        return super().load_state_dict(state_dict)
+
+    def _deferrable(self, p, g, group):
+        """The live rectangle of this step if p's update can be split, else None."""
+        info = getattr(p, "_tnl_live", None)
+        if not self.defer or info is None or info[0] is None or p.dim() != 5 or p.shape[0] != 3 or p.shape[2] != 3:
+            return None
+        if p.grad is None or p.grad.data_ptr() != info[3] or g.data_ptr() != info[3]:
+            return None        # not (only) the windowed chain's gradient: dense
+        n = p.shape[-1]
+        if p.shape[-2] != n or n & (n - 1) or n % 4 or group["weight_decay"] != 0 or g.shape != p.shape or not g.is_contiguous():
+            return None
+        return info
+
+    def _step_deferred(self, p, g, st, group, lr, found_inf, inv_scale, sink, sidx, info):
+        live, rect = info[0], info[1]
+        lib = L.lib()
+        b1, b2 = group["betas"]
+        ctx = (float(b1), float(b2), float(group["eps"]), float(group["l1"]))
+        d = self._deferred.get(p)
+        if d is None:
+            d = self._deferred[p] = {"ring": torch.zeros(16 * 4, dtype=torch.float32, device=p.device), "pending": 0,
+                                     "live": None, "ctx": ctx}
+        if d["pending"] and (d["live"] != list(live) or d["ctx"] != ctx or d["pending"] == 16):
+            self.flush_deferred([p])
+        d["live"], d["ctx"] = list(live), ctx
+        slot = d["pending"]
+        C = p.shape[1]
+        n = p.shape[-1]
+        L.check(lib.tnl_adam_record_step_l1(L.ptr(d["ring"]), L.i32(slot), L.f32(lr), L.ptr(st["step"].reshape(1)), L.f32(b1),
+                                            L.f32(b2), L.ptr(found_inf.reshape(-1)),
+                                            L.ptr(sink.vec[sidx:sidx + 1] if sink is not None else None), L.ptr(inv_scale),
+                                            L.stream()), "adam_record_step_l1")
+        L.check(lib.tnl_adam_l1_step_live(
+            L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.u32(3 * C), L.u32(C), L.u32(0), L.u32(1),
+            (C_.c_uint64 * 1)(0), (C_.c_uint32 * 1)(n), (C_.c_uint32 * 1)(3), _i32x8(live), _i32x8(rect),
+            (C_.c_float * 1)(group["l1"]), L.f32(lr), L.ptr(st["step"].reshape(1)), L.ptr(d["ring"][4 * slot:]), L.f32(b1),
+            L.f32(b2), L.f32(group["eps"]), L.f32(1.0), L.ptr(inv_scale), L.ptr(found_inf.reshape(-1)), L.ptr(None),
+            L.stream()), "adam_l1_step_live")
+        d["pending"] += 1
+        self.deferred_steps += 1
 
     def __setstate__(self, state):
         super().__setstate__(state)
@@ -193,6 +298,7 @@ class FusedAdamL1(torch.optim.Optimizer):
                     # included: the reference's Trainer.clear_grad() (nerf/utils.py:1105-1114) freezes coarse levels by
                     # setting .grad = None AFTER backward, and the term sitting in the sink must not outlive that.  A
                     # parameter that only the regulariser reaches is stepped when asked for (l1_without_grad=True).
+                    p._tnl_live = None
                     if sink is None or not self.l1_without_grad:
                         continue
                     p.grad = torch.zeros_like(p)
@@ -214,6 +320,14 @@ class FusedAdamL1(torch.optim.Optimizer):
                     use_g, use_inv = g, inv_scale
                 if sink is not None and use_inv is None and inv_scale is not None:
                     raise ValueError("FusedAdamL1: weight_decay together with a folded L1 term under GradScaler is not built")
+                info = self._deferrable(p, g, group)
+                if info is not None:
+                    self._step_deferred(p, g, st, group, lr, found_inf, inv_scale, sink, sidx, info)
+                    p._tnl_live = None
+                    steps.append(st["step"])
+                    continue
+                if p in self._deferred and self._deferred[p]["pending"]:
+                    self.flush_deferred([p])          # this step takes the whole-array pass: the pending ones first
                 L.check(lib.tnl_adam_l1_step_sink(
                     L.ptr(p), L.ptr(use_g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.u64(p.numel()), L.f32(lr),
                     L.ptr(st["step"].reshape(1)), L.f32(b1), L.f32(b2), L.f32(group["eps"]), L.ptr(use_inv),

@@ -1243,28 +1243,8 @@ class TrainStep:
         everything the windowed rebuild reads -- the level's output window halved and grown by 6 (the longest filter,
         bior6.8, reaches 4-5 coefficients to either side) -- and everything the windowed adjoint writes (rects).
         None: the whole level stays live.  tests/test_adam_deferred_gpu.py poisons everything outside with NaN."""
-        wins = self._forward_windows()
-        live = [None] * self.J
-        for lvl in range(self.J):
-            w, r = wins[lvl], rects[lvl]
-            if w is None or r is None:
-                continue
-            n = self.coef.params[lvl].shape[-1]
-
-            def span(o, size, ro, rsize, al):
-                lo = min(ro, max(o // 2 - 6, 0)) // al * al
-                hi = min((max(ro + rsize, (o + size) // 2 + 6) + al - 1) // al * al, n)
-                return lo, hi
-            # rows start on 128-byte lines (a row piece that ends inside a line costs the whole line: measured 4.7 vs
-            # 5.6 TB/s with 8-aligned columns); any 8 rows
-            xs = [span(w[p], w[6], r[p], r[6], getattr(self, "live_col_align", 32)) for p in range(3)]
-            ys = [span(w[3 + p], w[7], r[3 + p], r[7], 8) for p in range(3)]
-            rw = max(h - l for l, h in xs)
-            rh = max(h - l for l, h in ys)
-            if rw * rh > 0.8 * n * n:
-                continue
-            live[lvl] = [min(l, n - rw) for l, _ in xs] + [min(l, n - rh) for l, _ in ys] + [rw, rh]
-        return live
+        return occupancy.live_rects(self._forward_windows(), rects, [p.shape[-1] for p in self.coef.params],
+                                    getattr(self, "live_col_align", 32))
 
     def _level_needs(self):
         """Per level [3, n/8, 2] int arrays: for plane p and rows 8b .. 8b+7 of the level's n x n grid the column piece

@@ -121,6 +121,11 @@ class _IDWTChainWin(Function):
                         "idwt_level_forward_win")
             x = out
         ctx.meta = (wave_id, tuple(int(v) for v in roi), J, C, R)
+        # for optim.FusedAdamL1's live / deferred split: the coefficient parameters this chain was built from (weak) and the
+        # forward windows -- backward leaves each level's live rectangle on its parameter
+        import weakref
+        ctx.coef_refs = [weakref.ref(c) for c in coefs]
+        ctx.fwd_wins = wins
         return x
 
     @staticmethod
@@ -132,6 +137,7 @@ class _IDWTChainWin(Function):
         dev = g.device
         win = list(roi)
         grads = [None] * J
+        rects = [None] * J
         for lvl in reversed(range(J)):
             n = R >> (J - lvl)
             # the coarsest dx is the LL parameter's gradient: like the band gradients it must be zero outside the rectangle
@@ -143,7 +149,18 @@ class _IDWTChainWin(Function):
                     "idwt_level_backward_win")
             win = list(rect)
             grads[lvl] = dyh
+            rects[lvl] = list(rect)
             g = dx
+        # what a step's optimiser pass has to touch per level: everything the windowed rebuild reads united with the
+        # gradient's rectangle (occupancy.live_rects) -- left on the parameter together with the rectangle and the window
+        from .. import occupancy
+        live = occupancy.live_rects(ctx.fwd_wins, rects, [R >> (J - lvl) for lvl in range(J)])
+        for lvl, ref in enumerate(ctx.coef_refs):
+            prm = ref()
+            if prm is not None:
+                # (+ the address of the gradient tensor this backward returns: the optimiser takes the split only while
+                #  .grad is exactly that tensor -- anything accumulated into it, or another backward's gradient, is dense)
+                prm._tnl_live = (live[lvl], rects[lvl], roi, grads[lvl].data_ptr())
         return (None, None, g, *grads)
 
 
@@ -378,6 +395,13 @@ class _CoefView(torch.Tensor):
         return torch.utils._pytree.tree_map(lambda t: t.as_subclass(torch.Tensor) if type(t) is _CoefView else t, out)
 
 
+def _flush_deferred_optimisers(params):
+    """A reader of whole coefficient arrays is about to run (whole-plane rebuild, state_dict): optimisers that keep part of
+    these parameters' updates deferred (optim.FusedAdamL1(defer=True)) replay them now."""
+    from .. import optim
+    optim.flush_deferred(params)
+
+
 class _IDWTBuffers(nn.Module):
     """Holds pytorch_wavelets.DWTInverse's filter buffers (g0_col, g1_col, g0_row, g1_row) so that
     reference checkpoints (`encoder.idwt.*` keys) load and save unchanged.  Not used for compute."""
@@ -504,6 +528,9 @@ class TriPlaneVolume(torch.nn.Module):
         self.last_used_planes = None
         self._planes_tm = None
         self._planes_tm_window = None
+        # a checkpoint reads every coefficient: deferred optimiser passes over them are replayed first
+        self.register_state_dict_pre_hook(
+            lambda module, prefix, keep_vars: _flush_deferred_optimisers(module.planes_features_wavelet_coefs))
         self.window_provider = None      # callable -> occupancy window or None (see _autograd_window); set by NeRFNetwork
         self.windowed_autograd = WINDOWED_AUTOGRAD     # opt-in: see _autograd_window
         if self.inner_wavelet_scale <= 1:
@@ -614,6 +641,7 @@ class TriPlaneVolume(torch.nn.Module):
         # reference: triplane_encoder.py:364-405
         all_res = []
         current_scale = 1
+        _flush_deferred_optimisers(self.planes_features_wavelet_coefs)      # whole planes read every coefficient
         x = self.planes_features if planes_features is None else planes_features
         coefs = self.planes_features_wavelet_coefs if coefs is None else coefs
         all_level = self.planes_features_wavelet_all_level if all_level is None else all_level
@@ -654,6 +682,12 @@ class TriPlaneVolume(torch.nn.Module):
             return self.last_used_planes
         window = self._autograd_window(max_res, max_scale, get_all_resolutions)
         if window is not None:
+            key = tuple(int(v) for v in window)
+            if key != getattr(self, "_last_autograd_window", None):
+                # a new window reads coefficients the previous one did not: an optimiser that kept their updates deferred
+                # (optim.FusedAdamL1) replays them BEFORE this rebuild
+                _flush_deferred_optimisers(self.planes_features_wavelet_coefs)
+                self._last_autograd_window = key
             planes = _IDWTChainWin.apply(self.wave_id, window, self.planes_features, *self.planes_features_wavelet_coefs)
             planes._tnl_window = tuple(int(v) for v in window)      # read by nerf/network.py and get_planes_texel_major
             self.last_used_planes = planes
