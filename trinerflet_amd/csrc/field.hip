@@ -30,6 +30,9 @@ namespace {
 // ran slower at base (1.03 vs 0.95 ms), and an 8-wave workgroup for hidden 128 -- two waves per SIMD sharing the 92 KB
 // of weights -- measured 1.61 vs 1.62 ms.  With all of a tile's loads in flight the kernel sits at the ~4 TB/s that
 // 64-byte texel gathers reach here: 3.6 GB in 0.81 ms at base, 5.4 GB in 1.5 ms at C = 48.)
+#ifndef TNL_FWD_PREFETCH
+#define TNL_FWD_PREFETCH 1     // hidden 128: weight fragments a group ahead of their MFMAs (0: A/B builds)
+#endif
 #ifndef TNL_FWD_LDSW
 #define TNL_FWD_LDSW 0
 #endif
@@ -81,7 +84,10 @@ k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, cons
     // SAVE is a template parameter and rows past M store into row M - 1 what row M - 1 stores itself (their clamped
     // position is that sample's), so the store needs no predicate.
     // (hidden 128 is register-bound: there the planes are taken one at a time, 12 loads in flight instead of 36)
-    constexpr int PG = H > 64 ? 1 : 3;   // planes per group
+#ifndef TNL_FWD_PG128
+#define TNL_FWD_PG128 1
+#endif
+    constexpr int PG = H > 64 ? TNL_FWD_PG128 : 3;   // planes per group
     const uint32_t il = valid ? i : M - 1;
     f32x16 acc0[G::OB];
 #pragma unroll
@@ -96,19 +102,30 @@ k_field_fwd(const void* __restrict__ planes, const float* __restrict__ xyz, cons
 #pragma unroll
         for (int kk = 0; kk < C / 16; kk++) fk[(p - p0) * (C / 16) + kk] = gather_frag<C, HALFP>(planes, R, p, kk, h, t);
       }
+      if (TNL_FWD_PREFETCH && H > 64) {
+        // hidden 128 runs one wave per SIMD: the weight fragments a group ahead of their MFMAs (with_weights), as in the
+        // split backward -- left alone every MFMA waits out the LDS read of its own operand
 #pragma unroll
-      for (int q = 0; q < PG * (C / 16); q++) {
-        const int ks = p0 * (C / 16) + q;
-        // (a non-temporal store here was measured SLOWER: field_fwd 1.05 -> 1.14 ms)
-        if (SAVE) *reinterpret_cast<half8*>(feats_save + feat_slot<G::KS0>(il, ks, h)) = fk[q];
+        for (int q = 0; q < PG * (C / 16); q++)
+          if (SAVE) *reinterpret_cast<half8*>(feats_save + feat_slot<G::KS0>(il, p0 * (C / 16) + q, h)) = fk[q];
+        with_weights<PG * (C / 16) * G::OB, G::OB>(
+            [&](int i) { return w[(G::F0 + (i % G::OB) * G::KS0 + p0 * (C / 16) + i / G::OB) * 64 + lane]; },
+            [&](int i, const half8& f) { acc0[i % G::OB] = MFMA32(f, fk[i / G::OB], acc0[i % G::OB]); });
+      } else {
 #pragma unroll
-        for (int ob = 0; ob < G::OB; ob++) acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], fk[q], acc0[ob]);
+        for (int q = 0; q < PG * (C / 16); q++) {
+          const int ks = p0 * (C / 16) + q;
+          // (a non-temporal store here was measured SLOWER: field_fwd 1.05 -> 1.14 ms)
+          if (SAVE) *reinterpret_cast<half8*>(feats_save + feat_slot<G::KS0>(il, ks, h)) = fk[q];
+#pragma unroll
+          for (int ob = 0; ob < G::OB; ob++) acc0[ob] = MFMA32(w[(G::F0 + ob * G::KS0 + ks) * 64 + lane], fk[q], acc0[ob]);
+        }
       }
       if (PG < 3) __builtin_amdgcn_sched_barrier(0);
     }
     const float dx = cdx, dy = cdy, dz = cdz;
     Chain<C, H> ch;
-    chain_tail<C, H, DENSITY_ONLY>(w, w, lane, h, acc0, dx, dy, dz, ch);
+    chain_tail<C, H, DENSITY_ONLY, (TNL_FWD_PREFETCH && H > 64)>(w, w, lane, h, acc0, dx, dy, dz, ch);
     if (!DENSITY_ONLY && geo_save != nullptr && valid) {
       // hidden 128: the colour half of the split backward starts from the 16 sigma-net outputs instead of recomputing them
       half8 g;

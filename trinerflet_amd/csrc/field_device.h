@@ -167,7 +167,7 @@ __device__ __forceinline__ void chain_colour(const half8* w, const half8* wH, in
 
 // layers 1..4 given acc0 = W0 * F^T ; DENSITY_ONLY stops after layer 1.  `w` serves the fragments of layers 1 and 2,
 // `wH` those of layers 3 and 4 (the same table unless a kernel keeps only part of it in LDS).
-template <int C, int H, bool DENSITY_ONLY>
+template <int C, int H, bool DENSITY_ONLY, bool FENCE = false>
 __device__ __forceinline__ void chain_tail(const half8* w, const half8* wH, int lane, int h, f32x16 (&acc0)[H / 32],
                                            float dx, float dy, float dz, Chain<C, H>& ch) {
   using G = FieldGeom<C, H>;
@@ -176,12 +176,17 @@ __device__ __forceinline__ void chain_tail(const half8* w, const half8* wH, int 
     ch.h1[ks] = (ks & 1) ? acc_to_frag<true>(acc0[ks >> 1], 1) : acc_to_frag<true>(acc0[ks >> 1], 0);
   }
   f32x16 o = zero16();
+  if (FENCE) {
+    with_weights<G::KH, 4>([&](int i) { return w[(G::F1 + i) * 64 + lane]; },
+                           [&](int i, const half8& f) { o = MFMA32(f, ch.h1[i], o); });
+  } else {
 #pragma unroll
-  for (int ks = 0; ks < G::KH; ks++) o = MFMA32(w[(G::F1 + ks) * 64 + lane], ch.h1[ks], o);
+    for (int ks = 0; ks < G::KH; ks++) o = MFMA32(w[(G::F1 + ks) * 64 + lane], ch.h1[ks], o);
+  }
 #pragma unroll
   for (int g = 0; g < 8; g++) ch.o8[g] = o[g];
   if (DENSITY_ONLY) return;
-  chain_colour<C, H>(w, wH, lane, h, acc_to_frag<false>(o, 0), dx, dy, dz, ch);
+  chain_colour<C, H, FENCE>(w, wH, lane, h, acc_to_frag<false>(o, 0), dx, dy, dz, ch);
 }
 
 // layers 2..4 from the 16 sigma-net outputs as a fragment (slot 0 = the logit, multiplied by zero weights)
