@@ -18,4 +18,13 @@ run "-DTNL_RENDER_RT128=128" "tests/test_render_fused_gpu.py"
 run "-DTNL_IDWT_BWD_NT=0" "tests/test_idwt_walk_gpu.py tests/test_spans_gpu.py tests/test_roi_gpu.py"
 run "-DTNL_FWD_FB=8" "tests/test_idwt_walk_gpu.py tests/test_spans_gpu.py tests/test_roi_gpu.py"
 run "-DTNL_ROWS_STAMP=1" "tests/test_field_gpu.py"
+# round 5
+MARCH="tests/test_raymarching_gpu.py tests/test_full_geometry_gpu.py::test_march_60k_rays_bit_exact"
+run "-DTNL_MARCH_WAVE=0" "$MARCH"
+run "-DTNL_MARCH_FAST_LANE=0" "$MARCH"
+LARGE="tests/test_full_geometry_gpu.py tests/test_field_gpu.py"
+run "-DTNL_WG=8 -DTNL_DWG=2" "$LARGE"
+run "-DTNL_BWD_STAMP=1" "$LARGE"
+run "-DTNL_FWD_PREFETCH=0" "$LARGE"
+run "-DTNL_FWD_LDSW=1 -DTNL_FWD_MINWAVES=2" "$LARGE"
 python -m trinerflet_amd.build --force > /dev/null
