@@ -551,7 +551,9 @@ TNL_API int tnl_planes_half_to_texel_major_spans(const void *planes_roi_half, ui
                                                  void *stream);
 /* Launch-shape knobs of the walk kernels, for A/B measurements (tools/bench_idwt.py); results do not depend on them.
  * key 1: coarse rows per phase of the forward kernel (4 or 8); key 2: XCD-aware block order (0 / 1);
- * key 3: coarse rows per workgroup (multiple of 8; 0 = automatic). */
+ * key 3: coarse rows per workgroup (multiple of 8; 0 = automatic); key 4: form of the forward kernel -- 0 = a thread owns one
+ * coarse column, 2 / 4 = the one-wave pair form (two columns per thread, 8-byte loads) with 2 / 4 coarse rows per phase,
+ * -1 = the build's default. */
 TNL_API int tnl_idwt_set_tuning(int key, int value);
 TNL_API int tnl_adam_l1_step_rect(float *p, float *grad, float *m, float *v, uint32_t S, uint32_t bands, uint32_t n,
                                   uint32_t spp, uint32_t s0, const int32_t *rect, float lr,

@@ -13,6 +13,16 @@ from oracle import cref
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 2, 4], ids=["one-column", "pair-2-rows", "pair-4-rows"])
+def fwd_form(request, cuda):
+    """Both forms of the forward walk kernel (tnl_idwt_set_tuning key 4: one coarse column per thread / two, with 2 or 4
+    coarse rows per phase) run every test of this file: each must reproduce the tile kernels' bits."""
+    from trinerflet_amd import _lib as L
+    assert L.lib().tnl_idwt_set_tuning(4, request.param) == 0
+    yield request.param
+    assert L.lib().tnl_idwt_set_tuning(4, -1) == 0      # back to the build's default
+
+
 @pytest.fixture
 def walk(cuda):
     from trinerflet_amd import _lib as L

@@ -818,6 +818,148 @@ k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n
   }
 }
 
+// Forward walk, pair form: ONE WAVE per workgroup, a thread owns TWO adjacent coarse columns (8-byte loads: a wave row is
+// 512 contiguous bytes per band, half the load and LDS-store instructions per coefficient) and the vertical -> horizontal
+// hand-over through LDS needs no workgroup barrier (the wave is the workgroup).  The 2* of the LL band is folded into its
+// vertical taps (fma(2a, t, c) == fma(a, 2t, c) bit for bit), the window slides with 64-bit moves.  Same tile (128
+// staged / 120 produced coarse columns), same FMA order per output as k_idwt_fwd_walk: bit-identical planes.
+// Needs even coarse column origins and widths (the launcher checks; otherwise the one-column form runs).
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int PT = 64;         // pair form: threads (= WT / 2 column pairs)
+
+template <int W, bool HALF_OUT, int FB>
+__global__ void __launch_bounds__(PT)
+k_idwt_fwd_walk2(const float* __restrict__ x, const float* __restrict__ yh, int n, void* __restrict__ out, Roi roi,
+                 int seg, LGrid lg, const int* __restrict__ spans) {
+  constexpr WTaps T = wtaps(W);
+  constexpr int L = T.L, K = (L - 2) / 2, HW = L / 4;
+  static_assert(HW <= 4, "staged halo is 4 coarse samples");
+  constexpr int WW = FB + 8;                           // window rows: R0-4 .. R0+FB+3
+  constexpr int LSM = WT + 4;                          // mid row stride: 16-byte aligned rows
+  __shared__ __attribute__((aligned(16))) float mid[2][2 * FB][LSM];
+
+  int bx, by, s;
+  if (!logical_block(lg, bx, by, s)) return;
+  const int tid = threadIdx.x, m2 = 2 * n;
+  const int pl = roi.rw ? (s + roi.s0) / roi.spp : 0;
+  const int fox = roi.rw ? roi.ox[pl] : 0, foy = roi.rw ? roi.oy[pl] : 0;
+  const bool compact = roi.rw && !roi.strided;
+  const int orow = compact ? roi.rw : m2;
+  const size_t oplane = compact ? (size_t)roi.rh * roi.rw : (size_t)m2 * m2;
+  const int sox = compact ? fox : 0, soy = compact ? foy : 0;
+  const int cx0 = fox / 2, cy0 = foy / 2, cw = roi.rw ? roi.rw / 2 : n, ch = roi.rw ? roi.rh / 2 : n;
+  const int vx0 = cx0 + bx * WV, vx1 = min(vx0 + WV, cx0 + cw);        // coarse columns this tile produces
+  int ry0 = cy0 + by * seg, ry1 = min(ry0 + seg, cy0 + ch);            // coarse rows of this segment
+  if (vx0 >= vx1 || ry0 >= ry1) return;
+  __shared__ int s_span[2];
+  if (spans != nullptr && !narrow_rows(spans, n, pl, vx0, vx1, ry0, ry1, s_span)) return;   // nothing here is read
+  const int c = vx0 - 4 + 2 * tid;                                             // this thread's coarse columns c, c + 1
+  const bool col_ok = c >= 0 && c < n && c < vx1 + 4;                          // (all three even: true of both or neither)
+  const size_t nn = (size_t)n * n;
+  const float* b0 = x + (size_t)s * nn + (col_ok ? c : 0);
+  const float* b1 = yh + (size_t)s * 3 * nn + (col_ok ? c : 0);
+  auto ld4 = [&](int r, v2f& v0, v2f& v1, v2f& v2, v2f& v3) {
+    v0 = v1 = v2 = v3 = v2f{0.f, 0.f};
+    if (col_ok && r >= 0 && r < n) {
+      const size_t o = (size_t)r * n;
+      v0 = *reinterpret_cast<const v2f*>(b0 + o); v1 = *reinterpret_cast<const v2f*>(b1 + o);
+      v2 = *reinterpret_cast<const v2f*>(b1 + nn + o); v3 = *reinterpret_cast<const v2f*>(b1 + 2 * nn + o);
+    }
+  };
+  v2f w0[WW], w1[WW], w2[WW], w3[WW];                        // rows R0-4 .. R0+FB+3 of the four bands
+  v2f n0[FB], n1[FB], n2[FB], n3[FB];                        // rows R0+FB+4 .. R0+2FB+3 (next phase), in flight
+#pragma unroll
+  for (int i = 0; i < WW; i++) ld4(ry0 - 4 + i, w0[i], w1[i], w2[i], w3[i]);
+  char* const obase = reinterpret_cast<char*>(out);
+  for (int R0 = ry0; R0 < ry1; R0 += FB) {
+    const bool more = R0 + FB < ry1;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < FB; i++) ld4(R0 + FB + 4 + i, n0[i], n1[i], n2[i], n3[i]);
+    }
+    // vertical synthesis of this thread's two columns: coarse rows R0..R0+FB-1 -> fine rows 2*R0 .. of lo and hi
+#pragma unroll
+    for (int m = 0; m < FB; m++) {
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        v2f lo = {0.f, 0.f}, hi = {0.f, 0.f};
+#pragma unroll
+        for (int d = -HW; d <= HW; d++) {
+          const int k = e + K - 2 * d;
+          if (k >= 0 && k < L) {
+            const float t0 = T.g0[k], t1 = T.g1[k];
+            const float t0x2 = 2.0f * t0;                                // the 2* of triplane_encoder.py:379 (LL band)
+            if (t0 != 0.f) {
+              lo = __builtin_elementwise_fma(w0[m + d + 4], v2f{t0x2, t0x2}, lo);
+              hi = __builtin_elementwise_fma(w2[m + d + 4], v2f{t0, t0}, hi);
+            }
+            if (t1 != 0.f) {
+              lo = __builtin_elementwise_fma(w1[m + d + 4], v2f{t1, t1}, lo);
+              hi = __builtin_elementwise_fma(w3[m + d + 4], v2f{t1, t1}, hi);
+            }
+          }
+        }
+        *reinterpret_cast<v2f*>(&mid[0][2 * m + e][2 * tid]) = lo;
+        *reinterpret_cast<v2f*>(&mid[1][2 * m + e][2 * tid]) = hi;
+      }
+    }
+    __syncthreads();      // (one wave: no s_barrier, the LDS counter wait only)
+    // horizontal synthesis + store: 2*FB fine rows x 30 runs of 4 coarse (8 fine) columns; 32 lanes per row
+#pragma unroll
+    for (int trip = 0; trip < (2 * FB * 32) / PT; trip++) {
+      const int row = trip * (PT / 32) + (tid >> 5), run = tid & 31;
+      const int v = 4 * run, gcol = vx0 + v;
+      if (run < WV / 4 && gcol < vx1) {
+        float wl[12], wh[12];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const v4f a = *reinterpret_cast<const v4f*>(&mid[0][row][v + 4 * q]);
+          const v4f b = *reinterpret_cast<const v4f*>(&mid[1][row][v + 4 * q]);
+#pragma unroll
+          for (int i = 0; i < 4; i++) { wl[4 * q + i] = a[i]; wh[4 * q + i] = b[i]; }
+        }
+        float o[8];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int d = -HW; d <= HW; d++) {
+              const int k = e + K - 2 * d;
+              if (k >= 0 && k < L) {
+                const float t0 = T.g0[k], t1 = T.g1[k];
+                if (t0 != 0.f) acc = fmaf(wl[m + d + 4], t0, acc);
+                if (t1 != 0.f) acc = fmaf(wh[m + d + 4], t1, acc);
+              }
+            }
+            o[2 * m + e] = acc;
+          }
+        }
+        const int gr = 2 * R0 + row, gc = 2 * gcol;
+        const size_t off = (size_t)s * oplane + (size_t)(gr - soy) * orow + (gc - sox);
+        if (HALF_OUT) {
+          typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+          h8 hv;
+#pragma unroll
+          for (int i = 0; i < 8; i++) hv[i] = (_Float16)o[i];
+          *reinterpret_cast<h8*>(obase + off * 2) = hv;
+        } else {
+          float* p = reinterpret_cast<float*>(obase) + off;
+          reinterpret_cast<v4f*>(p)[0] = v4f{o[0], o[1], o[2], o[3]};
+          reinterpret_cast<v4f*>(p)[1] = v4f{o[4], o[5], o[6], o[7]};
+        }
+      }
+    }
+    __syncthreads();
+    // slide the window down by FB rows
+#pragma unroll
+    for (int i = 0; i < 8; i++) { w0[i] = w0[i + FB]; w1[i] = w1[i + FB]; w2[i] = w2[i + FB]; w3[i] = w3[i + FB]; }
+#pragma unroll
+    for (int i = 0; i < FB; i++) { w0[8 + i] = n0[i]; w1[8 + i] = n1[i]; w2[8 + i] = n2[i]; w3[8 + i] = n3[i]; }
+  }
+}
+
 // Adjoint walk: a thread owns one FINE column of the input gradient and walks down with an 18-row rolling window
 // (vertical analysis: v_lo = g0 . column, v_hi = g1 . column per coarse row), the horizontal analysis of WB coarse
 // rows at a time goes through LDS.  The output region is the gradient-support rectangle `orect` (or the whole plane):
@@ -1068,6 +1210,10 @@ int g_walk_min_n = 512;   // levels with n >= this (and n % 8 == 0) run the walk
 int g_fwd_fb = TNL_FWD_FB;   // tnl_idwt_set_tuning(1, 4 | 8): coarse rows per phase of the forward walk kernel
 int g_xcd = 1;               // tnl_idwt_set_tuning(2, 0 | 1): XCD-aware block order of the walk kernels
 int g_seg = 0;               // tnl_idwt_set_tuning(3, rows): rows per workgroup (0 = pick_seg)
+#ifndef TNL_FWD_PAIR
+#define TNL_FWD_PAIR 0
+#endif
+int g_fwd_pair = TNL_FWD_PAIR;   // tnl_idwt_set_tuning(4, 0 | 2 | 4): pair form of the forward walk (rows per phase), 0 = one column
 
 // launch geometry of a walk kernel: the logical grid, or its XCD-ordered 1-D form
 inline void walk_grid(uint32_t gx, uint32_t gy, uint32_t gz, dim3& grid, LGrid& lg) {
@@ -1109,9 +1255,18 @@ int launch_fwd(const float* x, const float* yh, uint32_t S, uint32_t n, void* ou
     walk_grid(tiles, cdiv(ch, seg), S, grid, lg);
 #define TNL_FWD_WALK(HALF, FB) \
   hipLaunchKernelGGL((k_idwt_fwd_walk<W, HALF, FB>), grid, dim3(WT), 0, st, x, yh, (int)n, out, roi, seg, lg, spans)
-    if (half_out) { if (g_fwd_fb == 4) TNL_FWD_WALK(true, 4); else TNL_FWD_WALK(true, 8); }
+#define TNL_FWD_WALK2(HALF, FB) \
+  hipLaunchKernelGGL((k_idwt_fwd_walk2<W, HALF, FB>), grid, dim3(PT), 0, st, x, yh, (int)n, out, roi, seg, lg, spans)
+    // pair form: even coarse origins and widths (true of every window TrainStep builds: 64-texel alignment)
+    bool pair = g_fwd_pair != 0 && cw % 2 == 0;
+    if (roi.rw) for (int p = 0; p < 3; p++) pair = pair && roi.ox[p] % 4 == 0;
+    if (pair) {
+      if (half_out) { if (g_fwd_pair == 2) TNL_FWD_WALK2(true, 2); else TNL_FWD_WALK2(true, 4); }
+      else { if (g_fwd_pair == 2) TNL_FWD_WALK2(false, 2); else TNL_FWD_WALK2(false, 4); }
+    } else if (half_out) { if (g_fwd_fb == 4) TNL_FWD_WALK(true, 4); else TNL_FWD_WALK(true, 8); }
     else { if (g_fwd_fb == 4) TNL_FWD_WALK(false, 4); else TNL_FWD_WALK(false, 8); }
 #undef TNL_FWD_WALK
+#undef TNL_FWD_WALK2
   } else if (n % 4 == 0) {
     const uint32_t ntx = roi.rw ? roi.rw / (2 * TI) : cdiv(n, TI), nty = roi.rw ? roi.rh / (2 * TI) : cdiv(n, TI);
     const int tpw = pick_tpw(ntx, nty, S);
@@ -1205,6 +1360,10 @@ int tnl_idwt_set_tuning(int key, int value) {
     case 1: if (value != 4 && value != 8) return (int)hipErrorInvalidValue; g_fwd_fb = value; return 0;
     case 2: g_xcd = value != 0; return 0;
     case 3: if (value < 0 || value % 8) return (int)hipErrorInvalidValue; g_seg = value; return 0;
+    case 4:   // (-1: the build's default)
+      if (value == -1) value = TNL_FWD_PAIR;
+      if (value != 0 && value != 2 && value != 4) return (int)hipErrorInvalidValue;
+      g_fwd_pair = value; return 0;
     default: return (int)hipErrorInvalidValue;
   }
 }
