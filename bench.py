@@ -79,6 +79,9 @@ def build(workload, device, dist_mode, plane_dtype=None, shell=(0.8, 0.0), **ts_
         ts.side_count_form = int(os.environ["TNL_SIDE_COUNT_FORM"])
     if os.environ.get("TNL_PREFETCH_AT"):     # A/B: where the next batch's march + tile sort start (bwd | reduce | adjoint)
         ts.prefetch_at = os.environ["TNL_PREFETCH_AT"]
+    if os.environ.get("TNL_FUSE_LIVE"):       # A/B: 0 = separate adjoint and optimiser passes on every level
+        ts.fuse_live = os.environ["TNL_FUSE_LIVE"] != "0"
+        ts.fuse_live_levels = max(int(os.environ["TNL_FUSE_LIVE"]), 1)
     if os.environ.get("TNL_NO_OVERLAP"):      # experiments: march + tile sort in order on the launch stream (kernels alone)
         ts.overlap_march = False
     bitfield = torch.from_numpy(synthetic.sphere_bitfield(128, model.cascade, 1.5, shell[0], shell[1])).to(device)
@@ -413,8 +416,9 @@ def adam_accounting(ts, world):
     # the coefficients outside it are replayed by k_adam_l1_catchup once per flush (24 B each, reported separately)
     live = ts.last_live if (ts.defer_adam and rects is not None and ts.last_live is not None) else [None] * ts.J
     tables = ts.last_live_bands if (ts.last_live_bands is not None and live[0] is ts.last_live[0]) else [None] * ts.J
-    adam_bytes, n_launch, deferred_coefs = 0.0, 0, 0.0
+    adam_bytes, n_launch, deferred_coefs, fused_bytes = 0.0, 0, 0.0, 0.0
     band_share = [None] * ts.J
+    fused = tuple(ts.last_fused_levels) if (ts.fuse_live and ts.defer_adam and rects is not None) else ()
 
     def band_counts(lv, tbl, r):
         """Coefficients per (slice, band) of a level's band pieces, and how many of them lie inside the stored-gradient
@@ -437,7 +441,12 @@ def adam_accounting(ts, world):
             rect_area = domain
             domain, inside = band_counts(live[lvl], tables[lvl][2], rects[lvl])
             band_share[lvl] = round(domain / rect_area, 4)
-        adam_bytes += S_own * 3 * (24.0 * domain + 4.0 * inside)
+        if lvl in fused:
+            # the adjoint level carries the optimiser (TrainStep.fuse_live): p, m, v read and written, the band gradients
+            # never leave the kernel -- counted with the adjoint section
+            fused_bytes += S_own * 3 * 24.0 * domain
+        else:
+            adam_bytes += S_own * 3 * (24.0 * domain + 4.0 * inside)
         deferred_coefs += S_own * 3 * float(n_l * n_l - domain)
         n_launch += 1
     n_ll = ts.ll.params[0].shape[-1]
@@ -446,7 +455,7 @@ def adam_accounting(ts, world):
     if ts.defer_adam and rects is not None:
         n_launch = 2          # all wavelet levels in one k_adam_l1_live launch + the LL launch
     return {"adam_bytes": adam_bytes, "n_launch": n_launch, "deferred_coefs": deferred_coefs, "band_share": band_share,
-            "live": live, "rects": rects, "S_own": S_own}
+            "live": live, "rects": rects, "S_own": S_own, "fused_levels": fused, "fused_bytes": fused_bytes}
 
 
 def section_specs(ts, model, samples_per_step, world, acct):
@@ -468,7 +477,13 @@ def section_specs(ts, model, samples_per_step, world, acct):
         out_b = e_pl if lvl == ts.J - 1 else 4
         fwd_bytes += S_own * win_area(lvl, m) * (4.0 + out_b)      # 4 input bands at a quarter of the area + output
         rect = rects[lvl][6] * rects[lvl][7] if rects is not None else (m // 2) ** 2
-        adj_bytes += S_own * (win_area(lvl, m) * 4.0 + 4.0 * rect * 4.0)   # gradient window in, 4 bands out
+        if lvl in acct["fused_levels"]:
+            # gradient window in, the low-pass band out over the live rectangle; the three detail bands feed the optimiser
+            # in the kernel (its 24 B per live coefficient: acct["fused_bytes"], added below)
+            adj_bytes += S_own * (win_area(lvl, m) * 4.0 + 4.0 * acct["live"][lvl][6] * acct["live"][lvl][7])
+        else:
+            adj_bytes += S_own * (win_area(lvl, m) * 4.0 + 4.0 * rect * 4.0)   # gradient window in, 4 bands out
+    adj_bytes += acct["fused_bytes"]
     fwd_bytes += (3 * Cc // (world if ts.dist_mode == "sharded" else 1)) * win_area(ts.J - 1, Rr) * 2 * e_pl  # layout
     spec = {
         "field_fwd": {"bytes": Ms * (12 * Cc * e_pl + 48 + 6 * Cc), "flops": 2.0 * mac * Ms,
@@ -477,13 +492,15 @@ def section_specs(ts, model, samples_per_step, world, acct):
                       "per_unit": "per sample: 6*C B features in + 6*C B fp16 dF out + 40 B (xyz, dir, g_sigma, g_rgb); "
                                   "recompute + dX + dW = 6*MAC flops"},
         "adam_coef": {"bytes": adam_bytes, "flops": 0.0,
-                      "per_unit": "per live coefficient: 28 B inside the gradient rectangle, 24 B outside it; nothing outside a live rectangle"},
+                      "per_unit": "per live coefficient of the levels the adjoint has not updated already: 28 B inside the gradient rectangle, 24 B outside it; nothing outside a live rectangle"},
         "plane_grad_binned": {"bytes": Ms * 3 * (2 * Cc + 1.13 * 12) + 3 * Cc * win_area(ts.J - 1, Rr) * 4, "flops": 0.0,
                               "per_unit": "per sample and plane: 2*C B dF + 1.13 list entries of 12 B (sample id + its texel coordinates on the plane); + 4 B per window texel and channel stored"},
         "idwt_fwd": {"bytes": fwd_bytes, "flops": 0.0,
                      "per_unit": "per computed output texel and slice: 4 B of input bands + e (finest) or 4 B out, + 2*e for the texel-major layout pass"},
         "idwt_adjoint": {"bytes": adj_bytes, "flops": 0.0,
-                         "per_unit": "per slice: 4 B per gradient-window texel in + 16 B per coefficient-rectangle position out"},
+                         "per_unit": "per slice: 4 B per gradient-window texel in + 16 B per coefficient-rectangle position out; on the "
+                                     "levels that carry the optimiser (fuse_live): 4 B in + 4 B of low-pass gradient out per live-rectangle "
+                                     "position + 24 B per live coefficient (p, m, v read and written; the band gradients stay in registers)"},
     }
     launches = {"field_fwd": 1, "field_bwd": 1 if Hh == 64 else 2, "adam_coef": acct["n_launch"], "plane_grad_binned": 1,
                 "idwt_fwd": ts.J + 1, "idwt_adjoint": ts.J}
@@ -774,6 +791,7 @@ def main():
                                                          "origin_y": lv[3:6], "width": lv[6], "height": lv[7]}
                                 for k, lv in enumerate(live)],
             "band_pieces_share_of_rectangle": band_share,
+            "levels_updated_inside_the_adjoint": list(acct["fused_levels"]),
             "deferred_share_of_coefficients": round(deferred_coefs / all_coefs, 4),
             "steps_deferred_in_timed_region": timed_deferred, "flushes_in_timed_region": timed_flushes,
             "catchup": None if cu_ms != cu_ms else {

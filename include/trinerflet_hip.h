@@ -530,6 +530,8 @@ TNL_API int tnl_idwt_level_backward_win(const float *dout, uint32_t S, uint32_t 
  * before launching work.  The kernel choice depends on n only, so windowed and whole-plane calls of one level always
  * take the same kernel (their results are bit-identical). */
 TNL_API int tnl_idwt_set_walk_min_n(uint32_t walk_min_n);
+/* the value in force (after the defaulting rule of the setter): levels with n >= it and n % 8 == 0 are column-walk levels */
+TNL_API int tnl_idwt_get_walk_min_n(void);
 /* The windowed level calls restricted to the pieces anything reads.  `spans`: device int32 [3][n / 8][2] on the level's
  * own n x n (coarse) grid -- for plane pl and coarse rows 8g .. 8g+7 the coarse columns [lo, end) -- or, for the
  * layout change, [3][R / 8][2] on the R x R plane grid (what tnl_occupancy_row_extents writes); NULL = no restriction.
@@ -546,6 +548,24 @@ TNL_API int tnl_idwt_level_forward_spans(const float *x, const float *yh, uint32
 TNL_API int tnl_idwt_level_backward_spans(const float *dout, uint32_t S, uint32_t n, int wave, float *dx, float *dyh,
                                           const int32_t *win, int strided, int32_t *out_rect, const int32_t *spans,
                                           void *stream);
+/* A column-walk level of the windowed adjoint with the optimiser in its epilogue (TrainStep's live / deferred split,
+ * steady state): the band gradients of the level's LIVE pieces are applied to p / m / v:[S,3,n,n] where they are produced
+ * and never written -- tnl_adam_l1_step_live_bands' arithmetic with the step's scalars read from `step_rec` (one slot of
+ * the ring tnl_adam_record_step writes; record the step BEFORE this call) -- 24 instead of 32 bytes per live coefficient
+ * over the adjoint + optimiser pair.  live_rect: the level's live rectangle (8 host ints {x[3], y[3], w, h}; x, w % 4 == 0,
+ * y, h % 8 == 0), a superset of the gradient's support (the rectangle tnl_idwt_level_backward_spans returns for this
+ * window): outside the support the gradient is exactly zero, as the unfused pass takes it.  band_table / spans: the live
+ * band pieces in the two forms of tnl_adam_l1_step_live_bands and tnl_idwt_level_backward_spans (device), or both NULL:
+ * the whole rectangle.  dx:[S,n,n] receives the low-pass gradient over the live rectangle.  abs_sum += sum |p| of the
+ * updated pieces.  Replaces reconstruction/nerf/utils.py:1166-1173 (scaler.step(optimizer)) for this level's
+ * coefficients together with autograd's backward of triplane_encoder.py:392-394.  n must be a column-walk level. */
+TNL_API int tnl_idwt_level_backward_live_adam(const float *dout, uint32_t S, uint32_t n, int wave, float *dx,
+                                              const int32_t *win, int strided, const int32_t *live_rect,
+                                              const int32_t *spans, float *p, float *m, float *v,
+                                              const int32_t *band_table, uint32_t nb, const float *step_rec,
+                                              float beta1, float beta2, float eps, float inv_scale,
+                                              const float *inv_scale_dev, float l1_coef, const float *found_inf,
+                                              float *abs_sum, void *stream);
 TNL_API int tnl_planes_half_to_texel_major_spans(const void *planes_roi_half, uint32_t C, uint32_t R,
                                                  void *planes_tm_half, const int32_t *roi, const int32_t *spans,
                                                  void *stream);

@@ -4,7 +4,7 @@ Every one of these switches changes HOW the step is executed, none WHAT it compu
 reduction (deterministic=True) all of them are documented as bit-identical to the plain step -- the occupancy window
 (use_roi), the live / deferred optimiser split (defer_adam), its band pieces (live_bands), the next batch's march on the
 side stream (overlap_march) with its two start positions (prefetch_at) and count-pass forms (side_count_form), the far
-clip of the in-order march (clip_far_in_order), the banded plane-gradient exchange (overlap_exchange) and the captured
+clip of the in-order march (clip_far_in_order), the optimiser inside the adjoint's column-walk levels (fuse_live), the banded plane-gradient exchange (overlap_exchange) and the captured
 steps (graph).  Here a seeded sample of their cross-product (plus every single flag flipped on its own) trains the same
 small model over three density-grid periods -- refresh steps, window changes of the re-imposed occupancy and ring flushes
 inside -- and must end on the SAME BITS as the default configuration, parameters and Adam moments alike."""
@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 FLAGS = {            # name -> (default, alternative)
     "use_roi": (True, False), "defer_adam": (True, False), "live_bands": (True, False), "overlap_march": (True, False),
     "prefetch_at": ("bwd", "adjoint"), "side_count_form": (1, 0), "clip_far_in_order": (True, False),
-    "overlap_exchange": (0, 3), "graph": (False, True),
+    "overlap_exchange": (0, 3), "graph": (False, True), "fuse_live": (True, False),
 }
 
 
@@ -58,7 +58,7 @@ def _run(cuda, combo):
     ctor = {k: v for k, v in combo.items() if k in ("use_roi", "defer_adam", "live_bands", "overlap_exchange", "graph")}
     ctor.setdefault("defer_adam", True)      # (the constructor's own default turns the split on from 32 M coefficients)
     ts = TrainStep(m, lr=1e-2, wavelet_regularization=0.2, iters=200, update_extra_interval=8, deterministic=True, **ctor)
-    for k in ("overlap_march", "prefetch_at", "side_count_form", "clip_far_in_order"):
+    for k in ("overlap_march", "prefetch_at", "side_count_form", "clip_far_in_order", "fuse_live"):
         if k in combo:
             setattr(ts, k, combo[k])
     period = {"n": 0}
@@ -75,21 +75,34 @@ def _run(cuda, combo):
         nz = np.random.default_rng(b).random(4096).astype(np.float32)
         batches.append((t(o), t(d), t(synthetic.target_colors(d)), t(nz)))
     losses = []
+    fused_seen = set()
     for k in range(26):                                   # refreshes at 0, 8, 16, 24
         o, d, gt, nz = batches[k % 4]
         nxt = batches[(k + 1) % 4]
         ts.step(o, d, gt, noises=nz, next_rays=(nxt[0], nxt[1], nxt[3]))
+        fused_seen.update(ts._fused_levels)
         losses.append(float(ts.last["mse"]))      # (the step's loss also carries the L1 value, whose deferred share is reported apart)
     ts.flush_deferred()
     ts.sync_sharded_parameters()
     return (losses, [p.detach().clone() for p in m.parameters()], ts.coef.m.clone(), ts.coef.v.clone(), ts.ll.m.clone(),
-            {"deferred": ts.deferred_steps, "replays": getattr(ts, "graph_replays", 0)})
+            {"deferred": ts.deferred_steps, "replays": getattr(ts, "graph_replays", 0), "fused": fused_seen})
+
+
+@pytest.fixture(scope="module", autouse=True)
+def walk_levels(cuda):
+    """The 128-, 64- and 32-coefficient levels of this small model on the column-walk kernels (production: n >= 512), so that
+    the adjoint levels that carry the optimiser (fuse_live) are part of every configuration, the baseline's included."""
+    from trinerflet_amd import _lib as L
+    L.lib().tnl_idwt_set_walk_min_n(L.u32(32))
+    yield
+    L.lib().tnl_idwt_set_walk_min_n(L.u32(0))
 
 
 @pytest.fixture(scope="module")
-def baseline(cuda):
+def baseline(cuda, walk_levels):
     out = _run(cuda, {})
     assert out[5]["deferred"] > 8          # the geometry exercises the live / deferred split
+    assert len(out[5]["fused"]) >= 2       # ... and adjoint levels with the optimiser in their epilogue
     return out
 
 

@@ -54,8 +54,6 @@ __device__ __forceinline__ void st_nt(float4* p, const float4& v) {
   __builtin_nontemporal_store(v.z, &p->z); __builtin_nontemporal_store(v.w, &p->w);
 }
 
-// one slot of the step ring (k_adam_record): the step's bias-corrected scalars and GradScaler's verdict
-struct AdamStepRec { float step_size, bias2_sqrt, skip, pad; };
 
 template <bool RECT, bool NTMP = false>
 __global__ void __launch_bounds__(256)

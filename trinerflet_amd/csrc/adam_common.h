@@ -28,6 +28,10 @@ static inline AdamArgs make_adam_args(float step_size, float bias2_sqrt, float b
                   adam_decimal(beta1), adam_decimal(beta2)};
 }
 
+// one slot of the step ring (k_adam_record): the step's bias-corrected scalars, GradScaler's verdict, and (optim.FusedAdamL1)
+// a folded L1 coefficient
+struct AdamStepRec { float step_size, bias2_sqrt, skip, pad; };
+
 __device__ __forceinline__ float adam_sgn(float x) { return (x > 0.f) - (x < 0.f); }
 // c * sign(x) for c >= 0 (sign(+-0) = 0): the magnitude with x's sign bit, or zero -- three instructions
 __device__ __forceinline__ float adam_signed(float c, float x) { return x == 0.f ? 0.f : copysignf(c, x); }

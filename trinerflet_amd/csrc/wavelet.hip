@@ -964,10 +964,32 @@ k_idwt_fwd_walk2(const float* __restrict__ x, const float* __restrict__ yh, int 
 // (vertical analysis: v_lo = g0 . column, v_hi = g1 . column per coarse row), the horizontal analysis of WB coarse
 // rows at a time goes through LDS.  The output region is the gradient-support rectangle `orect` (or the whole plane):
 // every element of it is written -- computed from the input window `roi` (zero outside it) -- nothing outside is.
-template <int W>
-__global__ void __launch_bounds__(AT)
+//
+// FUSE: the level's band gradients are consumed where they are produced -- the Adam(+L1) update of the LIVE pieces of the
+// level (adam.hip k_adam_l1_live's arithmetic, the step's scalars from its ring record) runs in this kernel's epilogue and
+// dyh is never written: 24 instead of 32 bytes per live coefficient over the adjoint + optimiser pair.  `orect` is then the
+// level's LIVE rectangle (a superset of the gradient's support: outside the support the sums below are exact zeros, the
+// g = 0 the unfused pass takes there), `spans` the live band pieces as a span table and wa.bt the same pieces as the
+// optimiser's band table (or nullptr: the whole rectangle is live).  p, m, v of a thread's three quads are requested at
+// the top of the phase that produces their gradients.
+struct WalkAdam {
+  float *p, *m, *v;              // [S][3][n][n] of this level (the slices the launch covers)
+  AdamArgs a;
+  const AdamStepRec* rec;
+  const float* inv_scale_dev;
+  const float* found_inf;
+  float* abs_sum;
+  const int* bt;
+  int nb;
+};
+
+#ifndef TNL_BWD_WALK_WAVES
+#define TNL_BWD_WALK_WAVES 1
+#endif
+template <int W, bool FUSE>
+__global__ void __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(TNL_BWD_WALK_WAVES)))
 k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh, Roi roi,
-                Roi orect, int seg, LGrid lg, const int* __restrict__ spans) {
+                Roi orect, int seg, LGrid lg, const int* __restrict__ spans, WalkAdam wa) {
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2;
   constexpr int KA = (K + 3) / 4 * 4, SH = KA - K;       // staged left halo (fine samples), 16-byte aligned
@@ -1018,12 +1040,65 @@ k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, f
   for (int i = 0; i < 4 * WB; i++) w[i] = ld(2 * ry0 - K + i);
   const size_t nn = (size_t)n * n;
   float* o_ll = dx + (size_t)s * nn;
-  float* o_h = dyh + (size_t)s * 3 * nn;
+  float* o_h = FUSE ? nullptr : dyh + (size_t)s * 3 * nn;
+  // FUSE: the step's scalars, and this thread's output quad of every phase (row R0 + qj, columns qcol .. qcol + 3)
+  AdamArgs aa = wa.a;
+  bool skip = false;
+  float abs_acc = 0.f;
+  const int qj = tid >> 5, qcol = vx0 + 4 * (tid & 31);
+  const bool qcol_ok = (tid & 31) < AVC / 4 && qcol < vx1;
+  if (FUSE) {
+    aa.step_size = wa.rec->step_size;
+    aa.bias2_sqrt = wa.rec->bias2_sqrt;
+    if (wa.inv_scale_dev != nullptr) aa.inv_scale *= wa.inv_scale_dev[0];
+    skip = (wa.found_inf != nullptr && wa.found_inf[0] != 0.f) || wa.rec->skip != 0.f;
+    aa.l1_coef = wa.a.l1_coef + wa.rec->pad;
+  }
+  float* const pq = FUSE ? wa.p + (size_t)s * 3 * nn : nullptr;
+  float* const mq = FUSE ? wa.m + (size_t)s * 3 * nn : nullptr;
+  float* const vq = FUSE ? wa.v + (size_t)s * 3 * nn : nullptr;
+  v4f Pq[3], Mq[3], Vq[3];
+  // the live column piece [first, first + width) of each 8-row band of this segment (seg <= 256 rows)
+  __shared__ int s_piece[2][32];
+  if (FUSE) {
+    for (int k = tid; k < (ry1 - ry0 + 7) / 8; k += AT) {
+      const int b = ((ry0 - oy0) >> 3) + k;
+      s_piece[0][k] = wa.bt != nullptr ? wa.bt[2 * wa.nb + 1 + pl * wa.nb + b] : ox0;
+      s_piece[1][k] = wa.bt != nullptr ? 4 * wa.bt[wa.nb + 1 + b] : ow;
+    }
+    __syncthreads();
+  }
+  const size_t off_idle = (size_t)ry0 * n + vx0;      // what a thread without a live quad loads (and never stores)
   for (int R0 = ry0; R0 < ry1; R0 += WB) {
     const bool more = R0 + WB < ry1;
-    if (more) {
+    uint32_t nx_ok = 0;       // FUSE: which of the rows in flight exist (masked when the window slides, not at the load)
+    if (FUSE) {
+      // unconditional loads from clamped rows: a value selected at the load is a wait at the load, and the waits of this
+      // loop must leave the optimiser's stores of the previous phase in flight
+#pragma unroll
+      for (int i = 0; i < 2 * WB; i++) {
+        const int r = 2 * R0 - K + 4 * WB + i, gr = r - foy;
+        if (col_ok && gr >= 0 && gr < fh) nx_ok |= 1u << i;
+        const int rc = min(max(gr, 0), fh - 1) + foy;
+        nx[i] = colp[(size_t)(rc - soy) * sw];
+      }
+    } else if (more) {
 #pragma unroll
       for (int i = 0; i < 2 * WB; i++) nx[i] = ld(2 * R0 - K + 4 * WB + i);
+    }
+    bool member = false;
+    if (FUSE) {
+      // unconditional loads (a thread without a live quad reads one that exists): no merge of loaded and unloaded
+      // values for the compiler to wait on -- the nine quads stay in flight until the epilogue
+      const int kb = (R0 - ry0) >> 3, x0 = s_piece[0][kb], wq = s_piece[1][kb];
+      member = qcol_ok && R0 + qj < ry1 && qcol >= x0 && qcol < x0 + wq;
+      const size_t off = member ? (size_t)(R0 + qj) * n + qcol : off_idle;
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        Pq[b] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(pq + b * nn + off));
+        Mq[b] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(mq + b * nn + off));
+        Vq[b] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(vq + b * nn + off));
+      }
     }
 #pragma unroll
     for (int j = 0; j < WB; j++) {
@@ -1037,11 +1112,46 @@ k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, f
       mid[0][j][tid] = lo;
       mid[1][j][tid] = hi;
     }
+    if (FUSE) {
+      // the window slides HERE (nothing below reads it): the wait for the rows in flight then falls a whole vertical pass
+      // behind the previous phase's stores instead of right behind this phase's
+#pragma unroll
+      for (int i = 0; i < 2 * WB; i++) { w[i] = w[i + 2 * WB]; w[i + 2 * WB] = ((nx_ok >> i) & 1u) ? nx[i] : 0.f; }
+#pragma unroll
+      for (int i = 0; i < 2 * WB; i++) asm volatile("" : "+v"(w[i + 2 * WB]));      // (here, not sunk behind the stores)
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
     {
       const int j = tid >> 5, run = tid & 31;            // 8 coarse rows x 30 runs of 4 coarse columns
       const int v = 4 * run, gcol = vx0 + v, gr = R0 + j;
       if (run < AVC / 4 && gcol < vx1 && gr < ry1) {
+        v4f r0, r1, r2, r3;
+        if (FUSE) {
+          // the same four chains per output, the vertical-low half first, then the vertical-high half: half the window
+          // registers at a time (the optimiser's p, m, v quads are in flight beside them)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            float wx[24];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+              const v4f a = *reinterpret_cast<const v4f*>(&mid[h][j][2 * v + 4 * q]);
+#pragma unroll
+              for (int i = 0; i < 4; i++) wx[4 * q + i] = a[i];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+              float a = 0.f, cc = 0.f;
+#pragma unroll
+              for (int k = 0; k < L; k++) {
+                const float t0 = T.g0[k], t1 = T.g1[k];
+                if (t0 != 0.f) a = fmaf(wx[SH + 2 * jj + k], t0, a);
+                if (t1 != 0.f) cc = fmaf(wx[SH + 2 * jj + k], t1, cc);
+              }
+              if (h == 0) { r0[jj] = 2.0f * a; r2[jj] = cc; } else { r1[jj] = a; r3[jj] = cc; }
+            }
+          }
+        } else {
         float wl[24], wh[24];
 #pragma unroll
         for (int q = 0; q < 6; q++) {
@@ -1050,7 +1160,6 @@ k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, f
 #pragma unroll
           for (int i = 0; i < 4; i++) { wl[4 * q + i] = a[i]; wh[4 * q + i] = b[i]; }
         }
-        v4f r0, r1, r2, r3;
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) {
           float a = 0.f, b = 0.f, cc = 0.f, d = 0.f;
@@ -1063,8 +1172,36 @@ k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, f
           }
           r0[jj] = 2.0f * a; r1[jj] = b; r2[jj] = cc; r3[jj] = d;
         }
+        }
         const size_t off = (size_t)gr * n + gcol;
-        if (TNL_IDWT_BWD_NT) {
+        if (FUSE) {
+          *reinterpret_cast<v4f*>(o_ll + off) = r0;
+          if (member) {
+            const v4f gq[3] = {r1, r2, r3};
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+              if (!skip) {
+                // (a wavefront whose coefficients all sit at the p = m = v = g = 0 fixed point stores nothing: k_adam_l1_live)
+                auto bits = [](const v4f& t) { return __float_as_uint(t[0]) | __float_as_uint(t[1]) | __float_as_uint(t[2]) | __float_as_uint(t[3]); };
+                const uint32_t any = (bits(Pq[b]) | bits(gq[b]) | bits(Mq[b]) | bits(Vq[b])) & 0x7fffffffu;
+                const bool moved = __ballot(any != 0u) != 0ull;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  float pp = Pq[b][e], mm = Mq[b][e], vv = Vq[b][e];
+                  adam1(pp, gq[b][e], mm, vv, aa, abs_acc);
+                  Pq[b][e] = pp; Mq[b][e] = mm; Vq[b][e] = vv;
+                }
+                if (moved) {
+                  __builtin_nontemporal_store(Pq[b], reinterpret_cast<v4f*>(pq + b * nn + off));
+                  __builtin_nontemporal_store(Mq[b], reinterpret_cast<v4f*>(mq + b * nn + off));
+                  __builtin_nontemporal_store(Vq[b], reinterpret_cast<v4f*>(vq + b * nn + off));
+                }
+              } else {
+                abs_acc += fabsf(Pq[b][0]) + fabsf(Pq[b][1]) + fabsf(Pq[b][2]) + fabsf(Pq[b][3]);
+              }
+            }
+          }
+        } else if (TNL_IDWT_BWD_NT) {
           __builtin_nontemporal_store(r0, reinterpret_cast<v4f*>(o_ll + off));
           __builtin_nontemporal_store(r1, reinterpret_cast<v4f*>(o_h + off));
           __builtin_nontemporal_store(r2, reinterpret_cast<v4f*>(o_h + nn + off));
@@ -1079,7 +1216,20 @@ k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, f
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2 * WB; i++) { w[i] = w[i + 2 * WB]; w[i + 2 * WB] = nx[i]; }
+    for (int i = 0; i < 2 * WB; i++) if (!FUSE) { w[i] = w[i + 2 * WB]; w[i + 2 * WB] = nx[i]; }
+  }
+  if (FUSE && wa.abs_sum != nullptr) {       // sum |p| as this step saw it (the L1 value), one atomic per workgroup
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) abs_acc += __shfl_xor(abs_acc, off);
+    __shared__ float part[AT / 64];
+    if ((tid & 63) == 0) part[tid >> 6] = abs_acc;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < AT / 64; k++) t += part[k];
+      atomicAdd(wa.abs_sum, t);
+    }
   }
 }
 
@@ -1334,7 +1484,8 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
     LGrid lg;
     walk_grid(tiles, cdiv(oh, seg), S, grid, lg);
     if (spans != nullptr && (out_rect == nullptr || dx == nullptr)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_idwt_bwd_walk<W>, grid, dim3(AT), 0, st, dout, (int)n, dx, dyh, roi, orect, seg, lg, spans);
+    hipLaunchKernelGGL((k_idwt_bwd_walk<W, false>), grid, dim3(AT), 0, st, dout, (int)n, dx, dyh, roi, orect, seg, lg, spans,
+                       WalkAdam{});
   } else if (n % 2 == 0) {
     const int tpw = pick_tpw(cdiv(n, TI), cdiv(n, TI), S);
     hipLaunchKernelGGL((k_idwt_bwd_pipe<W, false>), dim3(cdiv(cdiv(n, TI), tpw), cdiv(n, TI), S), dim3(NT), 0, st, dout,
@@ -1346,9 +1497,29 @@ int launch_bwd(const float* dout, uint32_t S, uint32_t n, float* dx, float* dyh,
   return (int)hipGetLastError();
 }
 
+// the walk kernel with the optimiser in its epilogue (k_idwt_bwd_walk<W, true>): the launch covers the live rectangle
+template <int W>
+int launch_bwd_fused(const float* dout, uint32_t S, uint32_t n, float* dx, hipStream_t st, Roi roi, const int32_t* live,
+                     const int* spans, const WalkAdam& wa) {
+  Roi orect{};
+  for (int p = 0; p < 3; p++) { orect.ox[p] = live[p]; orect.oy[p] = live[3 + p]; }
+  orect.rw = live[6]; orect.rh = live[7];
+  orect.spp = roi.spp; orect.s0 = roi.s0;
+  const uint32_t tiles = cdiv(orect.rw, AVC);
+  const int seg = g_seg ? g_seg : pick_seg(tiles, orect.rh, S);
+  dim3 grid;
+  LGrid lg;
+  walk_grid(tiles, cdiv(orect.rh, seg), S, grid, lg);
+  hipLaunchKernelGGL((k_idwt_bwd_walk<W, true>), grid, dim3(AT), 0, st, dout, (int)n, dx, (float*)nullptr, roi, orect, seg, lg,
+                     spans, wa);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
+
+int tnl_idwt_get_walk_min_n(void) { return g_walk_min_n; }
 
 int tnl_idwt_set_walk_min_n(uint32_t n) {
   g_walk_min_n = n == 0 ? 512 : (int)n;
@@ -1497,6 +1668,39 @@ static int idwt_backward_any(const float* dout, uint32_t S, uint32_t n, int wave
     case 2: return launch_bwd<2>(dout, S, n, dx, dyh, st, roi, out_rect, spans);
     case 3: return launch_bwd<3>(dout, S, n, dx, dyh, st, roi, out_rect, spans);
     case 4: return launch_bwd<4>(dout, S, n, dx, dyh, st, roi, out_rect, spans);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
+int tnl_idwt_level_backward_live_adam(const float* dout, uint32_t S, uint32_t n, int wave, float* dx, const int32_t* win,
+                                      int strided, const int32_t* live_rect, const int32_t* spans, float* p, float* m,
+                                      float* v, const int32_t* band_table, uint32_t nb, const float* step_rec, float beta1,
+                                      float beta2, float eps, float inv_scale, const float* inv_scale_dev, float l1_coef,
+                                      const float* found_inf, float* abs_sum, void* stream) {
+  if (S == 0 || n == 0) return 0;
+  if (S > 65535 || win == nullptr || live_rect == nullptr || dx == nullptr || step_rec == nullptr) return (int)hipErrorInvalidValue;
+  if (!(n % 8 == 0 && (int)n >= g_walk_min_n)) return (int)hipErrorInvalidValue;      // a column-walk level
+  if ((band_table == nullptr) != (spans == nullptr) || (band_table != nullptr && (nb == 0 || nb > 128))) return (int)hipErrorInvalidValue;
+  for (int q = 0; q < 3; q++)        // 16-byte quads of p, m, v; 8-row bands
+    if (live_rect[q] % 4 || live_rect[3 + q] % 8 || live_rect[q] < 0 || live_rect[3 + q] < 0 ||
+        live_rect[q] + live_rect[6] > (int)n || live_rect[3 + q] + live_rect[7] > (int)n)
+      return (int)hipErrorInvalidValue;
+  if (live_rect[6] <= 0 || live_rect[7] <= 0 || live_rect[6] % 4 || live_rect[7] % 8) return (int)hipErrorInvalidValue;
+  if (band_table != nullptr && (int)nb != live_rect[7] / 8) return (int)hipErrorInvalidValue;
+  Roi roi;
+  if (!make_roi(win, S, 2 * n, roi, strided ? 4 : 64)) return (int)hipErrorInvalidValue;
+  roi.strided = (roi.rw && strided) ? 1 : 0;
+  if (!roi.rw) return (int)hipErrorInvalidValue;
+  // step_size / bias2_sqrt come from the record on the device
+  WalkAdam wa{p, m, v, make_adam_args(0.f, 1.f, beta1, beta2, eps, inv_scale, l1_coef),
+              reinterpret_cast<const AdamStepRec*>(step_rec), inv_scale_dev, found_inf, abs_sum, band_table, (int)nb};
+  hipStream_t st = (hipStream_t)stream;
+  switch (wave) {
+    case 0: return launch_bwd_fused<0>(dout, S, n, dx, st, roi, live_rect, spans, wa);
+    case 1: return launch_bwd_fused<1>(dout, S, n, dx, st, roi, live_rect, spans, wa);
+    case 2: return launch_bwd_fused<2>(dout, S, n, dx, st, roi, live_rect, spans, wa);
+    case 3: return launch_bwd_fused<3>(dout, S, n, dx, st, roi, live_rect, spans, wa);
+    case 4: return launch_bwd_fused<4>(dout, S, n, dx, st, roi, live_rect, spans, wa);
     default: return (int)hipErrorInvalidValue;
   }
 }

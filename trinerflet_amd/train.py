@@ -188,6 +188,14 @@ class TrainStep:
         # SLOWER at base (3.8 ms vs 0.95 + 2.03 ms): the epilogue's 4-byte p/m/v accesses are issued late and in
         # 128-B pieces, while the stand-alone pass streams 16 B/lane at the HBM ceiling.  Kept as an option.
         self.fuse_adam = fuse_adam
+        # fuse_live: in the steady state of the live / deferred split (occupancy window, its rectangles and band pieces known)
+        # the column-walk levels of the adjoint apply the optimiser to their live pieces in the kernel's epilogue
+        # (tnl_idwt_level_backward_live_adam): the band gradients of the two finest levels -- 81 % of the live coefficients at
+        # base -- are neither written nor read back.  Bit-identical to the separate passes.
+        self.fuse_live = True
+        self.fuse_live_levels = 2     # how many of the finest column-walk levels (all of them: 2 at R = 2048)
+        self._fused_levels = ()
+        self.last_fused_levels = ()
         # use_roi: between two density-grid refreshes no sample can leave the bounding window of the occupied cells,
         # so the finest IDWT level, the fp16 layout change, the plane gradient and the finest adjoint only touch
         # that window (compact arrays).  Refresh steps rebuild whole planes (the grid update queries density
@@ -553,7 +561,7 @@ class TrainStep:
         t = self.global_step + 1
         return lr_t / (1 - self.b1 ** t), math.sqrt(1 - self.b2 ** t)
 
-    def _adjoint(self, grad_tm, g_cm=None, fuse=None, roi=None, scattered=False):
+    def _adjoint(self, grad_tm, g_cm=None, fuse=None, roi=None, scattered=False, live_adam=None):
         """plane gradient (texel-major [3,R,R,C], or already (3,C,R,R) in g_cm) -> coefficient / LL gradients.
         fuse=None: fills self.ll.grad / self.coef.grad (dense).  fuse=(lr_t, l1, found_inf, inv_scale): every
         level applies Adam(+L1) to its coefficients where their gradients are produced (no gradient buffer)."""
@@ -600,7 +608,21 @@ class TrainStep:
                 dyh = self.coef.grad_view(lvl).view(S, 3, n, n)[s0:s1]  # contiguous slice range of the flat buffer
                 if lvl == 0:
                     dx = self.ll.grad_view(0).view(S, n, n)[s0:s1]
-                if roi is not None and self._rect_ok:
+                if roi is not None and self._rect_ok and live_adam is not None and lvl in self._fused_levels:
+                    # steady state: this level's live pieces are updated in the adjoint kernel's epilogue (fuse_live)
+                    slot, l1_, found_inf_, inv_scale_ = live_adam
+                    win = list(roi) if lvl == self.J - 1 else list(self._rects[lvl + 1])
+                    lv, bt, cf = self._live[lvl], self._live_bands[lvl], self.coef
+                    o = cf.offsets[lvl] + s0 * per
+                    L.check(lib.tnl_idwt_level_backward_live_adam(
+                        L.ptr(g), L.u32(ns), L.u32(n), L.i32(self.enc.wave_id), L.ptr(dx), L.roi_array(win + [C, s0]),
+                        L.i32(0 if lvl == self.J - 1 else 1), (C_.c_int32 * 8)(*lv[:8]),
+                        L.ptr(None if bt is None else bt[3]), L.ptr(cf.data[o:]), L.ptr(cf.m[o:]), L.ptr(cf.v[o:]),
+                        L.ptr(None if bt is None else bt[0]), L.u32(0 if bt is None else lv[7] // 8),
+                        L.ptr(self._ring[4 * slot:]), L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0),
+                        L.ptr(inv_scale_), L.f32(l1_), L.ptr(found_inf_), L.ptr(self.abs_sum), L.stream()),
+                        "idwt_level_backward_live_adam")
+                elif roi is not None and self._rect_ok:
                     # gradient-support chain: the window of this level's input -> the rectangle of coarse tiles it
                     # reaches; nothing is stored outside it, the next level reads it as a strided window and the
                     # Adam pass of this level takes g = 0 outside (self._rects[lvl])
@@ -952,13 +974,29 @@ class TrainStep:
                     self._prefetch_next(st.next_rays)
                 self._mark("idwt_adjoint_adam")
             else:
-                s0, s1 = self._adjoint(None, st.g_cm, roi=st.roi, scattered=getattr(st, "scattered", False))
+                scattered = getattr(st, "scattered", False)
+                begun = None
+                self._fused_levels = ()
+                if (self.fuse_live and self.defer_adam and st.roi is not None and self._rect_ok and self._rects_roi is self._roi
+                        and all(r is not None for r in self._rects)):
+                    # the window's rectangles are known from the adjoint of an earlier step under it: the step is recorded
+                    # (and the live pieces fixed) before the adjoint, whose column-walk levels then carry the optimiser
+                    sl = self._slice_range() if (scattered or (self.multi and self.dist_mode == "sharded")) else (0, 3 * self.C)
+                    begun = self._adam_live_begin(lr_t, l1, found_inf, sl[0], sl[1], self._rects)
+                    wmin = int(lib.tnl_idwt_get_walk_min_n())
+                    self._fused_levels = tuple(
+                        lvl for lvl in range(self.J)
+                        if self._live[lvl] is not None and self.coef.params[lvl].shape[-1] >= wmin
+                        and self.coef.params[lvl].shape[-1] % 8 == 0)[-self.fuse_live_levels:]
+                    self.last_fused_levels = self._fused_levels      # (for reports: kept over refresh steps)
+                s0, s1 = self._adjoint(None, st.g_cm, roi=st.roi, scattered=scattered,
+                                       live_adam=None if begun is None else (begun, l1, found_inf, inv_scale))
                 if self.prefetch_at == "adjoint":
                     self._prefetch_next(st.next_rays)
                 self._mark("idwt_adjoint")
                 rects = self._rects if (st.roi is not None and self._rect_ok) else None
                 if self.defer_adam and rects is not None:
-                    self._adam_levels_live(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
+                    self._adam_levels_live(lr_t, l1, found_inf, inv_scale, s0, s1, rects, begun=begun)
                 else:
                     self._adam_levels(lr_t, l1, found_inf, inv_scale, s0, s1, rects)
                 self._mark("adam_coef")
@@ -1039,7 +1077,8 @@ class TrainStep:
         ext = None if self._row_ext is None else hash(self._row_ext.tobytes())
         tup = lambda rs: tuple(None if r is None else tuple(int(x) for x in r) for r in rs)
         return (roi, ext, tup(self._rects), tup(self._live), int(self.model.mean_count), st.N, st.n_glob, float(self.bg),
-                bool(self.deterministic), bool(self.live_bands), self.update_extra_interval, self.max_steps, self.dt_gamma)
+                bool(self.deterministic), bool(self.live_bands), self.update_extra_interval, self.max_steps, self.dt_gamma,
+                bool(self.fuse_live))
 
     def drop_graphs(self):
         self._graphs = {}
@@ -1341,10 +1380,11 @@ class TrainStep:
         self._band_cache[key] = out
         return out
 
-    def _adam_levels_live(self, lr_t, l1, found_inf, inv_scale, s0, s1, rects):
-        """_adam_levels over the live rectangles only; the step's scalars are recorded for the replay."""
+    def _adam_live_begin(self, lr_t, l1, found_inf, s0, s1, rects):
+        """Opens the step of the live / deferred split: the deferred part catches up first if the regulariser's weight or
+        the slice range changed, the live pieces are fixed at the first pending step, and the step's scalars go into their
+        ring slot (returned) -- for the live pass, the replay, and the adjoint levels that carry the optimiser (fuse_live)."""
         lib = L.lib()
-        ns = s1 - s0
         if self._pending and self._defer_ctx != (s0, s1, l1):
             self.flush_deferred()                  # the regulariser's weight (or the slice range) changed: new period
         if self._pending == 0:
@@ -1362,21 +1402,33 @@ class TrainStep:
             L.check(lib.tnl_adam_record_step(L.ptr(self._ring), L.i32(slot), L.f32(lr_t), L.ptr(self.opt_steps),
                                              L.f32(self.b1), L.f32(self.b2), L.ptr(found_inf), L.stream()),
                     "adam_record_step")
-        # every level in ONE launch: its live rectangle, or the whole level where nothing is deferred
-        J, cf = self.J, self.coef
-        sizes = [cf.params[lvl].shape[-1] for lvl in range(J)]
-        offs = [cf.offsets[lvl] + s0 * 3 * sizes[lvl] ** 2 for lvl in range(J)]
-        live = [lv if lv is not None else [0, 0, 0, 0, 0, 0, sizes[k], sizes[k]] for k, lv in enumerate(self._live)]
-        flat = lambda rs: (C_.c_int32 * (8 * J))(*[x for r in rs for x in r[:8]])
-        bt = self._live_bands
-        L.check(lib.tnl_adam_l1_step_live_bands(
-            L.ptr(cf.data), L.ptr(cf.grad), L.ptr(cf.m), L.ptr(cf.v), L.u32(ns), L.u32(self.C), L.u32(s0), L.u32(J),
-            (C_.c_uint64 * J)(*offs), (C_.c_uint32 * J)(*sizes), (C_.c_uint32 * J)(*([3] * J)), flat(live), flat(rects),
-            (C_.c_void_p * J)(*[None if b is None else b[0].data_ptr() for b in bt]),
-            (C_.c_uint32 * J)(*[0 if b is None else b[1] for b in bt]),
-            (C_.c_float * J)(*([l1] * J)), L.f32(lr_t), L.ptr(self.opt_steps), L.ptr(self._ring[4 * slot:]),
-            L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0), L.ptr(inv_scale), L.ptr(found_inf),
-            L.ptr(self.abs_sum), L.stream()), "adam_l1_step_live_bands")
+        return slot
+
+    def _adam_levels_live(self, lr_t, l1, found_inf, inv_scale, s0, s1, rects, begun=None):
+        """_adam_levels over the live rectangles only; the step's scalars are recorded for the replay (begun: already, in
+        that ring slot, and the levels in self._fused_levels were updated by the adjoint)."""
+        lib = L.lib()
+        ns = s1 - s0
+        slot = self._adam_live_begin(lr_t, l1, found_inf, s0, s1, rects) if begun is None else begun
+        keep = [lvl for lvl in range(self.J) if begun is None or lvl not in self._fused_levels]
+        # every level (that the adjoint has not updated already) in ONE launch: its live rectangle, or the whole level where
+        # nothing is deferred
+        cf, K = self.coef, len(keep)
+        sizes = [cf.params[lvl].shape[-1] for lvl in keep]
+        offs = [cf.offsets[lvl] + s0 * 3 * n ** 2 for lvl, n in zip(keep, sizes)]
+        live = [self._live[lvl] if self._live[lvl] is not None else [0, 0, 0, 0, 0, 0, n, n] for lvl, n in zip(keep, sizes)]
+        flat = lambda rs: (C_.c_int32 * (8 * K))(*[x for r in rs for x in r[:8]])
+        bt = [self._live_bands[lvl] for lvl in keep]
+        if K:
+            L.check(lib.tnl_adam_l1_step_live_bands(
+                L.ptr(cf.data), L.ptr(cf.grad), L.ptr(cf.m), L.ptr(cf.v), L.u32(ns), L.u32(self.C), L.u32(s0), L.u32(K),
+                (C_.c_uint64 * K)(*offs), (C_.c_uint32 * K)(*sizes), (C_.c_uint32 * K)(*([3] * K)), flat(live),
+                flat([rects[lvl] for lvl in keep]),
+                (C_.c_void_p * K)(*[None if b_ is None else b_[0].data_ptr() for b_ in bt]),
+                (C_.c_uint32 * K)(*[0 if b_ is None else b_[1] for b_ in bt]),
+                (C_.c_float * K)(*([l1] * K)), L.f32(lr_t), L.ptr(self.opt_steps), L.ptr(self._ring[4 * slot:]),
+                L.f32(self.b1), L.f32(self.b2), L.f32(self.eps), L.f32(1.0), L.ptr(inv_scale), L.ptr(found_inf),
+                L.ptr(self.abs_sum), L.stream()), "adam_l1_step_live_bands")
         n0 = self.ll.params[0].shape[-1]
         ll = self.ll
         off = s0 * n0 * n0
