@@ -79,6 +79,8 @@ def build(workload, device, dist_mode, plane_dtype=None, shell=(0.8, 0.0), **ts_
         ts.side_count_form = int(os.environ["TNL_SIDE_COUNT_FORM"])
     if os.environ.get("TNL_PREFETCH_AT"):     # A/B: where the next batch's march + tile sort start (bwd | reduce | adjoint)
         ts.prefetch_at = os.environ["TNL_PREFETCH_AT"]
+    if os.environ.get("TNL_SIDE_CAPS"):       # A/B: "emit,fill" workgroups of the prefetched march's wide passes (0 = uncapped)
+        ts.side_caps = tuple(int(x) for x in os.environ["TNL_SIDE_CAPS"].split(","))
     if os.environ.get("TNL_FUSE_LIVE"):       # A/B: 0 = separate adjoint and optimiser passes on every level
         ts.fuse_live = os.environ["TNL_FUSE_LIVE"] != "0"
         ts.fuse_live_levels = max(int(os.environ["TNL_FUSE_LIVE"]), 1)

@@ -121,6 +121,16 @@ TNL_API int tnl_march_rays_train_binned(const float *rays_o, const float *rays_d
  * outputs bit for bit.  Process-wide; returns the previous value (any other argument only queries). */
 TNL_API int tnl_march_count_form(int form);
 
+/* Launch width of the two wide passes of a march + tile sort that is enqueued BESIDE other kernels (TrainStep's prefetch of
+ * the next batch on a second stream): the emit pass of tnl_march_rays_train* (one wavefront per ray, grid-stride over the
+ * rays when capped) and the fill pass of tnl_plane_grad_sort* (grid-stride over the samples).  At full width the two flood
+ * every CU's wave slots for ~0.5 ms and a main-stream launch of larger workgroups that starts meanwhile waits for slots (base
+ * step: 550 us for a 190-us kernel); capped at 2 / 1 workgroups per CU they take about as long by themselves and leave the
+ * slots: -0.14 ms per step.  blocks = 0 (default): uncapped, the form for work the caller waits for; < 0 only queries.
+ * Process-wide; each returns the previous value.  Same outputs (the fill's order inside a tile list is unordered either way). */
+TNL_API int tnl_march_emit_cap(int blocks);
+TNL_API int tnl_plane_grad_fill_cap(int blocks);
+
 /* raymarching.h:14 composite_rays_train_forward ; kernel raymarching.cu:501-577.
  * One 64-lane wavefront per ray; transmittance by a wavefront product scan. */
 TNL_API int tnl_composite_rays_train_forward(const float *sigmas, const float *rgbs,

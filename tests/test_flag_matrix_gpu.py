@@ -4,7 +4,7 @@ Every one of these switches changes HOW the step is executed, none WHAT it compu
 reduction (deterministic=True) all of them are documented as bit-identical to the plain step -- the occupancy window
 (use_roi), the live / deferred optimiser split (defer_adam), its band pieces (live_bands), the next batch's march on the
 side stream (overlap_march) with its two start positions (prefetch_at) and count-pass forms (side_count_form), the far
-clip of the in-order march (clip_far_in_order), the optimiser inside the adjoint's column-walk levels (fuse_live), the banded plane-gradient exchange (overlap_exchange) and the captured
+clip of the in-order march (clip_far_in_order), the optimiser inside the adjoint's column-walk levels (fuse_live), the launch width of the prefetched march's wide passes (side_caps), the banded plane-gradient exchange (overlap_exchange) and the captured
 steps (graph).  Here a seeded sample of their cross-product (plus every single flag flipped on its own) trains the same
 small model over three density-grid periods -- refresh steps, window changes of the re-imposed occupancy and ring flushes
 inside -- and must end on the SAME BITS as the default configuration, parameters and Adam moments alike."""
@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 FLAGS = {            # name -> (default, alternative)
     "use_roi": (True, False), "defer_adam": (True, False), "live_bands": (True, False), "overlap_march": (True, False),
     "prefetch_at": ("bwd", "adjoint"), "side_count_form": (1, 0), "clip_far_in_order": (True, False),
-    "overlap_exchange": (0, 3), "graph": (False, True), "fuse_live": (True, False),
+    "overlap_exchange": (0, 3), "graph": (False, True), "fuse_live": (True, False), "side_caps": ("device", (0, 0)),
 }
 
 
@@ -58,9 +58,11 @@ def _run(cuda, combo):
     ctor = {k: v for k, v in combo.items() if k in ("use_roi", "defer_adam", "live_bands", "overlap_exchange", "graph")}
     ctor.setdefault("defer_adam", True)      # (the constructor's own default turns the split on from 32 M coefficients)
     ts = TrainStep(m, lr=1e-2, wavelet_regularization=0.2, iters=200, update_extra_interval=8, deterministic=True, **ctor)
-    for k in ("overlap_march", "prefetch_at", "side_count_form", "clip_far_in_order", "fuse_live"):
+    for k in ("overlap_march", "prefetch_at", "side_count_form", "clip_far_in_order", "fuse_live", "side_caps"):
         if k in combo:
             setattr(ts, k, combo[k])
+    if "side_caps" not in combo:
+        ts.side_caps = (3, 2)        # (the device's default caps exceed this small batch's grids: a few workgroups walk it here)
     period = {"n": 0}
 
     def reimpose():

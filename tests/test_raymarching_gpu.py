@@ -354,10 +354,14 @@ def test_march_train_record_path_equals_two_march_path(cuda):
 
 
 @pytest.mark.gpu
-def test_march_fused_tile_count_equals_sort(cuda):
+@pytest.mark.parametrize("caps", [(0, 0), (3, 2), (1, 1)], ids=["full-width", "capped-3-2", "one-workgroup-each"])
+def test_march_fused_tile_count_equals_sort(cuda, caps):
     """march_rays_train(sort=(R, ws)) + plane_grad_sort_counted against plane_grad_sort on the samples it wrote: same
     bin offsets, and per bin the same set of sample ids (the order inside a bin is the atomics' in both); with a budget
-    that drops rays as well (the zeroed tail rows are samples of the sort too)."""
+    that drops rays as well (the zeroed tail rows are samples of the sort too).  caps: the emit and fill passes launched
+    with that many workgroups (raymarching.side_caps: grid-stride over the rays / samples, TrainStep's prefetch) -- the
+    same samples to the bit as the full-width launch, the same lists."""
+    from trinerflet_amd import _lib as L
     from trinerflet_amd import raymarching, synthetic
     from trinerflet_amd.nerf import field as gfield
     N, max_steps, Cc, Hg, bound, R = 3000, 256, 2, 64, 1.5, 256
@@ -381,10 +385,21 @@ def test_march_fused_tile_count_equals_sort(cuda):
         counter = torch.zeros(2, dtype=torch.int32, device=cuda)
         mc = budget + (128 - budget % 128)
         ws = gfield.plane_grad_sort_workspace(mc, R, cuda)
-        xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, bound, bits, Cc, Hg, nears, fars, counter, budget,
-                                                                True, 128, False, 0, max_steps, noise, False, (R, ws))
-        assert xyzs.shape[0] == mc
-        gfield.plane_grad_sort_counted(ws, xyzs, bound, R, counter)
+        with raymarching.side_caps(*caps):
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, bound, bits, Cc, Hg, nears, fars, counter, budget,
+                                                                    True, 128, False, 0, max_steps, noise, False, (R, ws))
+            assert xyzs.shape[0] == mc
+            gfield.plane_grad_sort_counted(ws, xyzs, bound, R, counter)
+        assert L.lib().tnl_march_emit_cap(-1) == 0 and L.lib().tnl_plane_grad_fill_cap(-1) == 0      # restored
+        if caps != (0, 0):
+            c2 = torch.zeros(2, dtype=torch.int32, device=cuda)
+            full = raymarching.march_rays_train(o, d, bound, bits, Cc, Hg, nears, fars, c2, budget, True, 128, False, 0,
+                                                max_steps, noise, False, None)
+            assert torch.equal(c2, counter)
+            m_used = min(int(counter[0]), mc)          # (rows behind the samples are whatever the allocation held)
+            for a_, b_ in zip((xyzs, dirs, deltas), full[:3]):
+                assert torch.equal(a_[:m_used], b_[:m_used])
+            assert torch.equal(rays, full[3])
         ref = gfield.plane_grad_sort(xyzs, bound, R, counter)
         torch.cuda.synchronize()
         (off_a, ent_a), (off_b, ent_b) = parse(ws), parse(ref)

@@ -11,6 +11,8 @@
 //  * Marching arithmetic is float32 with explicit fmaf where nvcc contracts `a + b*c`; this TU is
 //    compiled with -ffp-contract=off so per-ray sample counts are bit-identical to the oracle.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/trinerflet_hip.h"
@@ -582,13 +584,13 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
   // bin_counts != NULL: the first pass of the plane-gradient tile sort (scatter.hip k_bin<false>) rides along -- here
   // the lanes of a wave ARE consecutive samples of one ray, the case its run aggregation is made for
   const int TNX = binR / TSX, TNY = binR / TSY;
-  const uint32_t n = blockIdx.x * (MARCH_BLOCK / WAVE) + (threadIdx.x / WAVE);
   const int lane = threadIdx.x % WAVE;
-  if (n >= N) return;
+  // (a launch of fewer workgroups than rays walks them with the grid's stride: tnl_march_side_caps)
+  for (uint32_t n = blockIdx.x * (MARCH_BLOCK / WAVE) + (threadIdx.x / WAVE); n < N; n += gridDim.x * (MARCH_BLOCK / WAVE)) {
   const int* r = rays + ((size_t)counter[1] + n) * 3;
   const uint32_t off = (uint32_t)r[1];
   const int ns = r[2];
-  if (ns == 0) return;
+  if (ns == 0) continue;
   if (off + (uint32_t)ns > M) {
     // a ray the sample budget drops: the rows it would have started in stay in the buffer (off < M for at most one
     // such ray) and are consumed as samples of no ray -- zero them, whatever the caller's buffers held
@@ -602,7 +604,7 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
       }
       if (bin_counts != nullptr) bin_sample<false>(0.f, 0.f, 0.f, live, q, bound, binR, TNX, TNY, bin_counts, nullptr, lane);
     }
-    return;
+    continue;
   }
   MarchCtx m;
   march_init(m, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, nullptr);
@@ -630,6 +632,7 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
       deltas[o * 2 + 1] = t_next - last_t;
     }
     if (bin_counts != nullptr) bin_sample<false>(px, py, pz, live, (uint32_t)o, bound, binR, TNX, TNY, bin_counts, nullptr, lane);
+  }
   }
 }
 
@@ -1396,6 +1399,8 @@ uint32_t tnl_march_rays_train_workspace_rec(uint32_t N, uint32_t max_steps) {
 
 // tnl_march_count_form: 0 = the per-wavefront count pass wherever it applies, 1 = always one ray per lane
 static int g_count_form = 0;
+// tnl_march_emit_cap: most workgroups the emit pass is launched with (0 = one wavefront per ray all at once)
+static int g_emit_cap = 0;
 
 static int march_rays_train_impl(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                                  float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
@@ -1431,7 +1436,9 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
     hipLaunchKernelGGL((k_march_train_write<true, false>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
                        dt_gamma, max_steps, N, C, H, M, nears, fars, noises, num_steps, block_sums, counter, xyzs,
                        dirs, deltas, rays);
-    hipLaunchKernelGGL(k_march_train_emit, dim3(cdiv(N, MARCH_BLOCK / WAVE)), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d,
+    // (tnl_march_emit_cap: a march enqueued beside other kernels keeps to a few waves per SIMD)
+    const uint32_t emit_blocks = g_emit_cap > 0 ? std::min<uint32_t>(cdiv(N, MARCH_BLOCK / WAVE), (uint32_t)g_emit_cap) : cdiv(N, MARCH_BLOCK / WAVE);
+    hipLaunchKernelGGL(k_march_train_emit, dim3(emit_blocks), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d,
                        bound, dt_gamma, max_steps, N, C, H, M, nears, noises, counter, tbuf, rays, xyzs, dirs, deltas,
                        (int)binR, reinterpret_cast<int*>(sort_workspace));
   } else if (sort_workspace != nullptr) {
@@ -1451,6 +1458,12 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
   }
   hipLaunchKernelGGL(k_march_train_finalize, dim3(1), dim3(MARCH_BLOCK), 0, st, block_sums, nb, N, counter);
   return launch_status();
+}
+
+int tnl_march_emit_cap(int blocks) {
+  const int prev = g_emit_cap;
+  if (blocks >= 0) g_emit_cap = blocks;
+  return prev;
 }
 
 int tnl_march_count_form(int form) {

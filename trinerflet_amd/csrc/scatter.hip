@@ -20,7 +20,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <mutex>
+#include <stdlib.h>
 
 #include "../../include/trinerflet_hip.h"
 #include "roi_common.h"
@@ -30,6 +32,7 @@
 namespace {
 
 constexpr int NT = 256;
+int g_fill_cap = 0;   // tnl_plane_grad_fill_cap: most workgroups of the sort's fill pass (0 = one thread per sample all at once)
 
 __device__ __forceinline__ uint32_t eff_m(uint32_t M, const int32_t* m_actual) {
   return m_actual ? min(M, (uint32_t)max(*m_actual, 0)) : M;
@@ -41,11 +44,14 @@ __global__ void __launch_bounds__(NT)
 k_bin(const float* __restrict__ xyz, float bound, uint32_t M, const int32_t* __restrict__ m_actual, int R, int TNX,
       int TNY, int* __restrict__ counts_or_cursor, uint32_t* __restrict__ entries, float2* __restrict__ epos) {
   const uint32_t Me = eff_m(M, m_actual);
-  const uint32_t i = blockIdx.x * NT + threadIdx.x;
-  const bool live = i < Me;
-  const uint32_t il = live ? i : 0;
-  bin_sample<FILL>(xyz[(size_t)il * 3], xyz[(size_t)il * 3 + 1], xyz[(size_t)il * 3 + 2], live, i, bound, R, TNX, TNY,
-                   counts_or_cursor, entries, threadIdx.x & 63, epos);
+  // (a launch of fewer workgroups than M / NT walks the samples with the grid's stride; uniform trip count per wave)
+  for (uint32_t i0 = blockIdx.x * NT; i0 < M; i0 += gridDim.x * NT) {
+    const uint32_t i = i0 + threadIdx.x;
+    const bool live = i < Me;
+    const uint32_t il = live ? i : 0;
+    bin_sample<FILL>(xyz[(size_t)il * 3], xyz[(size_t)il * 3 + 1], xyz[(size_t)il * 3 + 2], live, i, bound, R, TNX, TNY,
+                     counts_or_cursor, entries, threadIdx.x & 63, epos);
+  }
 }
 
 // exclusive scan of the bin counts; also leaves a copy as the fill cursors.  Two tiny launches: (1) each
@@ -478,7 +484,9 @@ static int plane_grad_sort_impl(const float* xyz, float bound, uint32_t M, const
   hipLaunchKernelGGL(k_scan_local, dim3(w.nblk), dim3(256), 0, st, w.counts, w.nb, w.offsets, w.block_tot);
   hipLaunchKernelGGL(k_scan_fix, dim3(w.nblk), dim3(256), 0, st, w.nb, w.nblk, w.block_tot, w.offsets, w.cursor);
   if (M > 0) {
-    hipLaunchKernelGGL(k_bin<true>, dim3(cdiv(M, NT)), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
+    // (tnl_plane_grad_fill_cap: a sort enqueued beside other kernels keeps to about a wave per SIMD)
+    const uint32_t fill_blocks = g_fill_cap > 0 ? std::min<uint32_t>(cdiv(M, NT), (uint32_t)g_fill_cap) : cdiv(M, NT);
+    hipLaunchKernelGGL(k_bin<true>, dim3(fill_blocks), dim3(NT), 0, st, xyz, bound, M, m_actual, (int)R, TNX, TNY,
                        w.cursor, w.entries, w.epos);
   }
   return (int)hipGetLastError();
@@ -491,6 +499,12 @@ int tnl_plane_grad_sort(const float* xyz, float bound, uint32_t M, const int32_t
 
 // The same with the per-bin counts already in the workspace (tnl_march_rays_train_binned counted them while it wrote
 // the samples): scan + fill only.
+int tnl_plane_grad_fill_cap(int blocks) {
+  const int prev = g_fill_cap;
+  if (blocks >= 0) g_fill_cap = blocks;
+  return prev;
+}
+
 int tnl_plane_grad_sort_counted(const float* xyz, float bound, uint32_t M, const int32_t* m_actual, uint32_t R,
                                 void* workspace, void* stream) {
   return plane_grad_sort_impl(xyz, bound, M, m_actual, R, workspace, true, stream);

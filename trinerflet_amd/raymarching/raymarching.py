@@ -11,7 +11,7 @@ from torch.autograd import Function
 from .. import _lib as L
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "occupied_box", "clip_fars",
-           "march_rays_train", "count_form", "composite_rays_train", "march_rays", "composite_rays", "compact_rays"]
+           "march_rays_train", "count_form", "side_caps", "composite_rays_train", "march_rays", "composite_rays", "compact_rays"]
 
 
 def _f32c(t):
@@ -184,6 +184,24 @@ class count_form:
 
     def __exit__(self, *exc):
         L.lib().tnl_march_count_form(L.i32(self.prev))
+        return False
+
+
+class side_caps:
+    """with raymarching.side_caps(emit_blocks, fill_blocks): ... -- the emit pass of march_rays_train and the fill pass of
+    the plane-gradient tile sort launched inside the block keep to that many workgroups (tnl_march_emit_cap,
+    tnl_plane_grad_fill_cap; 0 = full width): for work enqueued beside other kernels.  Process-wide, restored on exit."""
+
+    def __init__(self, emit_blocks, fill_blocks):
+        self.caps = (int(emit_blocks), int(fill_blocks))
+
+    def __enter__(self):
+        self.prev = (L.lib().tnl_march_emit_cap(L.i32(self.caps[0])), L.lib().tnl_plane_grad_fill_cap(L.i32(self.caps[1])))
+        return self
+
+    def __exit__(self, *exc):
+        L.lib().tnl_march_emit_cap(L.i32(self.prev[0]))
+        L.lib().tnl_plane_grad_fill_cap(L.i32(self.prev[1]))
         return False
 
 

@@ -307,6 +307,15 @@ class TrainStep:
         # ("bwd"), behind the tile reduction ("reduce") or behind the adjoint IDWT ("adjoint")
         self.prefetch_at = "bwd"
         self.side_count_form = 1     # raymarching.count_form of the prefetched march (0: the wavefront-per-ray count pass)
+        # workgroups of the prefetched march's emit pass and of its tile sort's fill pass (raymarching.side_caps): 2 and 1 per
+        # CU.  At full width the two flood the wave slots just as the adjoint's second column-walk level (two 192-register
+        # workgroups per CU) is launched: 550 us for 190 alone; capped, the step is 0.14 ms shorter (3.86-3.89 vs 4.01-4.03
+        # in alternation; (0, 0) = uncapped)
+        # ... where the step's tail has the slack: base -0.091 ms [-0.106, -0.077], large -0.136 [-0.22, -0.05]; at small (50 M
+        # coefficients: tail 0.8 ms against a side chain of 1.0) the capped chain is the critical path: +0.097 -- uncapped below
+        # 2^27 coefficients
+        n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
+        self.side_caps = (2 * n_cu, n_cu) if 3 * self.C * self.R * self.R >= (1 << 27) else (0, 0)
         self.post_refresh = None    # optional callable run right after every density-grid refresh
         self.section_events = None  # set to [] to record HIP events (on the launch stream) around every stage
         # distributed
@@ -769,7 +778,7 @@ class TrainStep:
         # beside the step's kernels the count pass runs one ray per lane: a seventh of the wavefront form's instructions at
         # one wave per SIMD (3x longer alone, but it takes almost nothing from the kernels it runs next to: A/B at base,
         # wavefront form on the side stream 4.13-4.26 ms per step at every start position vs 3.9)
-        with torch.cuda.stream(self._side), raymarching.count_form(self.side_count_form):
+        with torch.cuda.stream(self._side), raymarching.count_form(self.side_count_form), raymarching.side_caps(*self.side_caps):
             out = self._march(o, d, nz)
         for t_ in out[0]:
             t_.record_stream(main)
