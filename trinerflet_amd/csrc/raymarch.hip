@@ -229,6 +229,22 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* smem4, int* total
   return base + incl - v;
 }
 
+// One bit per 64-bit word of the occupancy bitfield (64 cells in Morton order = a 4 x 4 x 4 block): set where the word is not
+// zero.  2 cascades x 128^3 cells = 65 536 words = NZ_WORDS x 32 bits (8 KiB: staged in LDS by the per-lane count pass).
+#ifndef TNL_MARCH_NZ_FILTER
+#define TNL_MARCH_NZ_FILTER 1
+#endif
+constexpr int NZ_WORDS = 2048;
+__global__ void __launch_bounds__(MARCH_BLOCK)
+k_nonzero_words(const unsigned long long* __restrict__ grid64, uint32_t n_words, uint32_t* __restrict__ nzmap) {
+  const uint32_t w = blockIdx.x * MARCH_BLOCK + threadIdx.x;        // (the launch covers NZ_WORDS * 32 words exactly)
+  const unsigned long long b = __ballot(w < n_words && grid64[w] != 0ull);
+  if ((threadIdx.x & 63) == 0) {
+    nzmap[w >> 5] = (uint32_t)b;
+    nzmap[(w >> 5) + 1] = (uint32_t)(b >> 32);
+  }
+}
+
 // The serial march of one ray on one lane (march_run<false, true, true, REC>) for the fast path of the level arithmetic
 // (dt_gamma = 0, <= 2 cascades, H <= 256), with the per-ray constants hoisted, the Morton code from a 256-entry LDS table
 // and the exact-by-construction steps folded -- the identities listed in k_march_train_count_wave, the same values bit
@@ -242,7 +258,7 @@ struct FastProbe {
 
 template <bool REC>
 __device__ __forceinline__ uint32_t march_run_fast(const MarchCtx& m, float& t, float far, uint32_t limit, float* trec,
-                                                   const uint32_t* __restrict__ lut) {
+                                                   const uint32_t* __restrict__ lut, const uint32_t* __restrict__ nz) {
 #pragma clang fp contract(off)
   const float hH = 0.5f * m.Hf, rH2 = m.rH * 2, hmax = (float)(m.H - 1), dt = m.dt0;
   const int incx = __float_as_uint(m.dx) >> 31 ? 0 : 1, incy = __float_as_uint(m.dy) >> 31 ? 0 : 1,
@@ -265,7 +281,9 @@ __device__ __forceinline__ uint32_t march_run_fast(const MarchCtx& m, float& t, 
     const uint32_t index = (lv1 ? H3u : 0u) + (lut[q.nx] | (lut[q.ny] << 1) | (lut[q.nz] << 2));
     const uint32_t blk = index >> 6;
     if (blk != cached_blk) {
-      cached_bits = grid64[blk];
+      // nz (LDS): one bit per 64-cell word of the bitfield, set where the word is not zero (k_nonzero_words) -- an empty
+      // 4 x 4 x 4 block of cells costs no trip to L2 / HBM (two thirds of a ray's probes are in empty space)
+      cached_bits = (nz == nullptr || ((nz[blk >> 5] >> (blk & 31u)) & 1u)) ? grid64[blk] : 0ull;
       cached_blk = blk;
     }
     q.occ = (cached_bits >> (index & 63u)) & 1ull;
@@ -309,12 +327,16 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
                     const uint8_t* __restrict__ grid, float bound, float dt_gamma, uint32_t max_steps,
                     uint32_t N, uint32_t C, uint32_t H, const float* __restrict__ nears,
                     const float* __restrict__ fars, const float* __restrict__ noises,
-                    int* __restrict__ num_steps_out, int* __restrict__ block_sums, float* __restrict__ tbuf) {
+                    int* __restrict__ num_steps_out, int* __restrict__ block_sums, float* __restrict__ tbuf,
+                    const uint32_t* __restrict__ nzmap = nullptr) {
   __shared__ int smem4[4];
   __shared__ uint32_t s_lut[MARCH_BLOCK];
+  __shared__ uint32_t s_nz[NZ_WORDS];
   const bool fast = WIDE && TNL_MARCH_FAST_LANE && dt_gamma == 0.f && C <= 2 && H <= 256;     // block-uniform
   if (fast) {
     s_lut[threadIdx.x] = expand_bits(threadIdx.x);
+    if (nzmap != nullptr)
+      for (int k = threadIdx.x; k < NZ_WORDS; k += MARCH_BLOCK) s_nz[k] = nzmap[k];
     __syncthreads();
   }
   const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
@@ -325,7 +347,8 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
     float t = nears[n];
     t = fmaf(clampf_(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
     if (fast)
-      ns = (int)march_run_fast<REC>(m, t, fars[n], max_steps, REC ? tbuf + (size_t)n * max_steps : nullptr, s_lut);
+      ns = (int)march_run_fast<REC>(m, t, fars[n], max_steps, REC ? tbuf + (size_t)n * max_steps : nullptr, s_lut,
+                                    nzmap != nullptr ? s_nz : nullptr);
     else
       ns = (int)march_run<false, WIDE, true, REC>(m, t, fars[n], max_steps, nullptr, nullptr, nullptr,
                                                   REC ? tbuf + (size_t)n * max_steps : nullptr);
@@ -1393,7 +1416,7 @@ uint32_t tnl_march_rays_train_workspace(uint32_t N) { return N + cdiv(N, MARCH_B
 // with room for the count pass's record of every sample's t (N * max_steps floats): the samples are then written
 // from the record instead of by a second march; 0 if that does not fit 32 bits
 uint32_t tnl_march_rays_train_workspace_rec(uint32_t N, uint32_t max_steps) {
-  const uint64_t w = (uint64_t)tnl_march_rays_train_workspace(N) + (uint64_t)N * max_steps + 4;
+  const uint64_t w = (uint64_t)tnl_march_rays_train_workspace(N) + (uint64_t)N * max_steps + 4 + NZ_WORDS;   // + k_nonzero_words' map
   return w > 0xffffffffull ? 0u : (uint32_t)w;
 }
 
@@ -1427,10 +1450,18 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
       hipLaunchKernelGGL((k_march_train_count_wave<true>), dim3(cdiv(N, MARCH_BLOCK / WAVE)), dim3(MARCH_BLOCK), 0, st, rays_o,
                          rays_d, grid, bound, max_steps, N, C, H, nears, fars, noises, num_steps, tbuf);
       hipLaunchKernelGGL(k_march_block_sums, dim3(nb), dim3(MARCH_BLOCK), 0, st, num_steps, N, block_sums);
-    } else if (wide_bitfield(grid, C, H))
+    } else if (wide_bitfield(grid, C, H)) {
+      // the per-lane count pass skips the loads of all-empty 64-cell words through a one-bit-per-word map (behind the record)
+      uint32_t* nzmap = nullptr;
+      const uint64_t n_words = (uint64_t)C * H * H * H / 64;
+      if (TNL_MARCH_NZ_FILTER && TNL_MARCH_FAST_LANE && dt_gamma == 0.f && C <= 2 && H <= 256 && n_words <= (uint64_t)NZ_WORDS * 32) {
+        nzmap = reinterpret_cast<uint32_t*>(tbuf + (size_t)N * max_steps);   // (the 4 spare words cover tbuf's alignment)
+        hipLaunchKernelGGL(k_nonzero_words, dim3(NZ_WORDS * 32 / MARCH_BLOCK), dim3(MARCH_BLOCK), 0, st,
+                           reinterpret_cast<const unsigned long long*>(grid), (uint32_t)n_words, nzmap);
+      }
       hipLaunchKernelGGL((k_march_train_count<true, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid,
-                         bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf);
-    else
+                         bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf, nzmap);
+    } else
       hipLaunchKernelGGL((k_march_train_count<false, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid,
                          bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf);
     hipLaunchKernelGGL((k_march_train_write<true, false>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid, bound,
