@@ -81,6 +81,11 @@ def build(workload, device, dist_mode, plane_dtype=None, shell=(0.8, 0.0), **ts_
         ts.prefetch_at = os.environ["TNL_PREFETCH_AT"]
     if os.environ.get("TNL_SIDE_CAPS"):       # A/B: "emit,fill" workgroups of the prefetched march's wide passes (0 = uncapped)
         ts.side_caps = tuple(int(x) for x in os.environ["TNL_SIDE_CAPS"].split(","))
+    if os.environ.get("TNL_IDWT_TUNING"):     # A/B: "key=value,..." of tnl_idwt_set_tuning (3: rows per walk workgroup, 4: forward form)
+        from trinerflet_amd import _lib as _L
+        for kv in os.environ["TNL_IDWT_TUNING"].split(","):
+            k_, v_ = kv.split("=")
+            assert _L.lib().tnl_idwt_set_tuning(int(k_), int(v_)) == 0
     if os.environ.get("TNL_FUSE_LIVE"):       # A/B: 0 = separate adjoint and optimiser passes on every level
         ts.fuse_live = os.environ["TNL_FUSE_LIVE"] != "0"
         ts.fuse_live_levels = max(int(os.environ["TNL_FUSE_LIVE"]), 1)
