@@ -1506,7 +1506,8 @@ int launch_bwd_fused(const float* dout, uint32_t S, uint32_t n, float* dx, hipSt
   orect.rw = live[6]; orect.rh = live[7];
   orect.spp = roi.spp; orect.s0 = roi.s0;
   const uint32_t tiles = cdiv(orect.rw, AVC);
-  const int seg = g_seg ? g_seg : pick_seg(tiles, orect.rh, S);
+  int seg = g_seg ? g_seg : pick_seg(tiles, orect.rh, S);
+  if (seg > 256) seg = 256;        // the kernel stages one live piece per 8-row band of a segment: 32 of them
   dim3 grid;
   LGrid lg;
   walk_grid(tiles, cdiv(orect.rh, seg), S, grid, lg);
