@@ -1681,6 +1681,9 @@ int tnl_idwt_level_backward_live_adam(const float* dout, uint32_t S, uint32_t n,
   if (S == 0 || n == 0) return 0;
   if (S > 65535 || win == nullptr || live_rect == nullptr || dx == nullptr || step_rec == nullptr) return (int)hipErrorInvalidValue;
   if (!(n % 8 == 0 && (int)n >= g_walk_min_n)) return (int)hipErrorInvalidValue;      // a column-walk level
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+       reinterpret_cast<uintptr_t>(dx)) & 15)
+    return (int)hipErrorInvalidValue;                                                 // 16-byte quads
   if ((band_table == nullptr) != (spans == nullptr) || (band_table != nullptr && (nb == 0 || nb > 128))) return (int)hipErrorInvalidValue;
   for (int q = 0; q < 3; q++)        // 16-byte quads of p, m, v; 8-row bands
     if (live_rect[q] % 4 || live_rect[3 + q] % 8 || live_rect[q] < 0 || live_rect[3 + q] < 0 ||
