@@ -43,7 +43,8 @@ SECTION_PREV = {"idwt_fwd": "begin", "field_fwd": "march", "field_bwd": "composi
 SECTION_KERNELS = {"field_fwd": ["k_field_fwd"], "field_bwd": ["k_field_bwd", "k_slab_reduce"],
                    "adam_coef": ["k_adam_l1_live", "k_adam_l1", "k_adam_record"],
                    "plane_grad_binned": ["k_tile_accumulate"], "idwt_fwd": ["k_idwt_fwd", "k_to_texel_major"],
-                   "idwt_adjoint": ["k_idwt_bwd"]}
+                   # (k_idwt_bwd_walk<W, true>: the column-walk levels with the optimiser's live pass in their epilogue, TrainStep.fuse_live)
+                   "idwt_adjoint": ["k_idwt_bwd_walk", "k_idwt_bwd_pipe"]}
 
 WORKLOADS = {
     # name: (channels, resolution, wavelet scale, hidden, rays, lambda)
