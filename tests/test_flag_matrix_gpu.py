@@ -129,3 +129,43 @@ def test_the_matrix_covers_every_flag_both_ways():
         assert any(c.get(n, dflt) == alt for c in COMBOS) and any(c.get(n, dflt) == dflt for c in COMBOS), n
     assert len(COMBOS) == len({tuple(sorted(c.items())) for c in COMBOS}) >= 20
     assert sum(len(c) >= 3 for c in COMBOS) >= 6              # real mixtures, not only single flips
+
+
+def test_a_skipped_step_in_the_steady_state_moves_nothing(cuda, walk_levels):
+    """GradScaler's verdict reaches the adjoint levels that carry the optimiser (fuse_live) through the step record: a step
+    whose gradients overflow leaves every coefficient, moment and MLP weight where it was -- the live pieces the fused levels
+    would have updated included -- and halves the scale; the step after it trains on."""
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    from trinerflet_amd.train import TrainStep
+    torch.manual_seed(0)
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=1.0, cuda_ray=True, density_thresh=10, hidden_dim=64,
+                    hidden_dim_color=64, triplane_channels=16, triplane_resolution=512, triplane_wavelet_levels=8,
+                    wavelet_type="bior6.8").to(cuda)
+    synthetic.init_field_parameters(m, seed=3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    m.density_bitfield.copy_(t(synthetic.sphere_bitfield(128, 1, 1.0, 0.3, 0.0)))
+    ts = TrainStep(m, lr=1e-2, wavelet_regularization=0.2, iters=200, update_extra_interval=0, defer_adam=True)
+    m.mean_count = 600000
+    o, d = synthetic.training_rays(4096, n_cams=6, seed=20)
+    o, d, gt = t(o), t(d), t(synthetic.target_colors(d))
+    for _ in range(3):
+        ts.step(o, d, gt)
+    assert len(ts._fused_levels) >= 1 and float(ts.last["found_inf"]) == 0.0          # the steady state, fused
+    snap = lambda: ([p.detach().clone() for p in m.parameters()], ts.coef.m.clone(), ts.coef.v.clone(), ts.ll.m.clone(),
+                    ts.mlp.m.clone())
+    before = snap()
+    scale = float(ts.scale)
+    ts.scale.fill_(2.0 ** 60)                             # this step's fp16 gradients overflow
+    ts.step(o, d, gt)
+    assert float(ts.last["found_inf"]) == 1.0 and len(ts._fused_levels) >= 1
+    assert float(ts.scale) == 2.0 ** 59
+    after = snap()
+    for a, b in zip(before[0], after[0]):
+        assert torch.equal(a, b)
+    for a, b in zip(before[1:], after[1:]):
+        assert torch.equal(a, b)
+    ts.scale.fill_(scale)
+    ts.step(o, d, gt)
+    assert float(ts.last["found_inf"]) == 0.0
+    assert not torch.equal(after[1], ts.coef.m)            # ... and the next step moves them again
+    ts.flush_deferred()
