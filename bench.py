@@ -46,6 +46,15 @@ SECTION_KERNELS = {"field_fwd": ["k_field_fwd"], "field_bwd": ["k_field_bwd", "k
                    # (k_idwt_bwd_walk<W, true>: the column-walk levels with the optimiser's live pass in their epilogue, TrainStep.fuse_live)
                    "idwt_adjoint": ["k_idwt_bwd_walk", "k_idwt_bwd_pipe"]}
 
+def section_owns(section, kernel):
+    """Whether a kernel (its short name, _short) belongs to a section: a listed name or a listed name + "_suffix"
+    (k_field_bwd -> k_field_bwd_rows, k_idwt_bwd_walk -> k_idwt_bwd_walk_..., k_to_texel_major -> k_to_texel_major_h).
+    The replay of the deferred optimiser pass (k_adam_l1_catchup) is its own section, not part of the per-step pass."""
+    if kernel.startswith("k_adam_l1_catchup"):
+        return False
+    return any(kernel == sub or kernel.startswith(sub + "_") for sub in SECTION_KERNELS[section])
+
+
 WORKLOADS = {
     # name: (channels, resolution, wavelet scale, hidden, rays, lambda)
     "base": (32, 2048, 32, 64, 60000, 0.4),
@@ -276,7 +285,7 @@ def variant_report(workload, device, batches, steps=16, shell=(0.8, 0.0), **kw):
                         "ms_per_step": rf.get("ms_per_step"), "launches_per_step": launches[dominant],
                         "algorithmic_bytes": rf.get("algorithmic_bytes"), "algorithmic_flops": rf.get("algorithmic_flops"),
                         "note": "the section with the largest median time over an instrumented density-grid period; "
-                                "traffic counters: profiles/r04_<workload>_* (tools/profile_round.sh --workload)"},
+                                "traffic counters: profiles/r06_<workload>_* (tools/profile_round.sh --workload)"},
            "sections_roofline": {k: (lambda r_: None if r_ is None else {"ms": r_["ms_per_step"], "bound": r_["bound"],
                                                                          "frac": round(r_["frac"], 4)})(roof(spec, k, sec.get(k, float("nan"))))
                                  for k in spec}}
@@ -870,7 +879,7 @@ def main():
         f = w = 0.0
         per = {}
         for kn, v in pmc.items():
-            if kn in SECTION_KERNELS[name] or (name.startswith("idwt") and any(kn.startswith(sub) for sub in SECTION_KERNELS[name])):
+            if section_owns(name, kn):
                 f += v.get("FETCH_SIZE", 0.0)
                 w += v.get("WRITE_SIZE", 0.0)
                 per[kn] = {"FETCH_SIZE_KB": round(v.get("FETCH_SIZE", 0.0), 1), "WRITE_SIZE_KB": round(v.get("WRITE_SIZE", 0.0), 1)}
@@ -904,6 +913,9 @@ def main():
             e["traffic_uncorrected"] = None if tr is None else tr["bytes_uncorrected"]
             e["traffic_per_kernel"] = None if tr is None else tr["per_kernel"]
             e["traffic_over_algorithmic"] = None if tr is None else round(tr["bytes"] / e["algorithmic_bytes"], 3)
+            if tr is not None and args.workload != "tiny" and not 0.3 < e["traffic_over_algorithmic"] < 3:
+                print(f"bench.py: section {k}: counter traffic / algorithmic bytes = {e['traffic_over_algorithmic']} "
+                      f"(outside 0.3 .. 3: check SECTION_KERNELS against {sorted(tr['per_kernel'])})", file=sys.stderr)
             top.append(e)
         dom = dict(kernels[dominant]) if kernels.get(dominant) else {}
         dtr = traffic_of(dominant)

@@ -66,6 +66,13 @@ def test_default_bench_line_is_short_flat_and_last(cuda, tmp_path):
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["host_threads"] >= cb["cores"] and cb["value"] > 0
     full = json.loads(detail.read_text())
     assert full["value"] == d["value"] and "kernels" in full["config"] and "sample" in full["cpu_baseline"]
+    # counter traffic of the three longest sections: summed over the section's OWN kernels (round 5's line had 0.014 for
+    # the field backward: only k_slab_reduce was matched).  On the tiny workload the planes fit the MALL, so the ratio to
+    # the algorithmic bytes only has to be a positive number below 3; bench.py itself warns outside (0.3, 3) at the README sizes
+    for e, fe in zip(d["roofline"]["top"], full["roofline"]["top"]):
+        assert e["traffic_over_algorithmic"] is not None and 0 < e["traffic_over_algorithmic"] < 3, e
+        if e["section"] == "field_bwd":
+            assert any(k.startswith("k_field_bwd") for k in fe["traffic_per_kernel"]), fe["traffic_per_kernel"]
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])

@@ -20,8 +20,12 @@ from trinerflet_amd import synthetic
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = {"base": (32, 64, 0.4), "large": (48, 128, 0.6)}
+CONFIGS = {"base": (32, 64, 0.4), "large": (48, 128, 0.6), "small": (16, 64, 0.2), "small1": (16, 64, 0.2)}
+# README.md:46-58: plane resolution, --triplane_wavelet_levels (the ratio to the 64^2 LL plane), rays per step of the stage
+# the configuration ENDS in; "small1" is small's first stage (512 res, scale 8, 20 000 rays = BASELINE config 1's geometry)
+GEOM = {"base": (2048, 32, 60000), "large": (2048, 32, 60000), "small": (1024, 16, 60000), "small1": (512, 8, 20000)}
 R, SCALE, N, BOUND = 2048, 32, 60000, 1.5
+ALL = ["base", "large", "small", "small1"]
 
 
 def _need_memory():
@@ -35,15 +39,23 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-def _model(dev, cfg, seed=0):
+def _model(dev, cfg, seed=0, **kw):
     from trinerflet_amd.nerf.network import NeRFNetwork
     C, H, _ = CONFIGS[cfg]
+    Rc, sc, _ = GEOM[cfg]
     m = NeRFNetwork(encoding="triplane_wavelet", bound=BOUND, cuda_ray=True, density_thresh=10, hidden_dim=H,
-                    hidden_dim_color=H, triplane_channels=C, triplane_resolution=R, triplane_wavelet_levels=SCALE,
-                    wavelet_type="bior6.8").to(dev)
+                    hidden_dim_color=H, triplane_channels=C, triplane_resolution=Rc, triplane_wavelet_levels=sc,
+                    wavelet_type="bior6.8", **kw).to(dev)
     synthetic.init_field_parameters(m, seed=seed)
-    assert [p.shape[-1] for p in m.encoder.planes_features_wavelet_coefs] == [64, 128, 256, 512, 1024]
+    assert [p.shape[-1] for p in m.encoder.planes_features_wavelet_coefs] == [64 << i for i in range(int(np.log2(sc)))]
     return m
+
+
+def _rays(rays60k, cfg):
+    """The configuration's batch: the first N rays of the 60 000 (a seeded permutation of the pixel pool)."""
+    o, d, noise, bf = rays60k
+    n = GEOM[cfg][2]
+    return np.ascontiguousarray(o[:n]), np.ascontiguousarray(d[:n]), np.ascontiguousarray(noise[:n]), bf
 
 
 @pytest.fixture(scope="module")
@@ -58,9 +70,12 @@ def rays60k():
     return o, d, noise, bf
 
 
-def test_march_60k_rays_bit_exact(cuda, rays60k):
+@pytest.mark.parametrize("cfg", ["base", "small1"])
+def test_march_60k_rays_bit_exact(cuda, rays60k, cfg):
+    """All rays of a step (60 000; small's first stage: 20 000, README.md:46) against the C oracle, bit for bit."""
     from trinerflet_amd import raymarching
-    o, d, noise, bf = rays60k
+    o, d, noise, bf = _rays(rays60k, cfg)
+    N = GEOM[cfg][2]
     aabb = np.array([-BOUND] * 3 + [BOUND] * 3, np.float32)
     nears, fars = cref.near_far_from_aabb(o, d, aabb, 0.2)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
@@ -69,7 +84,7 @@ def test_march_60k_rays_bit_exact(cuda, rays60k):
     x, dd, dl, rr = raymarching.march_rays_train(t(o), t(d), BOUND, t(bf), 2, 128, t(nears), t(fars), counter, -1, True,
                                                  128, False, 0, 1024, t(noise))
     total = int(counter[0])
-    assert 3_000_000 < total < 8_000_000                      # the bench's workload (~4.65 M samples)
+    assert 3_000_000 * N // 60000 < total < 8_000_000 * N // 60000         # the bench's workload (~4.65 M samples at 60 000)
     xr, dr, lr, rro, cr = cref.march_rays_train(o, d, BOUND, bf, 2, 128, nears, fars, noise, total + 128)
     assert np.array_equal(counter.cpu().numpy(), cr) and np.array_equal(rr.cpu().numpy(), rro)
     assert np.array_equal(x[:total].cpu().numpy(), xr[:total]) and np.array_equal(dl[:total].cpu().numpy(), lr[:total])
@@ -84,10 +99,12 @@ def test_march_60k_rays_bit_exact(cuda, rays60k):
     assert np.array_equal(x2.cpu().numpy(), xr) and np.array_equal(dl2.cpu().numpy(), lr)
 
 
-@pytest.mark.parametrize("cfg", ["base", "large"])
+@pytest.mark.parametrize("cfg", ALL)
 def test_five_level_idwt_and_adjoint_slices(cuda, cfg):
+    """(five levels at base / large, four at small's final stage, three at its first)"""
     _need_memory()
     C = CONFIGS[cfg][0]
+    R, J = GEOM[cfg][0], int(np.log2(GEOM[cfg][1]))
     m = _model(cuda, cfg, seed=1)
     enc = m.encoder
     with torch.no_grad():
@@ -110,23 +127,24 @@ def test_five_level_idwt_and_adjoint_slices(cuda, cfg):
         cot[p, c] = torch.randn(R, R, generator=g, device=cuda)
     planes.backward(cot)
     dpl = np.stack([cot[p, c].cpu().numpy() for p, c in slices])[None]
-    dll, dco = cref.build_planes_adj(dpl, 5, "bior6.8")
+    dll, dco = cref.build_planes_adj(dpl, J, "bior6.8")
     got_ll = np.stack([enc.planes_features.grad[p, c].cpu().numpy() for p, c in slices])
     assert _rel(got_ll, dll[0]) < 2e-5
     for lvl, q in enumerate(enc.planes_features_wavelet_coefs):
         got = np.stack([q.grad[p, c].cpu().numpy() for p, c in slices])
         assert _rel(got, dco[lvl][0]) < 2e-5, (cfg, lvl)
     # slices that received no cotangent get exactly zero
-    assert float(enc.planes_features_wavelet_coefs[4].grad[0, 1].abs().max()) == 0.0
+    assert float(enc.planes_features_wavelet_coefs[J - 1].grad[0, 1].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("cfg", ["base", "large"])
+@pytest.mark.parametrize("cfg", ALL)
 def test_fused_field_on_marched_subset(cuda, rays60k, cfg):
     _need_memory()
     from trinerflet_amd import raymarching
     from trinerflet_amd.nerf import field as gfield
     C, H, _ = CONFIGS[cfg]
-    o, d, noise, bf = rays60k
+    R = GEOM[cfg][0]
+    o, d, noise, bf = _rays(rays60k, cfg)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
     m = _model(cuda, cfg, seed=2)
     with torch.no_grad():
@@ -175,14 +193,17 @@ def test_fused_field_on_marched_subset(cuda, rays60k, cfg):
     assert np.array_equal(got != 0, ref != 0) or float(np.abs(got[ref == 0]).max()) == 0.0
 
 
-@pytest.mark.parametrize("cfg", ["base", "large"])
+@pytest.mark.parametrize("cfg", ALL)
 def test_trainstep_window_equals_whole_plane(cuda, rays60k, cfg):
     """Five steps from an untrained sample budget (mean_count = 0: the march's worst-case buffers and the .item()
-    path), one grid refresh at step 4; with the occupancy window + support rectangles vs whole planes."""
+    path), one grid refresh at step 4; with the occupancy window + support rectangles vs whole planes.
+    small (R = 1024: side_caps = (0, 0), one column-walk level) and its first stage (R = 512, 20 000 rays: no column-walk
+    level, 12.6 M coefficients = below defer_adam's default threshold) take the branches base / large do not."""
     _need_memory()
     from trinerflet_amd.train import TrainStep
     C, H, lam = CONFIGS[cfg]
-    o, d, noise, bf = rays60k
+    R, _, N = GEOM[cfg]
+    o, d, noise, bf = _rays(rays60k, cfg)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
     gt = t(synthetic.target_colors(d))
     o_t, d_t, nz, bf_t = t(o), t(d), t(noise), t(bf)
@@ -202,12 +223,14 @@ def test_trainstep_window_equals_whole_plane(cuda, rays60k, cfg):
             Ms.append(int(ts.last["counter"][0]))
             if use_roi and it % 4 != 0:
                 assert ts._roi is not None and ts._roi[6] < R and ts._rect_ok and ts._rects[0] is not None
-                assert ts._roi[6] == 1152 and ts._roi[7] == 1152          # the r = 0.8 sphere's window
-        assert all(np.isfinite(losses)) and Ms[0] > 3_000_000 and len(set(Ms)) == 1
+                # the r = 0.8 sphere's window: 0.53 of the plane's side + the cells' and the footprint's margin, in 64s
+                assert ts._roi[6] == ts._roi[7] == {2048: 1152, 1024: 640, 512: 384}[R], ts._roi
+        assert all(np.isfinite(losses)) and Ms[0] > 3_000_000 * N // 60000 and len(set(Ms)) == 1
         assert float(ts.last["found_inf"]) == 0.0
         # at this size the windowed run defers the optimiser pass outside the live rectangles (defer_adam): a step's
         # loss then carries the L1 value of the live coefficients only, the rest arrives with the replay
-        assert ts.defer_adam == bool(use_roi)
+        assert ts.defer_adam == (bool(use_roi) and 3 * C * R * R >= 32_000_000)
+        assert ts.side_caps == ((0, 0) if 3 * C * R * R < (1 << 27) else ts.side_caps) and (ts.side_caps != (0, 0)) == (R == 2048)
         total = sum(losses) + float(ts.pop_deferred_reg())
         res.append((losses, [p.detach() for p in m.parameters()], mses, total))
         del ts
@@ -224,6 +247,59 @@ def test_trainstep_window_equals_whole_plane(cuda, rays60k, cfg):
         bad = int(((a - b).abs() > 2e-3 + 1e-3 * b.abs()).sum())
         assert bad <= 3 * noise + max(2, int(1e-5 * a.numel())) and float((a - b).abs().max()) < 6e-2, \
             (cfg, bad, noise, a.numel())
+
+
+@pytest.mark.parametrize("fp32", [True, False])
+def test_run_at_small_first_stage_vs_cpu_torch_baseline(cuda, rays60k, fp32):
+    """BASELINE.json config 1: 'small (512 res, 16 ch, scale 8, 20k rays) pure-PyTorch path, no cuda_ray' =
+    NeRFRenderer.run (renderer.py:126-254: 512 uniform steps per ray, cumprod compositing, colour where weight > 1e-4).
+    renderer.run() here (HIP near/far + lookup + MLP under torch glue) at that stage's geometry against
+    oracle/torch_baseline.render_run -- the restatement the CPU baseline times, pinned to the reference's own run() by
+    tests/golden/network_reference.npz -- on planes the C oracle builds from the same coefficients.  2 048 of the
+    stage's 20 000 rays (1 M samples on the host).  fp32: the reference's precision (fp32 planes, modular kernels);
+    otherwise the default fused path (fp16 planes / MFMA operands) at the tolerance the fp32 reference fixture holds."""
+    from oracle import torch_baseline
+    o, d, _, _ = _rays(rays60k, "small1")
+    n = 2048
+    o, d = o[:n], d[:n]
+    m = _model(cuda, "small1", seed=7, **(dict(plane_dtype=torch.float32) if fp32 else {}))
+    m.force_modular = fp32
+    m.eval()
+    with torch.no_grad():
+        for p in m.encoder.planes_features_wavelet_coefs:
+            p.mul_(4.0)
+        # run() samples the whole box (no occupancy grid): a wider, lower logit distribution so that the rays' opacities
+        # spread over 0.2 .. 0.8 instead of all ending at 0.95
+        m.sigma_net[0].weight.mul_(6.0)
+        w = m.sigma_net[1].weight[0]
+        w.mul_(6.0).sub_(0.5 * w.abs().mean())
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    with torch.no_grad():
+        out = m.run(t(o)[None], t(d)[None], num_steps=512, upsample_steps=0, bg_color=1.0, perturb=False)
+    ll = m.encoder.planes_features.detach().cpu().numpy()
+    coefs = [p.detach().cpu().numpy() for p in m.encoder.planes_features_wavelet_coefs]
+    planes = torch.from_numpy(cref.build_planes(ll, coefs, "bior6.8"))
+    W = [w.detach().cpu() for w in (m.sigma_net[0].weight, m.sigma_net[1].weight, m.color_net[0].weight,
+                                    m.color_net[1].weight, m.color_net[2].weight)]
+    aabb = np.array([-BOUND] * 3 + [BOUND] * 3, np.float32)
+    nears, fars = cref.near_far_from_aabb(o, d, aabb, 0.2)
+    with torch.no_grad():
+        want = torch_baseline.render_run(planes, W, torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(nears),
+                                         torch.from_numpy(fars), BOUND, 512, bg=1.0, full=True)
+    image, depth, ws = want["image"], want["depth"], want["weights_sum"]
+    got_i, got_w = out["image"][0].cpu().numpy(), out["weights_sum"].reshape(-1).cpu().numpy()
+    ws = ws.numpy()
+    assert 0.05 * n < (ws > 0.5).sum() < 0.95 * n and ws.max() - ws.min() > 0.5, np.percentile(ws, [0, 5, 50, 95, 100])
+    err_i, err_w = np.abs(got_i - image.numpy()).max(), np.abs(got_w - ws).max()
+    print(f"run() at 512^2 x 16ch, 512 steps, fp32={fp32}: max|d image| {err_i:.2e}, max|d weights_sum| {err_w:.2e}")
+    # fp32: rounding of 512-term sums for weights_sum and depth (3e-6 measured); the image also carries the colour mask's
+    # threshold (renderer.py:216: colour only where weight > 1e-4 -- a sample whose weight sits at the threshold is in the
+    # mask on one side and not on the other: up to 1e-4 per such sample; 5e-5 measured).  fused: 2e-3 against an fp32
+    # computation (the fixture test's bound, DESIGN section 2)
+    tol, tol_i = (2e-5, 2e-4) if fp32 else (2e-3, 2e-3)
+    assert err_i < tol_i and err_w < tol, (err_i, err_w)
+    hit = np.isfinite(depth.numpy())
+    assert np.abs(out["depth"][0].cpu().numpy()[hit] - depth.numpy()[hit]).max() < tol
 
 
 def _render_model(cuda, bf, cfg="large"):
@@ -354,7 +430,7 @@ def test_test_render_800x800_device_loop_equals_host_loop_large_geometry(cuda):
     assert 0.1 < float((ws > 0.5).float().mean()) < 0.4                # the ball covers about a quarter of the image
 
 
-@pytest.mark.parametrize("cfg", ["base", "large"])
+@pytest.mark.parametrize("cfg", ["base", "large", "small"])
 def test_one_kernel_render_at_readme_geometry_vs_oracle_loop(cuda, rays60k, cfg):
     """The DEFAULT of run_cuda's eval branch -- render_mode="kernel", csrc/render.hip k_render_rays, for hidden 128 its
     one-workgroup-per-CU form -- at the README geometries (base: C 32 / hidden 64, large: C 48 / hidden 128; R = 2048,
@@ -473,19 +549,22 @@ def test_one_kernel_render_stops_at_exactly_max_steps(cuda, rays60k, cfg):
     assert torch.isfinite(full["weights_sum"]).all()
 
 
-def test_trainstep_window_equals_whole_plane_bit_for_bit_when_deterministic(cuda, rays60k):
+@pytest.mark.parametrize("cfg,plane_dtype", [("base", torch.float16), ("base", torch.float32), ("small", torch.float16),
+                                             ("small1", torch.float16), ("small1", torch.float32)])
+def test_trainstep_window_equals_whole_plane_bit_for_bit_when_deterministic(cuda, rays60k, cfg, plane_dtype):
     """With TrainStep(deterministic=True) every tile list of the plane-gradient reduction is ordered by sample id, so the
     summation order no longer depends on the fill pass's atomics: the windowed step (occupancy window, gradient-support
     rectangles, live rectangles + deferred optimiser pass) must then reproduce the whole-plane step BIT FOR BIT -- every
     parameter after five steps through a grid refresh, at the base geometry."""
     _need_memory()
     from trinerflet_amd.train import TrainStep
-    C, H, lam = CONFIGS["base"]
-    o, d, noise, bf = rays60k
+    C, H, lam = CONFIGS[cfg]
+    R = GEOM[cfg][0]
+    o, d, noise, bf = _rays(rays60k, cfg)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
     gt = t(synthetic.target_colors(d))
     o_t, d_t, nz, bf_t = t(o), t(d), t(noise), t(bf)
-    base = _model(cuda, "base", seed=4)
+    base = _model(cuda, cfg, seed=4, plane_dtype=plane_dtype)      # (fp32: the reference's training precision, F9)
     base.density_bitfield.copy_(bf_t)
     res = []
     for use_roi in (False, True):
@@ -499,7 +578,7 @@ def test_trainstep_window_equals_whole_plane_bit_for_bit_when_deterministic(cuda
             ts.step(o_t, d_t, gt, noises=nz)
             mses.append(float(ts.last["mse"]))
         ts.flush_deferred()
-        assert ts.defer_adam == use_roi and (ts._roi is not None) == use_roi
+        assert ts.defer_adam == (use_roi and 3 * C * R * R >= 32_000_000) and (ts._roi is not None) == use_roi
         res.append((mses, [p.detach().clone() for p in m.parameters()]))
         del ts
     # (the reported MSE is a float-atomic sum over the rays: equal to rounding, not to the bit; the gradients do not read it)

@@ -107,3 +107,43 @@ def test_a_step_outside_the_pattern_runs_eagerly(cuda):
     assert np.allclose(l0, l1, rtol=2e-6, atol=0)
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
+
+
+def test_graphs_that_are_recaptured_every_period_switch_themselves_off(cuda):
+    """On a real trajectory every density-grid refresh moves the sample budget (model.mean_count is part of the captured
+    launches' signature), so every steady-state step would be captured and replayed once -- never faster than the eager
+    step.  After three signatures in a row without a second replay TrainStep(graph=True) warns, drops
+    its graphs and continues eagerly; the training is the eager one bit for bit either way."""
+    from trinerflet_amd.train import TrainStep
+    outs = []
+    for graph in (False, True):
+        m = _model(cuda)
+        torch.manual_seed(5)
+        ts = TrainStep(m, lr=1e-2, wavelet_regularization=0.2, iters=1000, fp16=True, deterministic=True, defer_adam=True,
+                       graph=graph)
+        bf = torch.from_numpy(synthetic.sphere_bitfield(128, m.cascade, 1.5, 0.5, 0.0)).to(cuda)
+        state = {"k": 0}
+
+        def reimpose(m=m, bf=bf, state=state):
+            m.density_bitfield.copy_(bf)
+            state["k"] += 1
+            m.mean_count = 30000 + 128 * state["k"]            # a budget that moves with every refresh
+        ts.post_refresh = reimpose
+        b = _batches(cuda, 4, 4096)
+        losses = []
+        import warnings
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for k in range(16 * 6 + 2):
+                o, d, gt, nz = b[k % 4]
+                nxt = b[(k + 1) % 4]
+                losses.append(ts.step(o, d, gt, noises=nz, next_rays=(nxt[0], nxt[1], nxt[3])).clone())
+        ts.flush_deferred()
+        outs.append((torch.stack(losses).cpu().numpy(), {k_: v.detach().clone() for k_, v in m.named_parameters()}, ts,
+                     [str(w.message) for w in caught]))
+    (l0, p0, _, _), (l1, p1, ts1, msgs) = outs
+    assert ts1.graph_auto_disabled and not ts1.graph and any("graphs switched off" in m_ for m_ in msgs), msgs
+    assert 14 * 3 <= ts1.graph_captures <= 14 * 4 and ts1.graph_replays == ts1.graph_captures
+    assert np.allclose(l0, l1, rtol=2e-6, atol=0)
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k

@@ -437,3 +437,200 @@ def test_live_deferred_split_equals_the_whole_array_pass_bit_for_bit(cuda):
     assert any(d["pending"] for d in ob._deferred.values())
     mb.state_dict()
     assert all(d["pending"] == 0 for d in ob._deferred.values())
+
+
+@pytest.mark.parametrize("order", ["reg_first", "reg_last", "extra_term"])
+def test_a_dense_gradient_on_top_of_the_windowed_chain_is_not_split(cuda, order):
+    """the live / deferred split must be taken only while .grad is the windowed chain's own, untouched tensor.
+    With fold_l1=False the regulariser's gradient (utils.py:639-655) is materialised and reaches every coefficient; the
+    engine sums it with the chain's gradient in the leaf's input buffer -- in place, possibly IN the chain's tensor, whose
+    address then still matches what the backward recorded.  The version counter recorded beside the address catches it: the
+    step takes the whole-array pass, and defer=True leaves the same bits as defer=False.  (Before the fix the split was
+    taken and the L1 pull outside the rectangle silently dropped: g = 0 replayed there.)"""
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    from trinerflet_amd.optim import FusedAdamL1
+
+    def make():
+        m = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, hidden_dim=64, hidden_dim_color=64,
+                        triplane_channels=16, triplane_resolution=512, triplane_wavelet_levels=8).to(cuda)
+        g = torch.Generator(device=cuda).manual_seed(13)
+        with torch.no_grad():
+            for p in m.encoder.planes_features_wavelet_coefs:
+                p.copy_(torch.randn(p.shape, generator=g, device=cuda) * 0.05)
+        m.encoder.windowed_autograd = True
+        m.encoder.window_provider = lambda: [128, 192, 64, 64, 128, 192, 256, 192]
+        return m
+    ma, mb = make(), make()
+    mb.load_state_dict(ma.state_dict())
+    pa, pb = list(ma.encoder.parameters()), list(mb.encoder.parameters())
+    fold = order == "extra_term"        # (the extra term is dense by itself: the regulariser may stay folded there)
+    oa = FusedAdamL1(pa, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, defer=False, fold_l1=fold)
+    ob = FusedAdamL1(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, defer=True, fold_l1=fold)
+
+    def loss_of(m, k):
+        enc = m.encoder
+        enc.reset_cahce()
+
+        def reg():
+            wf = enc.get_wavelet_features()
+            tot = sum(v.numel() for v in wf)
+            return 0.3 * sum(v.abs().mean() * (v.numel() / tot) for v in wf) / len(wf)
+
+        def data():
+            planes = enc.get_planes()
+            w = planes._tnl_window
+            return sum((planes[p, :, w[3 + p]:w[3 + p] + w[7], w[p]:w[p] + w[6]] * (1.0 + 0.03 * k)).pow(2).mean()
+                       for p in range(3))
+        if order == "reg_first":
+            r = reg()
+            return r + data()
+        if order == "reg_last":
+            d = data()
+            return d + reg()
+        # another loss term that touches the coefficients directly, recorded before the render
+        extra = sum(1e-3 * (q * q).mean() for q in enc.planes_features_wavelet_coefs)
+        return extra + data() + reg()
+    for k in range(6):
+        for m, opt in ((ma, oa), (mb, ob)):
+            opt.zero_grad(set_to_none=True)
+            loss_of(m, k).backward()
+            opt.step()
+    assert ob.deferred_steps == 0, ob.deferred_steps          # every gradient was dense: no step may take the split
+    ob.flush_deferred()
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b), a.shape
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(oa.state[a][key], ob.state[b][key]), (a.shape, key)
+    # the pull did reach the coefficients outside the live rectangle (far corner of the finest level)
+    fine = [q for q in pb if q.dim() == 5][-1]
+    assert float(ob.state[fine]["exp_avg"][0, 0, 0, :8, :8].abs().max()) > 0
+
+
+class _TorchEmaLike:
+    """torch_ema.ExponentialMovingAverage's surface as the reference's Trainer uses it (utils.py:516-520, 838-841, 890,
+    1204-1207): shadow copies updated from the parameter tensors, store / copy_to / restore around an evaluation."""
+
+    def __init__(self, parameters, decay):
+        self.params = list(parameters)
+        self.decay = decay
+        self.shadow = [p.detach().clone() for p in self.params]
+        self.collected = None
+
+    def update(self):
+        with torch.no_grad():
+            for s, p in zip(self.shadow, self.params):
+                s.sub_((1.0 - self.decay) * (s - p))
+
+    def store(self):
+        self.collected = [p.detach().clone() for p in self.params]
+
+    def copy_to(self):
+        with torch.no_grad():
+            for s, p in zip(self.shadow, self.params):
+                p.copy_(s)
+
+    def restore(self):
+        with torch.no_grad():
+            for c, p in zip(self.collected, self.params):
+                p.copy_(c)
+
+
+def test_reference_loop_ema_beside_the_deferred_split(cuda, monkeypatch):
+    """the reference's loop keeps a torch_ema EMA (run_utils.py:93 default 0.95): update() after every epoch,
+    store() / copy_to() / restore() around every evaluation -- all of them read or write the parameter tensors directly.
+    FusedAdamL1(defer=True) guards the loaded torch_ema class (optim.guard_ema_class): each of those calls first replays the
+    pending steps.  Against defer=False: parameters, moments AND the EMA's shadow values are the same bits after two
+    "epochs" of 10 iterations (pending steps at each EMA call) with an evaluation's whole-plane read in between."""
+    import sys
+    import types
+    from trinerflet_amd import optim
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    fake = types.ModuleType("torch_ema")
+    fake.ExponentialMovingAverage = type("ExponentialMovingAverage", (_TorchEmaLike,), {})      # (a fresh class per test)
+    monkeypatch.setitem(sys.modules, "torch_ema", fake)
+
+    def make():
+        m = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, hidden_dim=64, hidden_dim_color=64,
+                        triplane_channels=16, triplane_resolution=512, triplane_wavelet_levels=8).to(cuda)
+        g = torch.Generator(device=cuda).manual_seed(17)
+        with torch.no_grad():
+            for p in m.encoder.planes_features_wavelet_coefs:
+                p.copy_(torch.randn(p.shape, generator=g, device=cuda) * 0.05)
+        m.encoder.windowed_autograd = True
+        m.encoder.window_provider = lambda: [128, 192, 64, 64, 128, 192, 256, 192]
+        return m
+    ma, mb = make(), make()
+    mb.load_state_dict(ma.state_dict())
+    pa, pb = list(ma.encoder.parameters()), list(mb.encoder.parameters())
+    oa = optim.FusedAdamL1(pa, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, defer=False)
+    ob = optim.FusedAdamL1(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, defer=True)
+    assert fake.ExponentialMovingAverage._tnl_flush_guard           # guarded when the optimiser was made
+    ea, eb = fake.ExponentialMovingAverage(pa, 0.95), fake.ExponentialMovingAverage(pb, 0.95)
+
+    def loss_of(m, k):
+        enc = m.encoder
+        enc.reset_cahce()
+        planes = enc.get_planes()
+        w = planes._tnl_window
+        data = sum((planes[p, :, w[3 + p]:w[3 + p] + w[7], w[p]:w[p] + w[6]] * (1.0 + 0.03 * k)).pow(2).mean() for p in range(3))
+        wf = enc.get_wavelet_features()
+        tot = sum(v.numel() for v in wf)
+        return data + 0.3 * sum(v.abs().mean() * (v.numel() / tot) for v in wf) / len(wf)
+    evals = []
+    for epoch in range(2):
+        for k in range(10):
+            for m, opt in ((ma, oa), (mb, ob)):
+                opt.zero_grad(set_to_none=True)
+                loss_of(m, 10 * epoch + k).backward()
+                opt.step()
+        assert any(d["pending"] for d in ob._deferred.values())         # the EMA calls below meet pending steps
+        for m, ema in ((ma, ea), (mb, eb)):
+            ema.update()                                                 # utils.py:1204-1207
+            ema.store()                                                  # utils.py:838-841: evaluate with the averaged weights
+            ema.copy_to()
+            with torch.no_grad():
+                m.encoder.reset_cahce()
+                evals.append(m.encoder.get_planes().float().clone())
+            ema.restore()                                                # :890
+            m.encoder.reset_cahce()
+        assert torch.equal(evals[-1], evals[-2])
+    assert ob.deferred_steps >= 18 and oa.deferred_steps == 0
+    ob.flush_deferred()
+    for a, b, sa_, sb_ in zip(pa, pb, ea.shadow, eb.shadow):
+        assert torch.equal(a, b) and torch.equal(sa_, sb_), a.shape
+        for key in ("exp_avg", "exp_avg_sq", "step"):
+            assert torch.equal(oa.state[a][key], ob.state[b][key]), (a.shape, key)
+
+
+def test_model_load_state_dict_meets_no_pending_steps(cuda):
+    """model.load_state_dict() while steps are pending -- the reference loads the model, then the optimiser
+    (utils.py:1482-1510).  The encoder's load_state_dict pre-hook replays the pending steps BEFORE the copy, so nothing of
+    the old run is replayed on top of the loaded values afterwards."""
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    from trinerflet_amd.optim import FusedAdamL1
+    m = NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, hidden_dim=64, hidden_dim_color=64,
+                    triplane_channels=16, triplane_resolution=512, triplane_wavelet_levels=8).to(cuda)
+    g = torch.Generator(device=cuda).manual_seed(19)
+    with torch.no_grad():
+        for p in m.encoder.planes_features_wavelet_coefs:
+            p.copy_(torch.randn(p.shape, generator=g, device=cuda) * 0.05)
+    ckpt = {k: v.clone() for k, v in m.state_dict().items()}
+    m.encoder.windowed_autograd = True
+    m.encoder.window_provider = lambda: [128, 192, 64, 64, 128, 192, 256, 192]
+    ps = list(m.encoder.parameters())
+    opt = FusedAdamL1(ps, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    for k in range(5):
+        opt.zero_grad(set_to_none=True)
+        m.encoder.reset_cahce()
+        planes = m.encoder.get_planes()
+        w = planes._tnl_window
+        loss = sum(planes[p, :, w[3 + p]:w[3 + p] + w[7], w[p]:w[p] + w[6]].pow(2).mean() for p in range(3))
+        wf = m.encoder.get_wavelet_features()
+        (loss + 0.3 * sum(v.abs().mean() for v in wf) / len(wf)).backward()
+        opt.step()
+    assert any(d["pending"] for d in opt._deferred.values())
+    m.load_state_dict(ckpt)
+    assert all(d["pending"] == 0 for d in opt._deferred.values())
+    opt.flush_deferred()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, ckpt[k]), k

@@ -182,11 +182,11 @@ def test_support_chain_adjoint_and_rect_adam_match_dense(cuda):
     assert torch.equal(p_, res[0][0][s0 * per:s1 * per]) and torch.equal(v_, res[0][2][s0 * per:s1 * per])
 
 
-def _model(dev, C=16, R=256, scale=4, H=64, bound=1.0):
+def _model(dev, C=16, R=256, scale=4, H=64, bound=1.0, **kw):
     from trinerflet_amd.nerf.network import NeRFNetwork
     m = NeRFNetwork(encoding="triplane_wavelet", bound=bound, cuda_ray=True, density_thresh=10, hidden_dim=H,
                     hidden_dim_color=H, triplane_channels=C, triplane_resolution=R, triplane_wavelet_levels=scale,
-                    wavelet_type="bior6.8").to(dev)
+                    wavelet_type="bior6.8", **kw).to(dev)
     synthetic.init_field_parameters(m, seed=3)
     return m
 
@@ -230,11 +230,14 @@ def test_window_covers_every_marched_footprint(cuda):
         assert t0[:, ya[p]].min() >= roi[3 + p] and t1[:, ya[p]].max() < roi[3 + p] + roi[7]
 
 
-def test_windowed_rebuild_equals_full_rebuild_inside_the_window(cuda):
+@pytest.mark.parametrize("plane_dtype", [torch.float16, torch.float32])
+def test_windowed_rebuild_equals_full_rebuild_inside_the_window(cuda, plane_dtype):
     """Three wavelet levels: the window chain (every level only computes what the next one needs) reproduces the full
-    rebuild inside the occupancy window bit for bit and leaves the rest of the persistent array alone."""
+    rebuild inside the occupancy window bit for bit and leaves the rest of the persistent array alone.  fp32 planes (the
+    reference's training precision, utils.py:1138-1140; windowed since round 6): the finest level writes its window of a
+    full-size fp32 array, the layout pass converts that window."""
     from trinerflet_amd.train import TrainStep
-    m = _model(cuda, R=512, scale=8, bound=1.0)
+    m = _model(cuda, R=512, scale=8, bound=1.0, plane_dtype=plane_dtype)
     with torch.no_grad():
         for p in m.encoder.planes_features_wavelet_coefs:
             p.normal_(0, 0.05)
@@ -248,6 +251,7 @@ def test_windowed_rebuild_equals_full_rebuild_inside_the_window(cuda):
     assert wins[2] == list(roi) and wins[1] is not None, (roi, wins)     # the level below the finest is windowed too
     ts._tm_full.fill_(5.0)
     tm = ts.rebuild_planes(roi=True)
+    assert tm.dtype == plane_dtype and tm is ts._tm_full
     for p in range(3):
         win = (slice(roi[3 + p], roi[3 + p] + roi[7]), slice(roi[p], roi[p] + roi[6]))
         assert torch.equal(tm[p][win], full[p][win])
@@ -256,7 +260,8 @@ def test_windowed_rebuild_equals_full_rebuild_inside_the_window(cuda):
         assert bool((tm[p][mask] == 5.0).all())
 
 
-def test_training_with_window_equals_whole_plane_training(cuda):
+@pytest.mark.parametrize("plane_dtype", [torch.float16, torch.float32])
+def test_training_with_window_equals_whole_plane_training(cuda, plane_dtype):
     """Six steps (one grid refresh inside) with and without the occupancy window: same parameters."""
     from trinerflet_amd.train import TrainStep
     N, bound = 2048, 1.0
@@ -264,13 +269,14 @@ def test_training_with_window_equals_whole_plane_training(cuda):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
     gt = t(synthetic.target_colors(d))
     noise = t(np.random.default_rng(0).random(N).astype(np.float32))
-    base = _model(cuda, bound=bound)
+    base = _model(cuda, bound=bound, plane_dtype=plane_dtype)
     bf = t(synthetic.sphere_bitfield(128, 1, bound, 0.4, 0.0))
     base.density_bitfield.copy_(bf)
     res = []
     for use_roi in (False, True):
         m = copy.deepcopy(base)
         ts = TrainStep(m, update_extra_interval=4, use_roi=use_roi)
+        assert m.encoder.plane_dtype == plane_dtype
         ts.post_refresh = lambda m=m: m.density_bitfield.copy_(bf)   # keep the analytic occupancy
         m.mean_count = 0
         losses = []

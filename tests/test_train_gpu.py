@@ -167,7 +167,7 @@ def test_scaler_skips_on_overflow(cuda):
 
 
 def test_train_parity_mode_fp32_planes_and_unscaled_loss(cuda):
-    """`plane_dtype=torch.float32` ("train-parity mode": fp32 texels, no occupancy window) and `fp16=False` (no
+    """`plane_dtype=torch.float32` ("train-parity mode": fp32 texels; the occupancy window applies to both precisions since round 6) and `fp16=False` (no
     GradScaler): the same step as the default fast mode up to the fp16 rounding of the texels."""
     from trinerflet_amd.nerf.network import NeRFNetwork
     from trinerflet_amd.train import TrainStep
@@ -402,3 +402,87 @@ def test_trainstep_with_wavelet_base_resolution(cuda):
         errs[i] = _relerr(ts.coef.grad_view(i).cpu().numpy() * inv, p.grad.cpu().numpy() * inv)
         assert float(p.grad.abs().sum()) > 0
     assert all(e < 2e-2 for e in errs.values()), errs
+
+
+@pytest.mark.parametrize("thr,windowed", [(64, False), (128, False), (128, True)])
+def test_frozen_levels_follow_the_reference_clear_grad(cuda, thr, windowed):
+    """--min_wavelet_resolution_to_learn (run_utils.py:88): Trainer.clear_grad (utils.py:1105-1114, called between backward
+    and scaler.step, :1168) drops every gradient except those of the encoder parameters whose last dimension exceeds the
+    threshold; torch.optim.Adam then skips the others entirely.  TrainStep(min_wavelet_resolution_to_learn=thr) against
+    that loop on the drop-in modules (autograd + torch.optim.Adam), three steps: the frozen tensors (MLP weights, LL plane,
+    levels with n <= thr) keep their bits in both, the learning levels agree where their gradient is significant, the
+    loss (which still carries the frozen levels' L1 value) agrees.  windowed: R = 512 with an occupancy window, so that
+    the live / deferred split and the adjoint's fused optimiser levels see the frozen prefix too."""
+    from trinerflet_amd.nerf.network import NeRFNetwork
+    from trinerflet_amd.train import TrainStep
+    Rt, sc, n_rays = (512, 8, 2048) if windowed else (256, 4, 1024)
+    m0 = NeRFNetwork(encoding="triplane_wavelet", bound=BOUND, cuda_ray=True, density_thresh=10, hidden_dim=H,
+                     hidden_dim_color=H, triplane_channels=C, triplane_resolution=Rt, triplane_wavelet_levels=sc,
+                     wavelet_type="bior6.8").to(cuda)
+    synthetic.init_field_parameters(m0, seed=3)
+    with torch.no_grad():
+        for p in m0.encoder.planes_features_wavelet_coefs:
+            p.mul_(5.0)
+    o, d = synthetic.training_rays(n_rays, n_cams=4, seed=7)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    gt = t(synthetic.target_colors(d))
+    noise = t(np.random.default_rng(0).random(n_rays).astype(np.float32))
+    bf = t(synthetic.sphere_bitfield(128, 2, BOUND, 0.5 if windowed else 0.8, 0.0))
+    m0.density_bitfield.copy_(bf)
+    init = {n: p.detach().clone() for n, p in m0.named_parameters()}
+    learns = lambda n, p: n.startswith("encoder.") and p.shape[-1] > thr
+    # (1) the reference's loop: backward, clear_grad, Adam
+    m2 = copy.deepcopy(m0)
+    m2.train()
+    m2.mean_count = 0
+    opt2 = torch.optim.Adam(m2.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    losses2 = []
+    for it in range(3):
+        opt2.zero_grad(set_to_none=True)
+        m2.encoder.reset_cahce(); m2.encoder.get_planes()
+        out = m2.render(t(o)[None], t(d)[None], staged=False, bg_color=0, perturb=True, force_all_rays=True,
+                        noises=noise, dt_gamma=0, max_steps=1024)
+        mse2 = ((out["image"][0] - gt) ** 2).mean()
+        wf = m2.encoder.get_wavelet_features()
+        tot = sum(v.numel() for v in wf)
+        reg2 = LAM * sum(v.abs().mean() * (v.numel() / tot) for v in wf) / len(wf)
+        ((mse2 + reg2) * 65536.0).backward()
+        wavelet_grad = [val.grad for val in m2.encoder.parameters()]          # clear_grad, utils.py:1105-1114
+        for val in m2.parameters():
+            val.grad = None
+        for idx, val in enumerate(m2.encoder.parameters()):
+            if val.shape[-1] > thr:
+                val.grad = wavelet_grad[idx]
+        for p in m2.parameters():
+            if p.grad is not None:
+                p.grad.mul_(1.0 / 65536.0)
+        opt2.step()
+        losses2.append(float(mse2 + reg2))
+    # (2) TrainStep
+    m1 = copy.deepcopy(m0)
+    ts = TrainStep(m1, lr=1e-2, wavelet_regularization=LAM, iters=30000, warmup_steps=0, fp16=True, init_scale=65536.0,
+                   update_extra_interval=0, min_wavelet_resolution_to_learn=thr, defer_adam=windowed)
+    m1.mean_count = 0
+    losses1 = [float(ts.step(t(o), t(d), gt, noises=noise)) for _ in range(3)]
+    if windowed:
+        assert ts._roi is not None and ts.defer_adam and ts._pending > 0, (ts._roi, ts._pending)
+    total1 = sum(losses1) + float(ts.pop_deferred_reg())
+    ts.flush_deferred()
+    assert ts.frozen_levels == sum(1 for n in (64, 128, 256) if n <= thr and n < Rt) and ts.freeze_ll and ts.freeze_mlp
+    np.testing.assert_allclose(total1, sum(losses2), rtol=2e-3)
+    p1, p2 = dict(m1.named_parameters()), dict(m2.named_parameters())
+    for n, p in init.items():
+        a, b = p1[n].detach(), p2[n].detach()
+        if not learns(n, p):
+            assert torch.equal(a, p) and torch.equal(b, p), n                 # frozen: the same bits in both loops
+            continue
+        assert not torch.equal(a, p), n
+        g2 = p2[n].grad.detach().abs()
+        sig = g2 > 1e-2 * g2.max()
+        frac = float(((a - b).abs()[sig] > 5e-4).float().mean())
+        assert frac < 1e-2, (n, frac)
+    # the optimiser's moments of the frozen tensors never moved
+    assert float(ts.mlp.m.abs().max()) == 0 and float(ts.ll.m.abs().max()) == 0
+    for lvl in range(ts.frozen_levels):
+        o_, n_ = ts.coef.offsets[lvl], ts.coef.sizes[lvl]
+        assert float(ts.coef.m[o_:o_ + n_].abs().max()) == 0 and float(ts.coef.v[o_:o_ + n_].abs().max()) == 0

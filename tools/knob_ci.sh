@@ -1,14 +1,10 @@
 # Every compile-time knob the kernels keep (an #ifndef default in csrc/): built in its non-default setting(s) and run
 # through the parity tests of the kernels it touches.  usage (GPU box): bash tools/knob_ci.sh   (~1 min per line)
-cd /root/repo
+# KNOB_CI_DRY=1: print "flags | tests" per line instead of building and testing (tests/test_tools_cpu.py reads that).
+cd "$(dirname "$0")/.."
 run() {  # flags, test selection
-  TNL_HIPCC_FLAGS="$1" # round 5, second half
-IDWT="tests/test_idwt_walk_gpu.py tests/test_spans_gpu.py tests/test_roi_gpu.py tests/test_flag_matrix_gpu.py"
-run "-DTNL_FWD_PAIR=2" "$IDWT"
-run "-DTNL_FWD_PAIR=4" "$IDWT"
-run "-DTNL_BWD_WALK_WAVES=3" "$IDWT tests/test_adam_deferred_gpu.py"
-run "-DTNL_MARCH_NZ_FILTER=0" "$MARCH tests/test_flag_matrix_gpu.py"
-python -m trinerflet_amd.build --force > /dev/null 2>&1 || { echo "BUILD FAILED: $1"; return; }
+  if [ -n "$KNOB_CI_DRY" ]; then echo "$1 | $2"; return; fi
+  TNL_HIPCC_FLAGS="$1" python -m trinerflet_amd.build --force > /dev/null 2>&1 || { echo "BUILD FAILED: $1"; return; }
   echo "[$1] $(python -m pytest $2 -m gpu -x -q 2>&1 | tail -1)"
 }
 ADAM="tests/test_adam_deferred_gpu.py tests/test_train_gpu.py tests/test_optim_gpu.py"
@@ -33,4 +29,10 @@ run "-DTNL_WG=8 -DTNL_DWG=2" "$LARGE"
 run "-DTNL_BWD_STAMP=1" "$LARGE"
 run "-DTNL_FWD_PREFETCH=0" "$LARGE"
 run "-DTNL_FWD_LDSW=1 -DTNL_FWD_MINWAVES=2" "$LARGE"
-python -m trinerflet_amd.build --force > /dev/null
+# round 5, second half
+IDWT="tests/test_idwt_walk_gpu.py tests/test_spans_gpu.py tests/test_roi_gpu.py tests/test_flag_matrix_gpu.py"
+run "-DTNL_FWD_PAIR=2" "$IDWT"
+run "-DTNL_FWD_PAIR=4" "$IDWT"
+run "-DTNL_BWD_WALK_WAVES=3" "$IDWT tests/test_adam_deferred_gpu.py"
+run "-DTNL_MARCH_NZ_FILTER=0" "$MARCH tests/test_flag_matrix_gpu.py"
+[ -n "$KNOB_CI_DRY" ] || python -m trinerflet_amd.build --force > /dev/null

@@ -25,7 +25,7 @@ class GraphMixin:
                 or self._roi_request is not None or self._rects_roi is not self._roi or self._live is None
                 or self._pending != j or self._pending >= 15 or st.noises is None or st.bg_color is not None
                 or torch.is_tensor(self.bg) or st.next_rays is None or len(st.next_rays) < 3 or st.next_rays[2] is None
-                or model.mean_count <= 0 or self._prefetched is None or self.R % 32 != 0):
+                or model.mean_count <= 0 or self._prefetched is None or self.R % 32 != 0 or self.min_res_learn > 0):
             return False
         pre = self._prefetched
         if not self._prefetch_matches(pre[0], st.rays_o, st.rays_d, st.noises):
@@ -55,7 +55,22 @@ class GraphMixin:
         j = self._graph_position()
         sig = self._graph_signature(st)
         if sig != self._graph_key:
+            # a signature under which no captured step was ever replayed a second time cost more than it saved: on a real
+            # trajectory every grid refresh moves the sample budget (part of the signature), so every step is captured AND
+            # replayed -- never faster than the eager step.  Three such signatures in a row: graphs
+            # are switched off for this object instead of being re-captured for ever (they pay with a pinned budget).
+            if self._graph_key is not None and self._key_captures > 0:
+                self._wasted_keys = self._wasted_keys + 1 if self._key_replays <= self._key_captures else 0
+            self._key_captures = self._key_replays = 0
             self._graphs, self._graph_key = {}, sig
+            if self._wasted_keys >= 3:
+                import warnings
+                warnings.warn("TrainStep(graph=True): the captured steps were re-captured at every density-grid refresh "
+                              f"({self.graph_captures} captures, {self.graph_replays} replays): graphs switched off")
+                self.graph = False
+                self.graph_auto_disabled = True
+                self.drop_graphs()
+                return self._eager_step(st)
         N = st.N
         if self._graph_in is None or self._graph_in["o"].shape[0] != N:
             mk = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
@@ -91,6 +106,7 @@ class GraphMixin:
             g = self._capture_step(st, j, pre)
             self._graphs[j] = g
             self.graph_captures += 1
+            self._key_captures += 1
         else:
             # the march this step consumes: where the captured launches expect it
             src = [t_ for t_ in pre[1][0] if torch.is_tensor(t_)]
@@ -106,6 +122,7 @@ class GraphMixin:
             self._stale_params = self._stale_moments = True
         g.graph.replay()
         self.graph_replays += 1
+        self._key_replays += 1
         # the graph joined its side work before it ended: whoever consumes the prefetch -- the next captured step (which
         # does not look at events) or an eager one -- is ordered behind it by the launch stream alone; the events the
         # capture recorded are not real ones, an eager consumer gets one recorded here

@@ -22,6 +22,25 @@ class OptimiserMixin:
             L.ptr(inv_scale_dev), L.f32(l1_coef), L.ptr(found_inf), L.ptr(abs_sum), L.i32(0), L.stream()),
             "adam_l1_step")
 
+    def _learn_from(self):
+        """Offset (in the flat coefficient buffer) of the first wavelet level that learns (min_wavelet_resolution_to_learn)."""
+        F = self.frozen_levels
+        return self.coef.total if F >= self.J else self.coef.offsets[F]
+
+    def _frozen_abs_sum(self):
+        """sum |coef| over the frozen levels (this rank's slices in the sharded mode, whose ranks' sums are all-reduced):
+        constant while they are frozen; recomputed after model.load_state_dict()."""
+        if self._frozen_abs is None:
+            tot = torch.zeros(1, dtype=torch.float32, device=self.dev)
+            for lvl in range(self.frozen_levels):
+                q = self.coef.params[lvl].detach()
+                if self.multi and self.dist_mode == "sharded":
+                    s0, s1 = self._slice_range()
+                    q = q.reshape(3 * self.C, -1)[s0:s1]
+                tot += q.abs().sum(dtype=torch.float32)
+            self._frozen_abs = tot
+        return self._frozen_abs
+
     def _time_adam_pass(self, data, grad, m, v, reps=3):
         """Milliseconds of one k_adam_l1 pass over whole arrays with lr = 0 (nothing changes when g = m = v = 0).  The pass
         is asked to store every wavefront (zero_grad bit 1): candidate buffers and zero-initialised coefficient sets would
@@ -63,10 +82,11 @@ class OptimiserMixin:
                 L.f32(l1c), L.ptr(found_inf), L.ptr(abs_sum), L.stream()), "adam_l1_step_rect")
 
         if rects is None and ns == S:
-            self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum)
-            self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
+            self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum, lo=self._learn_from())
+            if not self.freeze_ll:
+                self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
             return
-        for lvl in range(self.J):
+        for lvl in range(self.frozen_levels, self.J):
             n = self.coef.params[lvl].shape[-1]
             base = self.coef.offsets[lvl] + s0 * 3 * n * n
             if rects is not None:
@@ -74,6 +94,8 @@ class OptimiserMixin:
             else:
                 self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum, base, base + ns * 3 * n * n)
         n0 = self.ll.params[0].shape[-1]
+        if self.freeze_ll:
+            return
         if rects is not None:
             rect_step(self.ll, s0 * n0 * n0, 1, n0, rects[0], 0.0, None)
         else:
@@ -120,7 +142,7 @@ class OptimiserMixin:
         lib = L.lib()
         ns = s1 - s0
         slot = self._adam_live_begin(lr_t, l1, found_inf, s0, s1, rects) if begun is None else begun
-        keep = [lvl for lvl in range(self.J) if begun is None or lvl not in self._fused_levels]
+        keep = [lvl for lvl in range(self.frozen_levels, self.J) if begun is None or lvl not in self._fused_levels]
         # every level (that the adjoint has not updated already) in ONE launch: its live rectangle, or the whole level where
         # nothing is deferred
         cf, K = self.coef, len(keep)
@@ -142,7 +164,9 @@ class OptimiserMixin:
         n0 = self.ll.params[0].shape[-1]
         ll = self.ll
         off = s0 * n0 * n0
-        if self._capturing:      # the step's scalars from the ring slot just written (the same bits)
+        if self.freeze_ll:
+            pass
+        elif self._capturing:      # the step's scalars from the ring slot just written (the same bits)
             L.check(lib.tnl_adam_l1_step_rect_rec(
                 L.ptr(ll.data[off:]), L.ptr(ll.grad[off:]), L.ptr(ll.m[off:]), L.ptr(ll.v[off:]), L.u32(ns), L.u32(1),
                 L.u32(n0), L.u32(self.C), L.u32(s0), (C_.c_int32 * 8)(*rects[0]), L.ptr(self._ring[4 * slot:]),
@@ -203,10 +227,11 @@ class OptimiserMixin:
         """Each rank updates only its (plane, channel) slices; afterwards parameters are all-gathered so the
         replicas stay identical (needed for checkpoints; the next rebuild_planes only reads the own slices)."""
         S = 3 * self.C
-        for lvl in range(self.J):
+        for lvl in range(self.frozen_levels, self.J):
             n = self.coef.params[lvl].shape[-1]
             per = 3 * n * n
             base = self.coef.offsets[lvl]
             self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum, base + s0 * per, base + s1 * per)
         n0 = self.ll.params[0].shape[-1]
-        self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale, None, s0 * n0 * n0, s1 * n0 * n0)
+        if not self.freeze_ll:
+            self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale, None, s0 * n0 * n0, s1 * n0 * n0)

@@ -64,7 +64,14 @@ class PlanesMixin:
                 enc.last_used_planes = None
                 enc._planes_tm = None
                 enc._planes_tm_window = None
-                return half_roi_into_texel_major(planes, self._tm_full, self._roi10(), plane_spans)
+                if planes.dtype == torch.float16:
+                    return half_roi_into_texel_major(planes, self._tm_full, self._roi10(), plane_spans)
+                # fp32 planes: the finest level wrote its window of a full-size (3,C,R,R) array (_idwt_level_win); the
+                # layout pass converts that window into the persistent fp32 [3,R,R,C] array
+                L.check(L.lib().tnl_planes_to_texel_major_win(L.ptr(planes), L.u32(self.C), L.u32(self.R), L.i32(0),
+                                                              L.ptr(self._tm_full), L.roi_array(self._roi10()), L.stream()),
+                        "planes_to_texel_major_win")
+                return self._tm_full
             if planes.dtype == torch.float16:
                 # the (3,C,R,R) fp32 planes never exist on this path: only the sampler's copy is installed in the
                 # encoder's cache (get_planes() rebuilds on demand; get_planes_texel_major() serves this copy)
@@ -100,8 +107,24 @@ class PlanesMixin:
             else:
                 x = _IDWTLevel.apply(x, yh, enc.wave_id)
             x = self._crop(x, lvl)
-        if roi:
+        if roi and x.dtype == torch.float16:
             return D.all_gather_slices(x.reshape(s1 - s0, self._roi[7], self._roi[6]), self.pg)
+        if roi:
+            # fp32 planes: this rank's slices hold their window inside full-size arrays; the window travels compact and is
+            # put back into a full-size array for the layout pass (plain copies: the fp32 planes under several GPUs are
+            # the reference-precision check, not the fast path)
+            r, C = self._roi, self.C
+            xs = x.reshape(s1 - s0, self.R, self.R)
+            mine = torch.empty(s1 - s0, r[7], r[6], dtype=torch.float32, device=x.device)
+            for pl in range(3):
+                a0, a1 = max(pl * C, s0), min((pl + 1) * C, s1)
+                if a1 > a0:
+                    mine[a0 - s0:a1 - s0] = xs[a0 - s0:a1 - s0, r[3 + pl]:r[3 + pl] + r[7], r[pl]:r[pl] + r[6]]
+            allw = D.all_gather_slices(mine, self.pg)
+            full = torch.empty(3, C, self.R, self.R, dtype=torch.float32, device=x.device)
+            for pl in range(3):
+                full[pl, :, r[3 + pl]:r[3 + pl] + r[7], r[pl]:r[pl] + r[6]] = allw[pl * C:(pl + 1) * C]
+            return full
         mine = x.reshape(s1 - s0, self.R, self.R)
         return D.all_gather_slices(mine, self.pg).view(3, self.C, self.R, self.R)
 
@@ -130,7 +153,9 @@ class PlanesMixin:
             lr_t, l1, found_inf, inv_scale = fuse
             step_size, bias2_sqrt = self._adam_scalars(lr_t)
         adj_spans = self._adjoint_spans() if (roi is not None and fuse is None) else [None] * self.J
-        for lvl in reversed(range(self.J)):
+        # (min_wavelet_resolution_to_learn: the levels below the first one that learns -- and the LL plane -- take no step, so
+        #  the adjoint stops there: their gradients are never formed)
+        for lvl in reversed(range(self.frozen_levels, self.J)):
             if self._cropped(lvl):       # the level's output was cropped by k per side: its gradient is zero there
                 g = torch.nn.functional.pad(g, (self.crop_k,) * 4)
             n = (R >> (self.J - lvl)) if roi is not None else g.shape[-1] // 2

@@ -41,7 +41,9 @@ except its own three numbers and the step's scalars, so it is not done every ste
 in a 16-slot ring per parameter; the rest is replayed in registers, all pending steps in one pass
 (tnl_adam_l1_catchup), when the ring is full, when the rectangle changes, before a whole-plane rebuild
 (TriPlaneVolume.build_planes, e.g. the density-grid refresh every 16 steps), before state_dict() of the optimiser or of
-the encoder, and on flush_deferred().  p, m, v after a flush are the bits the undeferred pass leaves
+the encoder, before load_state_dict() of either, before any method of a guarded EMA helper touches the parameters
+(guard_ema_class: applied to torch_ema.ExponentialMovingAverage, the reference loop's EMA, automatically), and on
+flush_deferred().  p, m, v after a flush are the bits the undeferred pass leaves
 (tests/test_optim_gpu.py).  Until then the deferred coefficients' VALUES lag: code that reads the parameter tensors
 directly (not through the encoder or a state_dict) calls trinerflet_amd.optim.flush_deferred() first; the regulariser's
 reported VALUE (`.abs().mean()` over whole levels) lags by up to a period for them, its gradient does not.  1.95 -> ~1 ms of
@@ -100,6 +102,47 @@ def flush_deferred(params=None):
         opt.flush_deferred(params)
 
 
+_EMA_METHODS = ("update", "store", "copy_to", "restore", "state_dict", "load_state_dict")
+
+
+def guard_ema_class(cls):
+    """Make an EMA helper safe beside the live / deferred split: every method of `cls` that reads or writes the parameter
+    tensors directly (torch_ema.ExponentialMovingAverage's update / store / copy_to / restore / state_dict /
+    load_state_dict) first replays the deferred steps of every live FusedAdamL1.  The reference's loop runs such an EMA by
+    default (run_utils.py:93 `--ema_decay 0.95`; utils.py:1204-1207 update() after each epoch, :838-841 / :890 and
+    :984-994 store() / copy_to() / restore() around every evaluation).  Without the guard update() would average
+    coefficients that are up to 15 steps behind, and store() would save them -- the evaluation's whole-plane rebuild then
+    replays the pending steps onto the EMA's shadow values and restore() writes the stale ones back: the steps are lost.
+    Idempotent; returns cls.  FusedAdamL1(defer=True) applies it to `torch_ema` on its own when that module is loaded."""
+    if getattr(cls, "_tnl_flush_guard", False):
+        return cls
+    import functools
+    for name in _EMA_METHODS:
+        fn = getattr(cls, name, None)          # (inherited methods too: the wrapper lands on cls itself)
+        if fn is None or not callable(fn):
+            continue
+
+        def make(fn):
+            @functools.wraps(fn)
+            def guarded(self, *a, **kw):
+                flush_deferred()
+                return fn(self, *a, **kw)
+            return guarded
+        setattr(cls, name, make(fn))
+    cls._tnl_flush_guard = True
+    return cls
+
+
+def _guard_loaded_emas():
+    import sys
+    mod = sys.modules.get("torch_ema")
+    cls = getattr(mod, "ExponentialMovingAverage", None)
+    if isinstance(cls, type):
+        guard_ema_class(cls)
+        return True
+    return False
+
+
 class FusedAdamL1(torch.optim.Optimizer):
     # torch.amp.GradScaler: do not unscale the gradients in a pass of their own -- step() receives the scale
     # (self.grad_scale) and the non-finite flag (self.found_inf) and folds both into the update
@@ -117,6 +160,7 @@ class FusedAdamL1(torch.optim.Optimizer):
         self.l1_without_grad = bool(l1_without_grad)
         self.defer = bool(defer)
         self._deferred = {}            # parameter -> {"ring", "pending", "live", "ctx"}: see the module docstring
+        self._ema_guarded = bool(defer) and _guard_loaded_emas()      # (again at the first deferred step: import order)
         self.deferred_steps = self.deferred_flushes = 0
         _DEFERRING.add(self)
         self._sinks = {}
@@ -185,8 +229,8 @@ class FusedAdamL1(torch.optim.Optimizer):
         info = getattr(p, "_tnl_live", None)
         if not self.defer or info is None or info[0] is None or p.dim() != 5 or p.shape[0] != 3 or p.shape[2] != 3:
             return None
-        if p.grad is None or p.grad.data_ptr() != info[3] or g.data_ptr() != info[3]:
-            return None        # not (only) the windowed chain's gradient: dense
+        if p.grad is None or p.grad.data_ptr() != info[3] or g.data_ptr() != info[3] or p.grad._version != info[4]:
+            return None        # not (only) the windowed chain's gradient (another tensor, or this one added into): dense
         n = p.shape[-1]
         if p.shape[-2] != n or n & (n - 1) or n % 4 or group["weight_decay"] != 0 or g.shape != p.shape or not g.is_contiguous():
             return None
@@ -197,6 +241,8 @@ class FusedAdamL1(torch.optim.Optimizer):
         lib = L.lib()
         b1, b2 = group["betas"]
         ctx = (float(b1), float(b2), float(group["eps"]), float(group["l1"]))
+        if not self._ema_guarded:
+            self._ema_guarded = _guard_loaded_emas()
         d = self._deferred.get(p)
         if d is None:
             d = self._deferred[p] = {"ring": torch.zeros(16 * 4, dtype=torch.float32, device=p.device), "pending": 0,

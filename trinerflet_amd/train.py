@@ -47,7 +47,8 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
                  betas=(0.9, 0.99), eps=1e-15, fp16=True, update_extra_interval=16, background_color=0.0,
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
                  dist_mode=None, process_group=None, single_rank_collectives=False, binned=True, fuse_adam=False, use_roi=True, tune_placement=None,
-                 defer_adam=None, deterministic=False, live_bands=True, overlap_exchange=0, graph=False):
+                 defer_adam=None, deterministic=False, live_bands=True, overlap_exchange=0, graph=False,
+                 min_wavelet_resolution_to_learn=-1):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
@@ -87,9 +88,11 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
         # use_roi: between two density-grid refreshes no sample can leave the bounding window of the occupied cells,
         # so the finest IDWT level, the fp16 layout change, the plane gradient and the finest adjoint only touch
         # that window (compact arrays).  Refresh steps rebuild whole planes (the grid update queries density
-        # everywhere).  Results are bit-identical to the whole-plane step.
+        # everywhere).  Results are bit-identical to the whole-plane step.  Both plane precisions (round 6): with
+        # plane_dtype = float32 -- the reference's training precision, utils.py:1138-1140 -- the finest level writes its
+        # window of a full-size fp32 array and the layout pass converts that window (rebuild_planes).
         self.use_roi = (use_roi and binned and not fuse_adam and self.J > 0 and self.R % 64 == 0 and self.C % 8 == 0
-                        and enc.plane_dtype == torch.float16 and self.base_res == 0)
+                        and enc.plane_dtype in (torch.float16, torch.float32) and self.base_res == 0)
         self._roi = None          # 8 ints {ox[3], oy[3], rw, rh} or None (whole planes)
         self._roi_valid = False   # False: recompute from the bitfield before it is used
         self._roi_request = None  # (pinned host buffer, device buffer, event, ...) of a window read-back in flight
@@ -108,6 +111,30 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
         self.mlp = _Flat(self.Ws)
         assert self.mlp.total == sum(w.numel() for w in self.Ws) or True
         self.coef_numel = sum(self.coef.sizes)
+        # min_wavelet_resolution_to_learn (run_utils.py:88; Trainer.clear_grad, utils.py:1105-1114, called between backward
+        # and the optimiser step :1168): when > 0 every gradient of the model is dropped except those of the ENCODER
+        # parameters whose last dimension exceeds it -- the MLP weights, the LL plane and the coarse wavelet levels (a
+        # prefix: sizes grow with the level) then take no optimiser step at all (torch.optim.Adam skips a parameter
+        # without a gradient: no moment decay, no step count, no L1 pull), while the loss still carries their L1 value.
+        # Here: the adjoint stops above the frozen levels, their Adam passes (and the MLP's) are not launched, their
+        # |coef| sum is a cached constant.
+        thr = int(min_wavelet_resolution_to_learn or -1)
+        self.min_res_learn = thr
+        self.frozen_levels = sum(1 for q in self.coef.params if q.shape[-1] <= thr) if thr > 0 else 0
+        self.freeze_ll = thr > 0 and enc.planes_features.shape[-1] <= thr
+        self.freeze_mlp = thr > 0
+        assert self.frozen_levels == 0 or self.freeze_ll      # level 0 has the LL plane's size
+        if thr > 0 and fuse_adam:
+            raise NotImplementedError("fuse_adam with min_wavelet_resolution_to_learn")
+        self._frozen_abs = None
+        if thr > 0:
+            me_ = __import__("weakref").ref(self)
+
+            def _reloaded(module, incompatible):
+                ts_ = me_()
+                if ts_ is not None:
+                    ts_._frozen_abs = None
+            self._ld_hook = model.register_load_state_dict_post_hook(_reloaded)
         # placement of the coefficient arrays chosen by measurement (see _Flat.tune_placement): default for sets large
         # enough for the Adam pass to be the step's dominant kernel
         self.placement = None
@@ -190,6 +217,8 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
         self._lr_dev = None
         self.graph_replays = 0      # counters for reports / tests
         self.graph_captures = 0
+        self._key_captures = self._key_replays = self._wasted_keys = 0     # see _graph_step: graphs that never pay are dropped
+        self.graph_auto_disabled = False
         self._stale_params = self._stale_moments = False
         # where the following batch's march + tile sort start on the side stream (binned mode): behind the field backward
         # ("bwd"), behind the tile reduction ("reduce") or behind the adjoint IDWT ("adjoint")
@@ -480,7 +509,7 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
                 begun = None
                 self._fused_levels = ()
                 if (self.fuse_live and self.defer_adam and st.roi is not None and self._rect_ok and self._rects_roi is self._roi
-                        and all(r is not None for r in self._rects)):
+                        and all(r is not None for r in self._rects[self.frozen_levels:])):
                     # the window's rectangles are known from the adjoint of an earlier step under it: the step is recorded
                     # (and the live pieces fixed) before the adjoint, whose column-walk levels then carry the optimiser
                     sl = self._slice_range() if (scattered or (self.multi and self.dist_mode == "sharded")) else (0, 3 * self.C)
@@ -515,8 +544,9 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
             if self.dist_mode == "sharded":
                 self._adam_sharded(lr_t, l1, found_inf, inv_scale, s0, s1)
             else:
-                self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum)
-                self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
+                self._adam(self.coef, lr_t, l1, found_inf, inv_scale, self.abs_sum, lo=self._learn_from())
+                if not self.freeze_ll:
+                    self._adam(self.ll, lr_t, 0.0, found_inf, inv_scale)
             self._mark("adam_coef")
         if self._capturing:
             mlp = self.mlp
@@ -524,8 +554,10 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
                                              L.ptr(self._ring[4 * self._last_slot:]), L.f32(self.b1), L.f32(self.b2),
                                              L.f32(self.eps), L.ptr(inv_scale), L.f32(0.0), L.ptr(found_inf), L.ptr(None),
                                              L.stream()), "adam_l1_step_rec")
-        else:
+        elif not self.freeze_mlp:
             self._adam(self.mlp, lr_t, 0.0, found_inf, inv_scale)
+        if self.frozen_levels and l1 > 0:
+            self.abs_sum.add_(self._frozen_abs_sum())      # the frozen levels' share of the regulariser's VALUE
         # optimiser-step count, GradScaler.update(), L1 value: one launch
         reg = torch.empty((), dtype=torch.float32, device=self.dev)
         L.check(lib.tnl_step_epilogue(L.ptr(found_inf), L.ptr(self.opt_steps), L.ptr(self.scale),

@@ -69,7 +69,7 @@ class Trainer:
                  wavelet_regularization=0.0, background_color=0.0, train_rand_bg=False, fp16=True,
                  update_extra_interval=16, max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, use_checkpoint="latest",
                  max_keep_ckpt=2, eval_interval=1, fast_training=False, seed=0, dist_mode=None, process_group=None,
-                 mute=True, train_step_kwargs=None, infer_min_step=1):
+                 mute=True, train_step_kwargs=None, infer_min_step=1, min_wavelet_resolution_to_learn=-1):
         self.name, self.model, self.workspace = name, model, workspace
         self.lr, self.iters, self.warmup_steps, self.num_rays = lr, iters, warmup_steps, num_rays
         self.background_color, self.train_rand_bg = background_color, train_rand_bg
@@ -101,6 +101,8 @@ class Trainer:
             elif use_checkpoint:
                 self._pending_full = self.load_checkpoint(use_checkpoint, model_only=False, _defer_optimizer=True)
         kw = dict(train_step_kwargs or {})
+        # --min_wavelet_resolution_to_learn (run_utils.py:88; Trainer.clear_grad, utils.py:1105-1114)
+        kw.setdefault("min_wavelet_resolution_to_learn", min_wavelet_resolution_to_learn)
         self.ts = TrainStep(model, lr=lr, wavelet_regularization=wavelet_regularization, iters=iters,
                             warmup_steps=warmup_steps, fp16=fp16, update_extra_interval=update_extra_interval,
                             background_color=background_color, max_steps=max_steps, dt_gamma=dt_gamma,

@@ -22,6 +22,8 @@ reference does.  They switch the fused field / TrainStep fast path off (`is_plai
 tests/golden/triplane_options_reference.npz (the reference class run here).  Only wavelet_base_resolution > 0 raises
 NotImplementedError.
 """
+import weakref
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -158,9 +160,12 @@ class _IDWTChainWin(Function):
         for lvl, ref in enumerate(ctx.coef_refs):
             prm = ref()
             if prm is not None:
-                # (+ the address of the gradient tensor this backward returns: the optimiser takes the split only while
-                #  .grad is exactly that tensor -- anything accumulated into it, or another backward's gradient, is dense)
-                prm._tnl_live = (live[lvl], rects[lvl], roi, grads[lvl].data_ptr())
+                # (+ the address AND the version counter of the gradient tensor this backward returns: the optimiser takes
+                #  the split only while .grad is exactly that tensor, untouched.  The address alone does not tell: when
+                #  another recorded path reaches the coefficient -- a materialised regulariser, an extra loss term -- the
+                #  engine sums the two gradients IN PLACE in the leaf's input buffer, which may be this very tensor; an
+                #  in-place add bumps the version, a steal by AccumulateGrad (a detach) shares it)
+                prm._tnl_live = (live[lvl], rects[lvl], roi, grads[lvl].data_ptr(), grads[lvl]._version)
         return (None, None, g, *grads)
 
 
@@ -531,6 +536,11 @@ class TriPlaneVolume(torch.nn.Module):
         # a checkpoint reads every coefficient: deferred optimiser passes over them are replayed first
         self.register_state_dict_pre_hook(
             lambda module, prefix, keep_vars: _flush_deferred_optimisers(module.planes_features_wavelet_coefs))
+        # ... and load_state_dict() overwrites them: steps still pending would otherwise be replayed later, with the old
+        # run's moments, on top of the loaded values (the reference loads the model before the optimiser, utils.py:1482-1510)
+        self._register_load_state_dict_pre_hook(
+            lambda *a, _self=weakref.ref(self): (_self() is not None and
+                                                 _flush_deferred_optimisers(_self().planes_features_wavelet_coefs)) and None)
         self.window_provider = None      # callable -> occupancy window or None (see _autograd_window); set by NeRFNetwork
         self.windowed_autograd = WINDOWED_AUTOGRAD     # opt-in: see _autograd_window
         if self.inner_wavelet_scale <= 1:
@@ -680,6 +690,12 @@ class TriPlaneVolume(torch.nn.Module):
                     and not self._upgrading):
                 return self.get_planes_whole()       # a reader outside autograd gets every texel
             return self.last_used_planes
+        # what an earlier windowed backward left on the parameters describes THAT gradient: a rebuild starts a new one (the
+        # caching allocator hands a freed gradient's address to the next one, so the address check alone would not tell
+        # after model.zero_grad(), which -- unlike FusedAdamL1.zero_grad -- does not clear the mark)
+        for prm in self.planes_features_wavelet_coefs:
+            if getattr(prm, "_tnl_live", None) is not None:
+                prm._tnl_live = None
         window = self._autograd_window(max_res, max_scale, get_all_resolutions)
         if window is not None:
             key = tuple(int(v) for v in window)
