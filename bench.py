@@ -569,6 +569,10 @@ def compact_line(out):
         for k, v in col["bytes_on_the_wire"].items():
             if isinstance(v, (int, float)):
                 flat["wire_" + k] = _num(float(v))
+    ep = cfg.get("exchange_plan")
+    if isinstance(ep, dict):     # what the cost model of DESIGN.md section 5 predicts for this run: check ms_per_step against it
+        flat["exchange_bands"], flat["exchange_transport"] = ep.get("bands"), ep.get("transport")
+        flat["model_ms_per_step"], flat["model_link_GBs"] = ep.get("ms_predicted"), ep.get("link_GBs_assumed")
     tj = cfg.get("trajectory")
     if isinstance(tj, dict):
         flat["trajectory_512_steps_ms_per_step"] = tj.get("wall_ms_per_step")
@@ -618,7 +622,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="base", choices=sorted(WORKLOADS))
-    ap.add_argument("--dist-mode", default="sharded", choices=["sharded", "allreduce"])
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "sharded", "allreduce"],
+                    help="auto: mode and exchange bands from the cost model (distributed.plan_exchange, TNL_XGMI_GBS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="the steady-state steps of a density-grid period replayed as captured HIP graphs (TrainStep(graph=True)). "
@@ -832,6 +837,18 @@ def main():
 
     # ---- secondary figures, after the timed region (rank 0's GPU only; skipped by --no-extras and in multi-GPU runs)
     extras = {}
+    # what the run used and what the cost model (trinerflet_amd.distributed.plan_exchange) predicts for
+    # it: compare ms_predicted with ms_per_step of a multi-GPU run, ms_one_gpu with the one-GPU line
+    dist_mode_used = ts.dist_mode
+    exchange_plan = None
+    if world > 1 or lone:
+        from trinerflet_amd import distributed as D_
+        tex = ts.R * ts.R if ts._roi is None else ts._roi[6] * ts._roi[7]
+        plan = D_.plan_exchange(max(world, 1), 3 * ts.C, tex, samples_per_step, transports=(ts.grad_transport,))
+        bands = ts._exchange_bands(ts._roi)
+        exchange_plan = {"mode": dist_mode_used, "bands": 0 if bands is None else len(bands), "transport": ts.grad_transport,
+                         "link_GBs_assumed": plan.get("link_gbs"), "ms_predicted": None if world == 1 else round(plan["ms"], 3),
+                         "ms_one_gpu_model": round(plan["ms_one_gpu"], 3)}
     roi_window = None if ts._roi is None else {"origin_x": ts._roi[0:3], "origin_y": ts._roi[3:6], "width": ts._roi[6],
                                                 "height": ts._roi[7], "of": ts.R,
                                                 "note": "bounding window of the occupied cells per plane (r = 0.8 sphere): "
@@ -894,7 +911,7 @@ def main():
         wire = None
         if world > 1:
             S_all = 3 * C
-            if args.dist_mode == "sharded":
+            if dist_mode_used == "sharded":
                 win = (roi_window["width"] * roi_window["height"]) if roi_window else R * R
                 rs = S_all * win * 4.0 * (world - 1) / world       # reduce-scatter of the fp32 plane-gradient window
                 ag = S_all * win * 2.0 * (world - 1) / world       # all-gather of the rebuilt fp16 planes (window)
@@ -941,7 +958,8 @@ def main():
                                    f"fp16 planes + fp16 MFMA MLP, fp32 masters, Adam+L1",
                        "rays_per_step_per_gpu": N, "rays_per_step_global": n_global,
                        "samples_per_step_per_gpu": samples_per_step,
-                       "sample_budget_M": mean_count, "parallelism": f"ray-dp{world}" + (f"+{args.dist_mode}" if (world > 1 or lone) else ""),
+                       "sample_budget_M": mean_count, "parallelism": f"ray-dp{world}" + (f"+{dist_mode_used}" if (world > 1 or lone) else ""),
+                       "exchange_plan": exchange_plan,
                        "collectives": None if (world == 1 and not lone) else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                                                "bytes_on_the_wire": wire},
                        "samples_per_sec": samples_per_step * world * args.steps / elapsed,

@@ -109,3 +109,82 @@ def test_single_process_helpers_are_identity():
     assert D.reduce_scatter_slices(x) is x and D.all_gather_slices(x) is x and D.all_reduce_(x) is x
     with pytest.raises(ValueError):
         D.slice_range(7, 2, 0)
+
+
+def test_exchange_plan_follows_the_cost_model():
+    """distributed.plan_exchange: the mode, the band count of overlap_exchange and the transport of the
+    plane-gradient exchange per world size, with the xGMI link rate as a parameter (TNL_XGMI_GBS)."""
+    from trinerflet_amd import distributed as D
+    S, win, M = 96, 1152 * 1152, 4.65e6                     # base: 3 x 32 slices, the r = 0.8 window, samples per step
+    one = D.plan_exchange(1, S, win, M)
+    assert one["mode"] is None and 3.5 < one["ms"] < 4.2        # the measured one-GPU step (3.78) within the model's grain
+    p8 = D.plan_exchange(8, S, win, M, link_gbs=122.0)
+    # the slice-sharded step: the same bytes on the wire as an all-reduce, the dense work divided by 8
+    assert p8["mode"] == "sharded" and p8["ms"] < one["ms"] and 8 * one["ms"] / p8["ms"] > 6.0     # north_star: >= 6 x at 8
+    ar8 = min(e["ms"] for e in p8["table"] if e["mode"] == "allreduce")
+    assert ar8 > p8["ms"]
+    # two ranks: ONE link carries the whole exchange -- bands hide part of the reduce-scatter behind the tile reduction
+    p2 = D.plan_exchange(2, S, win, M, link_gbs=122.0)
+    k1 = next(e["ms"] for e in p2["table"] if e["mode"] == "sharded" and e["overlap_exchange"] == 0)
+    assert p2["mode"] == "sharded" and p2["overlap_exchange"] >= 2 and p2["ms"] < k1
+    # ... and bf16 transport of the gradient window halves its larger half (only where the caller allows it)
+    pb = D.plan_exchange(2, S, win, M, link_gbs=122.0, transports=("fp32", "bf16"))
+    assert pb["transport"] == "bf16" and pb["ms"] < p2["ms"] - 0.5
+    # a slower link moves every multi-GPU prediction, never the one-GPU one; the prediction is monotone in the rate
+    slow = D.plan_exchange(8, S, win, M, link_gbs=36.0)
+    assert slow["ms"] > p8["ms"] and slow["ms_one_gpu"] == p8["ms_one_gpu"]
+    # 3 * channels not divisible by the world size: only the all-reduce form exists
+    assert D.plan_exchange(8, 94, win, M)["mode"] == "allreduce"
+    # a short tile reduction (few samples) cannot hide anything: no bands are asked for
+    tiny = D.plan_exchange(8, S, win, 1e4, link_gbs=122.0)
+    assert tiny["overlap_exchange"] == 0
+    # the link rate comes from the environment
+    os.environ["TNL_XGMI_GBS"] = "61"
+    try:
+        assert D.link_rate_gbs() == 61.0 and D.plan_exchange(2, S, win, M)["link_gbs"] == 61.0
+    finally:
+        del os.environ["TNL_XGMI_GBS"]
+
+
+def _worker_bf16(rank, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from trinerflet_amd import distributed as D
+    try:
+        g_local = torch.from_numpy(np.random.default_rng(100 + rank).standard_normal((S, R, R)).astype(np.float32))
+        others = [torch.from_numpy(np.random.default_rng(100 + r).standard_normal((S, R, R)).astype(np.float32))
+                  for r in range(WORLD)]
+        s0, s1 = D.slice_range(S, WORLD, rank)
+        # the switch off: the fp32 exchange, bit for bit what it was
+        a = D.reduce_scatter_slices(g_local.clone())
+        b = D.reduce_scatter_slices(g_local.clone(), None, "fp32")
+        c, wait = D.reduce_scatter_slices_async(g_local.clone(), None, "fp32")
+        wait()
+        assert torch.equal(a, b) and torch.equal(a, c)
+        want32 = sum(others)[s0:s1]
+        assert torch.allclose(a, want32, atol=1e-6)
+        # bf16 transport: every rank's contribution rounded to bf16 once, summed in fp32 in rank order on the owner
+        h = D.reduce_scatter_slices(g_local.clone(), None, "bf16")
+        want16 = torch.stack([o_[s0:s1].to(torch.bfloat16).to(torch.float32) for o_ in others]).sum(0)
+        assert h.dtype == torch.float32 and torch.equal(h, want16)
+        h2, wait2 = D.reduce_scatter_slices_async(g_local.clone(), None, "bf16")
+        wait2()
+        assert torch.equal(h2, want16)
+        rel = float((h - want32).norm() / want32.norm())
+        assert 1e-4 < rel < 4e-3                              # bf16's 8 bits of mantissa, not fp32's sum
+        # the gathered result is the same on every rank (replicas stay identical)
+        full = D.all_gather_slices(h)
+        chk = full.clone()
+        dist.broadcast(chk, 0)
+        assert torch.equal(chk, full)
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_transport_of_the_plane_gradient_gloo_world2():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_bf16, args=(port, out), nprocs=WORLD, join=True)
+    assert dict(out) == {0: 1, 1: 1}

@@ -180,7 +180,7 @@ def _build_roi(dev, R=256):
     return m
 
 
-def _run_roi(mode, rank, world, R=256, defer=None, overlap=0):
+def _run_roi(mode, rank, world, R=256, defer=None, overlap=0, transport="fp32", report=None):
     from trinerflet_amd.train import TrainStep
     from trinerflet_amd import distributed as D
     dev = torch.device("cuda:0")
@@ -193,7 +193,7 @@ def _run_roi(mode, rank, world, R=256, defer=None, overlap=0):
     m = _build_roi(dev, R)
     bf = m.density_bitfield.clone()
     ts = TrainStep(m, lr=1e-2, wavelet_regularization=LAM, iters=1000, fp16=True, update_extra_interval=4, dist_mode=mode,
-                   defer_adam=defer, overlap_exchange=overlap)
+                   defer_adam=defer, overlap_exchange=overlap, grad_transport=transport)
     ts.post_refresh = lambda: m.density_bitfield.copy_(bf)          # keep the analytic occupancy
     losses = []
     for it in range(6):
@@ -208,17 +208,61 @@ def _run_roi(mode, rank, world, R=256, defer=None, overlap=0):
         assert ts._pending == 0
     ts.sync_sharded_parameters()
     params = {k: v.detach().cpu().numpy() for k, v in m.named_parameters()}
+    if report is not None:
+        bands = ts._exchange_bands(ts._roi)
+        report.update(mode=ts.dist_mode, overlap=ts.overlap_exchange, bands=0 if bands is None else len(bands))
     return (losses, params, live) if defer else (losses, params)
 
 
-def _roi_worker(rank, port, mode, out, R=256, defer=None, overlap=0):
+def _roi_worker(rank, port, mode, out, R=256, defer=None, overlap=0, transport="fp32"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=2)
     try:
         torch.cuda.set_device(0)
-        out[rank] = _run_roi(mode, rank, 2, R, defer, overlap)
+        rep = {}
+        res = _run_roi(mode, rank, 2, R, defer, overlap, transport, rep)
+        out[rank] = res
+        out[f"report{rank}"] = rep
     finally:
         dist.destroy_process_group()
+
+
+def test_two_ranks_with_the_mode_chosen_by_the_cost_model(cuda):
+    """TrainStep(dist_mode="auto"): the slice-sharded step (3 * 16 slices divide by 2) with the band count the cost model
+    asks for (distributed.plan_exchange with this window and sample budget: at 2 048 rays the tile reduction is too short
+    to hide anything, so one piece -- the rule itself is pinned by tests/test_dist_cpu.py, the banded exchange by
+    [sharded-overlap] above) -- the same training as the one-rank run, identical replicas."""
+    ref_losses, ref_params = _run_roi(None, 0, 1)
+    os.environ["TNL_XGMI_GBS"] = "2"
+    try:
+        port = _free_port()
+        out = _manager().dict()
+        mp.spawn(_roi_worker, args=(port, "auto", out, 256, None, 0), nprocs=2, join=True)
+    finally:
+        del os.environ["TNL_XGMI_GBS"]
+    (l0, p0), (l1, p1) = out[0], out[1]
+    rep = out["report0"]
+    assert rep["mode"] == "sharded" and rep["overlap"] == "auto" and rep["bands"] == 0, rep
+    assert np.allclose(l0, l1, rtol=1e-6) and np.allclose(l0, ref_losses, rtol=3e-3), (l0, l1, ref_losses)
+    for k in ref_params:
+        assert np.array_equal(p0[k], p1[k]), k
+        assert np.mean(np.abs(p0[k] - ref_params[k]) > 2e-3) < 2e-2, k
+
+
+@pytest.mark.parametrize("overlap", [0, 2])
+def test_two_ranks_with_bf16_transport_of_the_plane_gradient(cuda, overlap):
+    """TrainStep(grad_transport="bf16"): the plane-gradient window travels as bfloat16, the owner of a slice accumulates the
+    ranks' contributions in fp32 (distributed._reduce_scatter_bf16).  Replicas stay identical; against the fp32 transport
+    the losses agree to bf16's grain and the parameters where Adam's sign-like early steps allow."""
+    ref_losses, ref_params = _run_roi(None, 0, 1)
+    port = _free_port()
+    out = _manager().dict()
+    mp.spawn(_roi_worker, args=(port, "sharded", out, 256, None, overlap, "bf16"), nprocs=2, join=True)
+    (l0, p0), (l1, p1) = out[0], out[1]
+    assert np.allclose(l0, l1, rtol=1e-6) and np.allclose(l0, ref_losses, rtol=5e-3), (l0, l1, ref_losses)
+    for k in ref_params:
+        assert np.array_equal(p0[k], p1[k]), k
+        assert np.mean(np.abs(p0[k] - ref_params[k]) > 2e-3) < 4e-2, k
 
 
 @pytest.mark.parametrize("mode", ["sharded", "allreduce", "sharded-overlap"])

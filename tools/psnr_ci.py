@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--workload", default="base")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--arm", default=None, choices=[None, "bf16_transport"],
+                    help="bf16_transport: the fused step against ITSELF with the plane gradient rounded to bfloat16 before "
+                         "the adjoint (TrainStep(grad_transport='bf16') in one process = what a slice's owner receives from "
+                         "one rank: the gate of the multi-GPU bf16 exchange, SURVEY.md 8(e))")
     args = ap.parse_args()
     import importlib.util
     spec = importlib.util.spec_from_file_location("tnl_trajectory", os.path.join(ROOT, "tools", "trajectory.py"))
@@ -52,6 +56,29 @@ def main():
     dev = torch.device("cuda:0")
     scene = T.make_scene(dev, scene=args.scene)
     rows = []
+    if args.arm == "bf16_transport":
+        for seed in args.seeds:
+            batches = T.batches_of(scene[0], args.steps, 60000, seed)
+            a32 = T.run_fused(args.workload, dev, args.steps, 60000, scene, batches, seed=seed)
+            a32.pop("_model")
+            torch.cuda.empty_cache()
+            a16 = T.run_fused(args.workload, dev, args.steps, 60000, scene, batches, seed=seed,
+                              ts_kwargs={"grad_transport": "bf16"})
+            a16.pop("_model")
+            torch.cuda.empty_cache()
+            rows.append({"seed": seed, "fp32_transport_db": a32["held_out_psnr_db"], "bf16_transport_db": a16["held_out_psnr_db"]})
+            print(rows[-1], file=sys.stderr, flush=True)
+        rep = {"scene": args.scene, "workload": args.workload, "steps": args.steps, "reductions": "unordered (product default)",
+               "runs": rows, "bf16_minus_fp32_transport": ci([r["bf16_transport_db"] - r["fp32_transport_db"] for r in rows]),
+               "note": "paired by seed; both arms the fused TrainStep, one process; bf16 arm: the plane-gradient window rounded "
+                       "to bfloat16 once before the adjoint (the rounding every rank's contribution gets under "
+                       "grad_transport='bf16'; the owner's fp32 accumulation adds none)"}
+        s_ = json.dumps(rep, indent=1)
+        print(s_)
+        if args.out:
+            with open(args.out, "w") as f:
+                f.write(s_)
+        return
     for seed in args.seeds:
         batches = T.batches_of(scene[0], args.steps, 60000, seed)
         fused = T.run_fused(args.workload, dev, args.steps, 60000, scene, batches, seed=seed)

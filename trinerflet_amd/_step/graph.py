@@ -21,7 +21,7 @@ class GraphMixin:
         model = self.model
         if (self.multi or not (1 <= j <= min(self.update_extra_interval, 16) - 2) or st.refresh or self.section_events is not None
                 or not (self.binned and self.use_roi and self.defer_adam and self._rect_ok and self.overlap_march)
-                or self.fuse_adam or self.overlap_exchange > 1 or self._roi is None or not self._roi_valid
+                or self.fuse_adam or self.overlap_exchange == "auto" or self.overlap_exchange > 1 or self._roi is None or not self._roi_valid
                 or self._roi_request is not None or self._rects_roi is not self._roi or self._live is None
                 or self._pending != j or self._pending >= 15 or st.noises is None or st.bg_color is not None
                 or torch.is_tensor(self.bg) or st.next_rays is None or len(st.next_rays) < 3 or st.next_rays[2] is None

@@ -147,7 +147,11 @@ class PlanesMixin:
             dist.all_reduce(g, group=self.pg)
         elif self.dist_mode == "sharded":
             s0, s1 = self._slice_range()
-            g = D.reduce_scatter_slices(g, self.pg)
+            g = D.reduce_scatter_slices(g, self.pg, self.grad_transport)
+        elif self.grad_transport == "bf16" and not self.multi:
+            # one process: what a world of one would exchange -- its own contribution rounded to bf16 once (the form the
+            # PSNR check of the transport runs in: tools/psnr_ci.py --arm bf16_transport)
+            g = g.to(torch.bfloat16).to(torch.float32)
         ns = s1 - s0
         if fuse is not None:
             lr_t, l1, found_inf, inv_scale = fuse
@@ -219,6 +223,16 @@ class PlanesMixin:
         K > 1, an occupancy window, the slice-sharded mode (or a single process, where only the banded reduction's own
         cost shows: the measurement of DESIGN.md section 5), not the Adam-fused adjoint."""
         K = self.overlap_exchange
+        if K == "auto":      # from the cost model, for this window and sample budget (distributed.plan_exchange)
+            key = (tuple(roi) if roi is not None else None, int(self.model.mean_count))
+            if self._auto_plan is None or self._auto_plan[0] != key:
+                tex = self.R * self.R if roi is None else roi[6] * roi[7]
+                plan = D.plan_exchange(self.world, 3 * self.C, tex, max(int(self.model.mean_count), 1),
+                                       plane_bytes=self.enc.plane_dtype.itemsize if hasattr(self.enc.plane_dtype, "itemsize")
+                                       else 2, transports=(self.grad_transport,))
+                self._auto_plan = (key, plan)
+            plan = self._auto_plan[1]
+            K = plan["overlap_exchange"] if plan["mode"] == "sharded" else 0
         if K <= 1 or roi is None or self.fuse_adam or (self.multi and self.dist_mode != "sharded"):
             return None
         n64 = roi[7] // 64

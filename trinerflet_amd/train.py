@@ -48,7 +48,7 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
                  max_steps=1024, dt_gamma=0.0, T_thresh=1e-4, init_scale=65536.0, growth_interval=2000,
                  dist_mode=None, process_group=None, single_rank_collectives=False, binned=True, fuse_adam=False, use_roi=True, tune_placement=None,
                  defer_adam=None, deterministic=False, live_bands=True, overlap_exchange=0, graph=False,
-                 min_wavelet_resolution_to_learn=-1):
+                 min_wavelet_resolution_to_learn=-1, grad_transport="fp32"):
         enc = model.encoder
         assert model.cuda_ray, "TrainStep drives the cuda_ray renderer (every README configuration)"
         if not model._fused_ok():
@@ -195,7 +195,13 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
         # reduce-scattered in K bands of rows -- band b's collective runs on the communication stream while the tile
         # reduction of band b + 1 runs on the launch stream; slice ownership and everything downstream are unchanged
         # (the bands' results are concatenated into the [S/G, rh, rw] array the adjoint reads).  See DESIGN.md section 5.
-        self.overlap_exchange = int(overlap_exchange)
+        # ("auto": K from the cost model, distributed.plan_exchange, once the window and the sample budget are known)
+        self.overlap_exchange = overlap_exchange if overlap_exchange == "auto" else int(overlap_exchange)
+        self._auto_plan = None
+        # grad_transport "bf16": the plane-gradient window travels as bfloat16 and is accumulated in fp32 on the slice's
+        # owner (distributed._reduce_scatter_bf16: half the reduce-scatter's bytes); "fp32": as computed
+        assert grad_transport in ("fp32", "bf16")
+        self.grad_transport = grad_transport
         self._comm = None
         self.live_col_align = 32    # column granule of the live rectangles (see _live_rects)
         self.live_bands = live_bands
@@ -224,6 +230,10 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
         # ("bwd"), behind the tile reduction ("reduce") or behind the adjoint IDWT ("adjoint")
         self.prefetch_at = "bwd"
         self.side_count_form = 1     # raymarching.count_form of the prefetched march (0: the wavefront-per-ray count pass)
+        if __import__("os").environ.get("TNL_SIDE_COUNT_FORM") is not None:      # A/B knob (tools/ab_small.sh)
+            self.side_count_form = int(__import__("os").environ["TNL_SIDE_COUNT_FORM"])
+        if __import__("os").environ.get("TNL_PREFETCH_AT") is not None:
+            self.prefetch_at = __import__("os").environ["TNL_PREFETCH_AT"]
         # workgroups of the prefetched march's emit pass and of its tile sort's fill pass (raymarching.side_caps): 2 and 1 per
         # CU.  At full width the two flood the wave slots just as the adjoint's second column-walk level (two 192-register
         # workgroups per CU) is launched: 550 us for 190 alone; capped, the step is 0.14 ms shorter (3.86-3.89 vs 4.01-4.03
@@ -252,6 +262,13 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
         # distributed
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist_mode and dist.is_initialized()) else 1
+        # dist_mode "auto": what the cost model of DESIGN.md section 5 picks for this world size (distributed.plan_exchange:
+        # the slice-sharded step wherever 3 * channels divides by the world size -- it moves no more bytes than the
+        # all-reduce and divides the dense work -- with the band count of the exchange from the link rate TNL_XGMI_GBS)
+        if dist_mode == "auto":
+            dist_mode = "sharded" if (3 * self.C) % max(self.world, 1) == 0 else "allreduce"
+            if overlap_exchange == 0:
+                self.overlap_exchange = "auto"
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         # multi: the distributed code path is the one that runs.  single_rank_collectives=True takes it in a process group
         # of ONE rank as well (every collective issued, on RCCL each a real reduce_scatter_tensor / all_gather_into_tensor /
@@ -482,7 +499,7 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
                                          capacity=getattr(st.sort_ws, "_tnl_capacity", False))
                     self._comm.wait_stream(main)
                     with torch.cuda.stream(self._comm):
-                        part, wait = D.reduce_scatter_slices_async(buf, self.pg if self.multi else None)
+                        part, wait = D.reduce_scatter_slices_async(buf, self.pg if self.multi else None, self.grad_transport)
                     buf.record_stream(self._comm)
                     parts.append(part)
                     waits.append(wait)
