@@ -955,7 +955,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: 3x{C}ch x {R}^2 planes, bior6.8 scale {scale}, hidden {H}, "
                                    f"{N} rays/step/GPU, solid-sphere occupancy r=0.8 (re-imposed after each refresh), "
-                                   f"fp16 planes + fp16 MFMA MLP, fp32 masters, Adam+L1",
+                                   f"fp16 planes + fp16 MFMA MLP, fp32 masters, Adam+L1; GT colours = an analytic function "
+                                   f"of the ray direction (synthetic.target_colors), not a second seeded field's render",
                        "rays_per_step_per_gpu": N, "rays_per_step_global": n_global,
                        "samples_per_step_per_gpu": samples_per_step,
                        "sample_budget_M": mean_count, "parallelism": f"ray-dp{world}" + (f"+{dist_mode_used}" if (world > 1 or lone) else ""),

@@ -500,6 +500,13 @@ TNL_API int tnl_ray_batch(const float *poses, const float *intrinsics_host, uint
                           const float *bg_rand, float *rays_o, float *rays_d, float *gt_rgb, int64_t *pix_out,
                           void *stream);
 
+/* Marching work one ray may spend per trip of the one-kernel render before it pauses and rides along without a sample
+ * (a probe counts 8 units, an add of the empty-cell skip 1; default 96; 0 = unbounded: a ray marches to its next sample in
+ * one go, the form of rounds 4-5; -1 only queries).  A ray entering the volume at max_steps = 4096 walks ~30 empty cells of
+ * 28-55 dependent adds each: unbounded, the wave's other 31 rays wait for it every time a slot is refilled.  The samples
+ * are the same to the bit either way.  Process-wide tuning knob; returns the previous value. */
+TNL_API int tnl_render_work(int units);
+
 /* ---------------------------------------------------------------------------------------------
  * The inference render as one persistent kernel (csrc/render.hip; replaces the alive-ray loop of
  * reconstruction/nerf/renderer.py:338-372 and its march_rays / forward / composite_rays launches): every ray is marched

@@ -38,6 +38,50 @@ namespace {
 template <int H>
 constexpr int render_threads() { return H > 64 ? TNL_RENDER_RT128 : 256; }
 
+// march_one (march_device.h) in bounded pieces (round 6).  A ray that enters the volume walks ~30 empty cells before its
+// first sample, and at max_steps = 4096 (dt = 2 sqrt(3) / 4096) every empty cell is a probe plus 28-55 DEPENDENT adds of
+// march_skip's `do t += dt while (t < tt)`: ~7 us of one lane's work, for which the other 31 rays of the wave -- and their
+// field evaluation, ~5 us per trip -- used to wait whenever a slot had just been refilled.  On a trained field (23 samples
+// per ray) nearly every trip holds a fresh ray: 0.23 of the HBM roof against 0.62 on a field whose rays last 285 samples.
+// Now a trip spends at most TNL_RENDER_WORK units per ray (a probe counts 8, a skip add 1) and a ray that has not reached
+// its next sample rides along without one and resumes next trip, its skip target kept in the ray state.  The same
+// probes, adds and comparisons in the same order: the sample sequence is march_one's to the bit.
+#ifndef TNL_RENDER_WORK
+#define TNL_RENDER_WORK 96
+#endif
+enum { MARCH_SAMPLE = 0, MARCH_DONE = 1, MARCH_PAUSED = 2 };
+template <bool WIDE>
+__device__ __forceinline__ int march_one_bounded(const MarchCtx& m, float& t, float& last_t, float far, uint32_t& cached_blk,
+                                                 unsigned long long& cached_bits, MarchProbe& out, float& tdiff, float& tt,
+                                                 bool& skipping, int work) {
+#pragma clang fp contract(off)
+  while (true) {
+    if (skipping) {            // the rest of a `do t += dt while (t < tt)` (its first add was taken when the skip began)
+      while (t < tt && work > 0) {
+        t += m.fast ? m.dt0 : clampf_(t * m.dt_gamma, m.dt_min, m.dt_max);
+        work--;
+      }
+      if (t < tt) return MARCH_PAUSED;
+      skipping = false;
+    }
+    if (!(t < far)) return MARCH_DONE;
+    if (work <= 0) return MARCH_PAUSED;
+    const MarchProbe a = march_probe<WIDE>(m, t, cached_blk, cached_bits);
+    work -= 8;
+    if (a.occ) {
+      const float t_next = t + a.dt;
+      tdiff = t_next - last_t;
+      t = t_next;
+      last_t = t;
+      out = a;
+      return MARCH_SAMPLE;
+    }
+    tt = march_skip_target(m, a, t);
+    t += m.fast ? m.dt0 : clampf_(t * m.dt_gamma, m.dt_min, m.dt_max);
+    skipping = true;
+  }
+}
+
 template <int C, int H, bool HALFP, bool WIDE>
 __global__ void __launch_bounds__(render_threads<H>())
 k_render_rays(const void* __restrict__ planes, int R, const half8* __restrict__ packed,
@@ -45,7 +89,7 @@ k_render_rays(const void* __restrict__ planes, int R, const half8* __restrict__ 
               const float* __restrict__ fars, uint32_t N, const uint8_t* __restrict__ grid, float bound, float dt_gamma,
               uint32_t max_steps, uint32_t Cas, uint32_t Hg, float T_thresh, float density_scale,
               const float* __restrict__ noises, int* __restrict__ queue, float* __restrict__ weights_sum,
-              float* __restrict__ depth, float* __restrict__ image) {
+              float* __restrict__ depth, float* __restrict__ image, int work) {
   using G = FieldGeom<C, H>;
   constexpr int RT = render_threads<H>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,7 +101,8 @@ k_render_rays(const void* __restrict__ planes, int R, const half8* __restrict__ 
   // ray state, identical in lanes r and r + 32
   int idx = -1;
   MarchCtx m = {};     // a slot the queue never filled still rides through the MFMA chain: defined (zero) operands
-  float t = 0.f, last_t = 0.f, far = 0.f, tc = 0.f;
+  float t = 0.f, last_t = 0.f, far = 0.f, tc = 0.f, skip_to = 0.f;
+  bool skipping = false;
   uint32_t cblk = 0xffffffffu;
   unsigned long long cbits = 0ull;
   float ws = 0.f, dd = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
@@ -84,6 +129,7 @@ k_render_rays(const void* __restrict__ planes, int R, const half8* __restrict__ 
           // the composite's own t starts from the UNperturbed near (rays_t, raymarching.cu:866), see below
           tc = nears[id];
           last_t = t; far = fars[id];
+          skipping = false;
           cblk = 0xffffffffu;
           ws = dd = cr = cg = cb = 0.f;
           ns = 0;
@@ -98,8 +144,12 @@ k_render_rays(const void* __restrict__ planes, int R, const half8* __restrict__ 
     q.x = q.y = q.z = 0.f; q.dt = 0.f;
     float tdiff = 0.f;
     bool have = false;
-    if (idx >= 0) have = march_one<WIDE>(m, t, last_t, far, cblk, cbits, q, tdiff);
-    bool fin = idx >= 0 && !have;      // left the volume without another sample
+    int mst = MARCH_PAUSED;
+    if (idx >= 0) {
+      mst = march_one_bounded<WIDE>(m, t, last_t, far, cblk, cbits, q, tdiff, skip_to, skipping, work);
+      have = mst == MARCH_SAMPLE;
+    }
+    bool fin = idx >= 0 && mst == MARCH_DONE;      // left the volume without another sample
     // The loop's first iteration takes exactly ONE sample per ray (n_step = N / n_alive = 1) and hands rays_t = near +
     // (t_next - t_start) to the second one (raymarching.cu:893): the perturbation of the start is dropped there, and the
     // long first difference (entry skip) is where that sum can round away from t_next.  Same hand-over here.
@@ -169,6 +219,8 @@ k_render_rays(const void* __restrict__ planes, int R, const half8* __restrict__ 
   }
 }
 
+int g_render_work = TNL_RENDER_WORK;   // tnl_render_work: marching work units per ray and trip (<= 0: unbounded)
+
 template <int C, int H>
 int launch_render(const void* planes, int half_in, uint32_t R, const void* packed, const float* rays_o, const float* rays_d,
                   const float* nears, const float* fars, uint32_t N, const uint8_t* grid, float bound, float dt_gamma,
@@ -195,7 +247,7 @@ int launch_render(const void* planes, int half_in, uint32_t R, const void* packe
     }                                                                                                                    \
     hipLaunchKernelGGL((k_render_rays<C, H, HP, WD>), dim3(blocks), dim3(RT), lds, st, planes, (int)R, pk, rays_o, rays_d, \
                        nears, fars, N, grid, bound, dt_gamma, max_steps, Cas, Hg, T_thresh, density_scale, noises, queue,  \
-                       weights_sum, depth, image);                                                                        \
+                       weights_sum, depth, image, g_render_work > 0 ? g_render_work : 0x3fffffff);                        \
   } while (0)
   if (half_in) { if (wide) TNL_RENDER(true, true); else TNL_RENDER(true, false); }
   else { if (wide) TNL_RENDER(false, true); else TNL_RENDER(false, false); }
@@ -206,6 +258,12 @@ int launch_render(const void* planes, int half_in, uint32_t R, const void* packe
 }  // namespace
 
 extern "C" {
+
+int tnl_render_work(int units) {
+  const int prev = g_render_work;
+  if (units != -1) g_render_work = units;
+  return prev;
+}
 
 int tnl_render_rays(const void* planes_tm, int half_in, uint32_t C, uint32_t R, uint32_t Hd, uint32_t Hc, const void* packed,
                     const float* rays_o, const float* rays_d, const float* nears, const float* fars, uint32_t N,
