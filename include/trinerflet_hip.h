@@ -121,17 +121,6 @@ TNL_API int tnl_march_rays_train_binned(const float *rays_o, const float *rays_d
  * outputs bit for bit.  Process-wide; returns the previous value (any other argument only queries). */
 TNL_API int tnl_march_count_form(int form);
 
-/* tnl_march_rays_train_binned that FILLS capacity lists (see "One-pass tile lists" below) while it writes the samples:
- * sort_workspace = tnl_plane_grad_capacity_workspace(M, R) bytes, cap_table from tnl_plane_grad_capacity_build.  Nothing
- * follows on the sort's side; reduce with tnl_plane_grad_reduce_capacity. */
-TNL_API int tnl_march_rays_train_capacity(const float *rays_o, const float *rays_d, const uint8_t *grid,
-                                 float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
-                                 uint32_t C, uint32_t H, uint32_t M, const float *nears,
-                                 const float *fars, float *xyzs, float *dirs, float *deltas,
-                                 int32_t *rays, int32_t *counter, const float *noises,
-                                 int32_t *workspace, uint32_t workspace_words, uint32_t R, void *sort_workspace,
-                                 const int32_t *cap_table, void *stream);
-
 /* Launch width of the two wide passes of a march + tile sort that is enqueued BESIDE other kernels (TrainStep's prefetch of
  * the next batch on a second stream): the emit pass of tnl_march_rays_train* (one wavefront per ray, grid-stride over the
  * rays when capped) and the fill pass of tnl_plane_grad_sort* (grid-stride over the samples).  At full width the two flood
@@ -342,33 +331,6 @@ TNL_API int tnl_plane_grad_reduce(const void *dfeat_half, const float *xyz, floa
                                   uint32_t R,
                                   float grad_scale, float *grad_out, int channel_major, int32_t *nonfinite_flag,
                                   const int32_t *roi, const void *workspace, void *stream);
-
-/* ---------------------------------------------------------------------------------------------
- * One-pass tile lists ("capacity lists", round 6).  Same semantics being reproduced as tnl_plane_grad_sort* +
- * tnl_plane_grad_reduce -- grid_sampler_2d_backward's scatter, triplane_encoder.py:329 -- without the counting sort's
- * scan and second pass over the samples: between two density-grid refreshes the batches are i.i.d. draws through the same
- * occupancy grid, so the per-bin list lengths of one batch predict the next ones'.  A TABLE built from a counted batch
- * gives every sub-bin a fixed span (count + 12 sqrt(count) + 16); tnl_march_rays_train_capacity writes each sample's
- * entries straight into the spans while it writes the sample (slot = atomic counter per sub-bin); an entry that finds its
- * span full goes to a spill list, which tnl_plane_grad_reduce_capacity adds with float atomics behind the tile kernel.
- * Result: the plane gradient of the two-pass path up to fp32 summation order, whatever the table was built from (an empty
- * table spills everything: slow, still exact).
- *   tnl_plane_grad_capacity_workspace(M, R)   bytes of a per-batch workspace (lists + spill list) for M samples
- *   tnl_plane_grad_capacity_table_words(R)    int32 words of a table
- *   tnl_plane_grad_capacity_build             table from the per-bin counts a tnl_plane_grad_sort* /
- *                                             tnl_march_rays_train_binned call left in its workspace; M = the sample
- *                                             capacity of the workspaces it will be used with
- *   tnl_plane_grad_capacity_spill_index       out[0] = int32 index of the spill counter inside a capacity workspace
- * ------------------------------------------------------------------------------------------- */
-TNL_API uint64_t tnl_plane_grad_capacity_workspace(uint32_t M, uint32_t R);
-TNL_API uint32_t tnl_plane_grad_capacity_table_words(uint32_t R);
-TNL_API int tnl_plane_grad_capacity_build(const void *counted_workspace, uint32_t R, uint32_t M, int32_t *table,
-                                          void *stream);
-TNL_API int tnl_plane_grad_capacity_spill_index(uint32_t M, uint32_t R, int64_t *out);
-TNL_API int tnl_plane_grad_reduce_capacity(const void *dfeat_half, const float *xyz, float bound, uint32_t M, uint32_t C,
-                                           uint32_t R, float grad_scale, float *grad_out, int channel_major,
-                                           int32_t *nonfinite_flag, const int32_t *roi, const void *workspace,
-                                           void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Occupancy ROI variants (no reference predecessor: the reference rebuilds and differentiates whole planes).

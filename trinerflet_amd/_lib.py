@@ -30,12 +30,11 @@ def lib():
                 f"{LIB_PATH} not found: run `python -m trinerflet_amd.build` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback for the hot path.")
         _lib = C.CDLL(LIB_PATH)
-        for name in ("tnl_march_rays_train_workspace", "tnl_march_rays_train_workspace_rec", "tnl_field_packed_bytes",
-                     "tnl_plane_grad_capacity_table_words"):
+        for name in ("tnl_march_rays_train_workspace", "tnl_march_rays_train_workspace_rec", "tnl_field_packed_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_uint32
         for name in ("tnl_plane_grad_binned_workspace", "tnl_permute_index", "tnl_field_backward_workspace",
-                     "tnl_field_feats_save_bytes", "tnl_abs_mean_workspace", "tnl_plane_grad_capacity_workspace"):
+                     "tnl_field_feats_save_bytes", "tnl_abs_mean_workspace"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_uint64
     return _lib

@@ -26,30 +26,17 @@ class PrefetchMixin:
         # with a fixed sample budget the march also counts the samples per plane tile (first pass of the tile sort)
         fused_sort = self.binned and R % 32 == 0 and model.mean_count > 0
         sort_ws = None
-        cap_table = None
         if fused_sort:
             mc = model.mean_count + (128 - model.mean_count % 128)    # the wrapper's budget rule (align = 128)
-            if (self.capacity_lists and not self.deterministic and not self.graph and self._cap_table is not None
-                    and self._cap_key == (mc, o.shape[0])):
-                # one-pass tile lists: spans from this period's first batch, filled by the march itself
-                cap_table = self._cap_table
-                torch.cuda.current_stream().wait_event(self._cap_ready)
-                sort_ws = F_.plane_grad_capacity_workspace(mc, R, self.dev)
-                sort_ws._tnl_capacity = True
-            else:
-                sort_ws = F_.plane_grad_sort_workspace(mc, R, self.dev)
+            sort_ws = F_.plane_grad_sort_workspace(mc, R, self.dev)
         out = raymarching.march_rays_train(
             o, d, model.bound, model.density_bitfield, model.cascade, model.grid_size, nears, fars,
             counter, model.mean_count, True, 128, False, self.dt_gamma, self.max_steps, nz,
             model.mean_count <= 0,   # zero fill only when the buffers are sized by the worst case (first steps)
-            (R, sort_ws, cap_table) if fused_sort else None)
+            (R, sort_ws) if fused_sort else None)
         # the field forward needs the march only; the tile sort (needed much later, by the tile reduction) gets its own event
         ev_march = torch.cuda.Event()
         ev_march.record()
-        if cap_table is not None:          # the lists are complete with the march
-            assert out[0].shape[0] == mc
-            self.capacity_marches += 1
-            return (counter, *out, sort_ws), (ev_march, ev_march)
         if fused_sort and sort_stream is not None:
             assert out[0].shape[0] == mc
             sort_stream.wait_event(ev_march)
@@ -57,7 +44,6 @@ class PrefetchMixin:
                 F_.plane_grad_sort_counted(sort_ws, out[0], float(model.bound), R, counter)
                 ev_sort = torch.cuda.Event()
                 ev_sort.record()
-                self._capacity_table_from(sort_ws, mc, o.shape[0])
             for t_ in (counter, *out, sort_ws):
                 if torch.is_tensor(t_):
                     t_.record_stream(sort_stream)
@@ -65,25 +51,12 @@ class PrefetchMixin:
         if fused_sort:
             assert out[0].shape[0] == mc
             F_.plane_grad_sort_counted(sort_ws, out[0], float(model.bound), R, counter)
-            self._capacity_table_from(sort_ws, mc, o.shape[0])
         else:
             sort_ws = F_.plane_grad_sort(out[0], float(model.bound), R, counter) if (self.binned and R % 32 == 0) \
                 else torch.empty(0, device=self.dev)
         ev_sort = torch.cuda.Event()
         ev_sort.record()
         return (counter, *out, sort_ws), (ev_march, ev_sort)
-
-    def _capacity_table_from(self, sort_ws, mc, n_rays):
-        """The spans of the one-pass tile lists from the counts the counting sort just left in `sort_ws` (on the current
-        stream, behind that sort): once per density-grid period, for batches of this size under this sample budget."""
-        if not self.capacity_lists or self.deterministic or self.graph or self._cap_key == (mc, n_rays):
-            return
-        self._cap_table = F_.plane_grad_capacity_table(sort_ws, self.R, mc, table=self._cap_table)
-        self._cap_key = (mc, n_rays)
-        self._cap_ready = torch.cuda.Event()
-        self._cap_ready.record()
-        self._cap_table.record_stream(torch.cuda.current_stream())
-        self.capacity_tables += 1
 
     def _march_on_side(self, o, d, nz):
         main = torch.cuda.current_stream()

@@ -15,7 +15,6 @@ class WindowMixin:
         self._roi_valid = False
         self._roi_request = None
         self._occ_box = None
-        self._cap_key = None
         self._drop_prefetch()
 
     def _roi10(self, s0=0):

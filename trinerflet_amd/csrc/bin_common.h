@@ -16,11 +16,6 @@ constexpr int TSY = 8;   // tile height
 // 8: 2.44 | 0.91, 32: 2.34 | 0.86; base (4x the tiles, cooler counters) unchanged at 5.24-5.31 | 1.01 for 1-16, worse at 32.
 constexpr int BIN_SUBS = 4;   // (a constant, not a build knob: tests and tools read the lists through tnl_plane_grad_sort_layout)
 
-// scatter.hip, for raymarch.hip's capacity march (inside the library: not part of the C ABI)
-extern "C" int tnl_capacity_lists_begin(void* workspace, uint32_t R, uint32_t M, const int32_t* table, int** fill,
-                                        const int** cap_off, uint32_t** entries, void** epos, uint32_t** spill,
-                                        int** spill_count, void* stream);
-
 struct Foot {  // tiles touched by a bilinear footprint on one plane
   int tx0, ty0, tx1, ty1;
 };
@@ -42,25 +37,11 @@ __device__ __forceinline__ Foot footprint(const TexelTap& t) {
 // consumes the first returned slot: who leads which group and every lane's rank inside it follow from ballots alone.
 // The first version consumed each slot right behind its atomic -- about a dozen dependent L2 round trips per wave, 85 %
 // of the fill kernel's wave cycles parked (profiles/r02b_pmc_sq1.txt).
-//
-// MODE 0 counts, MODE 1 fills at exact positions (counts_or_cursor = the scanned cursors), MODE 2 fills CAPACITY lists in
-// the same pass that would otherwise only count (round 6, "one-pass tile lists"): every sub-bin owns a fixed span
-// [cap_off[bin], cap_off[bin + 1]) sized from an earlier batch's counts (tnl_plane_grad_capacity_build), counts_or_cursor
-// holds the entries handed out so far (from zero), and an entry that does not fit its span goes to the spill list as
-// {plane << 30 | direction << 28 | sample} -- tnl_plane_grad_reduce adds those with float atomics after the tile kernel.
-// The scan and the second pass over the samples (k_bin<true>: 0.5 ms on the side stream at base) disappear.
-constexpr uint32_t SPILL_ID_MASK = (1u << 28) - 1u;
-
-template <int MODE>
+template <bool FILL>
 __device__ __forceinline__ void bin_sample(float x, float y, float z, bool live, uint32_t i, float bound, int R, int TNX,
                                            int TNY, int* __restrict__ counts_or_cursor, uint32_t* __restrict__ entries,
-                                           int lane, float2* __restrict__ epos = nullptr,
-                                           const int* __restrict__ cap_off = nullptr, uint32_t* __restrict__ spill = nullptr,
-                                           int* __restrict__ spill_count = nullptr) {
-  constexpr bool FILL = MODE != 0;
-  constexpr bool CAP = MODE == 2;
+                                           int lane, float2* __restrict__ epos = nullptr) {
   int slot_r[3][4], lead_r[3][4], rank_r[3][4];
-  int base_r[3][4], cap_r[3][4];     // (MODE 2, group heads: first slot and size of the bin's span)
   bool act_r[3][4];
   float fxs[3], fys[3];
 #pragma unroll
@@ -80,11 +61,10 @@ __device__ __forceinline__ void bin_sample(float x, float y, float z, bool live,
     const int hp = 63 - __clzll((long long)below);                       // head of my run
     const unsigned long long above = (hp == 63) ? 0ull : (hmask >> (hp + 1)) << (hp + 1);
     const int nh = above ? (__ffsll((long long)above) - 1) : 64;         // head of the next run
-    slot_r[p][0] = 0; base_r[p][0] = 0; cap_r[p][0] = 0;
+    slot_r[p][0] = 0;
     if (head && live) {
       if (FILL) slot_r[p][0] = atomicAdd(counts_or_cursor + bin0, nh - hp);
       else atomicAdd(counts_or_cursor + bin0, nh - hp);
-      if (CAP) { base_r[p][0] = cap_off[bin0]; cap_r[p][0] = cap_off[bin0 + 1] - base_r[p][0]; }
     }
     lead_r[p][0] = hp; rank_r[p][0] = lane - hp; act_r[p][0] = live;
     // straddle tiles (footprint crosses a tile edge; ~15 % of the samples have one): the lanes that go to the same bin
@@ -95,7 +75,7 @@ __device__ __forceinline__ void bin_sample(float x, float y, float z, bool live,
       const bool dup = ((k & 1) && f.tx1 == f.tx0) || ((k & 2) && f.ty1 == f.ty0);
       const bool act = live && !dup;
       const int bin = (base + ty * TNX + tx) * BIN_SUBS + sub;
-      slot_r[p][k] = 0; lead_r[p][k] = lane; rank_r[p][k] = 0; act_r[p][k] = act; base_r[p][k] = 0; cap_r[p][k] = 0;
+      slot_r[p][k] = 0; lead_r[p][k] = lane; rank_r[p][k] = 0; act_r[p][k] = act;
       // groups of equal bins by ballot alone; the atomics follow the loop: a lane leads at most one group, so ONE
       // (exec-masked) atomic instruction per (plane, direction) serves every group of the wave, and no slot-returning
       // atomic sits inside a loop (where the compiler has to wait for each before the next reuses its register)
@@ -114,47 +94,21 @@ __device__ __forceinline__ void bin_sample(float x, float y, float z, bool live,
       if (is_lead) {
         if (FILL) slot_r[p][k] = atomicAdd(counts_or_cursor + bin, gsize);
         else atomicAdd(counts_or_cursor + bin, gsize);
-        if (CAP) { base_r[p][k] = cap_off[bin]; cap_r[p][k] = cap_off[bin + 1] - base_r[p][k]; }
       }
     }
   }
   if (FILL) {
-    uint32_t spilled = 0;   // MODE 2: bit 4p + k = this lane's entry (plane p, direction k) did not fit its span
 #pragma unroll
     for (int p = 0; p < 3; p++) {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        int slot = __shfl(slot_r[p][k], lead_r[p][k]) + rank_r[p][k];
-        bool put = act_r[p][k];
-        if (CAP) {
-          const int b0 = __shfl(base_r[p][k], lead_r[p][k]), cp = __shfl(cap_r[p][k], lead_r[p][k]);
-          if (put && slot >= cp) { put = false; spilled |= 1u << (4 * p + k); }
-          slot += b0;
-        }
-        if (put) {
-          entries[slot] = i;
+        const int slot = __shfl(slot_r[p][k], lead_r[p][k]);
+        if (act_r[p][k]) {
+          entries[slot + rank_r[p][k]] = i;
           // the sample's clipped texel coordinates on this plane ride along: the reduction reads them in list order
           // instead of gathering xyz[i] (a 12-byte read that costs a whole sector, as many requests as the dF row)
-          if (epos != nullptr) epos[slot] = make_float2(fxs[p], fys[p]);
+          if (epos != nullptr) epos[slot + rank_r[p][k]] = make_float2(fxs[p], fys[p]);
         }
-      }
-    }
-    if (CAP) {
-      if (__ballot(spilled != 0)) {   // wave-uniform, rare: one counter add for the wave
-        const int mine = __popc(spilled);
-        int incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const int u = __shfl_up(incl, off);
-          if (lane >= off) incl += u;
-        }
-        const int total = __shfl(incl, 63);
-        int start = 0;
-        if (lane == 0) start = atomicAdd(spill_count, total);
-        int at = __shfl(start, 0) + incl - mine;
-#pragma unroll
-        for (int q = 0; q < 12; q++)
-          if (spilled & (1u << q)) spill[at++] = ((uint32_t)(q >> 2) << 30) | ((uint32_t)(q & 3) << 28) | (i & SPILL_ID_MASK);
       }
     }
   }

@@ -628,31 +628,21 @@ k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ 
 // Samples from recorded t values: one wavefront per ray, lanes = consecutive samples (coalesced reads of the record and
 // writes of the 32 B per sample).  Position, dt and the t-difference are the expressions of march_run's probe() / take()
 // on the same operands, so the output is bit-identical to the marching writer's -- without marching a second time.
-// the arrays of a capacity workspace (bin_common.h MODE 2; scatter.hip tnl_capacity_lists_begin)
-struct CapLists {
-  const int* cap_off;
-  uint32_t* entries;
-  float2* epos;
-  uint32_t* spill;
-  int* spill_count;
-};
-
-template <int BIN_MODE>   // 0: count the tile sort's bins (or nothing: bin_counts NULL); 2: fill capacity lists in this pass
 __global__ void __launch_bounds__(MARCH_BLOCK)
 k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound, float dt_gamma,
                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                    const float* __restrict__ nears, const float* __restrict__ noises,
                    const int* __restrict__ counter, const float* __restrict__ tbuf, const int* __restrict__ rays,
                    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int binR,
-                   int* __restrict__ bin_counts, CapLists cl) {
+                   int* __restrict__ bin_counts) {
   // bin_counts != NULL: the first pass of the plane-gradient tile sort (scatter.hip k_bin<false>) rides along -- here
-  // the lanes of a wave ARE consecutive samples of one ray, the case its run aggregation is made for.  BIN_MODE 2: the
-  // ONLY pass -- every sub-bin has a span sized from an earlier batch, the entries are written here (bin_common.h)
+  // the lanes of a wave ARE consecutive samples of one ray, the case its run aggregation is made for
   const int TNX = binR / TSX, TNY = binR / TSY;
   const int lane = threadIdx.x % WAVE;
-  // (the sample rows staged in LDS and written as 16-byte pieces -- 16 full lines per 64 samples instead of ~50 line
-  //  requests -- was measured in round 6: the pass got SLOWER, 399 -> 443 us at its capped width, it is bound by the
-  //  latency of each trip, not by its requests; docs/EXPERIMENTS.md)
+  // (round 6, measured and not kept -- docs/EXPERIMENTS.md: the sample rows staged in LDS and written as 16-byte pieces,
+  //  16 full lines per 64 samples instead of ~50 line requests: 399 -> 443 us at the capped width, the pass is bound by the
+  //  latency of each trip; the tile lists FILLED here into fixed spans sized from the period's first batch, no scan and no
+  //  second pass: exact, and the interference with the step's HBM-bound kernels only moved)
   // (a launch of fewer workgroups than rays walks them with the grid's stride: tnl_march_side_caps)
   for (uint32_t n = blockIdx.x * (MARCH_BLOCK / WAVE) + (threadIdx.x / WAVE); n < N; n += gridDim.x * (MARCH_BLOCK / WAVE)) {
   const int* r = rays + ((size_t)counter[1] + n) * 3;
@@ -670,9 +660,7 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
         dirs[(size_t)q * 3 + 0] = 0.f; dirs[(size_t)q * 3 + 1] = 0.f; dirs[(size_t)q * 3 + 2] = 0.f;
         deltas[(size_t)q * 2 + 0] = 0.f; deltas[(size_t)q * 2 + 1] = 0.f;
       }
-      if (bin_counts != nullptr)
-        bin_sample<BIN_MODE>(0.f, 0.f, 0.f, live, q, bound, binR, TNX, TNY, bin_counts, cl.entries, lane, cl.epos, cl.cap_off,
-                             cl.spill, cl.spill_count);
+      if (bin_counts != nullptr) bin_sample<false>(0.f, 0.f, 0.f, live, q, bound, binR, TNX, TNY, bin_counts, nullptr, lane);
     }
     continue;
   }
@@ -701,9 +689,7 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
       deltas[o * 2 + 0] = dt;
       deltas[o * 2 + 1] = t_next - last_t;
     }
-    if (bin_counts != nullptr)
-      bin_sample<BIN_MODE>(px, py, pz, live, (uint32_t)o, bound, binR, TNX, TNY, bin_counts, cl.entries, lane, cl.epos,
-                           cl.cap_off, cl.spill, cl.spill_count);
+    if (bin_counts != nullptr) bin_sample<false>(px, py, pz, live, (uint32_t)o, bound, binR, TNX, TNY, bin_counts, nullptr, lane);
   }
   }
 }
@@ -1478,18 +1464,8 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
                                  float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                  const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                                  int32_t* rays, int32_t* counter, const float* noises, int32_t* workspace,
-                                 uint32_t workspace_words, uint32_t binR, void* sort_workspace, void* stream,
-                                 const int32_t* cap_table = nullptr) {
-  CapLists cl{};
-  int* cap_fill = nullptr;
-  if (cap_table != nullptr) {        // capacity lists: counters zeroed, the table's offsets copied, the arrays' addresses
-    if (sort_workspace == nullptr || binR == 0 || binR % TSX != 0) return (int)hipErrorInvalidValue;
-    void* ep = nullptr;
-    const int e = tnl_capacity_lists_begin(sort_workspace, binR, M, cap_table, &cap_fill, &cl.cap_off, &cl.entries, &ep,
-                                           &cl.spill, &cl.spill_count, stream);
-    if (e != 0) return e;
-    cl.epos = reinterpret_cast<float2*>(ep);
-  } else if (sort_workspace != nullptr) {   // the tile sort's bin counts (first nb + 1 ints of its workspace) start from zero
+                                 uint32_t workspace_words, uint32_t binR, void* sort_workspace, void* stream) {
+  if (sort_workspace != nullptr) {   // the tile sort's bin counts (first nb + 1 ints of its workspace) start from zero
     if (binR == 0 || binR % TSX != 0) return (int)hipErrorInvalidValue;
     const size_t nbins = 3ull * (binR / TSX) * (binR / TSY) * BIN_SUBS;
     hipError_t e = hipMemsetAsync(sort_workspace, 0, (nbins + 1) * sizeof(int), (hipStream_t)stream);
@@ -1528,14 +1504,9 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
                        dirs, deltas, rays);
     // (tnl_march_emit_cap: a march enqueued beside other kernels keeps to a few waves per SIMD)
     const uint32_t emit_blocks = g_emit_cap > 0 ? std::min<uint32_t>(cdiv(N, MARCH_BLOCK / WAVE), (uint32_t)g_emit_cap) : cdiv(N, MARCH_BLOCK / WAVE);
-    if (cap_table != nullptr)
-      hipLaunchKernelGGL(k_march_train_emit<2>, dim3(emit_blocks), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d,
-                         bound, dt_gamma, max_steps, N, C, H, M, nears, noises, counter, tbuf, rays, xyzs, dirs, deltas,
-                         (int)binR, cap_fill, cl);
-    else
-      hipLaunchKernelGGL(k_march_train_emit<0>, dim3(emit_blocks), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d,
-                         bound, dt_gamma, max_steps, N, C, H, M, nears, noises, counter, tbuf, rays, xyzs, dirs, deltas,
-                         (int)binR, reinterpret_cast<int*>(sort_workspace), cl);
+    hipLaunchKernelGGL(k_march_train_emit, dim3(emit_blocks), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d,
+                       bound, dt_gamma, max_steps, N, C, H, M, nears, noises, counter, tbuf, rays, xyzs, dirs, deltas,
+                       (int)binR, reinterpret_cast<int*>(sort_workspace));
   } else if (sort_workspace != nullptr) {
     return (int)hipErrorInvalidValue;   // the fused count needs the record path (workspace_rec words of scratch)
   } else if (wide_bitfield(grid, C, H)) {
@@ -1584,19 +1555,6 @@ int tnl_march_rays_train_binned(const float* rays_o, const float* rays_d, const 
   if (sort_workspace == nullptr) return (int)hipErrorInvalidValue;
   return march_rays_train_impl(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
                                deltas, rays, counter, noises, workspace, workspace_words, R, sort_workspace, stream);
-}
-
-// tnl_march_rays_train_binned that FILLS capacity lists while it writes the samples: no scan, no second pass
-// (sort_workspace: tnl_plane_grad_capacity_workspace(M, R) bytes; cap_table: tnl_plane_grad_capacity_build's)
-int tnl_march_rays_train_capacity(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
-                                  float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                                  const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
-                                  int32_t* rays, int32_t* counter, const float* noises, int32_t* workspace,
-                                  uint32_t workspace_words, uint32_t R, void* sort_workspace, const int32_t* cap_table,
-                                  void* stream) {
-  if (sort_workspace == nullptr || cap_table == nullptr) return (int)hipErrorInvalidValue;
-  return march_rays_train_impl(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
-                               deltas, rays, counter, noises, workspace, workspace_words, R, sort_workspace, stream, cap_table);
 }
 
 int tnl_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,

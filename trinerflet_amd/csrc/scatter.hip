@@ -45,7 +45,6 @@ k_bin(const float* __restrict__ xyz, float bound, uint32_t M, const int32_t* __r
       int TNY, int* __restrict__ counts_or_cursor, uint32_t* __restrict__ entries, float2* __restrict__ epos) {
   const uint32_t Me = eff_m(M, m_actual);
   // (a launch of fewer workgroups than M / NT walks the samples with the grid's stride; uniform trip count per wave)
-  // (the wave's 768 bytes of positions fetched as 16-byte pieces through LDS: measured slower in round 6, 525 -> 603 us)
   for (uint32_t i0 = blockIdx.x * NT; i0 < M; i0 += gridDim.x * NT) {
     const uint32_t i = i0 + threadIdx.x;
     const bool live = i < Me;
@@ -153,11 +152,7 @@ __global__ void __launch_bounds__(NT)
 k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float* __restrict__ xyz, float bound, int R, int TNX,
                   int TNY, const int* __restrict__ offsets, const uint32_t* __restrict__ entries,
                   const float2* __restrict__ epos, float grad_scale,
-                  float* __restrict__ grad_out, int layout, int* __restrict__ nonfinite_flag, Roi roi,
-                  const int* __restrict__ fill) {
-  // fill != NULL: CAPACITY lists (bin_common.h MODE 2): sub-bin b owns the span [offsets[b], offsets[b + 1]) and holds
-  // min(fill[b], span) entries; the tile's list is the concatenation of its BIN_SUBS partly filled spans.  fill == NULL:
-  // the counting sort's exact lists, one contiguous piece.
+                  float* __restrict__ grad_out, int layout, int* __restrict__ nonfinite_flag, Roi roi) {
   // layout: bit 0 = channel-major (3,C,R,R) output; bit 1 = the caller zero-filled the output (one contiguous fill):
   // untouched tiles are then skipped instead of being zeroed here in 128-byte row pieces; bit 2 (with a ROI) = the output
   // is the whole (3,C,R,R) array, of which only the window is written
@@ -195,23 +190,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
     ty = rem / TNX; tx = rem - ty * TNX;
   }
   const int bin = p * TNX * TNY + ty * TNX + tx;
-  // the list as up to BIN_SUBS pieces: piece k starts at seg[k] and covers the virtual positions [pre[k], pre[k + 1])
-  static_assert(BIN_SUBS == 4, "the piece lookup below compares against three boundaries");
-  int seg[BIN_SUBS], pre[BIN_SUBS + 1];
-  pre[0] = 0;
-  if (fill != nullptr) {
-#pragma unroll
-    for (int k = 0; k < BIN_SUBS; k++) {
-      seg[k] = offsets[bin * BIN_SUBS + k];
-      pre[k + 1] = pre[k] + max(min(fill[bin * BIN_SUBS + k], offsets[bin * BIN_SUBS + k + 1] - seg[k]), 0);
-    }
-  } else {
-    seg[0] = offsets[bin * BIN_SUBS];
-    pre[1] = offsets[(bin + 1) * BIN_SUBS] - seg[0];   // all sub-bins of the tile, contiguous
-#pragma unroll
-    for (int k = 1; k < BIN_SUBS; k++) { seg[k] = seg[0]; pre[k + 1] = pre[1]; }
-  }
-  const int beg = 0, end = pre[BIN_SUBS];
+  const int beg = offsets[bin * BIN_SUBS], end = offsets[(bin + 1) * BIN_SUBS];   // all sub-bins of the tile
   const int x_lo = tx * TSX, y_lo = ty * TSY;
   // channel-major output addressing: row stride, slice stride and origin of the (possibly compact) window
   // (layout bit 2: the window's tiles only, but written at their place in the whole (3,C,R,R) array)
@@ -275,13 +254,8 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
   uint32_t nid = 0;
   bool nv = false;
   auto fetch_id = [&](int base) {
-    const int v = base + (int)threadIdx.x;
-    nv = v < end;
-    if (nv) {
-      const int k = (int)(v >= pre[1]) + (int)(v >= pre[2]) + (int)(v >= pre[3]);
-      const int at = (k == 0 ? seg[0] : k == 1 ? seg[1] - pre[1] : k == 2 ? seg[2] - pre[2] : seg[3] - pre[3]) + v;
-      nid = entries[at]; npos = epos[at];
-    }
+    nv = base + (int)threadIdx.x < end;
+    if (nv) { nid = entries[base + threadIdx.x]; npos = epos[base + threadIdx.x]; }
   };
   auto prefetch = [&]() {   // data of the chunk whose ids are in (nid, nv)
     pv = nv;
@@ -408,77 +382,6 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
   }
 }
 
-// ---- capacity lists (one-pass tile sort; bin_common.h MODE 2) ------------------------------------------------------------
-// span of a sub-bin whose list held c entries in the batch the table is built from: c + 12 sqrt(c) + 16.  The entries of
-// a sub-bin arrive in runs (a ray crossing the tile leaves ~6 consecutive samples) and the sub-bin is chosen by the
-// sample id, so the count's standard deviation is ~2.5 sqrt(c): the slack is about five of them, an overflow (handled:
-// the spill list) a once-in-many-steps event for i.i.d. batches.
-__global__ void __launch_bounds__(256)
-k_capacity(const int* __restrict__ counts, int nb, int* __restrict__ caps) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < nb) {
-    const int c = max(counts[i], 0);
-    caps[i] = c + 12 * (int)ceilf(sqrtf((float)c)) + 16;
-  }
-}
-
-// the spans must fit the entry arrays whatever the source counts were (a table built from a larger batch): clamp the
-// scanned offsets -- spans past the end become empty and their entries spill
-__global__ void __launch_bounds__(256)
-k_clamp_offsets(int* __restrict__ offsets, int n, int e_max) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) offsets[i] = min(offsets[i], e_max);
-}
-
-// Entries that did not fit their span: {plane << 30 | direction << 28 | sample}.  The tile kernel has written every tile
-// of the output; these add their taps INSIDE the tile the entry was meant for with float atomics -- the same products
-// (fp16 column weight x fp16 row weight, rounded to fp16, times the fp16 gradient, summed in fp32), another order.
-template <int C>
-__global__ void __launch_bounds__(256)
-k_spill_scatter(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float* __restrict__ xyz, float bound, int R, int TNX,
-                int TNY, const uint32_t* __restrict__ spill, const int* __restrict__ spill_count, uint32_t spill_cap,
-                float grad_scale, float* __restrict__ grad_out, int layout, int* __restrict__ nonfinite_flag, Roi roi) {
-  const uint32_t n = (uint32_t)min((uint32_t)max(*spill_count, 0), spill_cap);
-  const bool channel_major = layout & 1;
-  for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < (uint64_t)n * C; g += (uint64_t)gridDim.x * 256) {
-    const uint32_t e = (uint32_t)(g / C);
-    const int c = (int)(g - (uint64_t)e * C);
-    const uint32_t w = spill[e];
-    const int p = (int)(w >> 30), k = (int)((w >> 28) & 3u);
-    const uint32_t i = w & SPILL_ID_MASK;
-    float fx, fy;
-    triplane_texel(xyz[(size_t)i * 3], xyz[(size_t)i * 3 + 1], xyz[(size_t)i * 3 + 2], bound, R, p, fx, fy);
-    TexelTap t;
-    tap_from_texel(fx, fy, R, t);
-    const Foot f = footprint(t);
-    const int tx = (k & 1) ? f.tx1 : f.tx0, ty = (k & 2) ? f.ty1 : f.ty0;
-    if (roi.rw) {   // tiles outside the window are not part of the output (the tile kernel drops their lists as well)
-      if (tx * TSX < roi.ox[p] || tx * TSX >= roi.ox[p] + roi.rw || ty * TSY < roi.oy[p] || ty * TSY >= roi.oy[p] + roi.rh) continue;
-    }
-    const bool compact = roi.rw != 0 && !(layout & 4);
-    const int ow = compact ? roi.rw : R, oh = compact ? roi.rh : R;
-    const int x_off = compact ? roi.ox[p] : 0, y_off = compact ? roi.oy[p] : 0;
-    const float wx = t.w01 + t.w11, wy = t.w10 + t.w11;
-    const float gv = (float)dfeat[((size_t)p * Mcap + i) * C + c];
-    const _Float16 cw0 = (_Float16)(1.f - wx), cw1 = (_Float16)wx;
-    const _Float16 rw0 = (_Float16)((1.f - wy) * grad_scale), rw1 = (_Float16)(wy * grad_scale);
-    bool bad = false;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int xq = (q & 1) ? t.x1 : t.x0, yq = (q & 2) ? t.y1 : t.y0;
-      if (((q & 1) && t.x1 == t.x0) || ((q & 2) && t.y1 == t.y0)) continue;    // the clamped +1 corner carries no weight
-      if (xq / TSX != tx || yq / TSY != ty) continue;                           // another entry's tile
-      const _Float16 af = (_Float16)(((q & 1) ? cw1 : cw0) * ((q & 2) ? rw1 : rw0));
-      const float v = (float)af * gv;
-      bad |= (v - v) != 0.f;
-      float* dst = channel_major ? grad_out + (((size_t)p * C + c) * oh + (yq - y_off)) * ow + (xq - x_off)
-                                 : grad_out + (((size_t)p * R + yq) * R + xq) * C + c;
-      atomicAdd(dst, v);
-    }
-    if (bad && nonfinite_flag != nullptr) *nonfinite_flag = 1;
-  }
-}
-
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 }  // namespace
@@ -520,32 +423,6 @@ static SortWs sort_ws(void* workspace, uint32_t R, uint32_t M = 0) {
   after += (reinterpret_cast<uintptr_t>(after) & 7) ? 1 : 0;    // 8-byte aligned
   w.epos = reinterpret_cast<float2*>(after);
   return w;
-}
-
-// ---- capacity lists: workspace = the sort workspace's layout for M_eff samples (12 * M_eff entry slots >= the largest
-// total span a table built from <= 12 * M entries can ask for: sum(c + 12 sqrt(c) + 16) <= 12 M + 12 sqrt(nb * 12 M) + 16 nb
-// by Cauchy-Schwarz) followed by the spill list (12 * M words: every entry of every sample in the worst case).
-static uint32_t cap_meff(uint32_t M, uint32_t R) {
-  const double nb = 3.0 * (R / TSX) * (R / TSY) * BIN_SUBS;
-  const double e_max = 12.0 * M + 12.0 * ceil(sqrt(nb * 12.0 * (double)M)) + 16.0 * nb;
-  const double m = ceil(e_max / 12.0) + 1.0;
-  return m > 4.0e9 ? 0u : (uint32_t)m;
-}
-
-struct CapWs {
-  SortWs w;
-  uint32_t* spill;
-  int* spill_count;      // = counts[nb]: zeroed with the counters
-  uint32_t meff;
-};
-
-static CapWs cap_ws(void* workspace, uint32_t R, uint32_t M) {
-  CapWs c;
-  c.meff = cap_meff(M, R);
-  c.w = sort_ws(workspace, R, c.meff);
-  c.spill = reinterpret_cast<uint32_t*>(c.w.epos + 12ull * c.meff);
-  c.spill_count = c.w.counts + c.w.nb;
-  return c;
 }
 
 // Where the tile lists lie inside the workspace, in int32 units: out = {number of bins (sub-bins included), index of
@@ -634,127 +511,32 @@ int tnl_plane_grad_sort_counted(const float* xyz, float bound, uint32_t M, const
 }
 
 // Part 2: one workgroup per (plane, tile) reduces the tile's sorted samples on the matrix cores.
-static int plane_grad_reduce_impl(const void* dfeat_half, const float* xyz, float bound, uint32_t M, uint32_t C, uint32_t R,
-                                  float grad_scale, float* grad_out, int channel_major, int32_t* nonfinite_flag,
-                                  const int32_t* roi_host, const void* workspace, bool capacity, void* stream) {
+int tnl_plane_grad_reduce(const void* dfeat_half, const float* xyz, float bound, uint32_t M, uint32_t C, uint32_t R,
+                          float grad_scale, float* grad_out, int channel_major, int32_t* nonfinite_flag,
+                          const int32_t* roi_host, const void* workspace, void* stream) {
   if (R % TSX != 0 || (C != 16 && C != 32 && C != 48)) return (int)hipErrorInvalidValue;
-  const uint32_t m_lay = capacity ? cap_meff(M, R) : M;     // the capacity the workspace's arrays were laid out for
-  if (capacity && m_lay == 0) return (int)hipErrorInvalidValue;
-  if ((reinterpret_cast<uintptr_t>(workspace) & 7) != 0 || !sort_matches(workspace, m_lay, R)) return (int)hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 7) != 0 || !sort_matches(workspace, M, R)) return (int)hipErrorInvalidValue;
   Roi roi;
   if (!make_roi(roi_host, 3 * C, R, roi) || (roi.rw && (!(channel_major & 1) || roi.spp != (int)C || roi.s0 != 0)))
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   const int TNX = R / TSX, TNY = R / TSY;
-  const SortWs w = sort_ws(const_cast<void*>(workspace), R, m_lay);
+  const SortWs w = sort_ws(const_cast<void*>(workspace), R, M);
   const int* offsets = w.offsets;
-  const int* fill = capacity ? w.counts : nullptr;
   const uint32_t* entries = w.entries;
   const float2* epos = w.epos;
   const _Float16* df = reinterpret_cast<const _Float16*>(dfeat_half);
   const int ntiles = roi.rw ? 3 * (roi.rw / TSX) * (roi.rh / TSY) : w.nb / BIN_SUBS;
   if (C == 16)
     hipLaunchKernelGGL(k_tile_accumulate<16>, dim3(ntiles), dim3(NT), 0, st, df, M, xyz, bound, (int)R, TNX, TNY,
-                       offsets, entries, epos, grad_scale, grad_out, channel_major, nonfinite_flag, roi, fill);
+                       offsets, entries, epos, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   else if (C == 32)
     hipLaunchKernelGGL(k_tile_accumulate<32>, dim3(ntiles), dim3(NT), 0, st, df, M, xyz, bound, (int)R, TNX, TNY,
-                       offsets, entries, epos, grad_scale, grad_out, channel_major, nonfinite_flag, roi, fill);
+                       offsets, entries, epos, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   else
     hipLaunchKernelGGL(k_tile_accumulate<48>, dim3(ntiles), dim3(NT), 0, st, df, M, xyz, bound, (int)R, TNX, TNY,
-                       offsets, entries, epos, grad_scale, grad_out, channel_major, nonfinite_flag, roi, fill);
-  if (capacity) {
-    // the entries that did not fit their span (none, for batches like the one the table was built from): behind the tile
-    // kernel, which has written every tile; a launch of 256 workgroups that ends at once when the list is empty
-    if (channel_major & 2) return (int)hipErrorInvalidValue;     // (skipped tiles of a pre-zeroed output: not with spills)
-    const CapWs c = cap_ws(const_cast<void*>(workspace), R, M);
-    const uint32_t spill_cap = 12u * M;
-    if (C == 16)
-      hipLaunchKernelGGL(k_spill_scatter<16>, dim3(256), dim3(256), 0, st, df, M, xyz, bound, (int)R, TNX, TNY, c.spill,
-                         c.spill_count, spill_cap, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
-    else if (C == 32)
-      hipLaunchKernelGGL(k_spill_scatter<32>, dim3(256), dim3(256), 0, st, df, M, xyz, bound, (int)R, TNX, TNY, c.spill,
-                         c.spill_count, spill_cap, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
-    else
-      hipLaunchKernelGGL(k_spill_scatter<48>, dim3(256), dim3(256), 0, st, df, M, xyz, bound, (int)R, TNX, TNY, c.spill,
-                         c.spill_count, spill_cap, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
-  }
+                       offsets, entries, epos, grad_scale, grad_out, channel_major, nonfinite_flag, roi);
   return (int)hipGetLastError();
-}
-
-int tnl_plane_grad_reduce(const void* dfeat_half, const float* xyz, float bound, uint32_t M, uint32_t C, uint32_t R,
-                          float grad_scale, float* grad_out, int channel_major, int32_t* nonfinite_flag,
-                          const int32_t* roi_host, const void* workspace, void* stream) {
-  return plane_grad_reduce_impl(dfeat_half, xyz, bound, M, C, R, grad_scale, grad_out, channel_major, nonfinite_flag, roi_host,
-                                workspace, false, stream);
-}
-
-int tnl_plane_grad_reduce_capacity(const void* dfeat_half, const float* xyz, float bound, uint32_t M, uint32_t C, uint32_t R,
-                                   float grad_scale, float* grad_out, int channel_major, int32_t* nonfinite_flag,
-                                   const int32_t* roi_host, const void* workspace, void* stream) {
-  return plane_grad_reduce_impl(dfeat_half, xyz, bound, M, C, R, grad_scale, grad_out, channel_major, nonfinite_flag, roi_host,
-                                workspace, true, stream);
-}
-
-// ---- capacity lists: host side ---------------------------------------------------------------------------------------------
-uint64_t tnl_plane_grad_capacity_workspace(uint32_t M, uint32_t R) {
-  const uint32_t meff = R % TSX == 0 ? cap_meff(M, R) : 0;
-  if (meff == 0) return 0;
-  return tnl_plane_grad_binned_workspace(meff, R) + 12ull * M * 4 + 16;
-}
-
-// words of a capacity table (device int32): [caps nb + 1][offsets nb + 1][cursor scratch nb + 1][block totals]
-uint32_t tnl_plane_grad_capacity_table_words(uint32_t R) {
-  if (R % TSX != 0) return 0;
-  const SortWs w = sort_ws(nullptr, R, 0);
-  return (uint32_t)(3 * (w.nb + 1) + w.nblk + 8);
-}
-
-// counted_workspace: a sort workspace whose per-bin counts are in place (after tnl_plane_grad_sort*, or after
-// tnl_march_rays_train_binned); table: tnl_plane_grad_capacity_table_words(R) ints.  The spans are sized from those
-// counts for batches of up to M samples (the capacity workspaces' M).
-int tnl_plane_grad_capacity_build(const void* counted_workspace, uint32_t R, uint32_t M, int32_t* table, void* stream) {
-  if (R % TSX != 0 || counted_workspace == nullptr || table == nullptr) return (int)hipErrorInvalidValue;
-  const uint32_t meff = cap_meff(M, R);
-  if (meff == 0 || 12ull * meff > 0x7fffffffull) return (int)hipErrorInvalidValue;
-  hipStream_t st = (hipStream_t)stream;
-  const SortWs src = sort_ws(const_cast<void*>(counted_workspace), R, 0);
-  const int nb = src.nb, nblk = src.nblk;
-  int* caps = table;
-  int* offsets = caps + nb + 1;
-  int* cursor = offsets + nb + 1;
-  int* block_tot = cursor + nb + 1;
-  hipLaunchKernelGGL(k_capacity, dim3(cdiv(nb, 256)), dim3(256), 0, st, src.counts, nb, caps);
-  hipLaunchKernelGGL(k_scan_local, dim3(nblk), dim3(256), 0, st, caps, nb, offsets, block_tot);
-  hipLaunchKernelGGL(k_scan_fix, dim3(nblk), dim3(256), 0, st, nb, nblk, block_tot, offsets, cursor);
-  hipLaunchKernelGGL(k_clamp_offsets, dim3(cdiv(nb + 1, 256)), dim3(256), 0, st, offsets, nb + 1, (int)(12ull * meff));
-  return (int)hipGetLastError();
-}
-
-// What a march in capacity mode needs from scatter.hip (raymarch.hip calls it): zeroed counters + spill count, the table's
-// offsets copied into the workspace (the reduce then needs the workspace alone), and the arrays' addresses.
-int tnl_capacity_lists_begin(void* workspace, uint32_t R, uint32_t M, const int32_t* table, int** fill, const int** cap_off,
-                             uint32_t** entries, void** epos, uint32_t** spill, int** spill_count, void* stream) {
-  if (R % TSX != 0 || workspace == nullptr || table == nullptr || (reinterpret_cast<uintptr_t>(workspace) & 7) != 0)
-    return (int)hipErrorInvalidValue;
-  const CapWs c = cap_ws(workspace, R, M);
-  if (c.meff == 0) return (int)hipErrorInvalidValue;
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(c.w.counts, 0, (size_t)(c.w.nb + 1) * sizeof(int), st);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemcpyAsync(c.w.offsets, table + c.w.nb + 1, (size_t)(c.w.nb + 1) * sizeof(int), hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) return (int)e;
-  note_sort(workspace, c.meff, R);
-  *fill = c.w.counts; *cap_off = c.w.offsets; *entries = c.w.entries; *epos = c.w.epos; *spill = c.spill;
-  *spill_count = c.spill_count;
-  return 0;
-}
-
-// the spill counter of a capacity workspace (device int32), for reports and tests
-int tnl_plane_grad_capacity_spill_index(uint32_t M, uint32_t R, int64_t* out) {
-  if (R % TSX != 0 || out == nullptr) return (int)hipErrorInvalidValue;
-  const SortWs w = sort_ws(nullptr, R, 0);
-  out[0] = w.nb;      // int32 index of the spill counter inside the workspace
-  return 0;
 }
 
 int tnl_plane_grad_binned_roi(const void* dfeat_half, const float* xyz, float bound, uint32_t M,

@@ -252,32 +252,6 @@ def plane_grad_sort_workspace(M, R, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
-def plane_grad_capacity_workspace(M, R, device):
-    """Per-batch workspace of the one-pass tile lists for M samples (uninitialised): lists + spill list."""
-    nbytes = L.lib().tnl_plane_grad_capacity_workspace(L.u32(M), L.u32(R))
-    if nbytes == 0:
-        raise NotImplementedError("capacity tile lists need plane_resolution % 32 == 0")
-    return torch.empty(nbytes, dtype=torch.uint8, device=device)
-
-
-def plane_grad_capacity_table(counted_ws, R, M, table=None):
-    """Span table of the one-pass tile lists from the per-bin counts a sort (plane_grad_sort / plane_grad_sort_counted /
-    march_rays_train(..., sort=(R, ws))) left in `counted_ws`; for capacity workspaces of M samples.  Reuses `table`."""
-    words = L.lib().tnl_plane_grad_capacity_table_words(L.u32(R))
-    if table is None or table.numel() != words:
-        table = torch.empty(words, dtype=torch.int32, device=counted_ws.device)
-    L.check(L.lib().tnl_plane_grad_capacity_build(L.ptr(counted_ws), L.u32(R), L.u32(M), L.ptr(table), L.stream()),
-            "plane_grad_capacity_build")
-    return table
-
-
-def plane_grad_capacity_spilled(ws, M, R):
-    """Device int32 view of a capacity workspace's spill counter (entries that did not fit their span)."""
-    lay = (C.c_int64 * 1)()
-    L.check(L.lib().tnl_plane_grad_capacity_spill_index(L.u32(M), L.u32(R), lay), "plane_grad_capacity_spill_index")
-    return ws.view(torch.int32)[int(lay[0]):int(lay[0]) + 1]
-
-
 def plane_grad_sort_counted(ws, xyz, bound, R, m_actual=None):
     """plane_grad_sort whose counting pass was done by march_rays_train(..., sort=(R, ws)): scan + fill."""
     L.check(L.lib().tnl_plane_grad_sort_counted(L.ptr(xyz), L.f32(bound), L.u32(xyz.shape[0]), L.ptr(m_actual), L.u32(R),
@@ -286,16 +260,14 @@ def plane_grad_sort_counted(ws, xyz, bound, R, m_actual=None):
 
 
 def plane_grad_reduce(ws, dfeat, xyz, bound, C, R, grad_out, grad_scale=1.0, channel_major=False, nonfinite_flag=None,
-                      roi=None, prezeroed=False, roi_in_place=False, capacity=False):
+                      roi=None, prezeroed=False, roi_in_place=False):
     """Second half: per-tile matrix-core reduction of dfeat over the sorted samples in `ws` (prezeroed / roi_in_place as
-    in plane_grad_binned).  capacity: `ws` is a capacity workspace filled by march_rays_train(..., sort=(R, ws, table));
-    its spilled entries are added behind the tile kernel."""
+    in plane_grad_binned)."""
     layout = int(channel_major) | (2 if prezeroed else 0) | (4 if (roi_in_place and roi is not None) else 0)
-    fn = L.lib().tnl_plane_grad_reduce_capacity if capacity else L.lib().tnl_plane_grad_reduce
-    L.check(fn(L.ptr(dfeat), L.ptr(xyz), L.f32(bound), L.u32(xyz.shape[0]), L.u32(C), L.u32(R),
-               L.f32(grad_scale), L.ptr(grad_out), L.i32(layout),
-               L.ptr(nonfinite_flag), L.roi_array(roi), L.ptr(ws), L.stream()),
-            "plane_grad_reduce_capacity" if capacity else "plane_grad_reduce")
+    L.check(L.lib().tnl_plane_grad_reduce(L.ptr(dfeat), L.ptr(xyz), L.f32(bound), L.u32(xyz.shape[0]), L.u32(C), L.u32(R),
+                                          L.f32(grad_scale), L.ptr(grad_out), L.i32(layout),
+                                          L.ptr(nonfinite_flag), L.roi_array(roi), L.ptr(ws), L.stream()),
+            "plane_grad_reduce")
     return grad_out
 
 

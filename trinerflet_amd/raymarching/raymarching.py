@@ -156,11 +156,6 @@ class _march_rays_train(Function):
                 L.ptr(deltas), L.ptr(rays), L.ptr(step_counter), L.ptr(noises), L.ptr(ws), L.u32(nws))
         if sort is None:
             L.check(lib.tnl_march_rays_train(*args, L.stream()), "march_rays_train")
-        elif len(sort) > 2 and sort[2] is not None:
-            # capacity lists: sort = (R, capacity workspace, table) -- the tile lists are written in this call, nothing
-            # of the tile sort follows (include/trinerflet_hip.h "One-pass tile lists")
-            L.check(lib.tnl_march_rays_train_capacity(*args, L.u32(sort[0]), L.ptr(sort[1]), L.ptr(sort[2]), L.stream()),
-                    "march_rays_train_capacity")
         else:
             L.check(lib.tnl_march_rays_train_binned(*args, L.u32(sort[0]), L.ptr(sort[1]), L.stream()),
                     "march_rays_train_binned")

@@ -243,20 +243,6 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
         # 2^27 coefficients
         n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
         self.side_caps = (2 * n_cu, n_cu) if 3 * self.C * self.R * self.R >= (1 << 27) else (0, 0)
-        # capacity_lists (round 6, "one-pass tile lists"; include/trinerflet_hip.h): between two grid refreshes the batches are
-        # i.i.d. draws through one occupancy grid, so the list lengths of the period's first batch (whose march runs in
-        # order, with the counting sort) size fixed spans for the following ones; their prefetched march then writes the
-        # tile lists while it writes the samples -- the sort's scan and second pass over the samples (0.55 ms of the side
-        # chain at base, which was within 0.1 ms of being the step's critical path) are not launched.  Entries that find
-        # their span full spill and are added with float atomics behind the tile kernel (exact either way).  Off with
-        # deterministic=True (the ordered lists need the contiguous form) and with graph=True.
-        env = __import__("os").environ.get("TNL_CAPACITY_LISTS")
-        self.capacity_lists = bool(int(env)) if env is not None else False
-        self._cap_table = None      # device int32 span table (F_.plane_grad_capacity_table)
-        self._cap_key = None        # (sample capacity, rays per batch) the table was built for; None: to be rebuilt
-        self._cap_ready = None      # event behind the table's construction
-        self.capacity_marches = 0   # counters for reports / tests
-        self.capacity_tables = 0
         self.post_refresh = None    # optional callable run right after every density-grid refresh
         self.section_events = None  # set to [] to record HIP events (on the launch stream) around every stage
         # distributed
@@ -377,7 +363,6 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
             if self.post_refresh is not None:
                 self.post_refresh()
             self._occ_box = None            # the bitfield changed: the march's far clip is rebuilt on first use
-            self._cap_key = None            # ... and the tile lists' spans come from this period's first batch
             if self.use_roi:
                 self._request_roi()         # read where the window is first needed (_stage_backward): no host stall here
                 self._roi_valid = True
@@ -480,8 +465,7 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
             bands = self._exchange_bands(st.roi)
             if bands is None:
                 F_.plane_grad_reduce(st.sort_ws, dfeat, st.xyzs, float(model.bound), C, R, st.g_cm, channel_major=True,
-                                     nonfinite_flag=self.nonfinite, roi=self._roi10() if st.roi is not None else None,
-                                     capacity=getattr(st.sort_ws, "_tnl_capacity", False))
+                                     nonfinite_flag=self.nonfinite, roi=self._roi10() if st.roi is not None else None)
             else:
                 # band b: tile reduction of its rows on the launch stream, then its reduce-scatter on the communication
                 # stream (RCCL: behind an event) while band b + 1 is being reduced
@@ -495,8 +479,7 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
                     sub[3:6] = [oy + y0 for oy in st.roi[3:6]]
                     sub[7] = hb
                     F_.plane_grad_reduce(st.sort_ws, dfeat, st.xyzs, float(model.bound), C, R, buf, channel_major=True,
-                                         nonfinite_flag=self.nonfinite, roi=sub + [C, 0],
-                                         capacity=getattr(st.sort_ws, "_tnl_capacity", False))
+                                         nonfinite_flag=self.nonfinite, roi=sub + [C, 0])
                     self._comm.wait_stream(main)
                     with torch.cuda.stream(self._comm):
                         part, wait = D.reduce_scatter_slices_async(buf, self.pg if self.multi else None, self.grad_transport)
