@@ -6,6 +6,10 @@
 // `#pragma clang fp contract(off)`, so the header can be included in a translation unit that is otherwise compiled with
 // the default contraction (render.hip: its field part must match field.hip's).
 #pragma once
+#ifndef TNL_CHAIN_JUMP
+#define TNL_CHAIN_JUMP 1     // 0: the empty-cell skip walks its chain of adds (the form of rounds 1-5), for A/B
+#endif
+#include "chain_skip.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -156,7 +160,11 @@ __device__ __forceinline__ void march_skip(const MarchCtx& m, const MarchProbe& 
 #pragma clang fp contract(off)
   const float tt = march_skip_target(m, q, t);
   if (m.fast) {
+#if TNL_CHAIN_JUMP
+    t = chain_skip_or_walk(t, m.dt0, tt);   // the loop below, long chains without walking them (chain_skip.h)
+#else
     do { t += m.dt0; } while (t < tt);
+#endif
   } else {
     do {
       t += clampf_(t * m.dt_gamma, m.dt_min, m.dt_max);

@@ -261,6 +261,9 @@ struct FastProbe {
 // as many memory requests as the HBM-bound adjoint beside which the pass runs issues lines.  Three values wait in
 // registers and the fourth stores a 16-byte quad (the record of a ray starts 16-byte aligned when max_steps % 4 == 0;
 // `vec` false otherwise: scalar stores); the tail of up to three goes out at the end.  The same record to the bit.
+#ifndef TNL_CHAIN_JUMP_COUNT
+#define TNL_CHAIN_JUMP_COUNT TNL_CHAIN_JUMP   // the per-lane count pass's empty-cell skip (7-14 adds per cell at max_steps 1024)
+#endif
 #ifndef TNL_MARCH_REC4
 #define TNL_MARCH_REC4 1
 #endif
@@ -324,7 +327,11 @@ __device__ __forceinline__ uint32_t march_run_fast(const MarchCtx& m, float& t, 
     const float ey = fmaf((float)(q.ny + incy) * rH2 - 1, q.mipb, -q.y) * m.rdy;
     const float ez = fmaf((float)(q.nz + incz) * rH2 - 1, q.mipb, -q.z) * m.rdz;
     const float tt = t + fmaxf(0.0f, fminf(ex, fminf(ey, ez)));
+#if TNL_CHAIN_JUMP_COUNT
+    t = chain_skip_or_walk(t, dt, tt);   // (chain_skip.h: the loop below, long chains in O(1))
+#else
     do { t += dt; } while (t < tt);
+#endif
   };
   uint32_t step = 0;
   while (t < far && step < limit) {

@@ -77,6 +77,13 @@ __device__ __forceinline__ int march_one_bounded(const MarchCtx& m, float& t, fl
       return MARCH_SAMPLE;
     }
     tt = march_skip_target(m, a, t);
+#if TNL_CHAIN_JUMP
+    if (m.fast) {            // constant step: the chain point behind the cell in O(1) (chain_skip.h), nothing to pause in
+      t = chain_skip_or_walk(t, m.dt0, tt);
+      work -= 4;
+      continue;
+    }
+#endif
     t += m.fast ? m.dt0 : clampf_(t * m.dt_gamma, m.dt_min, m.dt_max);
     skipping = true;
   }
