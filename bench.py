@@ -577,6 +577,10 @@ def compact_line(out):
     if isinstance(tj, dict):
         flat["trajectory_512_steps_ms_per_step"] = tj.get("wall_ms_per_step")
         flat["trajectory_held_out_psnr_db"] = tj.get("held_out_psnr_db")
+        it = tj.get("inference_trained")
+        if isinstance(it, dict) and "ms_per_image" in it:      # the `--test` render on the field that trajectory trained
+            flat["test_render_trained_800x800_ms"] = it["ms_per_image"]
+            flat["test_render_trained_frac_of_8_TB/s"] = it.get("frac_of_8_TB/s")
     inf = cfg.get("inference")
     if isinstance(inf, dict):
         flat["test_render_800x800_4096_steps_ms"] = inf.get("ms_per_image")

@@ -93,3 +93,32 @@ def test_fused_render_matches_reference_eval_branch(cuda, golden_dir):
     np.testing.assert_allclose(out["image"][0].cpu().numpy(), ref["infer/image"], atol=2e-3)
     np.testing.assert_allclose(out["weights_sum"].reshape(-1).cpu().numpy(), ref["infer/weights_sum"], atol=2e-3)
     np.testing.assert_allclose(out["depth"][0].cpu().numpy()[hit], ref["infer/depth"][hit], atol=2e-3)
+
+
+@pytest.mark.parametrize("C,H", [(16, 64), (48, 128)])
+def test_marching_in_bounded_pieces_changes_no_bit(cuda, C, H):
+    """tnl_render_work (round 6): a ray spends a bounded amount of marching work per trip and rides along without a sample
+    until it reaches its next one, instead of stalling the wave's other rays for its whole walk through empty cells.  The
+    probes, adds and comparisons are the unbounded march's in the same order: images, weights and depths for every budget --
+    down to one probe per trip -- are the unbounded render's to the bit (max_steps 4096: the `--test` setting, where an
+    empty cell is 28-55 chain steps; a hollow shell, so that rays also skip INSIDE the object)."""
+    from trinerflet_amd import _lib as L
+    m = _model(cuda, C=C, H=H)
+    o, d = synthetic.training_rays(20000, n_cams=6, seed=4)
+    ro, rd = torch.from_numpy(o).to(cuda)[None], torch.from_numpy(d).to(cuda)[None]
+    prev = L.lib().tnl_render_work(L.i32(-1))
+    assert prev == 96                                              # the default in force
+    outs = {}
+    try:
+        for work in (0, 8, 31, 96, 4096):
+            L.lib().tnl_render_work(L.i32(work))
+            assert L.lib().tnl_render_work(L.i32(-1)) == work
+            with torch.no_grad():
+                outs[work] = m.render(ro, rd, staged=True, bg_color=0.3, perturb=False, max_steps=4096, T_thresh=1e-4)
+    finally:
+        L.lib().tnl_render_work(L.i32(prev))
+    ws = outs[0]["weights_sum"].reshape(-1)
+    assert 0.05 < float((ws > 0.5).float().mean()) < 0.6
+    for work, out in outs.items():
+        assert torch.equal(out["image"], outs[0]["image"]) and torch.equal(out["weights_sum"], outs[0]["weights_sum"]), work
+        assert torch.equal(torch.nan_to_num(out["depth"]), torch.nan_to_num(outs[0]["depth"])), work

@@ -30,6 +30,11 @@ static inline float CHAIN_U2F(uint32_t u) { float x; memcpy(&x, &u, 4); return x
 // per-lane count pass with the jump on every cell was 5 % SLOWER at small, tools/ab_chain_jump.sh): callers use
 // chain_skip_or_walk, which walks short chains and jumps long ones -- the same float either way.
 CHAIN_HD float chain_skip(float t, float dt, float tt);
+CHAIN_HD float chain_skip_or_walk_n(float t, float dt, float tt, float walk_steps) {
+  if (tt - t > walk_steps * dt) return chain_skip(t, dt, tt);
+  do { t += dt; } while (t < tt);
+  return t;
+}
 CHAIN_HD float chain_skip_or_walk(float t, float dt, float tt) {
   if (tt - t > 16.0f * dt) return chain_skip(t, dt, tt);
   do { t += dt; } while (t < tt);

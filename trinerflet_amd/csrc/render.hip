@@ -46,6 +46,9 @@ constexpr int render_threads() { return H > 64 ? TNL_RENDER_RT128 : 256; }
 // Now a trip spends at most TNL_RENDER_WORK units per ray (a probe counts 8, a skip add 1) and a ray that has not reached
 // its next sample rides along without one and resumes next trip, its skip target kept in the ray state.  The same
 // probes, adds and comparisons in the same order: the sample sequence is march_one's to the bit.
+#ifndef TNL_RENDER_CHAIN_WALK
+#define TNL_RENDER_CHAIN_WALK 16     // skips of up to this many steps walk, longer ones jump (chain_skip.h)
+#endif
 #ifndef TNL_RENDER_WORK
 #define TNL_RENDER_WORK 96
 #endif
@@ -79,7 +82,7 @@ __device__ __forceinline__ int march_one_bounded(const MarchCtx& m, float& t, fl
     tt = march_skip_target(m, a, t);
 #if TNL_CHAIN_JUMP
     if (m.fast) {            // constant step: the chain point behind the cell in O(1) (chain_skip.h), nothing to pause in
-      t = chain_skip_or_walk(t, m.dt0, tt);
+      t = chain_skip_or_walk_n(t, m.dt0, tt, (float)TNL_RENDER_CHAIN_WALK);
       work -= 4;
       continue;
     }
