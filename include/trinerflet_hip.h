@@ -118,7 +118,7 @@ TNL_API int tnl_march_rays_train_binned(const float *rays_o, const float *rays_d
  * most two cascades, 8-byte aligned bitfield) -- 3x shorter alone (789 -> 263 us at 60 000 base rays), the form for a
  * march the caller waits for; 1: one ray per lane everywhere -- a seventh of the instructions at one wave per SIMD, the
  * form for a march that runs BESIDE other kernels on a second stream (TrainStep's prefetch of the next batch).  Same
- * outputs bit for bit.  Process-wide; returns the previous value (any other argument only queries). */
+ * outputs bit for bit.  Per host thread (thread-local); returns the previous value (any other argument only queries). */
 TNL_API int tnl_march_count_form(int form);
 
 /* Launch width of the two wide passes of a march + tile sort that is enqueued BESIDE other kernels (TrainStep's prefetch of
@@ -127,7 +127,7 @@ TNL_API int tnl_march_count_form(int form);
  * every CU's wave slots for ~0.5 ms and a main-stream launch of larger workgroups that starts meanwhile waits for slots (base
  * step: 550 us for a 190-us kernel); capped at 2 / 1 workgroups per CU they take about as long by themselves and leave the
  * slots: -0.14 ms per step.  blocks = 0 (default): uncapped, the form for work the caller waits for; < 0 only queries.
- * Process-wide; each returns the previous value.  Same outputs (the fill's order inside a tile list is unordered either way). */
+ * Per host thread; each returns the previous value.  Same outputs (the fill's order inside a tile list is unordered either way). */
 TNL_API int tnl_march_emit_cap(int blocks);
 TNL_API int tnl_plane_grad_fill_cap(int blocks);
 

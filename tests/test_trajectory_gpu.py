@@ -51,6 +51,26 @@ def test_recorded_psnr_confidence_interval(scene):
 
 
 
+def test_recorded_psnr_interval_of_the_bf16_gradient_transport():
+    """The gate of TrainStep(grad_transport="bf16") ("half with fp16/bf16 transport"):
+    profiles/r06_psnr_ci_bf16_transport.json holds, for seeds 0..23 (none left out), the held-out PSNR of the fused step
+    and of the fused step with the plane-gradient window rounded to bfloat16 before the adjoint (one process = what a
+    slice's owner receives from one rank; tools/psnr_ci.py --arm bf16_transport, base geometry, 512 steps, unordered
+    reductions).  Checked here: the file is what its runs say, and the paired difference satisfies the bar the fused step
+    itself is held to -- |mean| + 95 % half-width < 0.1 dB.  (A CPU test: it reads the recorded file.)"""
+    spec = importlib.util.spec_from_file_location("tnl_psnr_ci", os.path.join(ROOT, "tools", "psnr_ci.py"))
+    ci_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ci_mod)
+    with open(os.path.join(ROOT, "profiles", "r06_psnr_ci_bf16_transport.json")) as f:
+        rep = json.load(f)
+    runs = rep["runs"]
+    assert rep["steps"] == 512 and rep["workload"] == "base" and sorted(r["seed"] for r in runs) == list(range(24))
+    again = ci_mod.ci([r["bf16_transport_db"] - r["fp32_transport_db"] for r in runs])
+    assert again == rep["bf16_minus_fp32_transport"], (again, rep["bf16_minus_fp32_transport"])
+    assert again["abs_mean_plus_half_width_db"] < 0.1, again
+    assert min(r["bf16_transport_db"] for r in runs) > 25.0
+
+
 def _traj():
     spec = importlib.util.spec_from_file_location("tnl_trajectory", os.path.join(ROOT, "tools", "trajectory.py"))
     mod = importlib.util.module_from_spec(spec)

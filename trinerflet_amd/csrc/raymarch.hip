@@ -1463,9 +1463,11 @@ uint32_t tnl_march_rays_train_workspace_rec(uint32_t N, uint32_t max_steps) {
 }
 
 // tnl_march_count_form: 0 = the per-wavefront count pass wherever it applies, 1 = always one ray per lane
-static int g_count_form = 0;
+// (thread-local, like the emit / fill caps: a `with raymarching.count_form(...)` / `side_caps(...)` block of one host thread
+//  does not change the launches another thread makes meanwhile -- ADVICE r05)
+static thread_local int g_count_form = 0;
 // tnl_march_emit_cap: most workgroups the emit pass is launched with (0 = one wavefront per ray all at once)
-static int g_emit_cap = 0;
+static thread_local int g_emit_cap = 0;
 
 static int march_rays_train_impl(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                                  float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,

@@ -32,7 +32,7 @@
 namespace {
 
 constexpr int NT = 256;
-int g_fill_cap = 0;   // tnl_plane_grad_fill_cap: most workgroups of the sort's fill pass (0 = one thread per sample all at once)
+thread_local int g_fill_cap = 0;   // tnl_plane_grad_fill_cap: most workgroups of the sort's fill pass (0 = one thread per sample all at once)
 
 __device__ __forceinline__ uint32_t eff_m(uint32_t M, const int32_t* m_actual) {
   return m_actual ? min(M, (uint32_t)max(*m_actual, 0)) : M;

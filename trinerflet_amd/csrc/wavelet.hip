@@ -1233,12 +1233,20 @@ k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, f
   }
 }
 
-// fp16 (3,C,R,R) -> fp16 [3,R,R,C]: 16-byte loads along x, 16-byte stores along the channels
+// fp16 (3,C,R,R) -> fp16 [3,R,R,C]: 16-byte loads along x, 16-byte stores along the channels.
+// TY rows of a 64-texel segment per workgroup (round 6; the rows' loads are all issued before the barrier): with one row
+// a workgroup holds 2-4 KB in flight and the pass -- 62 000 workgroups at base -- was bound by the load latency of its ~30
+// rounds per CU (82 us for 254 MB = 3.1 TB/s); TNL_LAYOUT_ROWS = 1 restores that form.
+#ifndef TNL_LAYOUT_ROWS
+#define TNL_LAYOUT_ROWS 4
+#endif
+template <int TY>
 __global__ void __launch_bounds__(NT)
 k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __restrict__ tm, Roi roi,
                    const int* __restrict__ spans) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 tileh[];  // [C][TX + 8] + 8 halfs of shift per 8 channels
+  extern __shared__ __attribute__((aligned(16))) _Float16 tileh_all[];  // TY x ([C][TX + 8] + 8 halfs of shift per 8 channels)
   constexpr int LD = TX + 8;
+  const int row_halfs = C * LD + (C / 8) * 8;
   // row of channel c starts at c*LD + (c/8)*8: the extra 16 bytes per channel group put the four groups that one
   // transposed read touches on different banks (8*LD halfs = 288 dwords = 0 mod 32 otherwise: measured 67 % of
   // the LDS cycles were bank conflicts)
@@ -1246,30 +1254,41 @@ k_to_texel_major_h(const _Float16* __restrict__ cm, int C, int R, _Float16* __re
   // source: (3,C,R,R), or the compact ROI window [3*C][rh][rw]; destination: always the full [3,R,R,C] array
   const int p = blockIdx.z;
   const int sw = roi.rw ? roi.rw : R, shh = roi.rw ? roi.rh : R;
-  const int ys = blockIdx.y, xs0 = blockIdx.x * TX;                  // source coordinates
-  const int y = ys + (roi.rw ? roi.oy[p] : 0), x0 = xs0 + (roi.rw ? roi.ox[p] : 0);
+  const int ys0 = blockIdx.y * TY, xs0 = blockIdx.x * TX;            // source coordinates (TY rows: one 8-row group of the spans)
+  const int y0 = ys0 + (roi.rw ? roi.oy[p] : 0), x0 = xs0 + (roi.rw ? roi.ox[p] : 0);
   if (spans != nullptr) {     // [3][R / 8][2]: texel columns of this row group any sample can read
-    const int lo = spans[(p * (R >> 3) + (y >> 3)) * 2], hi = spans[(p * (R >> 3) + (y >> 3)) * 2 + 1];
+    const int lo = spans[(p * (R >> 3) + (y0 >> 3)) * 2], hi = spans[(p * (R >> 3) + (y0 >> 3)) * 2 + 1];
     if (!(lo < x0 + TX && hi > x0)) return;
   }
-  for (int idx = threadIdx.x; idx < C * (TX / 8); idx += NT) {
-    const int c = idx / (TX / 8), x8 = (idx - c * (TX / 8)) * 8;
-    h8 v;
 #pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = (_Float16)0.f;
-    if (xs0 + x8 < sw) v = *reinterpret_cast<const h8*>(cm + (((size_t)p * C + c) * shh + ys) * sw + xs0 + x8);
-    *reinterpret_cast<h8*>(&tileh[c * LD + (c >> 3) * 8 + x8]) = v;
-  }
-  __syncthreads();
-  const size_t base = (((size_t)p * R + y) * R + x0) * C;
-  const int CG = C / 8;
-  for (int idx = threadIdx.x; idx < TX * CG; idx += NT) {
-    const int xx = idx / CG, cg = idx - xx * CG;
-    if (x0 + xx < R) {
+  for (int ry = 0; ry < TY; ry++) {
+    _Float16* tileh = tileh_all + (size_t)ry * row_halfs;
+    const int ys = ys0 + ry;
+    for (int idx = threadIdx.x; idx < C * (TX / 8); idx += NT) {
+      const int c = idx / (TX / 8), x8 = (idx - c * (TX / 8)) * 8;
       h8 v;
 #pragma unroll
-      for (int j = 0; j < 8; j++) v[j] = tileh[(cg * 8 + j) * LD + cg * 8 + xx];
-      *reinterpret_cast<h8*>(tm + base + (size_t)xx * C + cg * 8) = v;
+      for (int i = 0; i < 8; i++) v[i] = (_Float16)0.f;
+      if (xs0 + x8 < sw && ys < shh) v = *reinterpret_cast<const h8*>(cm + (((size_t)p * C + c) * shh + ys) * sw + xs0 + x8);
+      *reinterpret_cast<h8*>(&tileh[c * LD + (c >> 3) * 8 + x8]) = v;
+    }
+  }
+  __syncthreads();
+  const int CG = C / 8;
+#pragma unroll
+  for (int ry = 0; ry < TY; ry++) {
+    const _Float16* tileh = tileh_all + (size_t)ry * row_halfs;
+    const int y = y0 + ry;
+    if (ys0 + ry >= shh) break;
+    const size_t base = (((size_t)p * R + y) * R + x0) * C;
+    for (int idx = threadIdx.x; idx < TX * CG; idx += NT) {
+      const int xx = idx / CG, cg = idx - xx * CG;
+      if (x0 + xx < R) {
+        h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = tileh[(cg * 8 + j) * LD + cg * 8 + xx];
+        *reinterpret_cast<h8*>(tm + base + (size_t)xx * C + cg * 8) = v;
+      }
     }
   }
 }
@@ -1618,9 +1637,13 @@ static int planes_half_to_tm(const void* planes_cm_half, uint32_t C, uint32_t R,
   Roi roi;
   if (!make_roi(roi_host, 3 * C, R, roi) || (roi.rw && (roi.spp != (int)C || roi.s0 != 0)))
     return (int)hipErrorInvalidValue;
-  const dim3 grid = roi.rw ? dim3(roi.rw / TX, roi.rh, 3) : dim3(cdiv(R, TX), R, 3);
-  const size_t lds = ((size_t)C * (TX + 8) + (C / 8) * 8) * sizeof(_Float16);
-  hipLaunchKernelGGL(k_to_texel_major_h, grid, dim3(NT), lds, (hipStream_t)stream,
+  // (R % 8 == 0 and window rows in multiples of 64: TY = 4 rows never straddle an 8-row group of the spans)
+  constexpr int TY = TNL_LAYOUT_ROWS;
+  static_assert(TY == 1 || TY == 2 || TY == 4 || TY == 8, "rows per workgroup must divide the spans' 8-row groups");
+  const uint32_t rows = roi.rw ? (uint32_t)roi.rh : R;
+  const dim3 grid = roi.rw ? dim3(roi.rw / TX, cdiv(rows, TY), 3) : dim3(cdiv(R, TX), cdiv(rows, TY), 3);
+  const size_t lds = (size_t)TY * ((size_t)C * (TX + 8) + (C / 8) * 8) * sizeof(_Float16);
+  hipLaunchKernelGGL(k_to_texel_major_h<TY>, grid, dim3(NT), lds, (hipStream_t)stream,
                      reinterpret_cast<const _Float16*>(planes_cm_half), (int)C, (int)R,
                      reinterpret_cast<_Float16*>(planes_tm_half), roi, roi.rw ? spans : nullptr);
   return (int)hipGetLastError();

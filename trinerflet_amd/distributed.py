@@ -16,8 +16,23 @@ import torch.distributed as dist
 FORCE_COLLECTIVES = False
 
 
-def _alone(world):
-    return world == 1 and not (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
+# ... or, scoped to the groups that asked for it (TrainStep(single_rank_collectives=True) registers ITS process group:
+# another TrainStep or model in the same process keeps the short cut): see force_collectives()
+_FORCED_GROUPS = set()
+
+
+def _group_key(pg):
+    return "default" if pg is None else id(pg)
+
+
+def force_collectives(pg=None, on=True):
+    """A process group of one rank issues every collective of this module (on=True) or takes the identity short cut again."""
+    (_FORCED_GROUPS.add if on else _FORCED_GROUPS.discard)(_group_key(pg))
+
+
+def _alone(world, pg=None):
+    forced = FORCE_COLLECTIVES or _group_key(pg) in _FORCED_GROUPS
+    return world == 1 and not (forced and dist.is_available() and dist.is_initialized())
 
 
 def world_rank(pg=None):
@@ -131,9 +146,9 @@ def reduce_scatter_slices(full, pg=None, transport="fp32"):
     """full: [S, ...] on every rank -> sum over ranks of the caller's block [S/G, ...].  transport "bf16": see
     _reduce_scatter_bf16 (a lone rank rounds its own contribution the same way: what a world of one would exchange)."""
     world, rank = world_rank(pg)
-    if transport == "bf16" and (world > 1 or not _alone(world)):
+    if transport == "bf16" and (world > 1 or not _alone(world, pg)):
         return _reduce_scatter_bf16(full, pg, world, rank)
-    if _alone(world):
+    if _alone(world, pg):
         return full
     s0, s1 = slice_range(full.shape[0], world, rank)
     if _native(pg):
@@ -150,7 +165,7 @@ def reduce_scatter_slices_async(full, pg=None, transport="fp32"):
     group's own stream behind the work already queued on the CURRENT stream -- and wait() makes the stream current at
     that time wait for it.  gloo (the CPU-testable transport) completes inside this call; wait() is then a no-op."""
     world, rank = world_rank(pg)
-    if transport == "bf16" and (world > 1 or not _alone(world)):
+    if transport == "bf16" and (world > 1 or not _alone(world, pg)):
         if _native(pg):
             s0, s1 = slice_range(full.shape[0], world, rank)
             half = full.to(torch.bfloat16).contiguous()
@@ -164,7 +179,7 @@ def reduce_scatter_slices_async(full, pg=None, transport="fp32"):
             box["out"] = torch.empty((s1 - s0, *full.shape[1:]), dtype=torch.float32, device=full.device)
             return box["out"], wait
         return _reduce_scatter_bf16(full, pg, world, rank), (lambda: None)
-    if _alone(world):
+    if _alone(world, pg):
         return full, (lambda: None)
     if _native(pg):
         s0, s1 = slice_range(full.shape[0], world, rank)
@@ -177,7 +192,7 @@ def reduce_scatter_slices_async(full, pg=None, transport="fp32"):
 def all_gather_slices(mine, pg=None):
     """mine: [S/G, ...] -> [S, ...] in rank order."""
     world, _ = world_rank(pg)
-    if _alone(world):
+    if _alone(world, pg):
         return mine
     mine = mine.contiguous()
     if _native(pg):
@@ -191,6 +206,6 @@ def all_gather_slices(mine, pg=None):
 
 def all_reduce_(t, pg=None, op=None):
     world, _ = world_rank(pg)
-    if not _alone(world):
+    if not _alone(world, pg):
         dist.all_reduce(t, op=op or dist.ReduceOp.SUM, group=pg)
     return t

@@ -173,7 +173,7 @@ march_rays_train = _march_rays_train.apply
 class count_form:
     """with raymarching.count_form(1): ... -- the count pass of march_rays_train inside the block walks one ray per lane
     (tnl_march_count_form: the small-footprint form for a march enqueued beside other kernels); 0 = the default, one
-    wavefront per ray.  Process-wide switch of the library, restored on exit."""
+    wavefront per ray.  A switch of the library for the calling host thread, restored on exit."""
 
     def __init__(self, form):
         self.form = int(form)
@@ -190,7 +190,7 @@ class count_form:
 class side_caps:
     """with raymarching.side_caps(emit_blocks, fill_blocks): ... -- the emit pass of march_rays_train and the fill pass of
     the plane-gradient tile sort launched inside the block keep to that many workgroups (tnl_march_emit_cap,
-    tnl_plane_grad_fill_cap; 0 = full width): for work enqueued beside other kernels.  Process-wide, restored on exit."""
+    tnl_plane_grad_fill_cap; 0 = full width): for work enqueued beside other kernels.  Per host thread, restored on exit."""
 
     def __init__(self, emit_blocks, fill_blocks):
         self.caps = (int(emit_blocks), int(fill_blocks))

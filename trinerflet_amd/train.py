@@ -243,6 +243,8 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
         # 2^27 coefficients
         n_cu = torch.cuda.get_device_properties(self.dev).multi_processor_count if torch.cuda.is_available() else 256
         self.side_caps = (2 * n_cu, n_cu) if 3 * self.C * self.R * self.R >= (1 << 27) else (0, 0)
+        if __import__("os").environ.get("TNL_SIDE_CAPS"):            # A/B knob: "emit,fill" workgroups (tools/ab_small.sh)
+            self.side_caps = tuple(int(v) for v in __import__("os").environ["TNL_SIDE_CAPS"].split(","))
         self.post_refresh = None    # optional callable run right after every density-grid refresh
         self.section_events = None  # set to [] to record HIP events (on the launch stream) around every stage
         # distributed
@@ -261,7 +263,9 @@ class TrainStep(WindowMixin, PlanesMixin, OptimiserMixin, PrefetchMixin, GraphMi
         # all_reduce over the group): the way to execute the 8-GPU call sequence on a one-GPU box (tests/test_dist_gpu.py)
         self.multi = self.world > 1 or bool(single_rank_collectives and dist_mode and dist.is_initialized())
         if self.multi and self.world == 1:
-            D.FORCE_COLLECTIVES = True
+            D.force_collectives(process_group)       # scoped to this step's group (not the module-wide switch)
+            import weakref
+            weakref.finalize(self, D.force_collectives, process_group, False)
         self.dist_mode = dist_mode if self.multi else None
         if self.dist_mode == "sharded":
             assert (3 * self.C) % self.world == 0, "3*channels must be divisible by the world size"
