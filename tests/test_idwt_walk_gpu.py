@@ -108,8 +108,9 @@ def test_window_entry_points_on_walk_kernels(cuda, walk, wave):
 def test_support_chain_on_walk_kernels(cuda, walk):
     from tests import test_roi_gpu as troi
     troi.test_support_chain_adjoint_and_rect_adam_match_dense(cuda)
-    troi.test_windowed_rebuild_equals_full_rebuild_inside_the_window(cuda)
-    troi.test_training_with_window_equals_whole_plane_training(cuda)
+    for plane_dtype in (torch.float16, torch.float32):
+        troi.test_windowed_rebuild_equals_full_rebuild_inside_the_window(cuda, plane_dtype)
+        troi.test_training_with_window_equals_whole_plane_training(cuda, plane_dtype)
 
 
 @pytest.mark.parametrize("wave", ["bior6.8", "bior4.4", "haar"])
