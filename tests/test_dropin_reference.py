@@ -202,3 +202,37 @@ def test_reference_wrappers_bind_native_names_unchanged():
     assert "_raymarching ['composite_rays', 'composite_rays_train_backward', 'composite_rays_train_forward', " \
            "'march_rays', 'march_rays_train', 'morton3D', 'morton3D_invert', 'near_far_from_aabb', 'packbits', " \
            "'sph_from_ray']" in out
+
+
+def test_ff_switch_constructs_the_reference_shapes_and_its_initial_weights(tmp_path):
+    """`--ff` (main_nerf.py:31-34: `from nerf.network_ff import NeRFNetwork`, network_ff.py:7 `from ffmlp import FFMLP`).
+    After install_dropin() both names resolve to this build.  Pinned against the reference's OWN aux_libs/ffmlp/ffmlp.py,
+    imported here with its CUDA backend replaced by an empty stand-in (only `allocate_splitk` is touched at construction):
+    the same parameter count, state-dict key, repr, and -- the initialisation is `manual_seed(42)` + uniform on the host --
+    the same initial weights to the bit, for both networks of the `--ff` model."""
+    out = _run(textwrap.dedent("""
+        import importlib.util, torch
+        import ffmlp, nerf.network_ff as nff
+        assert "/trinerflet_amd/" in ffmlp.__file__ and "/trinerflet_amd/" in nff.__file__
+        # the reference's module, backend stubbed
+        be = types.ModuleType("_ffmlp"); be.allocate_splitk = lambda n: None; be.free_splitk = lambda: None
+        sys.modules["_ffmlp"] = be
+        tu = types.ModuleType("turtle"); tu.backward = tu.forward = None      # ffmlp.py:2 (a stray import; needs tkinter)
+        sys.modules["turtle"] = tu
+        spec = importlib.util.spec_from_file_location("ref_ffmlp", "/root/reference/aux_libs/ffmlp/ffmlp.py")
+        ref = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref)
+        for args in ((48, 16, 64, 2), (32, 3, 64, 3), (144, 16, 128, 2), (32, 3, 128, 3)):
+            a, b = ref.FFMLP(*args), ffmlp.FFMLP(*args)
+            assert a.num_parameters == b.num_parameters and repr(a) == repr(b), (repr(a), repr(b))
+            assert list(a.state_dict()) == list(b.state_dict()) == ["weights"]
+            assert torch.equal(a.weights.detach(), b.weights.detach())
+            assert (a.padded_output_dim, a.activation, a.output_activation) == (b.padded_output_dim, b.activation, b.output_activation)
+        m = nff.NeRFNetwork(encoding="triplane_wavelet", bound=1.5, cuda_ray=True, density_scale=1, min_near=0.2,
+                            density_thresh=10, bg_radius=-1, triplane_channels=16, triplane_resolution=64,
+                            triplane_wavelet_levels=1, wavelet_type="bior6.8", hidden_dim=64, hidden_dim_color=64)
+        keys = set(m.state_dict())
+        assert {"sigma_net.weights", "color_net.weights", "encoder.planes_features", "density_grid", "density_bitfield"} <= keys
+        assert m.in_dim == 48 and m.in_dim_color == 32 and len(m.get_params(1e-2)) == 4
+        print("FF_OK")
+    """))
+    assert "FF_OK" in out

@@ -13,7 +13,7 @@ import sys
 
 __version__ = "0.2.0"
 
-_TOP = ("raymarching", "shencoder", "triplaneencoder", "encoding", "activation")
+_TOP = ("raymarching", "shencoder", "triplaneencoder", "encoding", "activation", "ffmlp")
 _BACKENDS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "backends")
 
 
@@ -28,8 +28,8 @@ def install_dropin(windowed_autograd=True, fused_adam=False):
     """Register the MI355X build under the reference's top-level names (main_nerf.py:15-16 puts aux_libs/ on sys.path
     and reconstruction/ is the script directory):
 
-      raymarching, shencoder, triplaneencoder[.triplane_encoder], encoding, activation  -> trinerflet_amd.<name>
-      nerf.network, nerf.renderer                                                       -> trinerflet_amd.nerf.<name>
+      raymarching, shencoder, triplaneencoder[.triplane_encoder], encoding, activation, ffmlp  -> trinerflet_amd.<name>
+      nerf.network, nerf.renderer, nerf.network_ff (the `--ff` switch)                        -> trinerflet_amd.nerf.<name>
 
     The reference's `nerf` package itself is NOT replaced: `nerf.provider`, `nerf.utils` (its Trainer), ... keep
     coming from reconstruction/nerf/ -- only the two hot-path modules inside it are overridden.  When no `nerf` package
@@ -61,7 +61,7 @@ def install_dropin(windowed_autograd=True, fused_adam=False):
             pkg = None
     if pkg is None or not hasattr(pkg, "__path__"):
         pkg = sys.modules["nerf"] = ours
-    for sub in ("network", "renderer"):
+    for sub in ("network", "renderer", "network_ff"):
         mod = importlib.import_module(f"trinerflet_amd.nerf.{sub}")
         sys.modules[f"nerf.{sub}"] = mod
         setattr(pkg, sub, mod)
