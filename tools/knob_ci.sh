@@ -36,7 +36,6 @@ run "-DTNL_FWD_PAIR=4" "$IDWT"
 run "-DTNL_BWD_WALK_WAVES=3" "$IDWT tests/test_adam_deferred_gpu.py"
 run "-DTNL_MARCH_NZ_FILTER=0" "$MARCH tests/test_flag_matrix_gpu.py"
 # round 6
-run "-DTNL_ADAM_REPLAY_FAST=0" "$ADAM tests/test_live_adam_gpu.py"
 run "-DTNL_LAYOUT_ROWS=1" "$IDWT tests/test_triplane_gpu.py"
 run "-DTNL_CHAIN_JUMP=0" "$MARCH tests/test_render_fused_gpu.py tests/test_renderer_gpu.py"
 run "-DTNL_CHAIN_JUMP_COUNT=0" "$MARCH"

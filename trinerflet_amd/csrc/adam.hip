@@ -418,9 +418,6 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
 // the live rectangle; abs_sums[r] += sum |p| as step r saw it (the L1 value's deferred share).  ALU-bound (count x two
 // divisions and a square root per coefficient against 24 bytes): two float4 per thread are in flight, the record loop
 // is a real loop (one scalar load per record and 8 coefficients), the per-record |p| sums live in per-thread LDS slots.
-#ifndef TNL_ADAM_REPLAY_FAST
-#define TNL_ADAM_REPLAY_FAST 1   // 0: the replay calls adam1 with g_in = 0 (the form of round 5), for A/B
-#endif
 __global__ void __launch_bounds__(256)
 k_adam_l1_catchup(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, uint64_t n, AdamArgs a,
                   const AdamStepRec* __restrict__ ring, int count, float* __restrict__ abs_sums, AdamRect live,
@@ -477,18 +474,9 @@ k_adam_l1_catchup(float* __restrict__ p, float* __restrict__ m, float* __restric
       a.step_size = rec.step_size;
       a.bias2_sqrt = rec.bias2_sqrt;
       a.l1_coef = l1_base + rec.pad;                        // (pad: a folded L1 coefficient of that step, else 0)
-      if (TNL_ADAM_REPLAY_FAST && a.l1_coef > 0.f && a.inv_scale == 1.0f) {       // uniform per record
-        float gg;
-        {
-#pragma clang fp contract(off)
-          gg = a.omb2 * a.l1_coef * a.l1_coef;              // adam1's `a.omb2 * g * g` for |g| = l1
-        }
-        adam1_replay(pi.x, mi.x, vi.x, a, gg); adam1_replay(pi.y, mi.y, vi.y, a, gg);
-        adam1_replay(pi.z, mi.z, vi.z, a, gg); adam1_replay(pi.w, mi.w, vi.w, a, gg);
-        adam1_replay(pj.x, mj.x, vj.x, a, gg); adam1_replay(pj.y, mj.y, vj.y, a, gg);
-        adam1_replay(pj.z, mj.z, vj.z, a, gg); adam1_replay(pj.w, mj.w, vj.w, a, gg);
-        continue;
-      }
+      // (round 6, measured and not kept: the update without its dead gradient terms -- g = l1 sign(p) directly and
+      //  omb2 g^2 as a per-record constant, 4 instructions of ~21 fewer, the same bits -- made the replay 8 % SLOWER,
+      //  1.51 -> 1.64 ms at base: profiles/r06g_ab_replay.txt)
       float unused = 0.f;
       adam1(pi.x, 0.f, mi.x, vi.x, a, unused); adam1(pi.y, 0.f, mi.y, vi.y, a, unused);
       adam1(pi.z, 0.f, mi.z, vi.z, a, unused); adam1(pi.w, 0.f, mi.w, vi.w, a, unused);

@@ -60,18 +60,3 @@ __device__ __forceinline__ void adam1(float& p, float g_in, float& m, float& v, 
   const float denom = adam_div(__builtin_amdgcn_sqrtf(v), a.bias2_sqrt) + a.eps;
   p = p - a.step_size * adam_div(m, denom);
 }
-
-// adam1 for a coefficient that NO data gradient reaches (the replay of deferred steps, k_adam_l1_catchup): g_in = 0, so
-// g = 0 * inv_scale + l1 sign(p) = l1 sign(p) exactly (inv_scale finite; l1 > 0: the caller takes adam1 for l1 = 0, where
-// the sum would turn -0 into +0), and omb2 * g * g = (omb2 * l1) * l1 =: gg whatever the sign -- a per-record constant.
-// Four vector instructions fewer of ~21 in a pass that is ALU-bound (round 6); the same bits as adam1(p, 0.f, m, v, a, .)
-// (tests/test_adam_deferred_gpu.py: parameters and both moments after a flush equal the whole-array pass bit for bit).
-__device__ __forceinline__ void adam1_replay(float& p, float& m, float& v, const AdamArgs& a, float gg) {
-#pragma clang fp contract(off)
-  const bool nz = p != 0.f;
-  const float g = nz ? copysignf(a.l1_coef, p) : 0.f;
-  m = m + (g - m) * a.omb1;
-  v = v * a.beta2 + (nz ? gg : 0.f);
-  const float denom = adam_div(__builtin_amdgcn_sqrtf(v), a.bias2_sqrt) + a.eps;
-  p = p - a.step_size * adam_div(m, denom);
-}
