@@ -91,21 +91,31 @@ def _march_train_exact(cuda, rays, shell, perturb):
         assert np.array_equal(deltas.cpu().numpy(), lr[:m])
 
 
-@pytest.mark.parametrize("case", ["one_cascade", "bound2", "cap64", "near_tiny", "cap7_dense"])
+@pytest.mark.parametrize("case", ["one_cascade", "bound2", "cap64", "near_tiny", "cap7_dense", "random_cells", "few_partial"])
 def test_march_wavefront_form_edge_cases(cuda, case):
     """The wavefront-per-ray count pass where its closed-form chain does not apply or its bookkeeping is stressed: one
     cascade, bound 2 (long rays: t crosses 2 and 4), a sample cap of 64 / 7 per ray on a fully occupied grid (the cap ends a run inside a chunk),
     min_near 0.01 (t starts in binades where 63 steps are no longer exact: the serial chunk form)."""
     from trinerflet_amd import raymarching
+    # (round 6, the per-lane form's occupancy table in LDS: "random_cells" = every 64-cell word partial, 65 536 of them, more
+    #  than the table holds: the words come from memory; "few_partial" = a thin shell, every partial word in LDS; the full
+    #  grids above = only all-ones words)
     bound, cas, max_steps, min_near, shell = {"one_cascade": (1.0, 1, 1024, 0.2, (0.8, 0.3)), "bound2": (2.0, 2, 1024, 0.2, (0.9, 0.0)),
                                               "cap64": (1.5, 2, 64, 0.2, None), "near_tiny": (1.5, 2, 512, 0.01, (1.4, 0.0)),
-                                              "cap7_dense": (1.5, 2, 7, 0.2, None)}[case]
+                                              "cap7_dense": (1.5, 2, 7, 0.2, None), "random_cells": (1.5, 2, 256, 0.2, "random"),
+                                              "few_partial": (1.5, 2, 1024, 0.2, (0.5, 0.45))}[case]
     o, d = scene.training_rays(3000, n_cams=6, seed=9)
     if case == "near_tiny":
         o *= 0.3            # cameras inside the box: the rays start at t = min_near
     aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
     nears, fars = cref.near_far_from_aabb(o, d, aabb, min_near)
-    bf = np.full(cas * HG ** 3 // 8, 255, np.uint8) if shell is None else scene.sphere_bitfield(HG, cas, bound, *shell)
+    if shell is None:
+        bf = np.full(cas * HG ** 3 // 8, 255, np.uint8)
+    elif shell == "random":
+        rb = np.random.default_rng(11)
+        bf = (rb.integers(0, 256, cas * HG ** 3 // 8) & rb.integers(0, 256, cas * HG ** 3 // 8)).astype(np.uint8)   # 25 % of the cells
+    else:
+        bf = scene.sphere_bitfield(HG, cas, bound, *shell)
     noises = np.random.default_rng(2).random(o.shape[0]).astype(np.float32)
     M = o.shape[0] * max_steps
     xr, dr, lr, rr, cr = cref.march_rays_train(o, d, bound, bf, cas, HG, nears, fars, noises, M, max_steps=max_steps)
