@@ -235,66 +235,14 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* smem4, int* total
 #define TNL_MARCH_NZ_FILTER 1
 #endif
 constexpr int NZ_WORDS = 2048;
-// Round 6: the WHOLE occupancy information in LDS.  Beside the step's HBM-bound kernels the per-lane count pass took 800 us
-// for 360 alone: what is left of its loads after the non-zero map -- the words of occupied 4 x 4 x 4 blocks -- wait out a
-// memory system that the adjoint / rebuild keep saturated, once per probe of a dependent chain.  A second map marks the
-// words that are ALL ONES (the inside of an object), and the remaining PARTIAL words (its surface: ~4 500 for the r = 0.8
-// ball, fewer for a trained scene) are compacted into one array (k_compact_words) that every workgroup of the count pass
-// copies into LDS with the two maps and a prefix count per 32 words: a probe then never leaves the CU.  More than
-// NZ_CAP partial words (an untrained grid): the words are loaded from memory as before.
-//   layout behind the t record: nz[NZ_WORDS] | full[NZ_WORDS] | pre[NZ_WORDS] | total | 3 pad | partial words[2 * NZ_CAP]
-#ifndef TNL_MARCH_LDS_GRID
-#define TNL_MARCH_LDS_GRID 1
-#endif
-constexpr int NZ_CAP = 8192;                       // partial words kept in LDS (64 KiB)
-constexpr int NZ_TABLE_WORDS = 3 * NZ_WORDS + 4 + 2 * NZ_CAP;
 __global__ void __launch_bounds__(MARCH_BLOCK)
 k_nonzero_words(const unsigned long long* __restrict__ grid64, uint32_t n_words, uint32_t* __restrict__ nzmap) {
   const uint32_t w = blockIdx.x * MARCH_BLOCK + threadIdx.x;        // (the launch covers NZ_WORDS * 32 words exactly)
-  const unsigned long long v = w < n_words ? grid64[w] : 0ull;
-  const unsigned long long b = __ballot(v != 0ull), f = __ballot(v == ~0ull);
+  const unsigned long long b = __ballot(w < n_words && grid64[w] != 0ull);
   if ((threadIdx.x & 63) == 0) {
     nzmap[w >> 5] = (uint32_t)b;
     nzmap[(w >> 5) + 1] = (uint32_t)(b >> 32);
-    nzmap[NZ_WORDS + (w >> 5)] = (uint32_t)f;
-    nzmap[NZ_WORDS + (w >> 5) + 1] = (uint32_t)(f >> 32);
   }
-}
-
-// one workgroup: per 32 words the number of partial words before them, their total, and the partial words themselves in
-// word order (the first NZ_CAP of them)
-__global__ void __launch_bounds__(MARCH_BLOCK)
-k_compact_words(const unsigned long long* __restrict__ grid64, uint32_t* __restrict__ nzmap) {
-  __shared__ int smem4[4];
-  const uint32_t* nz = nzmap;
-  const uint32_t* full = nzmap + NZ_WORDS;
-  uint32_t* pre = nzmap + 2 * NZ_WORDS;
-  uint32_t* total = nzmap + 3 * NZ_WORDS;
-  unsigned long long* words = reinterpret_cast<unsigned long long*>(nzmap + 3 * NZ_WORDS + 4);
-  constexpr int PER = NZ_WORDS / MARCH_BLOCK;
-  uint32_t part[PER];
-  int mine = 0;
-#pragma unroll
-  for (int k = 0; k < PER; k++) {
-    const int e = threadIdx.x * PER + k;
-    part[k] = nz[e] & ~full[e];
-    mine += __popc(part[k]);
-  }
-  int tot;
-  int run = block_excl_scan_256(mine, smem4, &tot);
-#pragma unroll
-  for (int k = 0; k < PER; k++) {
-    const int e = threadIdx.x * PER + k;
-    pre[e] = (uint32_t)run;
-    uint32_t bits = part[k];
-    while (bits) {
-      const int b = __ffs(bits) - 1;
-      bits &= bits - 1;
-      if (run < NZ_CAP) words[run] = grid64[(size_t)e * 32 + b];
-      run++;
-    }
-  }
-  if (threadIdx.x == 0) *total = (uint32_t)tot;
 }
 
 // The serial march of one ray on one lane (march_run<false, true, true, REC>) for the fast path of the level arithmetic
@@ -339,17 +287,9 @@ __device__ __forceinline__ void trec_flush(const TRec& q, uint32_t step, bool ve
   if (k > 2u) q.base[b + 2] = q.r2;
 }
 
-// the occupancy information of the per-lane count pass in LDS: nz / full maps, prefix counts, partial words (or none)
-struct LdsGrid {
-  const uint32_t* nz;          // NULL: every word is loaded from memory
-  const uint32_t* full;
-  const uint32_t* pre;
-  const unsigned long long* words;   // NULL: partial words are loaded from memory
-};
-
 template <bool REC>
 __device__ __forceinline__ uint32_t march_run_fast(const MarchCtx& m, float& t, float far, uint32_t limit, float* trec,
-                                                   const uint32_t* __restrict__ lut, const LdsGrid lg) {
+                                                   const uint32_t* __restrict__ lut, const uint32_t* __restrict__ nz) {
 #pragma clang fp contract(off)
   TRec rec{trec, 0.f, 0.f, 0.f};
   const bool vec4 = REC && TNL_MARCH_REC4 && (limit & 3u) == 0u && (reinterpret_cast<uintptr_t>(trec) & 15u) == 0u;
@@ -375,18 +315,8 @@ __device__ __forceinline__ uint32_t march_run_fast(const MarchCtx& m, float& t, 
     const uint32_t blk = index >> 6;
     if (blk != cached_blk) {
       // nz (LDS): one bit per 64-cell word of the bitfield, set where the word is not zero (k_nonzero_words) -- an empty
-      // 4 x 4 x 4 block of cells costs no trip to L2 / HBM (two thirds of a ray's probes are in empty space); full: set
-      // where it is all ones; the partial words from the compacted LDS copy when there is one
-      if (lg.nz == nullptr) {
-        cached_bits = grid64[blk];
-      } else {
-        const uint32_t e = blk >> 5, b = blk & 31u;
-        const uint32_t nzw = lg.nz[e], fw = lg.full[e];
-        if (!((nzw >> b) & 1u)) cached_bits = 0ull;
-        else if ((fw >> b) & 1u) cached_bits = ~0ull;
-        else if (lg.words != nullptr) cached_bits = lg.words[lg.pre[e] + __popc((nzw & ~fw) & ((1u << b) - 1u))];
-        else cached_bits = grid64[blk];
-      }
+      // 4 x 4 x 4 block of cells costs no trip to L2 / HBM (two thirds of a ray's probes are in empty space)
+      cached_bits = (nz == nullptr || ((nz[blk >> 5] >> (blk & 31u)) & 1u)) ? grid64[blk] : 0ull;
       cached_blk = blk;
     }
     q.occ = (cached_bits >> (index & 63u)) & 1ull;
@@ -436,26 +366,15 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
                     uint32_t N, uint32_t C, uint32_t H, const float* __restrict__ nears,
                     const float* __restrict__ fars, const float* __restrict__ noises,
                     int* __restrict__ num_steps_out, int* __restrict__ block_sums, float* __restrict__ tbuf,
-                    const uint32_t* __restrict__ nzmap = nullptr, int lds_words = 0) {
+                    const uint32_t* __restrict__ nzmap = nullptr) {
   __shared__ int smem4[4];
   __shared__ uint32_t s_lut[MARCH_BLOCK];
-  __shared__ uint32_t s_nz[3 * NZ_WORDS];          // nz | full | pre
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_words[];   // lds_words of them (0: none)
+  __shared__ uint32_t s_nz[NZ_WORDS];
   const bool fast = WIDE && TNL_MARCH_FAST_LANE && dt_gamma == 0.f && C <= 2 && H <= 256;     // block-uniform
-  LdsGrid lg{nullptr, nullptr, nullptr, nullptr};
   if (fast) {
     s_lut[threadIdx.x] = expand_bits(threadIdx.x);
-    if (nzmap != nullptr) {
-      for (int k = threadIdx.x; k < 3 * NZ_WORDS; k += MARCH_BLOCK) s_nz[k] = nzmap[k];
-      lg.nz = s_nz; lg.full = s_nz + NZ_WORDS; lg.pre = s_nz + 2 * NZ_WORDS;
-      const uint32_t total = nzmap[3 * NZ_WORDS];
-      if (lds_words > 0 && total <= (uint32_t)lds_words) {      // every partial word fits: none is read from memory again
-        const uint4* src = reinterpret_cast<const uint4*>(nzmap + 3 * NZ_WORDS + 4);
-        uint4* dst = reinterpret_cast<uint4*>(s_words);
-        for (uint32_t k = threadIdx.x; k < (total + 1) / 2; k += MARCH_BLOCK) dst[k] = src[k];
-        lg.words = s_words;
-      }
-    }
+    if (nzmap != nullptr)
+      for (int k = threadIdx.x; k < NZ_WORDS; k += MARCH_BLOCK) s_nz[k] = nzmap[k];
     __syncthreads();
   }
   const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
@@ -466,7 +385,8 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
     float t = nears[n];
     t = fmaf(clampf_(t * dt_gamma, m.dt_min, m.dt_max), noises[n], t);
     if (fast)
-      ns = (int)march_run_fast<REC>(m, t, fars[n], max_steps, REC ? tbuf + (size_t)n * max_steps : nullptr, s_lut, lg);
+      ns = (int)march_run_fast<REC>(m, t, fars[n], max_steps, REC ? tbuf + (size_t)n * max_steps : nullptr, s_lut,
+                                    nzmap != nullptr ? s_nz : nullptr);
     else
       ns = (int)march_run<false, WIDE, true, REC>(m, t, fars[n], max_steps, nullptr, nullptr, nullptr,
                                                   REC ? tbuf + (size_t)n * max_steps : nullptr);
@@ -731,36 +651,11 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
   //  latency of each trip; the tile lists FILLED here into fixed spans sized from the period's first batch, no scan and no
   //  second pass: exact, and the interference with the step's HBM-bound kernels only moved)
   // (a launch of fewer workgroups than rays walks them with the grid's stride: tnl_march_side_caps)
-  //
-  // Round 6: the NEXT ray's inputs are requested before this ray is worked on.  A wave of the capped launch walks ~117 rays
-  // one after the other, and each used to start with three levels of dependent loads (the ray's record -> its origin,
-  // direction, near, noise -> its t values), 1-2 us each beside the step's HBM-bound kernels: most of the pass's 400 us.
-  // The first 64 t values are fetched speculatively by lane (lanes past the ray's count are set right by a shuffle, which
-  // also yields the predecessor's t: no second load for the first chunk).
-#ifndef TNL_EMIT_PREFETCH
-#define TNL_EMIT_PREFETCH 1
-#endif
-  struct EmitIn {
-    uint32_t off;
-    int ns;
-    float o[3], d[3], near, noise, t;
-  };
-  const uint32_t stride = gridDim.x * (MARCH_BLOCK / WAVE);
-  const size_t ray_base = (size_t)counter[1];
-  auto fetch = [&](uint32_t n, EmitIn& q) {
-    const int* r = rays + (ray_base + n) * 3;
-    q.off = (uint32_t)r[1];
-    q.ns = r[2];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { q.o[c] = rays_o[(size_t)n * 3 + c]; q.d[c] = rays_d[(size_t)n * 3 + c]; }
-    q.near = nears[n];
-    q.noise = noises[n];
-    q.t = (uint32_t)lane < max_steps ? tbuf[(size_t)n * max_steps + lane] : 0.f;
-  };
-  auto body = [&](uint32_t n, const EmitIn& in) {
-  const uint32_t off = in.off;
-  const int ns = in.ns;
-  if (ns == 0) return;
+  for (uint32_t n = blockIdx.x * (MARCH_BLOCK / WAVE) + (threadIdx.x / WAVE); n < N; n += gridDim.x * (MARCH_BLOCK / WAVE)) {
+  const int* r = rays + ((size_t)counter[1] + n) * 3;
+  const uint32_t off = (uint32_t)r[1];
+  const int ns = r[2];
+  if (ns == 0) continue;
   if (off + (uint32_t)ns > M) {
     // a ray the sample budget drops: the rows it would have started in stay in the buffer (off < M for at most one
     // such ray) and are consumed as samples of no ray -- zero them, whatever the caller's buffers held
@@ -774,29 +669,22 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
       }
       if (bin_counts != nullptr) bin_sample<false>(0.f, 0.f, 0.f, live, q, bound, binR, TNX, TNY, bin_counts, nullptr, lane);
     }
-    return;
+    continue;
   }
   MarchCtx m;
-  march_init(m, in.o, in.d, bound, dt_gamma, max_steps, C, H, nullptr);
-  float t_start = in.near;
-  t_start = fmaf(clampf_(t_start * dt_gamma, m.dt_min, m.dt_max), in.noise, t_start);
+  march_init(m, rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, bound, dt_gamma, max_steps, C, H, nullptr);
+  float t_start = nears[n];
+  t_start = fmaf(clampf_(t_start * dt_gamma, m.dt_min, m.dt_max), noises[n], t_start);
   const float* tr = tbuf + (size_t)n * max_steps;
   auto step_dt = [&](float t) { return m.fast ? m.dt0 : clampf_(t * m.dt_gamma, m.dt_min, m.dt_max); };
   for (int k0 = 0; k0 < ns; k0 += WAVE) {   // uniform trip count (bin_sample shuffles across the wave)
     const int k = k0 + lane;
     const bool live = k < ns;
     const int kl = live ? k : ns - 1;
-    float t, tp = 0.f;
-    if (k0 == 0) {          // the prefetched chunk: lane kl's value, and lane kl - 1's as the predecessor
-      t = __shfl(in.t, kl);
-      tp = __shfl(in.t, max(kl - 1, 0));
-    } else {
-      t = tr[kl];
-      tp = tr[kl - 1];      // (kl >= 64 here)
-    }
+    const float t = tr[kl];
     const float dt = step_dt(t);
     float last_t = t_start;
-    if (kl > 0) last_t = tp + step_dt(tp);
+    if (kl > 0) { const float tp = tr[kl - 1]; last_t = tp + step_dt(tp); }
     const float t_next = t + dt;
     const size_t o = (size_t)off + kl;
     const float px = clampf_(fmaf(t, m.dx, m.ox), -m.bound, m.bound);
@@ -810,20 +698,6 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
     }
     if (bin_counts != nullptr) bin_sample<false>(px, py, pz, live, (uint32_t)o, bound, binR, TNX, TNY, bin_counts, nullptr, lane);
   }
-  };
-  uint32_t n = blockIdx.x * (MARCH_BLOCK / WAVE) + (threadIdx.x / WAVE);
-  if (n >= N) return;
-  EmitIn cur;
-  fetch(n, cur);
-  for (;;) {
-    const uint32_t nn = n + stride;
-    EmitIn nxt = cur;                      // (defined values where there is no next ray)
-    if (TNL_EMIT_PREFETCH && nn < N) fetch(nn, nxt);
-    body(n, cur);
-    if (nn >= N) break;
-    if (!TNL_EMIT_PREFETCH) fetch(nn, nxt);
-    n = nn;
-    cur = nxt;
   }
 }
 
@@ -1584,7 +1458,7 @@ uint32_t tnl_march_rays_train_workspace(uint32_t N) { return N + cdiv(N, MARCH_B
 // with room for the count pass's record of every sample's t (N * max_steps floats): the samples are then written
 // from the record instead of by a second march; 0 if that does not fit 32 bits
 uint32_t tnl_march_rays_train_workspace_rec(uint32_t N, uint32_t max_steps) {
-  const uint64_t w = (uint64_t)tnl_march_rays_train_workspace(N) + (uint64_t)N * max_steps + 8 + NZ_TABLE_WORDS;   // + the count pass's occupancy table
+  const uint64_t w = (uint64_t)tnl_march_rays_train_workspace(N) + (uint64_t)N * max_steps + 4 + NZ_WORDS;   // + k_nonzero_words' map
   return w > 0xffffffffull ? 0u : (uint32_t)w;
 }
 
@@ -1623,33 +1497,14 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
     } else if (wide_bitfield(grid, C, H)) {
       // the per-lane count pass skips the loads of all-empty 64-cell words through a one-bit-per-word map (behind the record)
       uint32_t* nzmap = nullptr;
-      int lds_words = 0;
       const uint64_t n_words = (uint64_t)C * H * H * H / 64;
       if (TNL_MARCH_NZ_FILTER && TNL_MARCH_FAST_LANE && dt_gamma == 0.f && C <= 2 && H <= 256 && n_words <= (uint64_t)NZ_WORDS * 32) {
-        // (16-byte aligned behind the record: the partial words are copied as 16-byte pieces)
-        nzmap = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(tbuf + (size_t)N * max_steps) + 15) & ~(uintptr_t)15);
+        nzmap = reinterpret_cast<uint32_t*>(tbuf + (size_t)N * max_steps);   // (the 4 spare words cover tbuf's alignment)
         hipLaunchKernelGGL(k_nonzero_words, dim3(NZ_WORDS * 32 / MARCH_BLOCK), dim3(MARCH_BLOCK), 0, st,
                            reinterpret_cast<const unsigned long long*>(grid), (uint32_t)n_words, nzmap);
-        hipLaunchKernelGGL(k_compact_words, dim3(1), dim3(MARCH_BLOCK), 0, st,
-                           reinterpret_cast<const unsigned long long*>(grid), nzmap);
-        // 64 KiB of partial words + 25 KiB of maps per workgroup = one workgroup per CU: for the launches of a training
-        // batch (a few hundred workgroups), not for a march over millions of rays
-        if (TNL_MARCH_LDS_GRID && nb <= 1024) {
-          static bool attr_set[64] = {};
-          int dev_ = 0;
-          (void)hipGetDevice(&dev_);
-          if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_march_train_count<true, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, NZ_CAP * 8);
-            if (e != hipSuccess) return (int)e;
-            if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
-          }
-          lds_words = NZ_CAP;
-        }
       }
-      hipLaunchKernelGGL((k_march_train_count<true, true>), dim3(nb), dim3(MARCH_BLOCK), (size_t)lds_words * 8, st, rays_o,
-                         rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf,
-                         nzmap, lds_words);
+      hipLaunchKernelGGL((k_march_train_count<true, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid,
+                         bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf, nzmap);
     } else
       hipLaunchKernelGGL((k_march_train_count<false, true>), dim3(nb), dim3(MARCH_BLOCK), 0, st, rays_o, rays_d, grid,
                          bound, dt_gamma, max_steps, N, C, H, nears, fars, noises, num_steps, block_sums, tbuf);

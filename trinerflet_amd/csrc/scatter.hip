@@ -45,30 +45,12 @@ k_bin(const float* __restrict__ xyz, float bound, uint32_t M, const int32_t* __r
       int TNY, int* __restrict__ counts_or_cursor, uint32_t* __restrict__ entries, float2* __restrict__ epos) {
   const uint32_t Me = eff_m(M, m_actual);
   // (a launch of fewer workgroups than M / NT walks the samples with the grid's stride; uniform trip count per wave)
-  // (round 6: the next trip's positions are requested before this trip's slot atomics are waited for -- a capped launch
-  //  walks ~70 trips per wave, each a load round trip followed by an atomic round trip; TNL_BIN_PREFETCH=0: one after the other)
-#ifndef TNL_BIN_PREFETCH
-#define TNL_BIN_PREFETCH 1
-#endif
-  const uint32_t stride = gridDim.x * NT;
-  uint32_t i0 = blockIdx.x * NT;
-  if (i0 >= M) return;
-  auto fetch = [&](uint32_t j0, float& x, float& y, float& z) {
-    const uint32_t j = j0 + threadIdx.x;
-    const uint32_t jl = j < Me ? j : 0;
-    x = xyz[(size_t)jl * 3]; y = xyz[(size_t)jl * 3 + 1]; z = xyz[(size_t)jl * 3 + 2];
-  };
-  float cx, cy, cz;
-  fetch(i0, cx, cy, cz);
-  for (;;) {
-    const uint32_t n0 = i0 + stride;
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    if (TNL_BIN_PREFETCH && n0 < M) fetch(n0, nx, ny, nz);
+  for (uint32_t i0 = blockIdx.x * NT; i0 < M; i0 += gridDim.x * NT) {
     const uint32_t i = i0 + threadIdx.x;
-    bin_sample<FILL>(cx, cy, cz, i < Me, i, bound, R, TNX, TNY, counts_or_cursor, entries, threadIdx.x & 63, epos);
-    if (n0 >= M) break;
-    if (!TNL_BIN_PREFETCH) fetch(n0, nx, ny, nz);
-    i0 = n0; cx = nx; cy = ny; cz = nz;
+    const bool live = i < Me;
+    const uint32_t il = live ? i : 0;
+    bin_sample<FILL>(xyz[(size_t)il * 3], xyz[(size_t)il * 3 + 1], xyz[(size_t)il * 3 + 2], live, i, bound, R, TNX, TNY,
+                     counts_or_cursor, entries, threadIdx.x & 63, epos);
   }
 }
 
