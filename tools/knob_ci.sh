@@ -38,7 +38,5 @@ run "-DTNL_MARCH_NZ_FILTER=0" "$MARCH tests/test_flag_matrix_gpu.py"
 # round 6
 run "-DTNL_LAYOUT_ROWS=1" "$IDWT tests/test_triplane_gpu.py"
 run "-DTNL_CHAIN_JUMP=0" "$MARCH tests/test_render_fused_gpu.py tests/test_renderer_gpu.py"
-run "-DTNL_CHAIN_JUMP_COUNT=0" "$MARCH"
-run "-DTNL_MARCH_REC4=0" "$MARCH"
 run "-DTNL_RENDER_CHAIN_WALK=0" "tests/test_render_fused_gpu.py"
 [ -n "$KNOB_CI_DRY" ] || python -m trinerflet_amd.build --force > /dev/null

@@ -256,43 +256,14 @@ struct FastProbe {
   bool occ;
 };
 
-// The record of a ray's sample t values, written FOUR AT A TIME (round 6).  One ray per lane means every lane writes its
-// own 4-KB record: a `*trec++ = t` is 64 separate 4-byte requests per wave instruction, 4.65 M of them per step at base --
-// as many memory requests as the HBM-bound adjoint beside which the pass runs issues lines.  Three values wait in
-// registers and the fourth stores a 16-byte quad (the record of a ray starts 16-byte aligned when max_steps % 4 == 0;
-// `vec` false otherwise: scalar stores); the tail of up to three goes out at the end.  The same record to the bit.
-#ifndef TNL_CHAIN_JUMP_COUNT
-#define TNL_CHAIN_JUMP_COUNT TNL_CHAIN_JUMP   // the per-lane count pass's empty-cell skip (7-14 adds per cell at max_steps 1024)
-#endif
-#ifndef TNL_MARCH_REC4
-#define TNL_MARCH_REC4 1
-#endif
-struct TRec {
-  float* base;
-  float r0, r1, r2;
-};
-__device__ __forceinline__ void trec_push(TRec& q, uint32_t step, float t, bool vec) {
-  if (!vec) { q.base[step] = t; return; }
-  const uint32_t k = step & 3u;
-  if (k == 3u) *reinterpret_cast<float4*>(q.base + (step - 3u)) = make_float4(q.r0, q.r1, q.r2, t);
-  q.r0 = k == 0u ? t : q.r0;
-  q.r1 = k == 1u ? t : q.r1;
-  q.r2 = k == 2u ? t : q.r2;
-}
-__device__ __forceinline__ void trec_flush(const TRec& q, uint32_t step, bool vec) {
-  if (!vec) return;
-  const uint32_t k = step & 3u, b = step - k;
-  if (k > 0u) q.base[b] = q.r0;
-  if (k > 1u) q.base[b + 1] = q.r1;
-  if (k > 2u) q.base[b + 2] = q.r2;
-}
-
+// (round 6, each measured against this form on one box and removed -- docs/EXPERIMENTS.md, profiles/r06k_*, r06i_*: the t record
+//  written four values at a time; the empty-cell skip through chain_skip.h (7-14 adds per cell at max_steps 1024: the walk is
+//  the shorter program); one probe per trip instead of two; every occupancy word in LDS.  Beside the step's kernels this pass
+//  is slowed by sharing the issue ports, and every instruction added to it showed in the small step.)
 template <bool REC>
 __device__ __forceinline__ uint32_t march_run_fast(const MarchCtx& m, float& t, float far, uint32_t limit, float* trec,
                                                    const uint32_t* __restrict__ lut, const uint32_t* __restrict__ nz) {
 #pragma clang fp contract(off)
-  TRec rec{trec, 0.f, 0.f, 0.f};
-  const bool vec4 = REC && TNL_MARCH_REC4 && (limit & 3u) == 0u && (reinterpret_cast<uintptr_t>(trec) & 15u) == 0u;
   const float hH = 0.5f * m.Hf, rH2 = m.rH * 2, hmax = (float)(m.H - 1), dt = m.dt0;
   const int incx = __float_as_uint(m.dx) >> 31 ? 0 : 1, incy = __float_as_uint(m.dy) >> 31 ? 0 : 1,
             incz = __float_as_uint(m.dz) >> 31 ? 0 : 1;
@@ -327,11 +298,7 @@ __device__ __forceinline__ uint32_t march_run_fast(const MarchCtx& m, float& t, 
     const float ey = fmaf((float)(q.ny + incy) * rH2 - 1, q.mipb, -q.y) * m.rdy;
     const float ez = fmaf((float)(q.nz + incz) * rH2 - 1, q.mipb, -q.z) * m.rdz;
     const float tt = t + fmaxf(0.0f, fminf(ex, fminf(ey, ez)));
-#if TNL_CHAIN_JUMP_COUNT
-    t = chain_skip_or_walk(t, dt, tt);   // (chain_skip.h: the loop below, long chains in O(1))
-#else
     do { t += dt; } while (t < tt);
-#endif
   };
   uint32_t step = 0;
   while (t < far && step < limit) {
@@ -339,12 +306,12 @@ __device__ __forceinline__ uint32_t march_run_fast(const MarchCtx& m, float& t, 
     const float t1 = t + dt;
     const FastProbe b = probe(t1);
     if (a.occ) {
-      if (REC) trec_push(rec, step, t, vec4);
+      if (REC) *trec++ = t;
       t = t1;
       step++;
       if (t < far && step < limit) {
         if (b.occ) {
-          if (REC) trec_push(rec, step, t, vec4);
+          if (REC) *trec++ = t;
           t = t + dt;
           step++;
         } else {
@@ -355,7 +322,6 @@ __device__ __forceinline__ uint32_t march_run_fast(const MarchCtx& m, float& t, 
       skip(a);
     }
   }
-  if (REC) trec_flush(rec, step, vec4);
   return step;
 }
 
@@ -646,10 +612,9 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
   // the lanes of a wave ARE consecutive samples of one ray, the case its run aggregation is made for
   const int TNX = binR / TSX, TNY = binR / TSY;
   const int lane = threadIdx.x % WAVE;
-  // (round 6, measured and not kept -- docs/EXPERIMENTS.md: the sample rows staged in LDS and written as 16-byte pieces,
-  //  16 full lines per 64 samples instead of ~50 line requests: 399 -> 443 us at the capped width, the pass is bound by the
-  //  latency of each trip; the tile lists FILLED here into fixed spans sized from the period's first batch, no scan and no
-  //  second pass: exact, and the interference with the step's HBM-bound kernels only moved)
+  // (round 6, measured and not kept -- docs/EXPERIMENTS.md: the sample rows staged in LDS and written as 16-byte pieces
+  //  (399 -> 443 us); the next ray's inputs requested a ray ahead (398 -> 385 us, step unchanged); the tile lists FILLED here
+  //  into fixed spans sized from the period's first batch, no scan and no second pass: exact, the interference only moved)
   // (a launch of fewer workgroups than rays walks them with the grid's stride: tnl_march_side_caps)
   for (uint32_t n = blockIdx.x * (MARCH_BLOCK / WAVE) + (threadIdx.x / WAVE); n < N; n += gridDim.x * (MARCH_BLOCK / WAVE)) {
   const int* r = rays + ((size_t)counter[1] + n) * 3;
