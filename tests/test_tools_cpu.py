@@ -32,3 +32,10 @@ def test_knob_ci_lists_every_knob_with_existing_tests_and_builds_with_the_flags(
     # run() hands its flags to the build (the line the bad patch lost)
     body = open(os.path.join(ROOT, "tools", "knob_ci.sh")).read()
     assert re.search(r'TNL_HIPCC_FLAGS="\$1" python -m trinerflet_amd\.build --force', body)
+
+
+def test_python_tools_compile():
+    """Every tools/*.py at least byte-compiles (their GPU runs are recorded under profiles/)."""
+    import py_compile
+    for f in glob.glob(os.path.join(ROOT, "tools", "*.py")):
+        py_compile.compile(f, doraise=True)
