@@ -23,8 +23,19 @@ COMMON += os.environ.get("TNL_HIPCC_FLAGS", "").split()
 # the MFMA kernels run one wave per SIMD and post-process every accumulator tile on the VALU: keep MFMA results in
 # VGPRs instead of AGPRs (saves the v_accvgpr_read per element; field backward 1.06 -> 1.01 ms at base)
 MFMA_VGPR = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+# the SLP vectoriser packs adjacent fp32 multiply-adds into v_pk_*_f32: a gain for some kernels (the hidden-64 field forward,
+# the replay of deferred optimiser steps), a loss for others -- switched off per object where an A/B on one box said so
+# (profiles/r06o_ab_no_slp.txt: hidden-128 field forward -10 %, one-kernel render of a trained field -7 %)
+NO_SLP = ["-fno-slp-vectorize"]
 PER_FILE = {"raymarch.hip": ["-ffp-contract=off"], "rays.hip": ["-ffp-contract=off"],
-            "field_bwd.hip": MFMA_VGPR, "field_bwd_rows.hip": MFMA_VGPR, "field.hip": MFMA_VGPR, "scatter.hip": MFMA_VGPR, "render.hip": MFMA_VGPR}
+            "field_bwd.hip": MFMA_VGPR, "field_bwd_rows.hip": MFMA_VGPR, "field.hip": MFMA_VGPR, "scatter.hip": MFMA_VGPR,
+            "render.hip": MFMA_VGPR + NO_SLP, "field_h128.hip": MFMA_VGPR + NO_SLP}
+# A/B builds on the GPU box: TNL_HIPCC_FILE_FLAGS="scatter.hip:-fno-slp-vectorize;wavelet.hip:-DX=1 -DY=2" adds flags per object
+for _spec in filter(None, os.environ.get("TNL_HIPCC_FILE_FLAGS", "").split(";")):
+    _name, _flags = _spec.split(":", 1)
+    PER_FILE[_name.strip()] = PER_FILE.get(_name.strip(), []) + _flags.split()
+# objects that are another source compiled under a macro
+INCLUDES = {"field_h128.hip": ["field.hip"]}
 
 
 def _newer(src, dst, extra=()):
@@ -43,7 +54,7 @@ def build(verbose=False, force=False):
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _newer(s, o, headers):
+        if force or _newer(s, o, headers + [os.path.join(CSRC, d) for d in INCLUDES.get(os.path.basename(s), [])]):
             jobs.append([HIPCC, *COMMON, *PER_FILE.get(os.path.basename(s), []), "-c", s, "-o", o])
 
     def run(cmd):

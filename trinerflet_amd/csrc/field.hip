@@ -199,6 +199,20 @@ int launch_fwd(const void* planes, int half_in, const float* xyz, const float* d
 
 }  // namespace
 
+// The hidden-128 instantiation is compiled as its own object, field_h128.hip (this file with TNL_FIELD_H128_ONLY), WITHOUT the
+// SLP vectoriser: packing the blend's fp32 multiply-adds into v_pk_*_f32 costs that kernel 10 % (large: forward 1.41 -> 1.27 ms)
+// and gains the hidden-64 kernels 8 % (base 0.78 vs 0.85 ms): profiles/r06o_ab_no_slp.txt.
+int tnl_field_forward_h128(const void* planes, int half_in, const float* xyz, const float* dirs, float bound, uint32_t M,
+                           uint32_t R, const void* packed, float* sigma, float* rgb, void* feats_save, bool density_only,
+                           const int32_t* m_actual, hipStream_t st);
+#ifdef TNL_FIELD_H128_ONLY
+int tnl_field_forward_h128(const void* planes, int half_in, const float* xyz, const float* dirs, float bound, uint32_t M,
+                           uint32_t R, const void* packed, float* sigma, float* rgb, void* feats_save, bool density_only,
+                           const int32_t* m_actual, hipStream_t st) {
+  return launch_fwd<48, 128>(planes, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, m_actual, st);
+}
+#else
+
 // backward kernels live in field_bwd.hip; these helpers are shared through this header-less pair
 extern "C" {
 
@@ -246,8 +260,9 @@ int tnl_field_forward(const void* planes_tm, int half_in, const float* xyz, cons
   if (C == 32 && Hd == 64)
     return launch_fwd<32, 64>(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, m_actual, st);
   if (C == 48 && Hd == 128)
-    return launch_fwd<48, 128>(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, m_actual, st);
+    return tnl_field_forward_h128(planes_tm, half_in, xyz, dirs, bound, M, R, packed, sigma, rgb, feats_save, density_only, m_actual, st);
   return (int)hipErrorInvalidValue;
 }
 
 }  // extern "C"
+#endif  // TNL_FIELD_H128_ONLY
