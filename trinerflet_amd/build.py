@@ -32,7 +32,7 @@ PER_FILE = {"raymarch.hip": ["-ffp-contract=off"], "rays.hip": ["-ffp-contract=o
             # the rows backward: the scheduler told to favour ILP (0.583-0.597 -> 0.570-0.574 ms at base in four alternating rounds,
             # small equal: profiles/r06o_ab_no_slp.txt section 6; the same switch costs field.hip and wavelet.hip 0.05-0.08 ms)
             "field_bwd_rows.hip": MFMA_VGPR + ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "field.hip": MFMA_VGPR, "scatter.hip": MFMA_VGPR,
-            "render.hip": MFMA_VGPR + NO_SLP, "field_h128.hip": MFMA_VGPR + NO_SLP}
+            "render.hip": MFMA_VGPR + NO_SLP, "field_h128.hip": MFMA_VGPR + NO_SLP + ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}   # (+ max-ilp: 1.26 -> 1.20 ms)
 # A/B builds on the GPU box: TNL_HIPCC_FILE_FLAGS="scatter.hip:-fno-slp-vectorize;wavelet.hip:-DX=1 -DY=2" adds flags per object
 for _spec in filter(None, os.environ.get("TNL_HIPCC_FILE_FLAGS", "").split(";")):
     _name, _flags = _spec.split(":", 1)
