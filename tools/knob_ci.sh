@@ -39,4 +39,5 @@ run "-DTNL_MARCH_NZ_FILTER=0" "$MARCH tests/test_flag_matrix_gpu.py"
 run "-DTNL_LAYOUT_ROWS=1" "$IDWT tests/test_triplane_gpu.py"
 run "-DTNL_CHAIN_JUMP=0" "$MARCH tests/test_render_fused_gpu.py tests/test_renderer_gpu.py"
 run "-DTNL_RENDER_CHAIN_WALK=0" "tests/test_render_fused_gpu.py"
+run "-DTNL_SIDE_PRIO=0 -DTNL_MAIN_PRIO=3" "$MARCH $IDWT tests/test_train_gpu.py tests/test_field_gpu.py"
 [ -n "$KNOB_CI_DRY" ] || python -m trinerflet_amd.build --force > /dev/null

@@ -10,6 +10,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#ifndef TNL_MAIN_PRIO
+#define TNL_MAIN_PRIO 0   // A/B builds: static wave priority (s_setprio) of the step's kernels that run beside the side chain
+#endif
+#define TNL_SET_MAIN_PRIO() do { if (TNL_MAIN_PRIO) __builtin_amdgcn_s_setprio(TNL_MAIN_PRIO); } while (0)
 
 #include "../../include/trinerflet_hip.h"
 #include "adam_common.h"
@@ -279,6 +283,7 @@ k_adam_l1_live(float* __restrict__ p, const float* __restrict__ g, float* __rest
                AdamArgs a, const float* __restrict__ inv_scale_dev, const float* __restrict__ found_inf,
                float* __restrict__ abs_sum, const float* __restrict__ opt_step_dev,
                const AdamStepRec* __restrict__ rec, LiveSegs segs) {
+  TNL_SET_MAIN_PRIO();
   if (rec != nullptr) {
     a.step_size = rec->step_size;
     a.bias2_sqrt = rec->bias2_sqrt;

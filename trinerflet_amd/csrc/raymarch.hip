@@ -14,6 +14,14 @@
 #include <algorithm>
 #include <stdlib.h>
 #include <stdint.h>
+// Static wave priority (s_setprio) of the prefetched march passes: on the side stream they share their SIMDs with the step's
+// HBM-bound kernels and are short dependent chains -- served first they finish sooner and cost those kernels nothing
+// measurable: small 1.948 -> 1.915 ms per step (the forward no longer runs beside the fill pass: 0.40 -> 0.34), base 3.748 ->
+// 3.724, large equal (profiles/r06p_ab_wave_priority.txt; the reverse -- priority for the step's kernels -- speeds them by
+// 0.1 ms and makes the side chain the critical path: small + 0.11 ms).  0 = none (A/B builds, tools/knob_ci.sh).
+#ifndef TNL_SIDE_PRIO
+#define TNL_SIDE_PRIO 3
+#endif
 
 #include "../../include/trinerflet_hip.h"
 #include "bin_common.h"
@@ -333,6 +341,7 @@ k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ 
                     const float* __restrict__ fars, const float* __restrict__ noises,
                     int* __restrict__ num_steps_out, int* __restrict__ block_sums, float* __restrict__ tbuf,
                     const uint32_t* __restrict__ nzmap = nullptr) {
+  if (TNL_SIDE_PRIO) __builtin_amdgcn_s_setprio(TNL_SIDE_PRIO);
   __shared__ int smem4[4];
   __shared__ uint32_t s_lut[MARCH_BLOCK];
   __shared__ uint32_t s_nz[NZ_WORDS];
@@ -608,6 +617,7 @@ k_march_train_emit(const float* __restrict__ rays_o, const float* __restrict__ r
                    const int* __restrict__ counter, const float* __restrict__ tbuf, const int* __restrict__ rays,
                    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int binR,
                    int* __restrict__ bin_counts) {
+  if (TNL_SIDE_PRIO) __builtin_amdgcn_s_setprio(TNL_SIDE_PRIO);
   // bin_counts != NULL: the first pass of the plane-gradient tile sort (scatter.hip k_bin<false>) rides along -- here
   // the lanes of a wave ARE consecutive samples of one ray, the case its run aggregation is made for
   const int TNX = binR / TSX, TNY = binR / TSY;

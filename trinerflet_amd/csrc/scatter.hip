@@ -19,6 +19,18 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifndef TNL_MAIN_PRIO
+#define TNL_MAIN_PRIO 0   // A/B builds: static wave priority (s_setprio) of the step's kernels that run beside the side chain
+#endif
+#define TNL_SET_MAIN_PRIO() do { if (TNL_MAIN_PRIO) __builtin_amdgcn_s_setprio(TNL_MAIN_PRIO); } while (0)
+// Static wave priority (s_setprio) of the tile sort passes: on the side stream they share their SIMDs with the step's
+// HBM-bound kernels and are short dependent chains -- served first they finish sooner and cost those kernels nothing
+// measurable: small 1.948 -> 1.915 ms per step (the forward no longer runs beside the fill pass: 0.40 -> 0.34), base 3.748 ->
+// 3.724, large equal (profiles/r06p_ab_wave_priority.txt; the reverse -- priority for the step's kernels -- speeds them by
+// 0.1 ms and makes the side chain the critical path: small + 0.11 ms).  0 = none (A/B builds, tools/knob_ci.sh).
+#ifndef TNL_SIDE_PRIO
+#define TNL_SIDE_PRIO 3
+#endif
 
 #include <algorithm>
 #include <mutex>
@@ -43,6 +55,7 @@ template <bool FILL>
 __global__ void __launch_bounds__(NT)
 k_bin(const float* __restrict__ xyz, float bound, uint32_t M, const int32_t* __restrict__ m_actual, int R, int TNX,
       int TNY, int* __restrict__ counts_or_cursor, uint32_t* __restrict__ entries, float2* __restrict__ epos) {
+  if (TNL_SIDE_PRIO) __builtin_amdgcn_s_setprio(TNL_SIDE_PRIO);
   const uint32_t Me = eff_m(M, m_actual);
   // (a launch of fewer workgroups than M / NT walks the samples with the grid's stride; uniform trip count per wave)
   for (uint32_t i0 = blockIdx.x * NT; i0 < M; i0 += gridDim.x * NT) {
@@ -153,6 +166,7 @@ k_tile_accumulate(const _Float16* __restrict__ dfeat, uint32_t Mcap, const float
                   int TNY, const int* __restrict__ offsets, const uint32_t* __restrict__ entries,
                   const float2* __restrict__ epos, float grad_scale,
                   float* __restrict__ grad_out, int layout, int* __restrict__ nonfinite_flag, Roi roi) {
+  TNL_SET_MAIN_PRIO();
   // layout: bit 0 = channel-major (3,C,R,R) output; bit 1 = the caller zero-filled the output (one contiguous fill):
   // untouched tiles are then skipped instead of being zeroed here in 128-byte row pieces; bit 2 (with a ROI) = the output
   // is the whole (3,C,R,R) array, of which only the window is written

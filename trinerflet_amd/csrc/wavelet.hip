@@ -18,6 +18,16 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifndef TNL_MAIN_PRIO
+#define TNL_MAIN_PRIO 0   // A/B builds: static wave priority (s_setprio) of the step's kernels that run beside the side chain
+#endif
+#ifndef TNL_PRIO_FWD
+#define TNL_PRIO_FWD TNL_MAIN_PRIO
+#endif
+#ifndef TNL_PRIO_BWD
+#define TNL_PRIO_BWD TNL_MAIN_PRIO
+#endif
+#define TNL_SET_PRIO(P) do { if (P) __builtin_amdgcn_s_setprio(P); } while (0)
 
 #include "../../include/trinerflet_hip.h"
 #include "adam_common.h"
@@ -287,6 +297,7 @@ template <int W, bool HALF_OUT>
 __global__ void __launch_bounds__(NT)
 k_idwt_fwd_pipe(const float* __restrict__ x, const float* __restrict__ yh, int n, void* __restrict__ out, Roi roi,
                 int TPW) {
+  TNL_SET_PRIO(TNL_PRIO_FWD);
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2, HW = L / 4;
   constexpr int HWA = HW ? 4 : 0;            // staged halo, 16-byte aligned
@@ -445,6 +456,7 @@ template <int W, bool FUSE>
 __global__ void __launch_bounds__(NT)
 k_idwt_bwd_pipe(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh, FuseAdam fa,
                 Roi roi, Roi orect, int TPW) {
+  TNL_SET_PRIO(TNL_PRIO_BWD);
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2;
   constexpr int KA = (K + 3) / 4 * 4;                 // aligned left halo of the fine tile
@@ -694,6 +706,7 @@ template <int W, bool HALF_OUT, int FB>
 __global__ void __launch_bounds__(WT)
 k_idwt_fwd_walk(const float* __restrict__ x, const float* __restrict__ yh, int n, void* __restrict__ out, Roi roi,
                 int seg, LGrid lg, const int* __restrict__ spans) {
+  TNL_SET_PRIO(TNL_PRIO_FWD);
   // FB = coarse rows per phase (4 or 8): the rolling window holds FB + 8 rows of the four bands, FB more are in flight
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2, HW = L / 4;
@@ -990,6 +1003,7 @@ template <int W, bool FUSE>
 __global__ void __launch_bounds__(AT) __attribute__((amdgpu_waves_per_eu(TNL_BWD_WALK_WAVES)))
 k_idwt_bwd_walk(const float* __restrict__ dout, int n, float* __restrict__ dx, float* __restrict__ dyh, Roi roi,
                 Roi orect, int seg, LGrid lg, const int* __restrict__ spans, WalkAdam wa) {
+  TNL_SET_PRIO(TNL_PRIO_BWD);
   constexpr WTaps T = wtaps(W);
   constexpr int L = T.L, K = (L - 2) / 2;
   constexpr int KA = (K + 3) / 4 * 4, SH = KA - K;       // staged left halo (fine samples), 16-byte aligned
