@@ -311,16 +311,22 @@ def inference_figure(model, device, max_steps=4096, images=3):
     times = {k: [] for k in modes}
     sched = []
     with torch.no_grad():
+        rays = []
         for k in range(images + 1):
             pix = np.stack([np.full(640000, k % images, np.int64), np.arange(640000)], -1)
             o, d = synthetic.get_rays(poses, pix)
-            o, d = torch.from_numpy(o).to(device)[None], torch.from_numpy(d).to(device)[None]
-            for name, kw in modes.items():
+            rays.append((torch.from_numpy(o).to(device)[None], torch.from_numpy(d).to(device)[None]))
+        # each form renders its frames back to back, as `--test` renders a sequence of poses with one form (the first frame of
+        # a form is its warm-up); interleaved per frame with the two loop forms the one-kernel render took 5.45 / 6.09 ms against 5.03 / 5.56
+        for name, kw in modes.items():
+            for o, d in rays:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 model.render(o, d, staged=True, bg_color=0, perturb=False, max_steps=max_steps, **kw)
                 torch.cuda.synchronize()
                 times[name].append(time.perf_counter() - t0)
+        for k in (images,):
+            o, d = rays[k]
             if k == images:
                 # the schedule of that image (iterations, survivors, samples): the host-driven loop runs the same
                 # iterations (bit-identical image, tests/test_renderer_gpu.py) and passes them through march_rays
